@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the REAL reference (imported from
+/root/reference, build container only) on seeded inputs.
+
+    python -m oracle.gen_golden            # from the repo root
+
+The reference never travels: only the small input/output vectors written here
+are committed.  Shims: cv2 / torchvision stubbed in
+sys.modules (only touched by debug-image code that is never reached),
+``Tensor.cuda`` patched to identity, a dict-with-attributes cfg.
+Weights come from oracle.detinit (name-keyed Philox), not torch RNG, so the
+tests can rebuild them without storing 100 MB state dicts.
+"""
+import json
+import os
+import sys
+import types
+import logging
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+from oracle import detinit, configs                       # noqa: E402
+from oracle.posenet import posenet_spec                   # noqa: E402
+from oracle.unet import unet_spec, unet_transposed_names  # noqa: E402
+from oracle.synth import synth_batch, strided, checksum   # noqa: E402
+
+
+class AD(dict):
+    """dict with attribute access (ResNet uses cfg.MODEL.EXTRA.X, HRNet cfg['MODEL'])."""
+    __getattr__ = dict.__getitem__
+
+    @staticmethod
+    def wrap(d):
+        if isinstance(d, dict):
+            return AD({k: AD.wrap(v) for k, v in d.items()})
+        return d
+
+
+def import_reference():
+    sys.path.insert(0, os.path.join(REF, 'lib'))
+    for m in ('cv2', 'torchvision', 'torchvision.utils'):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.modules['torchvision'].utils = sys.modules['torchvision.utils']
+    for m in ('nms.cpu_nms', 'nms.gpu_nms'):              # dead native code
+        mod = types.ModuleType(m)
+        setattr(mod, m.split('.')[1], None)
+        sys.modules[m] = mod
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import models.pose_hrnet, models.pose_resnet, models.Unet_generator   # noqa
+    import core.loss, core.function, core.evaluate                        # noqa
+    import nms.nms                                                        # noqa
+    return sys.modules
+
+
+def make_cfg(name, extra, J):
+    return AD.wrap({'MODEL': {'NAME': name, 'EXTRA': extra, 'NUM_JOINTS': J,
+                              'INIT_WEIGHTS': False, 'PRETRAINED': ''},
+                    'PRINT_FREQ': 1000000, 'DEBUG': {'DEBUG': False}})
+
+
+def build_ref_models(M, net, extra, J, unet_downs, salt=0):
+    cfg = make_cfg(net, extra, J)
+    mod = M['models.' + net]
+    D = mod.get_pose_net(cfg, is_train=False)
+    Tm = mod.get_pose_net(cfg, is_train=False)
+    G = M['models.Unet_generator'].UnetGenerator(9, 3, unet_downs)
+    dspec = posenet_spec(net, extra, J)
+    gspec = unet_spec(9, 3, unet_downs)
+    detinit.mark_transposed(unet_transposed_names(9, 3, unet_downs))
+    sdD = detinit.fill_state_dict(dspec, salt=salt)
+    sdT = detinit.fill_state_dict(dspec, salt=salt + 1)
+    sdG = detinit.fill_state_dict(gspec, salt=salt + 2, gain=0.5)
+    D.load_state_dict(sdD, strict=True)
+    Tm.load_state_dict(sdT, strict=True)
+    G.load_state_dict(sdG, strict=True)
+    return cfg, D, G, Tm
+
+
+def calibrate_ref(model, x):
+    """One train-mode pass with BN momentum 1.0 (mirrors oracle.posenet.calibrate)."""
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    old = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0
+    model.train()
+    with torch.no_grad():
+        model(x)
+    for m, o in zip(bns, old):
+        m.momentum = o
+
+
+def gen_keys(M):
+    out = {}
+    for tag, net, extra, J in (('hrnet_w32', 'pose_hrnet', configs.HRNET_W32, 17),
+                               ('hrnet_w48', 'pose_hrnet', configs.HRNET_W48, 17),
+                               ('resnet50', 'pose_resnet', configs.RES50, 17),
+                               ('hrnet_tiny', 'pose_hrnet', configs.HRNET_TINY, 5),
+                               ('resnet18_tiny', 'pose_resnet', configs.RES18_TINY, 5)):
+        m = M['models.' + net].get_pose_net(make_cfg(net, extra, J), is_train=False)
+        out[tag] = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+    for downs in (5, 6):
+        g = M['models.Unet_generator'].UnetGenerator(9, 3, downs)
+        out['unet%d' % downs] = [[k, list(v.shape)] for k, v in g.state_dict().items()]
+    with open(os.path.join(OUT, 'state_dict_keys.json'), 'w') as f:
+        json.dump(out, f)
+
+
+def gen_loss(M):
+    L = M['core.loss'].JointsMSELoss
+    o = (torch.arange(48, dtype=torch.float32) / 8 - 1.5).reshape(2, 3, 4, 2)
+    t = torch.zeros(2, 3, 4, 2)
+    t[:, :, 1, 1] = 1
+    w = torch.tensor([[1, 0, 1], [1, 1, .5]]).reshape(2, 3, 1)
+    kat = {'smoothl1_w': float(L(True)(o, t, w)), 'mse_w': float(L(True, True)(o, t, w)),
+           'smoothl1_now': float(L(False)(o, t, w)), 'b1': float(L(True)(o[:1], t[:1], w[:1]))}
+    rnd = {}
+    for i, (B, J, H, W, sc) in enumerate([(4, 17, 64, 48, 1.0), (3, 16, 8, 8, 3.0), (2, 5, 16, 16, 0.3)]):
+        o = detinit.normal('loss.o%d' % i, (B, J, H, W), sc)
+        t = detinit.uniform('loss.t%d' % i, (B, J, H, W))
+        w = (detinit.uniform('loss.w%d' % i, (B, J, 1)) < 0.7).float()
+        o.requires_grad_(True)
+        v = L(True)(o, t, w)
+        v.backward()
+        rnd['case%d' % i] = {'shape': [B, J, H, W], 'scale': sc, 'loss': float(v),
+                             'grad_abs_sum': float(o.grad.double().abs().sum()),
+                             'grad_sample': strided(o.grad, 64).tolist()}
+    with open(os.path.join(OUT, 'loss_kat.json'), 'w') as f:
+        json.dump({'kat': kat, 'random': rnd}, f)
+
+
+def gen_forward(M):
+    """Per-model forward/backward vectors (train + eval mode)."""
+    res = {}
+    for tag, net, extra, J, B, H, W in (
+            ('hrnet_tiny', 'pose_hrnet', configs.HRNET_TINY, 5, 2, 64, 64),
+            ('resnet18_tiny', 'pose_resnet', configs.RES18_TINY, 5, 2, 64, 64),
+            ('hrnet_w32', 'pose_hrnet', configs.HRNET_W32, 17, 2, 256, 192),
+            ('resnet50', 'pose_resnet', configs.RES50, 17, 2, 256, 192)):
+        cfg, D, G, _ = build_ref_models(M, net, extra, J, 6 if H % 64 == 0 and W % 64 == 0 else 5)
+        views, tgt, tw = synth_batch(tag, B, J, H, W)
+        calibrate_ref(D, views[2])
+        D.eval()
+        with torch.no_grad():
+            ye = D(views[0])
+        D.train()
+        x = views[1].clone().requires_grad_(True)
+        yt = D(x)
+        loss = M['core.loss'].JointsMSELoss(True)(yt, tgt, tw)
+        loss.backward()
+        sd = D.state_dict()
+        gnames = [k for k, p in D.named_parameters()]
+        pick = gnames[:3] + gnames[len(gnames) // 2:len(gnames) // 2 + 3] + gnames[-4:]
+        res[tag + '.eval_out'] = strided(ye)
+        res[tag + '.train_out'] = strided(yt)
+        res[tag + '.loss'] = np.array([float(loss)])
+        res[tag + '.dx'] = strided(x.grad)
+        for k in pick:
+            g = dict(D.named_parameters())[k].grad
+            res['%s.grad.%s' % (tag, k)] = np.array([float(g.double().sum()), float(g.double().abs().sum())])
+        bn = [k for k in sd if k.endswith('running_mean')]
+        for k in (bn[0], bn[len(bn) // 2], bn[-1]):
+            res['%s.bn.%s' % (tag, k)] = sd[k].numpy().copy()
+            kv = k.replace('running_mean', 'running_var')
+            res['%s.bn.%s' % (tag, kv)] = sd[kv].numpy().copy()
+        # generator forward + backward
+        gi = torch.cat(views, 1)
+        lg = G(gi)
+        res[tag + '.unet_out'] = strided(lg)
+        (lg * detinit.normal(tag + '.gproj', lg.shape)).sum().backward()
+        gp = dict(G.named_parameters())
+        for k in list(gp)[:2] + list(gp)[-2:]:
+            res['%s.ggrad.%s' % (tag, k)] = np.array([float(gp[k].grad.double().sum()),
+                                                       float(gp[k].grad.double().abs().sum())])
+        print('forward', tag, float(loss), flush=True)
+    np.savez_compressed(os.path.join(OUT, 'forward.npz'), **res)
+
+
+class Rec:
+    """criterion wrapper that records every call's value (loss_D_hm, loss_D_kd, loss_G)."""
+
+    def __init__(self, fn):
+        self.fn, self.vals = fn, []
+
+    def __call__(self, *a):
+        v = self.fn(*a)
+        self.vals.append(float(v))
+        return v
+
+    def cuda(self):
+        return self
+
+
+def gen_advmix(M):
+    """2-3 iterations of the REAL train_advmix / train loops on tiny + full models."""
+    fn = M['core.function']
+    res, meta = {}, {}
+    for tag, net, extra, J, B, H, W, iters in (
+            ('hrnet_tiny', 'pose_hrnet', configs.HRNET_TINY, 5, 2, 64, 64, 3),
+            ('resnet18_tiny', 'pose_resnet', configs.RES18_TINY, 5, 2, 64, 64, 3),
+            ('hrnet_w32', 'pose_hrnet', configs.HRNET_W32, 17, 2, 256, 192, 2),
+            ('resnet50', 'pose_resnet', configs.RES50, 17, 2, 256, 192, 2)):
+        cfg, D, G, Tm = build_ref_models(M, net, extra, J, 6, salt=10)
+        args = AD(alpha=0.1, adv_loss_weight=1.0)
+        calib = synth_batch(tag + '.calib', B, J, H, W)[0][0]
+        calibrate_ref(Tm, calib)
+        calibrate_ref(D, calib)
+        optD = torch.optim.Adam(D.parameters(), lr=1e-3)      # utils.py:89-92
+        optG = torch.optim.Adam(G.parameters(), lr=1e-3)
+        crit = Rec(M['core.loss'].JointsMSELoss(True))
+        batches = []
+        for it in range(iters):
+            v, t, w = synth_batch('%s.it%d' % (tag, it), B, J, H, W)
+            batches.append((v, [t, t, t], [w, w, w], [{}, {}, {}]))
+        outs = []
+        hook = D.register_forward_hook(lambda m, i, o: outs.append(o.detach().clone()))
+        wd = {'writer': types.SimpleNamespace(add_scalar=lambda *a, **k: None), 'train_global_steps': 0}
+        cfg['PRINT_FREQ'] = 10 ** 9
+        # PRINT_FREQ huge: i % PRINT_FREQ == 0 still fires for i == 0 -> logging only
+        fn.save_debug_images = lambda *a, **k: None
+        fn.train_advmix(cfg, args, batches, [D, G, Tm], crit, [optD, optG], 0, '/tmp', '/tmp', wd)
+        hook.remove()
+        res[tag + '.losses'] = np.array(crit.vals).reshape(iters, 3)     # hm, kd, G(pos) per iter
+        for it in range(iters):
+            res['%s.out1.it%d' % (tag, it)] = strided(outs[2 * it], 2048)
+            res['%s.out2.it%d' % (tag, it)] = strided(outs[2 * it + 1], 2048)
+        sdD, sdG = D.state_dict(), G.state_dict()
+        meta[tag] = {'D': checksum(sdD, [k for k in sdD if sdD[k].is_floating_point()]),
+                     'G': checksum(sdG, list(sdG)),
+                     'nbt': int(sdD['bn1.num_batches_tracked'])}
+        print('advmix', tag, res[tag + '.losses'].tolist(), flush=True)
+
+        # plain (non-AdvMix) loop, function.py:30-95
+        cfg, D, _, _ = build_ref_models(M, net, extra, J, 6, salt=20)
+        calibrate_ref(D, calib)
+        optD = torch.optim.Adam(D.parameters(), lr=1e-3)
+        crit = Rec(M['core.loss'].JointsMSELoss(True))
+        pb = []
+        for it in range(2):
+            v, t, w = synth_batch('%s.plain%d' % (tag, it), B, J, H, W)
+            pb.append((v[0], [t, t], w, {}))
+        fn._tocuda = lambda x: x
+        fn.train(cfg, None, pb, D, crit, optD, 0, '/tmp', '/tmp', wd)
+        res[tag + '.plain_losses'] = np.array(crit.vals)
+        sdD = D.state_dict()
+        meta[tag]['plain_D'] = checksum(sdD, [k for k in sdD if sdD[k].is_floating_point()])
+        print('plain', tag, crit.vals, flush=True)
+    np.savez_compressed(os.path.join(OUT, 'advmix_steps.npz'), **res)
+    with open(os.path.join(OUT, 'advmix_checksums.json'), 'w') as f:
+        json.dump(meta, f)
+
+
+def gen_nms(M):
+    nm = M['nms.nms']
+    rng = np.random.Generator(np.random.Philox(key=77))
+    box, oks = {}, {}
+    for N in (1, 2, 63, 64, 65, 200, 1000):
+        for th in (0.3, 0.5, 0.7):
+            c = rng.random((N, 2)) * 200
+            wh = rng.random((N, 2)) * 80 + 4
+            sc = rng.permutation(N).astype(np.float32) / N + 0.001          # distinct scores
+            d = np.concatenate([c, c + wh, sc[:, None]], 1).astype(np.float32)
+            keep = [int(i) for i in nm.nms(d, th)]
+            box['N%d_t%g' % (N, th)] = {'dets': d.tolist() if N <= 65 else None, 'seed_N': N,
+                                        'thresh': th, 'keep': keep}
+            if N > 65:
+                np.save(os.path.join(OUT, 'nms_dets_N%d_t%g.npy' % (N, th)), d)
+    for N in (1, 5, 20, 40):
+        for th in (0.5, 0.9):
+            k = rng.random((N, 17, 3)) * 100
+            base = rng.random((1, 17, 3)) * 100
+            k[: N // 2] = base + rng.normal(0, 2.0, (N // 2, 17, 3))          # near-duplicates
+            db = [{'score': float(s), 'keypoints': kk, 'area': float(a)}
+                  for s, kk, a in zip(rng.permutation(N) / N + 0.01, k, rng.random(N) * 4000 + 500)]
+            oks['N%d_t%g' % (N, th)] = {
+                'score': [e['score'] for e in db], 'area': [e['area'] for e in db],
+                'kpts': k.tolist(), 'thresh': th,
+                'keep': [int(i) for i in nm.oks_nms(db, th)],
+                'soft_keep': [int(i) for i in nm.soft_oks_nms(db, th)]}
+    with open(os.path.join(OUT, 'nms.json'), 'w') as f:
+        json.dump({'box': box, 'oks': oks}, f)
+
+
+def main():
+    logging.basicConfig(level=logging.WARNING)
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    M = import_reference()
+    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix']
+    for w in which:
+        globals()['gen_' + w](M)
+        print('done', w, flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,166 @@
+"""Pin the CPU oracle against vectors produced by the REAL reference
+(oracle/gen_golden.py, build container).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import detinit
+from oracle import nms as onms
+from oracle.loss import joints_loss
+from oracle.posenet import posenet_spec, posenet_forward, calibrate, trainable
+from oracle.unet import unet_spec, unet_forward
+from oracle.step import Adam, advmix_step, plain_step
+from oracle.synth import synth_batch, strided, checksum
+from helpers import CASES, gold_json, gold_npz, build_states, close, checksum_close, GOLD
+from oracle import configs
+
+torch.set_num_threads(8)
+
+
+def test_state_dict_keys_match_reference():
+    ref = gold_json('state_dict_keys.json')
+    for tag, net, extra, J in (('hrnet_w32', 'pose_hrnet', configs.HRNET_W32, 17),
+                               ('hrnet_w48', 'pose_hrnet', configs.HRNET_W48, 17),
+                               ('resnet50', 'pose_resnet', configs.RES50, 17),
+                               ('hrnet_tiny', 'pose_hrnet', configs.HRNET_TINY, 5),
+                               ('resnet18_tiny', 'pose_resnet', configs.RES18_TINY, 5)):
+        mine = {k: list(s) for k, s in posenet_spec(net, extra, J)}
+        want = {k: s for k, s in ref[tag]}
+        assert mine == want, tag
+    for downs in (5, 6):
+        mine = {k: list(s) for k, s in unet_spec(9, 3, downs)}
+        assert mine == {k: s for k, s in ref['unet%d' % downs]}
+
+
+def test_loss_known_answers():
+    g = gold_json('loss_kat.json')
+    o = (torch.arange(48, dtype=torch.float32) / 8 - 1.5).reshape(2, 3, 4, 2)
+    t = torch.zeros(2, 3, 4, 2)
+    t[:, :, 1, 1] = 1
+    w = torch.tensor([[1, 0, 1], [1, 1, .5]]).reshape(2, 3, 1)
+    k = g['kat']
+    assert abs(k['smoothl1_w'] - 0.5127766728401184) < 1e-7
+    assert abs(float(joints_loss(o, t, w, True)) - k['smoothl1_w']) < 1e-6
+    assert abs(float(joints_loss(o, t, w, True, smooth_L1=True)) - k['mse_w']) < 1e-6
+    assert abs(float(joints_loss(o, t, w, False)) - k['smoothl1_now']) < 1e-6
+    assert abs(float(joints_loss(o[:1], t[:1], w[:1], True)) - k['b1']) < 1e-6
+    for i, (name, c) in enumerate(sorted(g['random'].items())):
+        B, J, H, W = c['shape']
+        o = detinit.normal('loss.o%d' % i, (B, J, H, W), c['scale']).requires_grad_(True)
+        t = detinit.uniform('loss.t%d' % i, (B, J, H, W))
+        w = (detinit.uniform('loss.w%d' % i, (B, J, 1)) < 0.7).float()
+        v = joints_loss(o, t, w, True)
+        v.backward()
+        assert abs(float(v) - c['loss']) < 1e-6 * max(1, abs(c['loss']))
+        close(strided(o.grad, 64), c['grad_sample'], 1e-8, 1e-5)
+
+
+def _dets(name, c):
+    if c['dets'] is not None:
+        return np.array(c['dets'], np.float32)
+    return np.load('%s/nms_dets_%s.npy' % (GOLD, name))
+
+
+def test_box_nms_matches_reference_numpy():
+    g = gold_json('nms.json')['box']
+    for name, c in g.items():
+        d = _dets(name, c)
+        assert onms.py_nms(d, c['thresh']) == c['keep'], name
+        # where no IoU sits on the threshold the three reference semantics coincide
+        assert onms.gpu_nms(d, c['thresh']) == c['keep'], name
+        assert onms.cpu_nms(d, c['thresh']) == c['keep'], name
+
+
+def test_box_nms_threshold_edge_semantics():
+    # two 10x10 boxes (+1 convention: 11x11 px) shifted so IoU == 1/3 exactly:
+    # inter = 11*5.5?  use integer geometry: a=[0,0,9,9] (100), b=[5,0,14,9] -> inter 50, union 150
+    d = np.array([[0, 0, 9, 9, 0.9], [5, 0, 14, 9, 0.8]], np.float32)
+    th = float(np.float32(50.0) / np.float32(150.0))          # the fp32 quotient, as a double
+    assert onms.py_nms(d, th) == [0, 1]                        # keeps ovr <= thresh (nms.py:69)
+    assert onms.gpu_nms(d, th) == [0, 1]                       # strict > in fp32 (nms_kernel.cu:70)
+    assert onms.cpu_nms(d, th) == [0]                          # >= in double (cpu_nms.pyx:68)
+    assert onms.py_nms(d[:0], 0.5) == [] and onms.gpu_nms(d[:0], 0.5) == []
+    keep, mask = onms.gpu_nms(d, 0.3, return_mask=True)
+    assert keep == [0] and mask[0, 0] == 2 and mask[1, 0] == 0
+
+
+def test_oks_nms_matches_reference():
+    g = gold_json('nms.json')['oks']
+    for name, c in g.items():
+        k = np.array(c['kpts'])
+        db = [{'score': s, 'keypoints': kk, 'area': a} for s, kk, a in zip(c['score'], k, c['area'])]
+        assert onms.oks_nms(db, c['thresh']) == c['keep'], name
+        assert onms.soft_oks_nms(db, c['thresh']) == c['soft_keep'], name
+
+
+@pytest.mark.parametrize('tag', list(CASES))
+def test_forward_backward_matches_reference(tag):
+    net, extra, J, B, H, W, _ = CASES[tag]
+    g = gold_npz('forward.npz')
+    D, _, G = build_states(net, extra, J)
+    views, tgt, tw = synth_batch(tag, B, J, H, W)
+    calibrate(net, D, views[2], extra)
+    with torch.no_grad():
+        ye = posenet_forward(net, D, views[0], extra, False)
+    names = trainable(D)
+    for k in names:
+        D[k].requires_grad_(True)
+    x = views[1].clone().requires_grad_(True)
+    yt = posenet_forward(net, D, x, extra, True)
+    loss = joints_loss(yt, tgt, tw, True)
+    grads = dict(zip(names + ['x'], torch.autograd.grad(loss, [D[k] for k in names] + [x])))
+    close(strided(ye), g[tag + '.eval_out'])
+    close(strided(yt), g[tag + '.train_out'])
+    close([float(loss)], g[tag + '.loss'], 1e-5, 1e-4)
+    close(strided(grads['x']), g[tag + '.dx'], 1e-6, 2e-3)
+    for key in g.files:
+        if key.startswith(tag + '.grad.'):
+            k = key[len(tag) + 6:]
+            s, a = g[key]
+            gs, ga = float(grads[k].double().sum()), float(grads[k].double().abs().sum())
+            assert abs(ga - a) <= 2e-3 * a and abs(gs - s) <= 2e-3 * a, (k, gs, ga, s, a)
+        if key.startswith(tag + '.bn.'):
+            close(D[key[len(tag) + 4:]].detach().numpy(), g[key], 1e-4, 1e-3)
+    for k in G:
+        G[k].requires_grad_(True)
+    lg = unet_forward(G, torch.cat(views, 1))
+    close(strided(lg), g[tag + '.unet_out'])
+    gg = dict(zip(G, torch.autograd.grad((lg * detinit.normal(tag + '.gproj', lg.shape)).sum(), list(G.values()))))
+    for key in g.files:
+        if key.startswith(tag + '.ggrad.'):
+            k = key[len(tag) + 7:]
+            s, a = g[key]
+            assert abs(float(gg[k].double().abs().sum()) - a) <= 2e-3 * a, k
+            assert abs(float(gg[k].double().sum()) - s) <= 2e-3 * a, k
+
+
+@pytest.mark.parametrize('tag', list(CASES))
+def test_advmix_and_plain_steps_match_reference(tag):
+    net, extra, J, B, H, W, iters = CASES[tag]
+    g = gold_npz('advmix_steps.npz')
+    meta = gold_json('advmix_checksums.json')[tag]
+    D, T, G = build_states(net, extra, J, salt=10)
+    calib = synth_batch(tag + '.calib', B, J, H, W)[0][0]
+    calibrate(net, T, calib, extra)
+    calibrate(net, D, calib, extra)
+    optD = Adam(D, trainable(D))
+    optG = Adam(G, list(G))
+    for it in range(iters):
+        v, t, w = synth_batch('%s.it%d' % (tag, it), B, J, H, W)
+        r = advmix_step(net, extra, D, G, T, optD, optG, v, t, w, alpha=0.1)
+        want = g[tag + '.losses'][it]
+        close([float(r['l_hm']), float(r['l_kd']), -float(r['loss_G'])], want, 1e-4, 1e-3)
+        close(strided(r['out1'], 2048), g['%s.out1.it%d' % (tag, it)])
+        close(strided(r['out2'], 2048), g['%s.out2.it%d' % (tag, it)], 2e-3, 2e-3)
+    assert int(D['bn1.num_batches_tracked']) == meta['nbt']       # calib + 2 per iteration
+    checksum_close(checksum(D, meta['D'].keys()), meta['D'])
+    checksum_close(checksum(G, meta['G'].keys()), meta['G'])
+
+    D, _, _ = build_states(net, extra, J, salt=20)
+    calibrate(net, D, calib, extra)
+    optD = Adam(D, trainable(D))
+    for it in range(2):
+        v, t, w = synth_batch('%s.plain%d' % (tag, it), B, J, H, W)
+        r = plain_step(net, extra, D, optD, v[0], t, w)
+        close([float(r['loss'])], [g[tag + '.plain_losses'][it]], 1e-4, 1e-3)
+    checksum_close(checksum(D, meta['plain_D'].keys()), meta['plain_D'])

@@ -1,0 +1,68 @@
+"""ctypes binding of libadvmix_hip.so (the C ABI in include/advmix_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing this module
+raises at import, and every op raises on a non-zero status.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, 'libadvmix_hip.so')
+
+if not os.path.exists(SO_PATH):
+    raise ImportError('advmix_amd: %s not found - build it with `python -m advmix_amd.build` '
+                      '(hipcc --offload-arch=gfx950); there is no CPU fallback.' % SO_PATH)
+lib = ctypes.CDLL(SO_PATH)
+
+_p, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+# name -> argtypes, mirrors include/advmix_hip.h line by line
+SIGNATURES = {
+    'advmix_version': [],
+    'advmix_conv_fwd': [_p, _p, _p, _p] + [_i] * 11 + [_p],
+    'advmix_conv_tr': [_p, _p, _p, _p] + [_i] * 11 + [_p],
+    'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],
+    'advmix_transpose_w': [_p, _p, _i, _i, _i, _p],
+    'advmix_bias_grad': [_p, _p, _l, _i, _p],
+    'advmix_norm_stats': [_p, _i, _l, _i, _f, _p, _p, _p, _p, _p, _f, _p, _p],
+    'advmix_norm_apply': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _i, _p],
+    'advmix_bn_eval': [_p, _p, _p, _p, _p, _f, _p, _p, _l, _i, _i, _p],
+    'advmix_norm_bwd': [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _p],
+    'advmix_act_copy': [_p, _i, _p, _i, _l, _i, _i, _p],
+    'advmix_act_bwd': [_p, _i, _p, _i, _p, _i, _l, _i, _i, _p],
+    'advmix_fuse_sum': [_p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
+    'advmix_fuse_sum_bwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'advmix_maxpool3x3s2': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'advmix_maxpool3x3s2_bwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'advmix_scale_dev': [_p, _p, _p, _f, _l, _p],
+    'advmix_axpy': [_p, _p, _f, _l, _p],
+    'advmix_cat_views': [_p, _p, _p, _p, _i, _i, _i, _p],
+    'advmix_mix_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    'advmix_mix_bwd': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    'advmix_joints_loss': [_p, _p, _i, _p, _p, _p, _f, _i, _i, _i, _i, _p],
+    'advmix_heatmap_argmax': [_p, _i, _p, _p, _i, _i, _i, _p],
+    'advmix_adam': [_p, _p, _p, _p, _l, _p, _p, _p],
+    'advmix_fill': [_p, _f, _l, _p],
+    'advmix_nms_mask': [_p, _i, _f, _p, _p],
+    'advmix_nms_host': [_p, _p, _p, _i, _i, _f, _i],
+    'advmix_oks_matrix': [_p, _p, _p, _i, _i, _p, _p],
+}
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here == header/library drift
+    _fn.argtypes = _args
+    _fn.restype = ctypes.c_int
+lib.advmix_norm_ws_bytes.argtypes = [_i, _i]
+lib.advmix_norm_ws_bytes.restype = ctypes.c_int64
+
+
+class AdvmixHipError(RuntimeError):
+    pass
+
+
+_ERR = {1: 'ADVMIX_EINVAL (bad argument / unsupported shape)', 2: 'ADVMIX_ELAUNCH (HIP runtime error)'}
+
+
+def call(name, *args):
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise AdvmixHipError('%s failed: %s' % (name, _ERR.get(rc, rc)))

@@ -1,0 +1,226 @@
+// AdvMix glue kernels (HBM-bound): view concat, softmax-mix fwd/bwd, joints loss fwd+bwd,
+// heat-map argmax, flat Adam.
+// Reference sites: lib/core/function.py:137-144; lib/core/loss.py:25-65;
+// lib/core/inference.py:22-49; lib/utils/utils.py:89-92 (torch.optim.Adam defaults).
+#include "common.h"
+
+namespace {
+
+static int stream_blocks(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+// views are NCHW [N,3,H,W]; out NHWC [N,H,W,9]: G_input = torch.cat(inputs, 1) (function.py:137)
+__global__ __launch_bounds__(256) void cat_views_kernel(const float* __restrict__ v0, const float* __restrict__ v1,
+                                                        const float* __restrict__ v2, float* __restrict__ out, int N,
+                                                        int HW) {
+    const int64_t total = (int64_t)N * HW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t n = i / HW, p = i - n * HW;
+        const int64_t base = n * 3 * HW + p;
+        float* o = out + i * 9;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            o[c] = v0[base + (int64_t)c * HW];
+            o[3 + c] = v1[base + (int64_t)c * HW];
+            o[6 + c] = v2[base + (int64_t)c * HW];
+        }
+    }
+}
+
+__device__ __forceinline__ void softmax3(const float* l, float* w) {
+    float m = fmaxf(l[0], fmaxf(l[1], l[2]));
+    float e0 = expf(l[0] - m), e1 = expf(l[1] - m), e2 = expf(l[2] - m);
+    float inv = 1.0f / (e0 + e1 + e2);
+    w[0] = e0 * inv; w[1] = e1 * inv; w[2] = e2 * inv;
+}
+
+// tmp = sum_k view_k * softmax(logits)_k (function.py:138-144); one thread per pixel
+__global__ __launch_bounds__(256) void mix_fwd_kernel(const float* __restrict__ v0, const float* __restrict__ v1,
+                                                      const float* __restrict__ v2, const float* __restrict__ logits,
+                                                      float* __restrict__ tmp, int N, int HW) {
+    const int64_t total = (int64_t)N * HW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t n = i / HW, p = i - n * HW;
+        const int64_t base = n * 3 * HW + p;
+        float w[3];
+        softmax3(logits + i * 3, w);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int64_t o = base + (int64_t)c * HW;
+            float t = v0[o] * w[0];
+            t += v1[o] * w[1];
+            t += v2[o] * w[2];
+            tmp[i * 3 + c] = t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mix_bwd_kernel(const float* __restrict__ v0, const float* __restrict__ v1,
+                                                      const float* __restrict__ v2, const float* __restrict__ logits,
+                                                      const float* __restrict__ dtmp, float* __restrict__ dlogits,
+                                                      int N, int HW) {
+    const int64_t total = (int64_t)N * HW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t n = i / HW, p = i - n * HW;
+        const int64_t base = n * 3 * HW + p;
+        float w[3];
+        softmax3(logits + i * 3, w);
+        float dw[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int64_t o = base + (int64_t)c * HW;
+            float d = dtmp[i * 3 + c];
+            dw[0] += d * v0[o];
+            dw[1] += d * v1[o];
+            dw[2] += d * v2[o];
+        }
+        float dot = w[0] * dw[0] + w[1] * dw[1] + w[2] * dw[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dlogits[i * 3 + k] = w[k] * (dw[k] - dot);
+    }
+}
+
+// pred NHWC [B,HW,J]; element index e = (b*HW + p)*J + j
+__global__ __launch_bounds__(256) void joints_loss_kernel(const float* __restrict__ pred,
+                                                          const float* __restrict__ target, int target_nhwc,
+                                                          const float* __restrict__ tw, float* __restrict__ loss_out,
+                                                          float* __restrict__ grad, float grad_scale, int B, int J,
+                                                          int HW, int mse) {
+    __shared__ double red[4];
+    const int64_t total = (int64_t)B * HW * J;
+    const float norm = 0.5f / ((float)J * (float)B * (float)HW);
+    double acc = 0.0;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int j = (int)(e % J);
+        int64_t bp = e / J;
+        int64_t b = bp / HW, p = bp - b * HW;
+        float w = tw ? tw[b * J + j] : 1.0f;
+        float t = target_nhwc ? target[e] : target[(b * J + j) * HW + p];
+        float d = pred[e] * w - t * w;                    // loss.py:58-60: pred.mul(w), gt.mul(w)
+        float l, g;
+        if (mse) { l = d * d; g = 2.0f * d; }
+        else {
+            float ad = fabsf(d);
+            if (ad < 1.0f) { l = 0.5f * d * d; g = d; }
+            else { l = ad - 0.5f; g = d > 0.f ? 1.0f : -1.0f; }
+        }
+        acc += (double)l;
+        if (grad) grad[e] = grad_scale * norm * w * g;
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = red[0] + red[1] + red[2] + red[3];
+        atomicAdd(loss_out, (float)(s * (double)norm));
+    }
+}
+
+// one wave per (b, j); first-occurrence argmax (numpy.argmax semantics, inference.py:33)
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ hm, int nhwc, int32_t* __restrict__ idx,
+                                                     float* __restrict__ mx, int B, int J, int HW) {
+    const int lane = threadIdx.x & 63;
+    const int64_t bj = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bj >= (int64_t)B * J) return;
+    const int64_t b = bj / J, j = bj - b * J;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int p = lane; p < HW; p += 64) {
+        float v = nhwc ? hm[(b * HW + p) * J + j] : hm[bj * HW + p];
+        if (v > best || (v == best && p < bi) || (bi == 0x7fffffff)) { best = v; bi = p; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_down(best, o, 64);
+        int oi = __shfl_down(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { idx[bj] = bi == 0x7fffffff ? 0 : bi; mx[bj] = best; }
+}
+
+__global__ void adam_tick_kernel(int64_t* step) { *step += 1; }
+
+// torch.optim.Adam single-tensor math (no wd, no amsgrad)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   const float* __restrict__ hyper, const int64_t* __restrict__ step) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
+    const double t = (double)*step;
+    const float bc1 = (float)(1.0 - pow((double)b1, t));
+    const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
+    const float step_size = lr / bc1;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        float mi = m[i] + (gi - m[i]) * (1.0f - b1);          // lerp_
+        float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        float denom = sqrtf(vi) / bc2s + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+
+}  // namespace
+
+extern "C" int advmix_version(void) { return 1; }
+
+extern "C" int advmix_cat_views(const float* v0, const float* v1, const float* v2, float* out, int N, int H, int W,
+                                void* stream) {
+    if (!v0 || !v1 || !v2 || !out || N <= 0) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(cat_views_kernel, dim3(stream_blocks((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       v0, v1, v2, out, N, H * W);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_mix_fwd(const float* v0, const float* v1, const float* v2, const float* logits, float* tmp,
+                              int N, int H, int W, void* stream) {
+    if (!v0 || !v1 || !v2 || !logits || !tmp || N <= 0) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(mix_fwd_kernel, dim3(stream_blocks((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, v0,
+                       v1, v2, logits, tmp, N, H * W);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_mix_bwd(const float* v0, const float* v1, const float* v2, const float* logits,
+                              const float* dtmp, float* dlogits, int N, int H, int W, void* stream) {
+    if (!v0 || !v1 || !v2 || !logits || !dtmp || !dlogits || N <= 0) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(mix_bwd_kernel, dim3(stream_blocks((int64_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, v0,
+                       v1, v2, logits, dtmp, dlogits, N, H * W);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_joints_loss(const float* pred, const float* target, int target_nhwc, const float* tw,
+                                  float* loss_out, float* grad, float grad_scale, int B, int J, int HW, int mse,
+                                  void* stream) {
+    if (!pred || !target || !loss_out || B <= 0 || J <= 0 || HW <= 0) return ADVMIX_EINVAL;
+    int64_t total = (int64_t)B * J * HW;
+    int blocks = stream_blocks(total);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(joints_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, target, target_nhwc,
+                       tw, loss_out, grad, grad_scale, B, J, HW, mse);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_heatmap_argmax(const float* hm, int nhwc, int32_t* idx_out, float* max_out, int B, int J,
+                                     int HW, void* stream) {
+    if (!hm || !idx_out || !max_out || B <= 0 || J <= 0 || HW <= 0) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(argmax_kernel, dim3(cdiv((int64_t)B * J, 4)), dim3(256), 0, (hipStream_t)stream, hm, nhwc,
+                       idx_out, max_out, B, J, HW);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                           int64_t* step, void* stream) {
+    if (!p || !g || !m || !v || !hyper || !step || n <= 0) return ADVMIX_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n)), dim3(256), 0, st, p, g, m, v, n, hyper, step);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}

@@ -1,0 +1,36 @@
+// Shared helpers for the gfx950 kernels (device code is CDNA4-only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/advmix_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define ADVMIX_CHECK_LAUNCH() \
+    do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return ADVMIX_ELAUNCH; } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == ADVMIX_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ADVMIX_ACT_LEAKY02) return v > 0.f ? v : 0.2f * v;
+    return v;
+}
+// derivative expressed through the activation OUTPUT y (both activations are sign-preserving)
+__device__ __forceinline__ float act_grad(float y, int act) {
+    if (act == ADVMIX_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == ADVMIX_ACT_LEAKY02) return y > 0.f ? 1.f : 0.2f;
+    return 1.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}

@@ -1,0 +1,486 @@
+// Convolution family for gfx950 as implicit GEMM on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact f32, bit-for-bit an fmaf chain).
+//
+//   conv_igemm<MODE=0>  forward gather   : Conv2d fwd, ConvTranspose2d dgrad
+//   conv_igemm<MODE=1>  transposed gather: Conv2d dgrad, ConvTranspose2d fwd
+//                       (phase-decomposed by output parity: only real taps are multiplied)
+//   conv_wgrad          weight gradient for both, pixels are the reduction axis
+//
+// GEMM view (fwd): rows = output pixels, cols = output channels, K = taps x input channels.
+// Both operands are K-contiguous in HBM (NHWC activations, [Cout][R][S][Cin] weights), so a
+// lane's 16-byte load is 4 consecutive k of one row; tiles are staged through LDS in
+// [row][16+4] layout (80-byte rows: conflict-free ds_read_b128 per the 16-lane groups) and
+// each ds_read_b128 feeds four MFMAs (k-pairs {j, j+4} of an 8-wide k group).
+//
+// Replaces (reference): nn.Conv2d / nn.ConvTranspose2d in lib/models/pose_hrnet.py,
+// lib/models/pose_resnet.py, lib/models/Unet_generator.py (see include/advmix_hip.h).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 16;      // k per LDS tile
+constexpr int LDT = 20;     // LDS row pitch in floats (16 + 4 pad)
+
+struct ConvP {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    int N, Hi, Wi, Ci;      // gathered tensor
+    int Ho, Wo, Co;         // produced tensor
+    int R, S, stride, pad;
+};
+
+template <int BM, int BN, int MODE, bool VEC>
+__global__ __launch_bounds__(256) void conv_igemm(ConvP p) {
+    constexpr int WAVES_N = BN / 32;
+    constexpr int WAVES_M = 4 / WAVES_N;
+    constexpr int TM = BM / (32 * WAVES_M);
+    constexpr int AROWS = BM / 64;                    // A rows staged per thread
+    constexpr int BROWS = (BN + 63) / 64;             // B rows staged per thread
+    static_assert(TM >= 1 && AROWS >= 1, "tile");
+
+    __shared__ __attribute__((aligned(16))) float As[BM * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+    __shared__ int4 taptab[64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+
+    // ---- phase geometry -------------------------------------------------------------
+    int Hp, Wp, Th, Tw, rh = 0, rw = 0, phh = 0, phw = 0;
+    if (MODE == 0) {
+        Hp = p.Ho; Wp = p.Wo; Th = p.R; Tw = p.S;
+    } else {
+        rh = blockIdx.z / p.stride; rw = blockIdx.z % p.stride;
+        Hp = p.Ho > rh ? (p.Ho - rh + p.stride - 1) / p.stride : 0;
+        Wp = p.Wo > rw ? (p.Wo - rw + p.stride - 1) / p.stride : 0;
+        phh = (rh + p.pad) % p.stride; phw = (rw + p.pad) % p.stride;
+        Th = phh < p.R ? (p.R - phh + p.stride - 1) / p.stride : 0;
+        Tw = phw < p.S ? (p.S - phw + p.stride - 1) / p.stride : 0;
+    }
+    const int Mp = p.N * Hp * Wp;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    if (m0 >= Mp) return;
+    const int ntaps = Th * Tw;
+    const int Ktot = ntaps * p.Ci;
+    const int nkt = (Ktot + BK - 1) / BK;
+    const int Kfull = p.R * p.S * p.Ci;
+
+    if (tid < ntaps) {
+        int4 t;
+        if (MODE == 0) {
+            t.x = tid / p.S; t.y = tid % p.S; t.z = tid * p.Ci;
+        } else {
+            int th = tid / Tw, tw = tid % Tw;
+            int r = phh + p.stride * th, s = phw + p.stride * tw;
+            t.x = -th; t.y = -tw; t.z = (r * p.S + s) * p.Ci;
+        }
+        t.w = 0;
+        taptab[tid] = t;
+    }
+
+    // ---- per-thread staging rows -----------------------------------------------------
+    const int kc = tid & 3;                            // which float4 of the 16-wide k tile
+    const int srow = tid >> 2;                         // 0..63
+    int a_nb[AROWS], a_h[AROWS], a_w[AROWS];
+    bool a_ok[AROWS];
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+        int m = m0 + srow + 64 * i;
+        a_ok[i] = m < Mp;
+        int mm = a_ok[i] ? m : 0;
+        int n = mm / (Hp * Wp);
+        int rem = mm - n * (Hp * Wp);
+        int hi_ = rem / Wp, wi_ = rem - hi_ * Wp;
+        a_nb[i] = n * p.Hi * p.Wi;
+        if (MODE == 0) {
+            a_h[i] = hi_ * p.stride - p.pad;
+            a_w[i] = wi_ * p.stride - p.pad;
+        } else {
+            a_h[i] = (rh + hi_ * p.stride + p.pad - phh) / p.stride;
+            a_w[i] = (rw + wi_ * p.stride + p.pad - phw) / p.stride;
+        }
+    }
+    bool b_ok[BROWS];
+    const float* b_ptr[BROWS];
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) {
+        int n = n0 + srow + 64 * i;
+        b_ok[i] = (srow + 64 * i < BN) && n < p.Co;
+        b_ptr[i] = p.w + (int64_t)(b_ok[i] ? n : 0) * Kfull;
+    }
+    __syncthreads();                                   // taptab visible
+
+    // k tracker for this thread's float4 slot (VEC path)
+    int kt_tap = (kc * 4) / p.Ci;
+    int kt_c = (kc * 4) - kt_tap * p.Ci;
+
+    f32x4 ra[AROWS], rb[BROWS];
+    auto load_tile = [&](int kt) {
+        if (VEC) {
+            const bool tv = kt_tap < ntaps;
+            int4 tt = taptab[tv ? kt_tap : 0];
+#pragma unroll
+            for (int i = 0; i < AROWS; ++i) {
+                int hi = a_h[i] + tt.x, wi = a_w[i] + tt.y;
+                bool ok = tv && a_ok[i] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
+                ra[i] = ok ? *reinterpret_cast<const f32x4*>(
+                                 p.x + (int64_t)(a_nb[i] + hi * p.Wi + wi) * p.Ci + kt_c)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i)
+                rb[i] = (tv && b_ok[i]) ? *reinterpret_cast<const f32x4*>(b_ptr[i] + tt.z + kt_c)
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int kf = kt * BK + kc * 4 + e;
+                int tap = kf / p.Ci;
+                int c = kf - tap * p.Ci;
+                const bool tv = tap < ntaps;
+                int4 tt = taptab[tv ? tap : 0];
+#pragma unroll
+                for (int i = 0; i < AROWS; ++i) {
+                    int hi = a_h[i] + tt.x, wi = a_w[i] + tt.y;
+                    bool ok = tv && a_ok[i] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
+                    ra[i][e] = ok ? p.x[(int64_t)(a_nb[i] + hi * p.Wi + wi) * p.Ci + c] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < BROWS; ++i) rb[i][e] = (tv && b_ok[i]) ? b_ptr[i][tt.z + c] : 0.f;
+            }
+        }
+    };
+    auto advance = [&]() {
+        kt_c += BK;
+        while (kt_c >= p.Ci) { kt_c -= p.Ci; ++kt_tap; }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i)
+            *reinterpret_cast<f32x4*>(&As[(srow + 64 * i) * LDT + kc * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i)
+            if (srow + 64 * i < BN) *reinterpret_cast<f32x4*>(&Bs[(srow + 64 * i) * LDT + kc * 4]) = rb[i];
+    };
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) { advance(); load_tile(kt + 1); }
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+            f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[(wn * 32 + l31) * LDT + kq * 8 + lh * 4]);
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                f32x4 a = *reinterpret_cast<const f32x4*>(
+                    &As[((wm * TM + t) * 32 + l31) * LDT + kq * 8 + lh * 4]);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (more) { store_tile(); __syncthreads(); }
+    }
+
+    // ---- epilogue: lane holds column l31, rows (r&3)+8*(r>>2)+4*lh of each 32x32 tile ------
+    const int col = n0 + wn * 32 + l31;
+    if (col >= p.Co) return;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int m = m0 + (wm * TM + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= Mp) continue;
+            int64_t off;
+            if (MODE == 0) {
+                off = (int64_t)m * p.Co + col;
+            } else {
+                int n = m / (Hp * Wp);
+                int rem = m - n * (Hp * Wp);
+                int hi_ = rem / Wp, wi_ = rem - hi_ * Wp;
+                off = ((int64_t)(n * p.Ho + rh + hi_ * p.stride) * p.Wo + rw + wi_ * p.stride) * p.Co + col;
+            }
+            p.y[off] = acc[t][r] + bv;
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// weight gradient: dw[Ca][R*S*Cb] += A^T[Ca][P] * Bg[P][R*S*Cb],  P = N*Ha*Wa pixels
+// -------------------------------------------------------------------------------------------
+struct WgP {
+    const float* a;
+    const float* b;
+    float* dw;
+    int N, Ha, Wa, Ca, Hb, Wb, Cb;
+    int R, S, stride, pad;
+    int chunk;               // pixels per z-slice (multiple of 16)
+};
+
+template <int WM, int WN, bool VEC>
+__global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
+    constexpr int BMw = 32 * WM, BNw = 32 * WN;
+    constexpr int ASL = (16 * BMw / 4 + 255) / 256;    // float4 slots per thread
+    constexpr int BSL = (16 * BNw / 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float As[16 * BMw];
+    __shared__ __attribute__((aligned(16))) float Bs[16 * BNw];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wid / WN, wn = wid % WN;
+    const int co0 = blockIdx.x * BMw, j0 = blockIdx.y * BNw;
+    const int P = p.N * p.Ha * p.Wa;
+    const int Ntot = p.R * p.S * p.Cb;
+    const int p_lo = blockIdx.z * p.chunk;
+    const int p_hi = min(P, p_lo + p.chunk);
+    if (p_lo >= P) return;
+
+    // fixed per-thread slot geometry
+    int a_k[ASL], a_c[ASL];
+    bool a_in[ASL];
+#pragma unroll
+    for (int i = 0; i < ASL; ++i) {
+        int s = tid + 256 * i;
+        a_in[i] = s < 16 * BMw / 4;
+        a_k[i] = s / (BMw / 4);
+        a_c[i] = (s % (BMw / 4)) * 4;
+    }
+    int b_k[BSL], b_c[BSL], b_dh[BSL][VEC ? 1 : 4], b_dw[BSL][VEC ? 1 : 4], b_cb[BSL][VEC ? 1 : 4];
+    bool b_in[BSL], b_jv[BSL][VEC ? 1 : 4];
+#pragma unroll
+    for (int i = 0; i < BSL; ++i) {
+        int s = tid + 256 * i;
+        b_in[i] = s < 16 * BNw / 4;
+        b_k[i] = s / (BNw / 4);
+        b_c[i] = (s % (BNw / 4)) * 4;
+#pragma unroll
+        for (int e = 0; e < (VEC ? 1 : 4); ++e) {
+            int j = j0 + b_c[i] + e;
+            b_jv[i][e] = j < Ntot;
+            int jj = b_jv[i][e] ? j : 0;
+            int tap = jj / p.Cb;
+            b_cb[i][e] = jj - tap * p.Cb;
+            int r = tap / p.S;
+            b_dh[i][e] = r - p.pad;
+            b_dw[i][e] = tap - r * p.S - p.pad;
+        }
+    }
+
+    f32x4 ra[ASL], rb[BSL];
+    auto load_tile = [&](int pt) {
+#pragma unroll
+        for (int i = 0; i < ASL; ++i) {
+            int pix = pt + a_k[i];
+            bool ok = a_in[i] && pix < p_hi;
+            const float* src = p.a + (int64_t)(ok ? pix : 0) * p.Ca + co0 + a_c[i];
+            if (VEC) {
+                ra[i] = (ok && co0 + a_c[i] < p.Ca) ? *reinterpret_cast<const f32x4*>(src)
+                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[i][e] = (ok && co0 + a_c[i] + e < p.Ca) ? src[e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BSL; ++i) {
+            int pix = pt + b_k[i];
+            bool ok = b_in[i] && pix < p_hi;
+            int pp = ok ? pix : 0;
+            int n = pp / (p.Ha * p.Wa);
+            int rem = pp - n * (p.Ha * p.Wa);
+            int ha = rem / p.Wa, wa = rem - ha * p.Wa;
+            int hb0 = ha * p.stride, wb0 = wa * p.stride;
+            if (VEC) {
+                int hb = hb0 + b_dh[i][0], wb = wb0 + b_dw[i][0];
+                bool v = ok && b_jv[i][0] && (unsigned)hb < (unsigned)p.Hb && (unsigned)wb < (unsigned)p.Wb;
+                rb[i] = v ? *reinterpret_cast<const f32x4*>(
+                                p.b + ((int64_t)(n * p.Hb + hb) * p.Wb + wb) * p.Cb + b_cb[i][0])
+                          : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int hb = hb0 + b_dh[i][e], wb = wb0 + b_dw[i][e];
+                    bool v = ok && b_jv[i][e] && (unsigned)hb < (unsigned)p.Hb && (unsigned)wb < (unsigned)p.Wb;
+                    rb[i][e] = v ? p.b[((int64_t)(n * p.Hb + hb) * p.Wb + wb) * p.Cb + b_cb[i][e]] : 0.f;
+                }
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < ASL; ++i)
+            if (a_in[i]) *reinterpret_cast<f32x4*>(&As[a_k[i] * BMw + a_c[i]]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BSL; ++i)
+            if (b_in[i]) *reinterpret_cast<f32x4*>(&Bs[b_k[i] * BNw + b_c[i]]) = rb[i];
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    load_tile(p_lo);
+    store_tile();
+    __syncthreads();
+    for (int pt = p_lo; pt < p_hi; pt += 16) {
+        const bool more = pt + 16 < p_hi;
+        if (more) load_tile(pt + 16);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            float a = As[(kk * 2 + lh) * BMw + wm * 32 + l31];
+            float b = Bs[(kk * 2 + lh) * BNw + wn * 32 + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) { store_tile(); __syncthreads(); }
+    }
+
+    const int j = j0 + wn * 32 + l31;
+    if (j >= Ntot) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co < p.Ca) atomicAdd(p.dw + (int64_t)co * Ntot + j, acc[r]);
+    }
+}
+
+__global__ void transpose_w_kernel(const float* __restrict__ in, float* __restrict__ out, int A, int T, int B) {
+    int64_t total = (int64_t)A * T * B;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int a = (int)(i % A);
+        int64_t q = i / A;
+        int t = (int)(q % T);
+        int b = (int)(q / T);
+        out[i] = in[((int64_t)a * T + t) * B + b];
+    }
+}
+
+__global__ void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int64_t rows, int C,
+                                 int64_t rows_per_block) {
+    int64_t r0 = blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s += dy[r * C + c];
+        atomicAdd(db + c, s);
+    }
+}
+
+template <int MODE>
+int launch_igemm(const ConvP& p, int64_t Mmax, hipStream_t st) {
+    const bool vec = (p.Ci % 4 == 0);
+    const int phases = MODE == 0 ? 1 : p.stride * p.stride;
+#define LAUNCH(BM_, BN_, V_)                                                              \
+    do {                                                                                  \
+        dim3 g(cdiv(Mmax, BM_), cdiv(p.Co, BN_), phases);                                 \
+        hipLaunchKernelGGL((conv_igemm<BM_, BN_, MODE, V_>), g, dim3(256), 0, st, p);     \
+    } while (0)
+    if (p.Co <= 32) {
+        if (vec) LAUNCH(128, 32, true); else LAUNCH(128, 32, false);
+    } else {
+        int64_t blocks128 = (int64_t)cdiv(Mmax, 128) * cdiv(p.Co, 64) * phases;
+        if (blocks128 >= 512) {
+            if (vec) LAUNCH(128, 64, true); else LAUNCH(128, 64, false);
+        } else {
+            if (vec) LAUNCH(64, 64, true); else LAUNCH(64, 64, false);
+        }
+    }
+#undef LAUNCH
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+}  // namespace
+
+extern "C" int advmix_conv_fwd(const float* x, const float* w, const float* bias, float* y,
+                               int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
+                               int R, int S, int stride, int pad, void* stream) {
+    if (!x || !w || !y || N <= 0 || Ci <= 0 || Co <= 0 || R * S > 64 || stride < 1) return ADVMIX_EINVAL;
+    if (Ho != (Hi + 2 * pad - R) / stride + 1 || Wo != (Wi + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
+    ConvP p{x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad};
+    return launch_igemm<0>(p, (int64_t)N * Ho * Wo, (hipStream_t)stream);
+}
+
+extern "C" int advmix_conv_tr(const float* x, const float* wt, const float* bias, float* y,
+                              int N, int Hs, int Ws, int Ck, int Hb, int Wb, int Cn,
+                              int R, int S, int stride, int pad, void* stream) {
+    if (!x || !wt || !y || N <= 0 || Ck <= 0 || Cn <= 0 || R * S > 64 || stride < 1 || stride > 8)
+        return ADVMIX_EINVAL;
+    // (Hb, Wb) must be a valid input size for a conv producing (Hs, Ws)
+    if (Hs != (Hb + 2 * pad - R) / stride + 1 || Ws != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
+    ConvP p{x, wt, bias, y, N, Hs, Ws, Ck, Hb, Wb, Cn, R, S, stride, pad};
+    int64_t Mmax = (int64_t)N * cdiv(Hb, stride) * cdiv(Wb, stride);
+    return launch_igemm<1>(p, Mmax, (hipStream_t)stream);
+}
+
+extern "C" int advmix_conv_wgrad(const float* a, const float* b, float* dw,
+                                 int N, int Ha, int Wa, int Ca, int Hb, int Wb, int Cb,
+                                 int R, int S, int stride, int pad, void* stream) {
+    if (!a || !b || !dw || N <= 0 || Ca <= 0 || Cb <= 0 || stride < 1) return ADVMIX_EINVAL;
+    if (Ha != (Hb + 2 * pad - R) / stride + 1 || Wa != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
+    WgP p{a, b, dw, N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad, 0};
+    const int64_t P = (int64_t)N * Ha * Wa;
+    const int Ntot = R * S * Cb;
+    const bool vec = (Ca % 4 == 0) && (Cb % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCHW(WM_, WN_, V_)                                                             \
+    do {                                                                                  \
+        int tiles = cdiv(Ca, 32 * WM_) * cdiv(Ntot, 32 * WN_);                            \
+        int64_t ns = 1024 / tiles;                                                        \
+        if (ns < 1) ns = 1;                                                               \
+        int64_t maxs = (P + 63) / 64;                                                     \
+        if (ns > maxs) ns = maxs;                                                         \
+        int64_t chunk = ((P + ns - 1) / ns + 15) / 16 * 16;                               \
+        p.chunk = (int)chunk;                                                             \
+        dim3 g(cdiv(Ca, 32 * WM_), cdiv(Ntot, 32 * WN_), cdiv(P, chunk));                 \
+        hipLaunchKernelGGL((conv_wgrad<WM_, WN_, V_>), g, dim3(256), 0, st, p);           \
+    } while (0)
+    if (Ca <= 32) {
+        if (vec) LAUNCHW(1, 4, true); else LAUNCHW(1, 4, false);
+    } else if (Ntot <= 32) {
+        if (vec) LAUNCHW(4, 1, true); else LAUNCHW(4, 1, false);
+    } else {
+        if (vec) LAUNCHW(2, 2, true); else LAUNCHW(2, 2, false);
+    }
+#undef LAUNCHW
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_transpose_w(const float* in, float* out, int A, int T, int B, void* stream) {
+    if (!in || !out || A <= 0 || T <= 0 || B <= 0) return ADVMIX_EINVAL;
+    int64_t total = (int64_t)A * T * B;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(transpose_w_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, A, T, B);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_bias_grad(const float* dy, float* db, int64_t rows, int C, void* stream) {
+    if (!dy || !db || rows <= 0 || C <= 0) return ADVMIX_EINVAL;
+    int64_t rpb = (rows + 511) / 512;
+    if (rpb < 64) rpb = 64;
+    int blocks = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, db, rows, C, rpb);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}

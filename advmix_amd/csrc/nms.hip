@@ -1,0 +1,126 @@
+// lib/nms on gfx950.
+//   nms_mask_kernel : the reference's only CUDA kernel (lib/nms/nms_kernel.cu:33-77) rebuilt for a
+//                     64-lane wavefront: one wave per 64x64 tile of the pairwise IoU matrix, the
+//                     64-bit suppression word of a row is produced directly as the wave's
+//                     __ballot over the 64 column lanes (no per-thread 64-iteration loop, no LDS).
+//   advmix_nms_host : drop-in for `_nms` (gpu_nms.hpp:1-2): H2D, mask, D2H, sequential greedy
+//                     OR-reduce on the host (nms_kernel.cu:126-138).
+//   oks_matrix      : float64 OKS similarity (lib/nms/nms.py:75-94) for all pairs.
+// Bit-exactness: devIoU is evaluated in fp32 with one IEEE operation per statement; the build
+// uses -ffp-contract=off for this file's arithmetic (no FMA contraction) and IEEE division.
+#include "common.h"
+#include <vector>
+#include <string.h>
+
+namespace {
+
+__device__ __forceinline__ float dev_iou(const float* a, const float* b) {
+#pragma clang fp contract(off)
+    float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+    float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+    float width = fmaxf(right - left + 1.f, 0.f), height = fmaxf(bottom - top + 1.f, 0.f);
+    float interS = width * height;
+    float Sa = (a[2] - a[0] + 1.f) * (a[3] - a[1] + 1.f);
+    float Sb = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
+    return __fdiv_rn(interS, (Sa + Sb - interS));
+}
+
+// grid (col_blocks, row_blocks), block = 256 threads = 4 waves; wave w handles rows
+// row_start*64 + w*16 .. +16 of the tile, lane = column within the tile.
+__global__ __launch_bounds__(256) void nms_mask_kernel(int n, float thresh, const float* __restrict__ boxes,
+                                                       unsigned long long* __restrict__ mask) {
+    const int col_blk = blockIdx.x, row_blk = blockIdx.y;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col_blocks = (n + 63) / 64;
+    const int cj = col_blk * 64 + lane;
+    float cb[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool cvalid = cj < n;
+    if (cvalid) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cb[k] = boxes[cj * 5 + k];
+    }
+    for (int rr = 0; rr < 16; ++rr) {
+        const int ri = row_blk * 64 + w * 16 + rr;       // wave-uniform
+        if (ri >= n) break;
+        float rb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rb[k] = boxes[ri * 5 + k];
+        bool hit = false;
+        if (cvalid && (row_blk != col_blk || cj > ri)) hit = dev_iou(rb, cb) > thresh;
+        unsigned long long word = __ballot(hit);
+        if (lane == 0) mask[(int64_t)ri * col_blocks + col_blk] = word;
+    }
+}
+
+__global__ void oks_matrix_kernel(const double* __restrict__ kpts, const double* __restrict__ areas,
+                                  const double* __restrict__ sigmas, int n, int K, double* __restrict__ ious) {
+    int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const double* g = kpts + (int64_t)i * K * 3;
+    const double* d = kpts + (int64_t)j * K * 3;
+    const double eps = 2.220446049250313e-16;             // np.spacing(1)
+    double s = 0.0;
+    for (int k = 0; k < K; ++k) {
+        double var = (sigmas[k] * 2) * (sigmas[k] * 2);
+        double dx = d[3 * k] - g[3 * k], dy = d[3 * k + 1] - g[3 * k + 1];
+        double e = (dx * dx + dy * dy) / var / ((areas[i] + areas[j]) / 2 + eps) / 2;
+        s += exp(-e);
+    }
+    ious[(int64_t)i * n + j] = K ? s / K : 0.0;
+}
+
+}  // namespace
+
+extern "C" int advmix_nms_mask(const float* boxes_dev, int n, float thresh, uint64_t* mask_dev, void* stream) {
+    if (!boxes_dev || !mask_dev || n <= 0) return ADVMIX_EINVAL;
+    int cb = (n + 63) / 64;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb), dim3(256), 0, (hipStream_t)stream, n, thresh, boxes_dev,
+                       (unsigned long long*)mask_dev);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_nms_host(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+                               float nms_overlap_thresh, int device_id) {
+    if (!keep_out || !num_out) return ADVMIX_EINVAL;
+    if (boxes_num == 0) { *num_out = 0; return ADVMIX_OK; }
+    if (!boxes_host || boxes_num < 0 || boxes_dim != 5) return ADVMIX_EINVAL;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return ADVMIX_ELAUNCH;
+    if (cur != device_id && hipSetDevice(device_id) != hipSuccess) return ADVMIX_ELAUNCH;
+    const int cb = (boxes_num + 63) / 64;
+    float* bd = nullptr;
+    unsigned long long* md = nullptr;
+    int rc = ADVMIX_OK;
+    std::vector<unsigned long long> mh((size_t)boxes_num * cb), remv(cb, 0ULL);
+    if (hipMalloc(&bd, sizeof(float) * 5 * boxes_num) != hipSuccess) return ADVMIX_ELAUNCH;
+    if (hipMalloc(&md, sizeof(unsigned long long) * (size_t)boxes_num * cb) != hipSuccess) { (void)hipFree(bd); return ADVMIX_ELAUNCH; }
+    if (hipMemcpy(bd, boxes_host, sizeof(float) * 5 * boxes_num, hipMemcpyHostToDevice) != hipSuccess) rc = ADVMIX_ELAUNCH;
+    if (rc == ADVMIX_OK) rc = advmix_nms_mask(bd, boxes_num, nms_overlap_thresh, (uint64_t*)md, nullptr);
+    if (rc == ADVMIX_OK &&
+        hipMemcpy(mh.data(), md, sizeof(unsigned long long) * mh.size(), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = ADVMIX_ELAUNCH;
+    (void)hipFree(bd);
+    (void)hipFree(md);
+    if (rc != ADVMIX_OK) return rc;
+    int k = 0;
+    for (int i = 0; i < boxes_num; ++i) {
+        int nb = i / 64, ib = i % 64;
+        if (!(remv[nb] & (1ULL << ib))) {
+            keep_out[k++] = i;
+            const unsigned long long* p = mh.data() + (size_t)i * cb;
+            for (int j = nb; j < cb; ++j) remv[j] |= p[j];
+        }
+    }
+    *num_out = k;
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_oks_matrix(const double* kpts, const double* areas, const double* sigmas, int n, int K,
+                                 double* ious, void* stream) {
+    if (!kpts || !areas || !sigmas || !ious || n <= 0 || K <= 0) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(oks_matrix_kernel, dim3(cdiv(n, 64), n), dim3(64), 0, (hipStream_t)stream, kpts, areas, sigmas,
+                       n, K, ious);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}

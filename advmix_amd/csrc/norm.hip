@@ -1,0 +1,354 @@
+// BatchNorm2d (train / eval) and InstanceNorm2d(affine=False) on NHWC fp32, forward + backward.
+// HBM-bound: each kernel streams rows with 16-byte lanes; per-channel statistics are reduced
+// block-partials (fp32, short runs) -> fp64 finalize, so results are deterministic (no atomics)
+// and E[x^2]-E[x]^2 is formed in double.
+//
+// groups = 1  : BatchNorm over all rows      (lib/models/pose_hrnet.py:34 and every nn.BatchNorm2d)
+// groups = N  : InstanceNorm per image       (lib/models/Unet_generator.py:19,43,45)
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_PARTIAL_BLOCKS = 1024;
+
+struct RowSplit { int nbg; int64_t rows_per_block; };
+
+static RowSplit split_rows(int groups, int64_t Mg) {
+    int cap = MAX_PARTIAL_BLOCKS / groups;
+    if (cap < 1) cap = 1;
+    int64_t nb = (Mg + 63) / 64;
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    RowSplit s;
+    s.rows_per_block = (Mg + nb - 1) / nb;
+    s.nbg = (int)((Mg + s.rows_per_block - 1) / s.rows_per_block);
+    return s;
+}
+
+// KIND 0: (x, x^2)     KIND 1: (g, g*xhat) with g = dy*act'(y)
+template <int KIND>
+__device__ __forceinline__ void accum4(f32x4& s0, f32x4& s1, const float* x, const float* dy, const float* y,
+                                       int64_t row, int ldy, int C, int c, const f32x4& mu, const f32x4& is,
+                                       int act) {
+    f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * C + c);
+    if (KIND == 0) {
+        s0 += xv;
+        s1 += xv * xv;
+    } else {
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + row * ldy + c);
+        if (act != ADVMIX_ACT_NONE) {
+            f32x4 yv = *reinterpret_cast<const f32x4*>(y + row * ldy + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] *= act_grad(yv[e], act);
+        }
+        s0 += g;
+        s1 += g * ((xv - mu) * is);
+    }
+}
+
+// partial[g][blk][2][C]
+template <int KIND>
+__global__ __launch_bounds__(256) void norm_partial(const float* __restrict__ x, const float* __restrict__ dy,
+                                                    const float* __restrict__ y, int ldy,
+                                                    const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd, float* __restrict__ partial,
+                                                    int64_t Mg, int C, int64_t rows_per_block, int act) {
+    __shared__ f32x4 red[2][256];
+    const int g = blockIdx.y, blk = blockIdx.x, nbg = gridDim.x;
+    const int64_t r0 = (int64_t)g * Mg + blk * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    const int64_t gend = (int64_t)(g + 1) * Mg;
+    if (r1 > gend) r1 = gend;
+    const int CV = C >> 2;
+    float* out = partial + ((int64_t)g * nbg + blk) * 2 * C;
+    const int tid = threadIdx.x;
+    if (CV >= 256) {
+        for (int cv = tid; cv < CV; cv += 256) {
+            f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+            if (KIND == 1) {
+                mu = *reinterpret_cast<const f32x4*>(mean + (int64_t)g * C + cv * 4);
+                is = *reinterpret_cast<const f32x4*>(invstd + (int64_t)g * C + cv * 4);
+            }
+            for (int64_t r = r0; r < r1; ++r) accum4<KIND>(s0, s1, x, dy, y, r, ldy, C, cv * 4, mu, is, act);
+            *reinterpret_cast<f32x4*>(out + cv * 4) = s0;
+            *reinterpret_cast<f32x4*>(out + C + cv * 4) = s1;
+        }
+        return;
+    }
+    const int RP = 256 / CV;
+    const int rr = tid / CV, cv = tid - rr * CV;
+    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    if (rr < RP) {
+        f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+        if (KIND == 1) {
+            mu = *reinterpret_cast<const f32x4*>(mean + (int64_t)g * C + cv * 4);
+            is = *reinterpret_cast<const f32x4*>(invstd + (int64_t)g * C + cv * 4);
+        }
+        for (int64_t r = r0 + rr; r < r1; r += RP) accum4<KIND>(s0, s1, x, dy, y, r, ldy, C, cv * 4, mu, is, act);
+    }
+    red[0][tid] = s0;
+    red[1][tid] = s1;
+    __syncthreads();
+    // tree over the RP row-lanes that share a column vector
+    for (int step = 1; step < RP; step <<= 1) {
+        if (rr < RP && (rr % (2 * step)) == 0 && rr + step < RP) {
+            red[0][tid] += red[0][tid + step * CV];
+            red[1][tid] += red[1][tid + step * CV];
+        }
+        __syncthreads();
+    }
+    if (rr == 0) {
+        *reinterpret_cast<f32x4*>(out + cv * 4) = red[0][tid];
+        *reinterpret_cast<f32x4*>(out + C + cv * 4) = red[1][tid];
+    }
+}
+
+// scalar fallback for C % 4 != 0 (one thread per channel, serial rows; tiny shapes only)
+template <int KIND>
+__global__ void norm_partial_scalar(const float* __restrict__ x, const float* __restrict__ dy,
+                                    const float* __restrict__ y, int ldy, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, float* __restrict__ partial, int64_t Mg,
+                                    int C, int64_t rows_per_block, int act) {
+    const int g = blockIdx.y, blk = blockIdx.x, nbg = gridDim.x;
+    const int64_t r0 = (int64_t)g * Mg + blk * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    const int64_t gend = (int64_t)(g + 1) * Mg;
+    if (r1 > gend) r1 = gend;
+    float* out = partial + ((int64_t)g * nbg + blk) * 2 * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s0 = 0.f, s1 = 0.f;
+        float mu = KIND ? mean[(int64_t)g * C + c] : 0.f, is = KIND ? invstd[(int64_t)g * C + c] : 0.f;
+        for (int64_t r = r0; r < r1; ++r) {
+            float xv = x[r * C + c];
+            if (KIND == 0) { s0 += xv; s1 += xv * xv; }
+            else {
+                float gg = dy[r * ldy + c] * act_grad(act != ADVMIX_ACT_NONE ? y[r * ldy + c] : 1.f, act);
+                s0 += gg; s1 += gg * ((xv - mu) * is);
+            }
+        }
+        out[c] = s0;
+        out[C + c] = s1;
+    }
+}
+
+__global__ void norm_finalize_fwd(const float* __restrict__ partial, int nbg, int groups, int64_t Mg, int C,
+                                  float eps, float* __restrict__ mean, float* __restrict__ invstd,
+                                  float* running_mean, float* running_var, int64_t* nbt, float momentum) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && nbt) *nbt += 1;
+    if (i >= groups * C) return;
+    int g = i / C, c = i - g * C;
+    double s = 0, ss = 0;
+    for (int b = 0; b < nbg; ++b) {
+        const float* pp = partial + ((int64_t)g * nbg + b) * 2 * C;
+        s += (double)pp[c];
+        ss += (double)pp[C + c];
+    }
+    double m = s / (double)Mg;
+    double var = ss / (double)Mg - m * m;
+    if (var < 0) var = 0;
+    mean[i] = (float)m;
+    invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {   // groups == 1
+        double unb = Mg > 1 ? var * (double)Mg / (double)(Mg - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + (double)momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + (double)momentum * unb);
+    }
+}
+
+// coef[g][0][C] = mean(g), coef[g][1][C] = mean(g*xhat); dgamma/dbeta += (groups == 1)
+__global__ void norm_finalize_bwd(const float* __restrict__ partial, int nbg, int groups, int64_t Mg, int C,
+                                  float* __restrict__ coef, float* dgamma, float* dbeta) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * C) return;
+    int g = i / C, c = i - g * C;
+    double s = 0, ss = 0;
+    for (int b = 0; b < nbg; ++b) {
+        const float* pp = partial + ((int64_t)g * nbg + b) * 2 * C;
+        s += (double)pp[c];
+        ss += (double)pp[C + c];
+    }
+    coef[((int64_t)g * 2) * C + c] = (float)(s / (double)Mg);
+    coef[((int64_t)g * 2 + 1) * C + c] = (float)(ss / (double)Mg);
+    if (dbeta) dbeta[c] += (float)s;
+    if (dgamma) dgamma[c] += (float)ss;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         const float* __restrict__ res, float* __restrict__ y,
+                                                         int ldy, int64_t Mg, int64_t rows, int C, int act) {
+    constexpr int V = VEC ? 4 : 1;
+    const int CV = C / V;
+    const int64_t total = rows * CV;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i / CV;
+        int c = (int)(i - r * CV) * V;
+        int64_t gc = (r / Mg) * C + c;
+        if (VEC) {
+            f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * C + c);
+            f32x4 mu = *reinterpret_cast<const f32x4*>(mean + gc);
+            f32x4 is = *reinterpret_cast<const f32x4*>(invstd + gc);
+            f32x4 o = (xv - mu) * is;
+            if (gamma) o = o * *reinterpret_cast<const f32x4*>(gamma + c) + *reinterpret_cast<const f32x4*>(beta + c);
+            if (res) o += *reinterpret_cast<const f32x4*>(res + r * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = act_fwd(o[e], act);
+            *reinterpret_cast<f32x4*>(y + r * ldy + c) = o;
+        } else {
+            float o = (x[r * C + c] - mean[gc]) * invstd[gc];
+            if (gamma) o = o * gamma[c] + beta[c];
+            if (res) o += res[r * C + c];
+            y[r * ldy + c] = act_fwd(o, act);
+        }
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_eval_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ rm,
+                                                      const float* __restrict__ rv, float eps,
+                                                      const float* __restrict__ res, float* __restrict__ y,
+                                                      int64_t rows, int C, int act) {
+    constexpr int V = VEC ? 4 : 1;
+    const int CV = C / V;
+    const int64_t total = rows * CV;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i / CV;
+        int c = (int)(i - r * CV) * V;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float is = 1.0f / sqrtf(rv[c + e] + eps);
+            float o = (x[r * C + c + e] - rm[c + e]) * is * gamma[c + e] + beta[c + e];
+            if (res) o += res[r * C + c + e];
+            y[r * C + c + e] = act_fwd(o, act);
+        }
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void norm_bwd_apply(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      int ldy, const float* __restrict__ x,
+                                                      const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ coef, float* __restrict__ dx,
+                                                      float* __restrict__ dres, int64_t Mg, int64_t rows, int C,
+                                                      int act) {
+    constexpr int V = VEC ? 4 : 1;
+    const int CV = C / V;
+    const int64_t total = rows * CV;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i / CV;
+        int c = (int)(i - r * CV) * V;
+        int64_t g = r / Mg;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            int cc = c + e;
+            float gg = dy[r * ldy + cc];
+            if (act != ADVMIX_ACT_NONE) gg *= act_grad(y[r * ldy + cc], act);
+            float is = invstd[g * C + cc];
+            float xh = (x[r * C + cc] - mean[g * C + cc]) * is;
+            float k = gamma ? gamma[cc] * is : is;
+            dx[r * C + cc] = k * (gg - coef[(g * 2) * C + cc] - xh * coef[(g * 2 + 1) * C + cc]);
+            if (dres) dres[r * C + cc] = gg;
+        }
+    }
+}
+
+static int stream_blocks(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int64_t advmix_norm_ws_bytes(int groups, int C) {
+    return ((int64_t)MAX_PARTIAL_BLOCKS * 2 * C + (int64_t)2 * groups * C) * (int64_t)sizeof(float);
+}
+
+extern "C" int advmix_norm_stats(const float* x, int groups, int64_t Mg, int C, float eps, float* mean,
+                                 float* invstd, float* running_mean, float* running_var, int64_t* nbt,
+                                 float momentum, void* ws, void* stream) {
+    if (!x || !mean || !invstd || !ws || groups <= 0 || Mg <= 0 || C <= 0) return ADVMIX_EINVAL;
+    if (running_mean && groups != 1) return ADVMIX_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    RowSplit sp = split_rows(groups, Mg);
+    float* partial = (float*)ws;
+    dim3 g(sp.nbg, groups);
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((norm_partial<0>), g, dim3(256), 0, st, x, nullptr, nullptr, 0, nullptr, nullptr, partial,
+                           Mg, C, sp.rows_per_block, 0);
+    else
+        hipLaunchKernelGGL((norm_partial_scalar<0>), g, dim3(256), 0, st, x, nullptr, nullptr, 0, nullptr, nullptr,
+                           partial, Mg, C, sp.rows_per_block, 0);
+    hipLaunchKernelGGL(norm_finalize_fwd, dim3(cdiv((int64_t)groups * C, 256)), dim3(256), 0, st, partial, sp.nbg,
+                       groups, Mg, C, eps, mean, invstd, running_mean, running_var, nbt, momentum);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_norm_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
+                                 const float* beta, const float* residual, float* y, int ldy, int groups,
+                                 int64_t Mg, int C, int act, void* stream) {
+    if (!x || !mean || !invstd || !y || ldy < C || (gamma && !beta)) return ADVMIX_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t rows = (int64_t)groups * Mg;
+    if (C % 4 == 0 && ldy % 4 == 0)
+        hipLaunchKernelGGL((norm_apply_kernel<true>), dim3(stream_blocks(rows * (C / 4))), dim3(256), 0, st, x, mean,
+                           invstd, gamma, beta, residual, y, ldy, Mg, rows, C, act);
+    else
+        hipLaunchKernelGGL((norm_apply_kernel<false>), dim3(stream_blocks(rows * C)), dim3(256), 0, st, x, mean,
+                           invstd, gamma, beta, residual, y, ldy, Mg, rows, C, act);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_bn_eval(const float* x, const float* gamma, const float* beta, const float* rm,
+                              const float* rv, float eps, const float* residual, float* y, int64_t rows, int C,
+                              int act, void* stream) {
+    if (!x || !gamma || !beta || !rm || !rv || !y) return ADVMIX_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((bn_eval_kernel<true>), dim3(stream_blocks(rows * (C / 4))), dim3(256), 0, st, x, gamma,
+                           beta, rm, rv, eps, residual, y, rows, C, act);
+    else
+        hipLaunchKernelGGL((bn_eval_kernel<false>), dim3(stream_blocks(rows * C)), dim3(256), 0, st, x, gamma, beta,
+                           rm, rv, eps, residual, y, rows, C, act);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_norm_bwd(const float* dy, const float* y, int ldy, const float* x, const float* mean,
+                               const float* invstd, const float* gamma, float* dx, float* dres, float* dgamma,
+                               float* dbeta, int groups, int64_t Mg, int C, int act, void* ws, void* stream) {
+    if (!dy || !x || !mean || !invstd || !dx || !ws || ldy < C) return ADVMIX_EINVAL;
+    if (act != ADVMIX_ACT_NONE && !y) return ADVMIX_EINVAL;
+    if ((dgamma || dbeta) && groups != 1) return ADVMIX_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    RowSplit sp = split_rows(groups, Mg);
+    float* partial = (float*)ws;
+    float* coef = partial + (int64_t)MAX_PARTIAL_BLOCKS * 2 * C;
+    dim3 g(sp.nbg, groups);
+    const bool vec = (C % 4 == 0) && (ldy % 4 == 0);
+    if (vec)
+        hipLaunchKernelGGL((norm_partial<1>), g, dim3(256), 0, st, x, dy, y, ldy, mean, invstd, partial, Mg, C,
+                           sp.rows_per_block, act);
+    else
+        hipLaunchKernelGGL((norm_partial_scalar<1>), g, dim3(256), 0, st, x, dy, y, ldy, mean, invstd, partial, Mg, C,
+                           sp.rows_per_block, act);
+    hipLaunchKernelGGL(norm_finalize_bwd, dim3(cdiv((int64_t)groups * C, 256)), dim3(256), 0, st, partial, sp.nbg,
+                       groups, Mg, C, coef, dgamma, dbeta);
+    int64_t rows = (int64_t)groups * Mg;
+    if (vec)
+        hipLaunchKernelGGL((norm_bwd_apply<true>), dim3(stream_blocks(rows * (C / 4))), dim3(256), 0, st, dy, y, ldy,
+                           x, mean, invstd, gamma, coef, dx, dres, Mg, rows, C, act);
+    else
+        hipLaunchKernelGGL((norm_bwd_apply<false>), dim3(stream_blocks(rows * C)), dim3(256), 0, st, dy, y, ldy, x,
+                           mean, invstd, gamma, coef, dx, dres, Mg, rows, C, act);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}

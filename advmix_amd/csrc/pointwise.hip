@@ -1,0 +1,300 @@
+// HBM-bound pointwise / data-movement kernels on NHWC fp32: activations, channel-slice copies
+// (cat), HRNet's nearest-upsample fuse sum, 3x3/s2 max-pool, axpy/fill.
+// Reference sites: pose_hrnet.py:35,54-55,206,254-265; pose_resnet.py:115;
+// Unet_generator.py:42,44,83.
+#include "common.h"
+
+namespace {
+
+static int stream_blocks(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void act_copy_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                       int ldy, int64_t rows, int C, int act) {
+    constexpr int V = VEC ? 4 : 1;
+    const int CV = C / V;
+    const int64_t total = rows * CV;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i / CV;
+        int c = (int)(i - r * CV) * V;
+        if (VEC) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], act);
+            *reinterpret_cast<f32x4*>(y + r * ldy + c) = v;
+        } else {
+            y[r * ldy + c] = act_fwd(x[r * ldx + c], act);
+        }
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, int lddy,
+                                                      const float* __restrict__ y, int ldy, float* __restrict__ dx,
+                                                      int lddx, int64_t rows, int C, int act) {
+    constexpr int V = VEC ? 4 : 1;
+    const int CV = C / V;
+    const int64_t total = rows * CV;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i / CV;
+        int c = (int)(i - r * CV) * V;
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+            dx[r * lddx + c + e] = dy[r * lddy + c + e] * act_grad(y[r * ldy + c + e], act);
+    }
+}
+
+struct FuseArgs {
+    const float* in[4];
+    float* din[4];
+    int shift[4];
+    int n;
+};
+
+// y = act(sum_j in_j[n, h>>s_j, w>>s_j, c])
+__global__ __launch_bounds__(256) void fuse_sum_kernel(FuseArgs a, float* __restrict__ y, int N, int H, int W,
+                                                       int CV, int act) {
+    const int64_t total = (int64_t)N * H * W * CV;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int cv = (int)(i % CV);
+        int64_t pix = i / CV;
+        int w = (int)(pix % W);
+        int64_t q = pix / W;
+        int h = (int)(q % H);
+        int n = (int)(q / H);
+        f32x4 s = {0, 0, 0, 0};
+        for (int j = 0; j < a.n; ++j) {
+            int sh = a.shift[j];
+            int64_t off = (((int64_t)n * (H >> sh) + (h >> sh)) * (W >> sh) + (w >> sh)) * CV + cv;
+            s += reinterpret_cast<const f32x4*>(a.in[j])[off];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = act_fwd(s[e], act);
+        reinterpret_cast<f32x4*>(y)[i] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void mask_grad_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                        float* __restrict__ g, int64_t n4, int act) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 d = reinterpret_cast<const f32x4*>(dy)[i];
+        f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] *= act_grad(yv[e], act);
+        reinterpret_cast<f32x4*>(g)[i] = d;
+    }
+}
+
+// din[n, hs, ws, c] = sum over the f x f block of g (f = 1 << shift); g is at full resolution
+__global__ __launch_bounds__(256) void pool_sum_kernel(const float* __restrict__ g, float* __restrict__ din, int N,
+                                                       int H, int W, int CV, int shift) {
+    const int Hs = H >> shift, Ws = W >> shift, f = 1 << shift;
+    const int64_t total = (int64_t)N * Hs * Ws * CV;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int cv = (int)(i % CV);
+        int64_t pix = i / CV;
+        int ws = (int)(pix % Ws);
+        int64_t q = pix / Ws;
+        int hs = (int)(q % Hs);
+        int n = (int)(q / Hs);
+        f32x4 s = {0, 0, 0, 0};
+        for (int dh = 0; dh < f; ++dh)
+            for (int dw = 0; dw < f; ++dw) {
+                int64_t off = (((int64_t)n * H + (hs * f + dh)) * W + (ws * f + dw)) * CV + cv;
+                s += reinterpret_cast<const f32x4*>(g)[off];
+            }
+        reinterpret_cast<f32x4*>(din)[i] = s;
+    }
+}
+
+// 3x3 stride-2 pad-1 max pool; idx = first maximum in (kh, kw) scan order (torch semantics)
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      uint8_t* __restrict__ idx, int N, int H, int W, int C, int Ho,
+                                                      int Wo) {
+    const int64_t total = (int64_t)N * Ho * Wo * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        int64_t pix = i / C;
+        int wo = (int)(pix % Wo);
+        int64_t q = pix / Wo;
+        int ho = (int)(q % Ho);
+        int n = (int)(q / Ho);
+        float best = -INFINITY;
+        int bi = 0;
+        bool first = true;
+        for (int kh = 0; kh < 3; ++kh) {
+            int h = ho * 2 - 1 + kh;
+            if ((unsigned)h >= (unsigned)H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                int w = wo * 2 - 1 + kw;
+                if ((unsigned)w >= (unsigned)W) continue;
+                float v = x[(((int64_t)n * H + h) * W + w) * C + c];
+                if (first || v > best || v != v) { best = v; bi = kh * 3 + kw; first = false; }
+            }
+        }
+        y[i] = best;
+        idx[i] = (uint8_t)bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                          float* __restrict__ dx, int N, int H, int W, int C, int Ho,
+                                                          int Wo) {
+    const int64_t total = (int64_t)N * H * W * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        int64_t pix = i / C;
+        int w = (int)(pix % W);
+        int64_t q = pix / W;
+        int h = (int)(q % H);
+        int n = (int)(q / H);
+        float s = 0.f;
+        // windows (ho, kh) with ho*2 - 1 + kh == h
+        for (int kh = 0; kh < 3; ++kh) {
+            int t = h + 1 - kh;
+            if (t < 0 || (t & 1)) continue;
+            int ho = t >> 1;
+            if (ho >= Ho) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                int u = w + 1 - kw;
+                if (u < 0 || (u & 1)) continue;
+                int wo = u >> 1;
+                if (wo >= Wo) continue;
+                int64_t o = (((int64_t)n * Ho + ho) * Wo + wo) * C + c;
+                if (idx[o] == kh * 3 + kw) s += dy[o];
+            }
+        }
+        dx[i] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ a, const float* __restrict__ b, float alpha,
+                                                   int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        a[i] += alpha * b[i];
+}
+
+__global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                        const float* __restrict__ s_dev, float s_host, int64_t n) {
+    const float s = (s_dev ? *s_dev : 1.0f) * s_host;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = x[i] * s;
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, float v, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+
+}  // namespace
+
+extern "C" int advmix_act_copy(const float* x, int ldx, float* y, int ldy, int64_t rows, int C, int act,
+                               void* stream) {
+    if (!x || !y || rows <= 0 || C <= 0 || ldx < C || ldy < C) return ADVMIX_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL((act_copy_kernel<true>), dim3(stream_blocks(rows * (C / 4))), dim3(256), 0, st, x, ldx, y,
+                           ldy, rows, C, act);
+    else
+        hipLaunchKernelGGL((act_copy_kernel<false>), dim3(stream_blocks(rows * C)), dim3(256), 0, st, x, ldx, y, ldy,
+                           rows, C, act);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_act_bwd(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx,
+                              int64_t rows, int C, int act, void* stream) {
+    if (!dy || !y || !dx || rows <= 0 || C <= 0) return ADVMIX_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    bool vec = (C % 4 == 0);
+    if (vec)
+        hipLaunchKernelGGL((act_bwd_kernel<true>), dim3(stream_blocks(rows * (C / 4))), dim3(256), 0, st, dy, lddy, y,
+                           ldy, dx, lddx, rows, C, act);
+    else
+        hipLaunchKernelGGL((act_bwd_kernel<false>), dim3(stream_blocks(rows * C)), dim3(256), 0, st, dy, lddy, y, ldy,
+                           dx, lddx, rows, C, act);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_fuse_sum(const float* const* ins, const int* shifts, int n_in, float* y, int N, int H, int W,
+                               int C, int act, void* stream) {
+    if (!ins || !shifts || !y || n_in < 1 || n_in > 4 || C % 4 != 0) return ADVMIX_EINVAL;
+    FuseArgs a{};
+    a.n = n_in;
+    for (int j = 0; j < n_in; ++j) {
+        if (!ins[j] || shifts[j] < 0 || (H % (1 << shifts[j])) || (W % (1 << shifts[j]))) return ADVMIX_EINVAL;
+        a.in[j] = ins[j];
+        a.shift[j] = shifts[j];
+    }
+    int64_t total = (int64_t)N * H * W * (C / 4);
+    hipLaunchKernelGGL(fuse_sum_kernel, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, a, y, N, H, W,
+                       C / 4, act);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_fuse_sum_bwd(const float* dy, const float* y, float* g_out, float* const* dins,
+                                   const int* shifts, int n_in, int N, int H, int W, int C, int act, void* stream) {
+    if (!dy || !y || !g_out || !dins || !shifts || n_in < 1 || n_in > 4 || C % 4 != 0) return ADVMIX_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t n4 = (int64_t)N * H * W * (C / 4);
+    hipLaunchKernelGGL(mask_grad_kernel, dim3(stream_blocks(n4)), dim3(256), 0, st, dy, y, g_out, n4, act);
+    for (int j = 0; j < n_in; ++j) {
+        if (shifts[j] == 0 || !dins[j]) continue;
+        int64_t t = n4 >> (2 * shifts[j]);
+        hipLaunchKernelGGL(pool_sum_kernel, dim3(stream_blocks(t)), dim3(256), 0, st, g_out, dins[j], N, H, W, C / 4,
+                           shifts[j]);
+    }
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_maxpool3x3s2(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, int Ho,
+                                   int Wo, void* stream) {
+    if (!x || !y || !idx || Ho != (H + 2 - 3) / 2 + 1 || Wo != (W + 2 - 3) / 2 + 1) return ADVMIX_EINVAL;
+    int64_t total = (int64_t)N * Ho * Wo * C;
+    hipLaunchKernelGGL(maxpool_kernel, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, idx, N, H,
+                       W, C, Ho, Wo);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C,
+                                       int Ho, int Wo, void* stream) {
+    if (!dy || !idx || !dx) return ADVMIX_EINVAL;
+    int64_t total = (int64_t)N * H * W * C;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx,
+                       N, H, W, C, Ho, Wo);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_axpy(float* a, const float* b, float alpha, int64_t n, void* stream) {
+    if (!a || !b || n < 0) return ADVMIX_EINVAL;
+    if (n == 0) return ADVMIX_OK;
+    hipLaunchKernelGGL(axpy_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, n);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_fill(float* p, float value, int64_t n, void* stream) {
+    if (!p || n < 0) return ADVMIX_EINVAL;
+    if (n == 0) return ADVMIX_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, value, n);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_scale_dev(float* y, const float* x, const float* s_dev, float s_host, int64_t n, void* stream) {
+    if (!y || !x || n < 0) return ADVMIX_EINVAL;
+    if (n == 0) return ADVMIX_OK;
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, y, x, s_dev, s_host,
+                       n);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}

@@ -1,0 +1,166 @@
+/* advmix_hip.h — C ABI of libadvmix_hip.so: the MI355X (gfx950) kernels behind the
+ * AdvMix training step and the lib/nms post-process.
+ *
+ * Conventions
+ *   - every entry point returns int: 0 ok, ADVMIX_EINVAL bad argument/unsupported
+ *     shape, ADVMIX_ELAUNCH HIP launch/runtime error.  Nothing throws.
+ *   - all tensor pointers are DEVICE pointers unless the name ends in _host.
+ *   - activations are dense NHWC fp32 ("channels-last"); a row is one pixel.
+ *   - no hidden allocation, no implicit synchronisation: work is enqueued on
+ *     `stream` (a hipStream_t passed as void*) and returns at once, so every call
+ *     is legal inside hipStreamBeginCapture/EndCapture (HIP graphs).
+ *     The *_host NMS entry points are the exception (they mirror the reference's
+ *     synchronous `_nms`).
+ *   - weights: conv  [Cout][R][S][Cin]  (= torch OIHW tensor in channels_last memory)
+ *              deconv[Cin][R][S][Cout]  (= torch IOHW tensor in channels_last memory)
+ *
+ * The reference has no op-level native ABI of its own (torch -> cuDNN/ATen is its
+ * "FFI"); each group below cites the reference call site(s) it replaces.  The one
+ * native symbol the reference does export, `_nms` (lib/nms/gpu_nms.hpp:1-2), is
+ * reproduced as advmix_nms_host with the same argument list.
+ */
+#ifndef ADVMIX_HIP_H
+#define ADVMIX_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADVMIX_OK 0
+#define ADVMIX_EINVAL 1
+#define ADVMIX_ELAUNCH 2
+
+#define ADVMIX_ACT_NONE 0
+#define ADVMIX_ACT_RELU 1
+#define ADVMIX_ACT_LEAKY02 2   /* LeakyReLU(0.2), lib/models/Unet_generator.py:42 */
+
+int advmix_version(void);
+
+/* ---- convolution family: replaces nn.Conv2d / nn.ConvTranspose2d forward+backward
+ * (lib/models/pose_hrnet.py:22-25,65-71,200-232,323-349,411-417;
+ *  lib/models/pose_resnet.py:22-27,111-112,140-141,179-186;
+ *  lib/models/Unet_generator.py:40-41,48-50,58-60,66-68).  fp32 MFMA implicit GEMM. */
+
+/* y[N,Ho,Wo,Co] = conv(x[N,Hi,Wi,Ci], w[Co][R][S][Ci]) (+bias[Co]); Ho = (Hi+2p-R)/s+1.
+ * Also the input-gradient of a ConvTranspose2d. */
+int advmix_conv_fwd(const float* x, const float* w, const float* bias, float* y,
+                    int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
+                    int R, int S, int stride, int pad, void* stream);
+
+/* "transposed gather": y[N,Hb,Wb,Cn] = sum_{r,s,c} x[N,(h+p-r)/s,(w+p-s)/s,c] * wt[Cn][R][S][Ck]
+ * for the taps where the division is exact and in range (phase-decomposed: no zero work).
+ * Conv2d input-gradient (x = dY, wt = transposed weight [Ci][R][S][Co]) and
+ * ConvTranspose2d forward (wt = [Cout][R][S][Cin], + bias). x is [N,Hs,Ws,Ck]. */
+int advmix_conv_tr(const float* x, const float* wt, const float* bias, float* y,
+                   int N, int Hs, int Ws, int Ck, int Hb, int Wb, int Cn,
+                   int R, int S, int stride, int pad, void* stream);
+
+/* dw[Ca][R][S][Cb] += sum_p a[p, Ca] * b[gather(p,r,s), Cb]   (fp32 atomics, split over pixels)
+ * a: [N,Ha,Wa,Ca] at the conv's OUTPUT resolution, b: [N,Hb,Wb,Cb] at its INPUT resolution.
+ * Conv2d: a = dY, b = X.   ConvTranspose2d: a = X, b = dY (gives [Cin][R][S][Cout]). */
+int advmix_conv_wgrad(const float* a, const float* b, float* dw,
+                      int N, int Ha, int Wa, int Ca, int Hb, int Wb, int Cb,
+                      int R, int S, int stride, int pad, void* stream);
+
+/* out[B][T][A] = in[A][T][B]  (weight re-layout for advmix_conv_tr) */
+int advmix_transpose_w(const float* in, float* out, int A, int T, int B, void* stream);
+
+/* db[c] += sum over rows of dy[rows, C] */
+int advmix_bias_grad(const float* dy, float* db, int64_t rows, int C, void* stream);
+
+/* ---- normalisation: replaces nn.BatchNorm2d (train / eval, pose_hrnet.py:34 etc.) and
+ * nn.InstanceNorm2d(affine=False) (Unet_generator.py:19,43,45).  groups = 1 -> BatchNorm
+ * over all N*H*W rows; groups = N -> InstanceNorm over H*W rows of each image.
+ * Statistics are reduced in fp64 from fp32 block partials (deterministic, no atomics).
+ * ws: workspace of advmix_norm_ws_bytes(groups, C) bytes. */
+int64_t advmix_norm_ws_bytes(int groups, int C);
+/* batch statistics -> mean[g,C], invstd[g,C]; if running_mean != NULL updates running stats
+ * (momentum, unbiased var) and increments *num_batches_tracked (int64, may be NULL). */
+int advmix_norm_stats(const float* x, int groups, int64_t rows_per_group, int C, float eps,
+                      float* mean, float* invstd, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, float momentum, void* ws, void* stream);
+/* y = act((x - mean)*invstd*gamma + beta + residual); gamma/beta/residual may be NULL.
+ * y rows have stride ldy floats (>= C) so the result can land in a channel slice. */
+int advmix_norm_apply(const float* x, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, const float* residual,
+                      float* y, int ldy, int groups, int64_t rows_per_group, int C, int act,
+                      void* stream);
+/* eval-mode BN: y = act(x*scale + shift + residual), scale/shift from running stats */
+int advmix_bn_eval(const float* x, const float* gamma, const float* beta,
+                   const float* running_mean, const float* running_var, float eps,
+                   const float* residual, float* y, int64_t rows, int C, int act, void* stream);
+/* backward of norm_apply(train): g = dy * act'(y); dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat));
+ * dgamma += sum g*xhat, dbeta += sum g (NULL to skip: frozen / affine=False);
+ * dres (NULL to skip) = g.  dy/y rows have stride ldy. */
+int advmix_norm_bwd(const float* dy, const float* y, int ldy, const float* x,
+                    const float* mean, const float* invstd, const float* gamma,
+                    float* dx, float* dres, float* dgamma, float* dbeta,
+                    int groups, int64_t rows_per_group, int C, int act, void* ws, void* stream);
+
+/* ---- pointwise / data movement (ReLU, LeakyReLU, residual add, cat, nearest-upsample fuse,
+ * max-pool): pose_hrnet.py:35,54-55,206,254-265; pose_resnet.py:115; Unet_generator.py:42,44,83 */
+/* y[r, yoff + c] = act(x[r, xoff + c]) for c < C, row strides ldx / ldy */
+int advmix_act_copy(const float* x, int ldx, float* y, int ldy, int64_t rows, int C, int act,
+                    void* stream);
+/* dx[r,c] = dy[r,c] * act'(y[r,c]) (y = saved OUTPUT of the activation) */
+int advmix_act_bwd(const float* dy, int lddy, const float* y, int ldy, float* dx, int lddx,
+                   int64_t rows, int C, int act, void* stream);
+/* y = act(sum_j up_{2^shift_j}(in_j)); in_j is [N, H>>shift_j, W>>shift_j, C]; n_in <= 4 */
+int advmix_fuse_sum(const float* const* ins_host, const int* shifts_host, int n_in, float* y,
+                    int N, int H, int W, int C, int act, void* stream);
+/* g = dy*act'(y) (written to g_out); for each j with shift_j>0: din_j = block-sum of g */
+int advmix_fuse_sum_bwd(const float* dy, const float* y, float* g_out, float* const* dins_host,
+                        const int* shifts_host, int n_in, int N, int H, int W, int C, int act,
+                        void* stream);
+int advmix_maxpool3x3s2(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C,
+                        int Ho, int Wo, void* stream);
+int advmix_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W,
+                            int C, int Ho, int Wo, void* stream);
+/* y = x * (*s_dev) * s_host  (s_dev may be NULL): scales a gradient by a device-resident scalar */
+int advmix_scale_dev(float* y, const float* x, const float* s_dev, float s_host, int64_t n, void* stream);
+/* a += alpha * b (n floats) */
+int advmix_axpy(float* a, const float* b, float alpha, int64_t n, void* stream);
+
+/* ---- AdvMix glue: lib/core/function.py:137-144 (cat + softmax-mix), lib/core/loss.py:25-65,
+ * lib/core/inference.py:22-49 (argmax), lib/utils/utils.py:89-92 (Adam) */
+/* out[N,H,W,3K] (NHWC) = cat_k views[k] (each NCHW [N,3,H,W]) */
+int advmix_cat_views(const float* v0, const float* v1, const float* v2, float* out,
+                     int N, int H, int W, void* stream);
+/* tmp[N,H,W,3] (NHWC) = sum_k softmax(logits[N,H,W,3])_k * view_k (NCHW) */
+int advmix_mix_fwd(const float* v0, const float* v1, const float* v2, const float* logits,
+                   float* tmp, int N, int H, int W, void* stream);
+/* dlogits[N,H,W,3] from dtmp[N,H,W,3] */
+int advmix_mix_bwd(const float* v0, const float* v1, const float* v2, const float* logits,
+                   const float* dtmp, float* dlogits, int N, int H, int W, void* stream);
+/* JointsMSELoss as constructed by the reference (= SmoothL1, loss.py:16-21):
+ * loss_out[0] = (0.5/(J*B*HW)) * sum smoothl1(w*(p - t)); grad (NHWC, may be NULL) = d loss/d p.
+ * pred is NHWC [B,HW,J]; target is NCHW [B,J,HW] or NHWC (target_nhwc); tw [B,J] or NULL.
+ * mse != 0 selects the plain-MSE variant (smooth_L1=True in the reference's inverted flag).
+ * loss_out must be zeroed by the caller (accumulated with one atomic per block). */
+int advmix_joints_loss(const float* pred, const float* target, int target_nhwc, const float* tw,
+                       float* loss_out, float* grad, float grad_scale, int B, int J, int HW,
+                       int mse, void* stream);
+/* first-occurrence argmax over HW per (b, j) of an NHWC (nhwc=1) or NCHW heat-map;
+ * idx_out[B*J] int32, max_out[B*J] */
+int advmix_heatmap_argmax(const float* hm, int nhwc, int32_t* idx_out, float* max_out,
+                          int B, int J, int HW, void* stream);
+/* flat Adam (no weight decay). hyper (device): [lr, beta1, beta2, eps]; step (device int64) is
+ * incremented by the kernel launch itself (graph-replay safe). */
+int advmix_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                int64_t* step, void* stream);
+int advmix_fill(float* p, float value, int64_t n, void* stream);
+
+/* ---- lib/nms: nms_kernel.cu:33-77 (bitmask) + :90-143 (host greedy) */
+/* device bitmask only: boxes_dev [n,5] sorted by score desc -> mask_dev [n, ceil(n/64)] uint64 */
+int advmix_nms_mask(const float* boxes_dev, int n, float thresh, uint64_t* mask_dev, void* stream);
+/* drop-in for `_nms` (lib/nms/gpu_nms.hpp:1-2): host buffers in/out, synchronous. */
+int advmix_nms_host(int* keep_out, int* num_out, const float* boxes_host, int boxes_num,
+                    int boxes_dim, float nms_overlap_thresh, int device_id);
+/* OKS matrix (float64, lib/nms/nms.py:75-94): ious[n,n] for kpts[n,17*3], areas[n] (device) */
+int advmix_oks_matrix(const double* kpts, const double* areas, const double* sigmas, int n, int K,
+                      double* ious, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

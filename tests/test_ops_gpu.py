@@ -1,0 +1,368 @@
+"""Per-kernel numerics on a real MI355X: every C-ABI op (through advmix_amd.ops) against a
+plain PyTorch CPU float64 reference of the same op.  Tolerance: fp32 results within
+1e-4 (abs, relative to the tensor's scale) - two orders inside the 1e-3 north-star bound."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from advmix_amd import ops
+    return ops
+
+
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return torch.device('cuda:0')
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
+
+
+def cl(t):
+    return t.float().to(dev()).contiguous(memory_format=torch.channels_last)
+
+
+def check(name, got, ref, tol=1e-4):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = max(float(ref.abs().max()), 1e-6)
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, '%s: max err %.3e vs scale %.3e (rel %.3e)' % (name, err, scale, err / scale)
+
+
+CONV_CASES = [
+    # B, Ci, H, W, Co, k, stride, pad, bias
+    (2, 32, 16, 12, 32, 3, 1, 1, False),
+    (2, 64, 9, 7, 48, 3, 2, 1, False),
+    (1, 3, 32, 24, 64, 3, 2, 1, False),
+    (2, 3, 30, 22, 64, 7, 2, 3, False),
+    (2, 256, 8, 6, 64, 1, 1, 0, False),
+    (2, 64, 8, 6, 256, 1, 1, 0, False),
+    (2, 9, 64, 64, 64, 4, 2, 1, True),
+    (2, 128, 16, 12, 17, 1, 1, 0, True),
+    (3, 8, 10, 10, 8, 3, 1, 1, False),
+    (2, 48, 12, 9, 96, 3, 2, 1, False),
+    (2, 64, 16, 12, 128, 1, 2, 0, False),
+    (4, 32, 64, 48, 32, 3, 1, 1, False),
+    (2, 256, 8, 6, 256, 3, 1, 1, False),
+    (2, 512, 6, 4, 512, 4, 2, 1, True),
+    (2, 40, 7, 5, 72, 3, 1, 1, True),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(case):
+    ops = _ops()
+    B, Ci, H, W, Co, k, s, p, hb = case
+    x = rnd(B, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, k, k, seed=2, scale=(Ci * k * k) ** -0.5)
+    b = rnd(Co, seed=3) if hb else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if hb else None
+    yr = F.conv2d(xr, wr, br, s, p)
+    dy = rnd(*yr.shape, seed=4)
+    yr.backward(dy)
+
+    xg = cl(x).requires_grad_(True)
+    wg = torch.nn.Parameter(cl(w))
+    bg = torch.nn.Parameter(b.float().to(dev())) if hb else None
+    y = ops.conv2d(xg, wg, bg, s, p)
+    check('y', y, yr)
+    y.backward(cl(dy))
+    check('dx', xg.grad, xr.grad)
+    check('dw', wg.grad, wr.grad, 2e-4)
+    if hb:
+        check('db', bg.grad, br.grad, 2e-4)
+    # accumulate semantics: a second backward doubles the parameter gradients
+    y2 = ops.conv2d(cl(x), wg, bg, s, p)
+    y2.backward(cl(dy))
+    check('dw x2', wg.grad, 2 * wr.grad, 2e-4)
+
+
+DECONV_CASES = [
+    (2, 64, 4, 3, 32, True), (2, 512, 4, 3, 512, True), (2, 128, 8, 6, 3, True),
+    (1, 16, 5, 7, 24, False), (2, 256, 16, 12, 256, False), (2, 2048, 4, 3, 256, False),
+]
+
+
+@pytest.mark.parametrize('case', DECONV_CASES)
+def test_conv_transpose2d(case):
+    ops = _ops()
+    B, Ci, H, W, Co, hb = case
+    x = rnd(B, Ci, H, W, seed=5)
+    w = rnd(Ci, Co, 4, 4, seed=6, scale=(Ci * 4) ** -0.5)
+    b = rnd(Co, seed=7) if hb else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if hb else None
+    yr = F.conv_transpose2d(xr, wr, br, 2, 1)
+    dy = rnd(*yr.shape, seed=8)
+    yr.backward(dy)
+    xg = cl(x).requires_grad_(True)
+    wg = torch.nn.Parameter(cl(w))
+    bg = torch.nn.Parameter(b.float().to(dev())) if hb else None
+    y = ops.conv_transpose2d(xg, wg, bg, 2, 1)
+    check('y', y, yr)
+    y.backward(cl(dy))
+    check('dx', xg.grad, xr.grad)
+    check('dw', wg.grad, wr.grad, 2e-4)
+    if hb:
+        check('db', bg.grad, br.grad, 2e-4)
+
+
+@pytest.mark.parametrize('case', [(4, 32, 16, 12, 1, True), (2, 64, 9, 7, 1, False), (2, 256, 8, 6, 0, True),
+                                  (2, 2048, 4, 3, 1, False), (3, 48, 5, 5, 1, True), (8, 32, 64, 48, 1, True),
+                                  (2, 6, 5, 5, 1, True)])
+def test_batch_norm_train(case):
+    ops = _ops()
+    B, C, H, W, act, has_res = case
+    x = rnd(B, C, H, W, seed=9, scale=2.0) + 0.7
+    g, bt = rnd(C, seed=10) * 0.2 + 1, rnd(C, seed=11) * 0.3
+    rm, rv = rnd(C, seed=12) * 0.1, rnd(C, seed=13).abs() + 0.5
+    res = rnd(B, C, H, W, seed=14) if has_res else None
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if has_res else None
+    rmr, rvr = rm.clone(), rv.clone()
+    yr = F.batch_norm(xr, rmr, rvr, gr, br, True, 0.1, 1e-5)
+    if has_res:
+        yr = yr + rr
+    if act:
+        yr = F.relu(yr)
+    dy = rnd(B, C, H, W, seed=15)
+    yr.backward(dy)
+
+    d = dev()
+    xg = cl(x).requires_grad_(True)
+    gg, bg = torch.nn.Parameter(g.float().to(d)), torch.nn.Parameter(bt.float().to(d))
+    rmg, rvg = rm.float().to(d), rv.float().to(d)
+    nbt = torch.zeros((), dtype=torch.int64, device=d)
+    rg = cl(res).requires_grad_(True) if has_res else None
+    y = ops.batch_norm(xg, gg, bg, rmg, rvg, nbt, rg, act, True, 0.1, 1e-5)
+    check('y', y, yr)
+    check('running_mean', rmg, rmr)
+    check('running_var', rvg, rvr)
+    assert int(nbt) == 1
+    y.backward(cl(dy))
+    check('dx', xg.grad, xr.grad, 3e-4)
+    check('dgamma', gg.grad, gr.grad, 3e-4)
+    check('dbeta', bg.grad, br.grad, 3e-4)
+    if has_res:
+        check('dres', rg.grad, rr.grad)
+    # eval mode
+    ye = ops.batch_norm(cl(x), gg, bg, rmg, rvg, nbt, cl(res) if has_res else None, act, False, 0.1, 1e-5)
+    yer = F.batch_norm(x, rmg.double().cpu(), rvg.double().cpu(), g, bt, False, 0.1, 1e-5)
+    if has_res:
+        yer = yer + res
+    if act:
+        yer = F.relu(yer)
+    check('eval', ye, yer)
+
+
+def test_batch_norm_frozen_params_input_grad_only():
+    """G-step mode: D frozen (set_require_grad False) but BN still in train mode."""
+    ops = _ops()
+    d = dev()
+    B, C, H, W = 2, 32, 8, 6
+    x = rnd(B, C, H, W, seed=21)
+    g, bt = rnd(C, seed=22) * 0.2 + 1, rnd(C, seed=23)
+    xr = x.clone().requires_grad_(True)
+    yr = F.relu(F.batch_norm(xr, None, None, g, bt, True, 0.1, 1e-5))
+    dy = rnd(B, C, H, W, seed=24)
+    yr.backward(dy)
+    xg = cl(x).requires_grad_(True)
+    gg = torch.nn.Parameter(g.float().to(d), requires_grad=False)
+    bg = torch.nn.Parameter(bt.float().to(d), requires_grad=False)
+    y = ops.batch_norm(xg, gg, bg, torch.zeros(C, device=d), torch.ones(C, device=d),
+                       torch.zeros((), dtype=torch.int64, device=d), None, 1, True)
+    y.backward(cl(dy))
+    check('dx', xg.grad, xr.grad, 3e-4)
+    assert gg.grad is None and bg.grad is None
+
+
+@pytest.mark.parametrize('case', [(2, 64, 32, 24, 2), (2, 512, 4, 3, 1), (3, 128, 16, 12, 0), (2, 8, 6, 6, 2)])
+def test_instance_norm(case):
+    ops = _ops()
+    B, C, H, W, act = case
+    x = rnd(B, C, H, W, seed=31, scale=1.5) + 0.3
+    xr = x.clone().requires_grad_(True)
+    yr = F.instance_norm(xr, eps=1e-5)
+    yr = F.relu(yr) if act == 1 else (F.leaky_relu(yr, 0.2) if act == 2 else yr)
+    dy = rnd(B, C, H, W, seed=32)
+    yr.backward(dy)
+    xg = cl(x).requires_grad_(True)
+    y = ops.instance_norm(xg, act)
+    check('y', y, yr)
+    y.backward(cl(dy))
+    check('dx', xg.grad, xr.grad, 3e-4)
+
+
+def test_act_cat_fuse_pool():
+    ops = _ops()
+    x = rnd(2, 24, 7, 5, seed=41)
+    for act, f in ((1, F.relu), (2, lambda t: F.leaky_relu(t, 0.2))):
+        xr = x.clone().requires_grad_(True)
+        yr = f(xr)
+        dy = rnd(2, 24, 7, 5, seed=42)
+        yr.backward(dy)
+        xg = cl(x).requires_grad_(True)
+        y = ops.activation(xg, act)
+        check('act', y, yr)
+        y.backward(cl(dy))
+        check('dact', xg.grad, xr.grad)
+    a, b = rnd(2, 8, 6, 4, seed=43), rnd(2, 20, 6, 4, seed=44)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.relu(torch.cat([ar, br], 1))
+    dy = rnd(2, 28, 6, 4, seed=45)
+    yr.backward(dy)
+    ag, bg = cl(a).requires_grad_(True), cl(b).requires_grad_(True)
+    y = ops.cat_act(ag, bg, 1)
+    check('cat', y, yr)
+    y.backward(cl(dy))
+    check('da', ag.grad, ar.grad)
+    check('db', bg.grad, br.grad)
+    # fuse: out = relu(x0 + up2(x1) + up4(x2) + up8(x3) + z) ; z same-res
+    B, C, H, W = 2, 32, 16, 24
+    xs = [rnd(B, C, H >> s, W >> s, seed=50 + s) for s in (0, 1, 2, 3)] + [rnd(B, C, H, W, seed=59)]
+    shifts = [0, 1, 2, 3, 0]
+    for sub in ([0, 1], [0, 1, 2, 3], [4, 0, 2], [1, 0]):
+        rs = [xs[i].clone().requires_grad_(True) for i in sub]
+        yr = 0
+        for t, i in zip(rs, sub):
+            yr = yr + (F.interpolate(t, scale_factor=2 ** shifts[i], mode='nearest') if shifts[i] else t)
+        yr = F.relu(yr)
+        dy = rnd(B, C, H, W, seed=60)
+        yr.backward(dy)
+        gs = [cl(xs[i]).requires_grad_(True) for i in sub]
+        y = ops.fuse_sum(gs, [shifts[i] for i in sub], 1)
+        check('fuse', y, yr)
+        y.backward(cl(dy))
+        for t, r in zip(gs, rs):
+            check('dfuse', t.grad, r.grad)
+    for shape in ((2, 64, 16, 12), (1, 8, 9, 7)):
+        x = rnd(*shape, seed=61)
+        xr = x.clone().requires_grad_(True)
+        yr = F.max_pool2d(xr, 3, 2, 1)
+        dy = rnd(*yr.shape, seed=62)
+        yr.backward(dy)
+        xg = cl(x).requires_grad_(True)
+        y = ops.max_pool3x3s2(xg)
+        check('pool', y, yr)
+        y.backward(cl(dy))
+        check('dpool', xg.grad, xr.grad)
+
+
+def test_mix_loss_argmax():
+    ops = _ops()
+    d = dev()
+    B, H, W = 2, 16, 12
+    views = [rnd(B, 3, H, W, seed=70 + k) for k in range(3)]
+    lg = rnd(B, 3, H, W, seed=73, scale=2.0)
+    lr = lg.clone().requires_grad_(True)
+    wts = F.softmax(lr, 1)
+    tr = sum(views[k] * wts[:, k:k + 1] for k in range(3))
+    dy = rnd(B, 3, H, W, seed=74)
+    tr.backward(dy)
+    vg = [v.float().to(d).contiguous() for v in views]
+    lgg = cl(lg).requires_grad_(True)
+    t = ops.softmax_mix(lgg, vg)
+    check('mix', t, tr)
+    t.backward(cl(dy))
+    check('dlogits', lgg.grad, lr.grad)
+    check('cat_views', ops.cat_views(vg), torch.cat(views, 1))
+
+    from oracle.loss import joints_loss as oloss
+    for (Bq, J, Hh, Ww, sc) in ((4, 17, 16, 12, 1.0), (3, 16, 8, 8, 3.0)):
+        o = rnd(Bq, J, Hh, Ww, seed=80, scale=sc)
+        tg = rnd(Bq, J, Hh, Ww, seed=81).abs()
+        tw = (rnd(Bq, J, 1, seed=82) > -0.5).double()
+        for mse in (False, True):
+            for tnhwc in (False, True):
+                orr = o.float().clone().requires_grad_(True)
+                lref = oloss(orr, tg.float(), tw.float(), True, smooth_L1=mse) * 0.7
+                lref.backward()
+                og = cl(o).requires_grad_(True)
+                tgt = cl(tg) if tnhwc else tg.float().to(d)
+                l = ops.joints_loss(og, tgt, tw.float().to(d), True, mse) * 0.7
+                assert abs(float(l) - float(lref)) <= 1e-5 * max(1.0, abs(float(lref)))
+                l.backward()
+                check('dloss', og.grad, orr.grad.double(), 1e-5)
+        l2 = ops.joints_loss(cl(o), tg.float().to(d), None, False, False)
+        assert abs(float(l2) - float(oloss(o.float(), tg.float(), tw.float(), False))) < 1e-5 * max(1, float(l2))
+    hm = rnd(3, 5, 16, 12, seed=83)
+    hm[0, 0] = 0.0                                    # all-equal map -> index 0
+    hm[1, 2, 3, 4] = hm[1, 2, 9, 9] = 50.0            # tie -> first occurrence
+    ref = hm.reshape(3, 5, -1).argmax(2)
+    for t in (cl(hm), hm.float().to(d)):
+        idx, mx = ops.heatmap_argmax(t)
+        assert torch.equal(idx.cpu().long(), torch.from_numpy(np.argmax(hm.reshape(3, 5, -1).float().numpy(), 2)))
+        check('max', mx, hm.reshape(3, 5, -1).float().max(2).values.double())
+    assert ref[1, 2] == 3 * 12 + 4
+
+
+def test_flat_adam_matches_torch():
+    import ctypes
+    from advmix_amd._lib import call
+    d = dev()
+    n = 10007
+    p0 = rnd(n, seed=90)
+    pr = torch.nn.Parameter(p0.float().clone())
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    p = p0.float().to(d)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    hyper = torch.tensor([1e-3, 0.9, 0.999, 1e-8], device=d)
+    step = torch.zeros((), dtype=torch.int64, device=d)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for it in range(5):
+        g = rnd(n, seed=91 + it, scale=10.0 ** (it - 2))
+        pr.grad = g.float().clone()
+        opt.step()
+        gg = g.float().to(d)
+        call('advmix_adam', ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(gg.data_ptr()),
+             ctypes.c_void_p(m.data_ptr()), ctypes.c_void_p(v.data_ptr()), n,
+             ctypes.c_void_p(hyper.data_ptr()), ctypes.c_void_p(step.data_ptr()), st)
+        check('adam step %d' % it, p, pr.detach().double(), 1e-6)
+    assert int(step) == 5
+
+
+def test_nms_bit_exact_vs_oracle():
+    import ctypes
+    from advmix_amd._lib import call
+    from oracle import nms as onms
+    rng = np.random.Generator(np.random.Philox(key=5))
+    for N in (1, 2, 63, 64, 65, 130, 200, 1000):
+        for th in (0.3, 0.5, 0.7):
+            c = rng.random((N, 2)) * 200
+            wh = rng.random((N, 2)) * 80 + 4
+            sc = rng.permutation(N).astype(np.float32) / N + 0.001
+            dets = np.concatenate([c, c + wh, sc[:, None]], 1).astype(np.float32)
+            keep_ref, mask_ref = onms.gpu_nms(dets, th, return_mask=True)
+            order = dets[:, 4].argsort()[::-1].astype(np.int32)
+            sd = np.ascontiguousarray(dets[order])
+            keep = np.zeros(N, np.int32)
+            num = ctypes.c_int(0)
+            call('advmix_nms_host', keep.ctypes.data_as(ctypes.c_void_p), ctypes.byref(num),
+                 sd.ctypes.data_as(ctypes.c_void_p), N, 5, ctypes.c_float(th), 0)
+            assert [int(i) for i in order[keep[:num.value]]] == keep_ref, (N, th)
+            bd = torch.from_numpy(sd).cuda()
+            md = torch.zeros(N * ((N + 63) // 64), dtype=torch.int64, device='cuda')
+            call('advmix_nms_mask', ctypes.c_void_p(bd.data_ptr()), N, ctypes.c_float(th),
+                 ctypes.c_void_p(md.data_ptr()), None)
+            torch.cuda.synchronize()
+            assert np.array_equal(md.cpu().numpy().view(np.uint64).reshape(mask_ref.shape), mask_ref), (N, th)
+    # exact-threshold edge: strict > in fp32
+    d2 = np.array([[0, 0, 9, 9, 0.9], [5, 0, 14, 9, 0.8]], np.float32)
+    th = float(np.float32(50.0) / np.float32(150.0))
+    keep = np.zeros(2, np.int32)
+    num = ctypes.c_int(0)
+    call('advmix_nms_host', keep.ctypes.data_as(ctypes.c_void_p), ctypes.byref(num),
+         d2.ctypes.data_as(ctypes.c_void_p), 2, 5, ctypes.c_float(th), 0)
+    assert list(keep[:num.value]) == [0, 1]
+    call('advmix_nms_host', keep.ctypes.data_as(ctypes.c_void_p), ctypes.byref(num),
+         d2.ctypes.data_as(ctypes.c_void_p), 0, 5, ctypes.c_float(th), 0)
+    assert num.value == 0

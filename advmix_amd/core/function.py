@@ -1,0 +1,163 @@
+"""Mirror of the training half of lib/core/function.py: ``train`` (:30-95),
+``set_require_grad`` (:98-104), ``train_advmix`` (:107-197), ``AverageMeter`` (:383-398) with
+identical signatures.  The per-batch bodies are factored into ``plain_step`` / ``advmix_step``
+so bench.py, the HIP-graph runner and the loops share one implementation.
+
+What changed underneath (MI355X-first): models run hand-written HIP kernels; the 3-view
+concat and the softmax-mix are single fused kernels; the accuracy argmax runs on the device;
+gradients of per-GPU replicas are averaged with two flat RCCL all-reduces (``dp.GradSync``)
+instead of nn.DataParallel's broadcast/scatter/gather."""
+import logging
+import os
+import time
+
+import torch
+
+from .. import ops
+from .evaluate import accuracy
+
+logger = logging.getLogger(__name__)
+
+
+def set_require_grad(nets, requires_grad=True):
+    if not isinstance(nets, list):
+        nets = [nets]
+    for net in nets:
+        if net is not None:
+            for param in net.parameters():
+                param.requires_grad = requires_grad
+
+
+def _cuda(t):
+    return t.cuda(non_blocking=True) if not t.is_cuda else t
+
+
+def plain_step(model, criterion, optimizer, input, target, target_weight, grad_sync=None):
+    """function.py:48-59: forward, loss, zero_grad, backward, step.  Returns (loss, outputs)."""
+    outputs = model(_cuda(input).float())
+    loss = criterion(outputs, target, target_weight)
+    optimizer.zero_grad()
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync.sync(optimizer)
+    optimizer.step()
+    return loss.detach(), outputs.detach()
+
+
+def advmix_step(args, model, model_G, model_teacher, criterion, optimizer, optimizer_G,
+                inputs, target, target_weight, grad_sync=None):
+    """function.py:137-164, one batch.  ``inputs``: 3 contiguous NCHW fp32 CUDA views.
+    Returns (loss_D, output) with output = D(tmp) after the D update (the tensor the reference
+    feeds to ``accuracy``)."""
+    G_input = ops.cat_views(inputs)                                       # :137
+    logits = model_G(G_input)                                             # :138 (softmax fused below)
+
+    set_require_grad(model, True)                                         # :140
+    optimizer.zero_grad()
+    tmp = ops.softmax_mix(logits, inputs)                                 # :138,142-144
+
+    D_output_detach = model(tmp.detach())                                 # :146
+    with torch.no_grad():
+        teacher_output = model_teacher(inputs[0])                         # :148-149
+
+    loss_D_hm = criterion(D_output_detach, target, target_weight)
+    loss_D_kd = criterion(D_output_detach, teacher_output, target_weight)
+    loss_D = loss_D_hm * (1 - args.alpha) + loss_D_kd * args.alpha        # :151-153
+    loss_D.backward()
+    if grad_sync is not None:
+        grad_sync.sync(optimizer)
+    optimizer.step()                                                      # :155
+
+    set_require_grad(model, False)                                        # :158
+    optimizer_G.zero_grad()
+    output = model(tmp)                                                   # :160
+    loss_G = -criterion(output, target, target_weight) * args.adv_loss_weight
+    loss_G.backward()
+    if grad_sync is not None:
+        grad_sync.sync(optimizer_G)
+    optimizer_G.step()                                                    # :164
+    return loss_D.detach(), output.detach()
+
+
+def _log(config, epoch, i, n, batch_time, data_time, losses, acc, bs, writer_dict):
+    msg = 'Epoch: [{0}][{1}/{2}]\t' \
+          'Time {batch_time.val:.3f}s ({batch_time.avg:.3f}s)\t' \
+          'Speed {speed:.1f} samples/s\t' \
+          'Data {data_time.val:.3f}s ({data_time.avg:.3f}s)\t' \
+          'Loss {loss.val:.5f} ({loss.avg:.5f})\t' \
+          'Accuracy {acc.val:.3f} ({acc.avg:.3f})'.format(
+              epoch, i, n, batch_time=batch_time, speed=bs / batch_time.val,
+              data_time=data_time, loss=losses, acc=acc)
+    logger.info(msg)
+    if writer_dict:
+        writer = writer_dict['writer']
+        global_steps = writer_dict['train_global_steps']
+        writer.add_scalar('train_loss', losses.val, global_steps)
+        writer.add_scalar('train_acc', acc.val, global_steps)
+        writer_dict['train_global_steps'] = global_steps + 1
+
+
+def train(config, args, train_loader, model, criterion, optimizer, epoch,
+          output_dir, tb_log_dir, writer_dict, grad_sync=None):
+    batch_time, data_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
+    if isinstance(model, list):
+        model = model[0]
+    model.train()
+    end = time.time()
+    n = len(train_loader) if hasattr(train_loader, '__len__') else -1
+    for i, (input, target, target_weight, meta) in enumerate(train_loader):
+        data_time.update(time.time() - end)
+        target = _cuda(target[0] if isinstance(target, (list, tuple)) else target)      # :50
+        target_weight = _cuda(target_weight)
+        loss, outputs = plain_step(model, criterion, optimizer, input, target, target_weight, grad_sync)
+        losses.update(loss.item(), input.size(0))                                        # :62
+        _, avg_acc, cnt, pred = accuracy(outputs, target)
+        acc.update(avg_acc, cnt)
+        batch_time.update(time.time() - end)
+        end = time.time()
+        if i % config.PRINT_FREQ == 0:
+            _log(config, epoch, i, n, batch_time, data_time, losses, acc, input.size(0), writer_dict)
+
+
+def train_advmix(config, args, train_loader, models, criterion, optimizers, epoch,
+                 output_dir, tb_log_dir, writer_dict, grad_sync=None):
+    batch_time, data_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
+    model = models[0].train()
+    model_G = models[1].train()
+    model_teacher = models[2].eval()
+    optimizer, optimizer_G = optimizers[0], optimizers[1]
+    end = time.time()
+    n = len(train_loader) if hasattr(train_loader, '__len__') else -1
+    for i, (inputs, targets, target_weights, metas) in enumerate(train_loader):
+        data_time.update(time.time() - end)
+        inputs = [_cuda(v).float().contiguous() for v in inputs]                         # :129-133
+        target = _cuda(targets[0])
+        target_weight = _cuda(target_weights[0])
+        loss_D, output = advmix_step(args, model, model_G, model_teacher, criterion, optimizer,
+                                     optimizer_G, inputs, target, target_weight, grad_sync)
+        losses.update(loss_D.item(), inputs[0].size(0))                                  # :167
+        _, avg_acc, cnt, pred = accuracy(output, target)                                 # :168
+        acc.update(avg_acc, cnt)
+        batch_time.update(time.time() - end)
+        end = time.time()
+        if i % config.PRINT_FREQ == 0:
+            _log(config, epoch, i, n, batch_time, data_time, losses, acc, inputs[0].size(0), writer_dict)
+
+
+class AverageMeter(object):
+    """Computes and stores the average and current value"""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = 0
+        self.avg = 0
+        self.sum = 0
+        self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count if self.count != 0 else 0

@@ -1,7 +1,7 @@
 // BatchNorm2d (train / eval) and InstanceNorm2d(affine=False) on NHWC fp32, forward + backward.
-// HBM-bound: each kernel streams rows with 16-byte lanes; per-channel statistics are reduced
-// block-partials (fp32, short runs) -> fp64 finalize, so results are deterministic (no atomics)
-// and E[x^2]-E[x]^2 is formed in double.
+// HBM-bound: each kernel streams rows with 16-byte lanes; per-channel statistics are accumulated
+// in fp64 (block partials -> fp64 finalize): deterministic (no atomics), and E[x^2]-E[x]^2 keeps
+// its precision when |mean| >> std.
 //
 // groups = 1  : BatchNorm over all rows      (lib/models/pose_hrnet.py:34 and every nn.BatchNorm2d)
 // groups = N  : InstanceNorm per image       (lib/models/Unet_generator.py:19,43,45)
@@ -25,15 +25,28 @@ static RowSplit split_rows(int groups, int64_t Mg) {
     return s;
 }
 
-// KIND 0: (x, x^2)     KIND 1: (g, g*xhat) with g = dy*act'(y)
+struct d4 { double v[4]; };
+__device__ __forceinline__ void d4_zero(d4& a) { a.v[0] = a.v[1] = a.v[2] = a.v[3] = 0.0; }
+__device__ __forceinline__ void d4_add(d4& a, const d4& b) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a.v[e] += b.v[e];
+}
+
+// KIND 0: (x, x^2)     KIND 1: (g, g*xhat) with g = dy*act'(y).   Accumulated in fp64: the
+// variance is later formed as E[x^2]-E[x]^2, which needs ~2x the input precision when
+// |mean| >> std (fp32 partials lose it: relative variance error ~1e-7*(1+mean^2/var)).
 template <int KIND>
-__device__ __forceinline__ void accum4(f32x4& s0, f32x4& s1, const float* x, const float* dy, const float* y,
+__device__ __forceinline__ void accum4(d4& s0, d4& s1, const float* x, const float* dy, const float* y,
                                        int64_t row, int ldy, int C, int c, const f32x4& mu, const f32x4& is,
                                        int act) {
     f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * C + c);
     if (KIND == 0) {
-        s0 += xv;
-        s1 += xv * xv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            double d = (double)xv[e];
+            s0.v[e] += d;
+            s1.v[e] += d * d;
+        }
     } else {
         f32x4 g = *reinterpret_cast<const f32x4*>(dy + row * ldy + c);
         if (act != ADVMIX_ACT_NONE) {
@@ -41,43 +54,49 @@ __device__ __forceinline__ void accum4(f32x4& s0, f32x4& s1, const float* x, con
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] *= act_grad(yv[e], act);
         }
-        s0 += g;
-        s1 += g * ((xv - mu) * is);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s0.v[e] += (double)g[e];
+            s1.v[e] += (double)g[e] * (double)((xv[e] - mu[e]) * is[e]);
+        }
     }
 }
 
-// partial[g][blk][2][C]
+// partial[g][blk][2][C] (double)
 template <int KIND>
 __global__ __launch_bounds__(256) void norm_partial(const float* __restrict__ x, const float* __restrict__ dy,
                                                     const float* __restrict__ y, int ldy,
                                                     const float* __restrict__ mean,
-                                                    const float* __restrict__ invstd, float* __restrict__ partial,
+                                                    const float* __restrict__ invstd, double* __restrict__ partial,
                                                     int64_t Mg, int C, int64_t rows_per_block, int act) {
-    __shared__ f32x4 red[2][256];
+    __shared__ d4 red[2][256];
     const int g = blockIdx.y, blk = blockIdx.x, nbg = gridDim.x;
     const int64_t r0 = (int64_t)g * Mg + blk * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     const int64_t gend = (int64_t)(g + 1) * Mg;
     if (r1 > gend) r1 = gend;
     const int CV = C >> 2;
-    float* out = partial + ((int64_t)g * nbg + blk) * 2 * C;
+    double* out = partial + ((int64_t)g * nbg + blk) * 2 * C;
     const int tid = threadIdx.x;
     if (CV >= 256) {
         for (int cv = tid; cv < CV; cv += 256) {
-            f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+            d4 s0, s1;
+            d4_zero(s0); d4_zero(s1);
+            f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
             if (KIND == 1) {
                 mu = *reinterpret_cast<const f32x4*>(mean + (int64_t)g * C + cv * 4);
                 is = *reinterpret_cast<const f32x4*>(invstd + (int64_t)g * C + cv * 4);
             }
             for (int64_t r = r0; r < r1; ++r) accum4<KIND>(s0, s1, x, dy, y, r, ldy, C, cv * 4, mu, is, act);
-            *reinterpret_cast<f32x4*>(out + cv * 4) = s0;
-            *reinterpret_cast<f32x4*>(out + C + cv * 4) = s1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { out[cv * 4 + e] = s0.v[e]; out[C + cv * 4 + e] = s1.v[e]; }
         }
         return;
     }
     const int RP = 256 / CV;
     const int rr = tid / CV, cv = tid - rr * CV;
-    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    d4 s0, s1;
+    d4_zero(s0); d4_zero(s1);
     if (rr < RP) {
         f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
         if (KIND == 1) {
@@ -92,14 +111,14 @@ __global__ __launch_bounds__(256) void norm_partial(const float* __restrict__ x,
     // tree over the RP row-lanes that share a column vector
     for (int step = 1; step < RP; step <<= 1) {
         if (rr < RP && (rr % (2 * step)) == 0 && rr + step < RP) {
-            red[0][tid] += red[0][tid + step * CV];
-            red[1][tid] += red[1][tid + step * CV];
+            d4_add(red[0][tid], red[0][tid + step * CV]);
+            d4_add(red[1][tid], red[1][tid + step * CV]);
         }
         __syncthreads();
     }
     if (rr == 0) {
-        *reinterpret_cast<f32x4*>(out + cv * 4) = red[0][tid];
-        *reinterpret_cast<f32x4*>(out + C + cv * 4) = red[1][tid];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { out[cv * 4 + e] = red[0][tid].v[e]; out[C + cv * 4 + e] = red[1][tid].v[e]; }
     }
 }
 
@@ -107,23 +126,23 @@ __global__ __launch_bounds__(256) void norm_partial(const float* __restrict__ x,
 template <int KIND>
 __global__ void norm_partial_scalar(const float* __restrict__ x, const float* __restrict__ dy,
                                     const float* __restrict__ y, int ldy, const float* __restrict__ mean,
-                                    const float* __restrict__ invstd, float* __restrict__ partial, int64_t Mg,
+                                    const float* __restrict__ invstd, double* __restrict__ partial, int64_t Mg,
                                     int C, int64_t rows_per_block, int act) {
     const int g = blockIdx.y, blk = blockIdx.x, nbg = gridDim.x;
     const int64_t r0 = (int64_t)g * Mg + blk * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     const int64_t gend = (int64_t)(g + 1) * Mg;
     if (r1 > gend) r1 = gend;
-    float* out = partial + ((int64_t)g * nbg + blk) * 2 * C;
+    double* out = partial + ((int64_t)g * nbg + blk) * 2 * C;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float s0 = 0.f, s1 = 0.f;
+        double s0 = 0.0, s1 = 0.0;
         float mu = KIND ? mean[(int64_t)g * C + c] : 0.f, is = KIND ? invstd[(int64_t)g * C + c] : 0.f;
         for (int64_t r = r0; r < r1; ++r) {
             float xv = x[r * C + c];
-            if (KIND == 0) { s0 += xv; s1 += xv * xv; }
+            if (KIND == 0) { s0 += (double)xv; s1 += (double)xv * (double)xv; }
             else {
                 float gg = dy[r * ldy + c] * act_grad(act != ADVMIX_ACT_NONE ? y[r * ldy + c] : 1.f, act);
-                s0 += gg; s1 += gg * ((xv - mu) * is);
+                s0 += (double)gg; s1 += (double)gg * (double)((xv - mu) * is);
             }
         }
         out[c] = s0;
@@ -131,7 +150,7 @@ __global__ void norm_partial_scalar(const float* __restrict__ x, const float* __
     }
 }
 
-__global__ void norm_finalize_fwd(const float* __restrict__ partial, int nbg, int groups, int64_t Mg, int C,
+__global__ void norm_finalize_fwd(const double* __restrict__ partial, int nbg, int groups, int64_t Mg, int C,
                                   float eps, float* __restrict__ mean, float* __restrict__ invstd,
                                   float* running_mean, float* running_var, int64_t* nbt, float momentum) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -140,9 +159,9 @@ __global__ void norm_finalize_fwd(const float* __restrict__ partial, int nbg, in
     int g = i / C, c = i - g * C;
     double s = 0, ss = 0;
     for (int b = 0; b < nbg; ++b) {
-        const float* pp = partial + ((int64_t)g * nbg + b) * 2 * C;
-        s += (double)pp[c];
-        ss += (double)pp[C + c];
+        const double* pp = partial + ((int64_t)g * nbg + b) * 2 * C;
+        s += pp[c];
+        ss += pp[C + c];
     }
     double m = s / (double)Mg;
     double var = ss / (double)Mg - m * m;
@@ -157,16 +176,16 @@ __global__ void norm_finalize_fwd(const float* __restrict__ partial, int nbg, in
 }
 
 // coef[g][0][C] = mean(g), coef[g][1][C] = mean(g*xhat); dgamma/dbeta += (groups == 1)
-__global__ void norm_finalize_bwd(const float* __restrict__ partial, int nbg, int groups, int64_t Mg, int C,
+__global__ void norm_finalize_bwd(const double* __restrict__ partial, int nbg, int groups, int64_t Mg, int C,
                                   float* __restrict__ coef, float* dgamma, float* dbeta) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= groups * C) return;
     int g = i / C, c = i - g * C;
     double s = 0, ss = 0;
     for (int b = 0; b < nbg; ++b) {
-        const float* pp = partial + ((int64_t)g * nbg + b) * 2 * C;
-        s += (double)pp[c];
-        ss += (double)pp[C + c];
+        const double* pp = partial + ((int64_t)g * nbg + b) * 2 * C;
+        s += pp[c];
+        ss += pp[C + c];
     }
     coef[((int64_t)g * 2) * C + c] = (float)(s / (double)Mg);
     coef[((int64_t)g * 2 + 1) * C + c] = (float)(ss / (double)Mg);
@@ -267,7 +286,8 @@ static int stream_blocks(int64_t total) {
 }  // namespace
 
 extern "C" int64_t advmix_norm_ws_bytes(int groups, int C) {
-    return ((int64_t)MAX_PARTIAL_BLOCKS * 2 * C + (int64_t)2 * groups * C) * (int64_t)sizeof(float);
+    return (int64_t)MAX_PARTIAL_BLOCKS * 2 * C * (int64_t)sizeof(double) +
+           (int64_t)2 * groups * C * (int64_t)sizeof(float);
 }
 
 extern "C" int advmix_norm_stats(const float* x, int groups, int64_t Mg, int C, float eps, float* mean,
@@ -277,7 +297,7 @@ extern "C" int advmix_norm_stats(const float* x, int groups, int64_t Mg, int C, 
     if (running_mean && groups != 1) return ADVMIX_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     RowSplit sp = split_rows(groups, Mg);
-    float* partial = (float*)ws;
+    double* partial = (double*)ws;
     dim3 g(sp.nbg, groups);
     if (C % 4 == 0)
         hipLaunchKernelGGL((norm_partial<0>), g, dim3(256), 0, st, x, nullptr, nullptr, 0, nullptr, nullptr, partial,
@@ -330,8 +350,8 @@ extern "C" int advmix_norm_bwd(const float* dy, const float* y, int ldy, const f
     if ((dgamma || dbeta) && groups != 1) return ADVMIX_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     RowSplit sp = split_rows(groups, Mg);
-    float* partial = (float*)ws;
-    float* coef = partial + (int64_t)MAX_PARTIAL_BLOCKS * 2 * C;
+    double* partial = (double*)ws;
+    float* coef = (float*)(partial + (int64_t)MAX_PARTIAL_BLOCKS * 2 * C);
     dim3 g(sp.nbg, groups);
     const bool vec = (C % 4 == 0) && (ldy % 4 == 0);
     if (vec)

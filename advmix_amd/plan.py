@@ -1,0 +1,352 @@
+"""Static execution plans for the hot-path networks.
+
+Instead of one nn.Module per layer, a network is compiled ONCE into a flat list of
+fused kernel-level steps over numbered activation slots (conv, conv-transpose,
+norm+residual+activation, cat+activation, multi-resolution fuse, max-pool).  The same
+plan drives parameter registration (names/shapes identical to the reference's
+state-dict keys) and execution, and is what a HIP-graph capture replays.
+
+Builders below restate the topologies of lib/models/pose_hrnet.py:274-460,
+lib/models/pose_resnet.py:103-207 and lib/models/Unet_generator.py:13-112.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_NONE, ACT_RELU, ACT_LEAKY
+
+BN_MOMENTUM = 0.1     # pose_hrnet.py:18; fuse/transition BNs use the torch default (also 0.1)
+BN_EPS = 1e-5
+
+
+class Plan:
+    def __init__(self, in_channels):
+        self.params = []          # (name, shape, kind) kind in conv|deconv|bias|bn_w|bn_b
+        self.buffers = []         # (name, shape, kind) kind in rm|rv|nbt
+        self.steps = []
+        self.ch = [in_channels]   # channels per slot; slot 0 is the input
+        self.out = None
+
+    # -- slot helpers ------------------------------------------------------------------
+    def _new(self, c):
+        self.ch.append(c)
+        return len(self.ch) - 1
+
+    def conv(self, x, name, cout, k, stride, pad, bias=False):
+        self.params.append((name + '.weight', (cout, self.ch[x], k, k), 'conv'))
+        if bias:
+            self.params.append((name + '.bias', (cout,), 'bias:%d' % (self.ch[x] * k * k)))
+        y = self._new(cout)
+        self.steps.append(('conv', name, x, y, stride, pad, bias))
+        return y
+
+    def deconv(self, x, name, cout, k, stride, pad, bias=False):
+        self.params.append((name + '.weight', (self.ch[x], cout, k, k), 'deconv'))
+        if bias:
+            self.params.append((name + '.bias', (cout,), 'bias:%d' % (cout * k * k)))
+        y = self._new(cout)
+        self.steps.append(('deconv', name, x, y, stride, pad, bias))
+        return y
+
+    def bn(self, x, name, act=ACT_NONE, res=None):
+        c = self.ch[x]
+        self.params += [(name + '.weight', (c,), 'bn_w'), (name + '.bias', (c,), 'bn_b')]
+        self.buffers += [(name + '.running_mean', (c,), 'rm'), (name + '.running_var', (c,), 'rv'),
+                         (name + '.num_batches_tracked', (), 'nbt')]
+        y = self._new(c)
+        self.steps.append(('bn', name, x, y, res, act))
+        return y
+
+    def conv_bn(self, x, cname, bname, cout, k, stride, pad, act, res=None):
+        return self.bn(self.conv(x, cname, cout, k, stride, pad), bname, act, res)
+
+    def inorm(self, x, act=ACT_NONE):
+        y = self._new(self.ch[x])
+        self.steps.append(('inorm', x, y, act))
+        return y
+
+    def act(self, x, act):
+        y = self._new(self.ch[x])
+        self.steps.append(('act', x, y, act))
+        return y
+
+    def catact(self, a, b, act=ACT_NONE):
+        y = self._new(self.ch[a] + self.ch[b])
+        self.steps.append(('catact', a, b, y, act))
+        return y
+
+    def fuse(self, xs, shifts, act=ACT_RELU):
+        y = self._new(self.ch[xs[shifts.index(0)]])
+        self.steps.append(('fuse', list(xs), list(shifts), y, act))
+        return y
+
+    def maxpool(self, x):
+        y = self._new(self.ch[x])
+        self.steps.append(('maxpool', x, y))
+        return y
+
+    # -- residual blocks (pose_hrnet.py:28-98 / pose_resnet.py:29-100) ------------------
+    def block(self, kind, x, pre, planes, stride=1):
+        cin = self.ch[x]
+        if kind == 'BASIC':
+            cout = planes
+            o = self.conv_bn(x, pre + '.conv1', pre + '.bn1', planes, 3, stride, 1, ACT_RELU)
+            o = self.conv(o, pre + '.conv2', planes, 3, 1, 1)
+            last_bn = pre + '.bn2'
+        else:
+            cout = planes * 4
+            o = self.conv_bn(x, pre + '.conv1', pre + '.bn1', planes, 1, 1, 0, ACT_RELU)
+            o = self.conv_bn(o, pre + '.conv2', pre + '.bn2', planes, 3, stride, 1, ACT_RELU)
+            o = self.conv(o, pre + '.conv3', cout, 1, 1, 0)
+            last_bn = pre + '.bn3'
+        res = x
+        if stride != 1 or cin != cout:
+            res = self.conv_bn(x, pre + '.downsample.0', pre + '.downsample.1', cout, 1, stride, 0, ACT_NONE)
+        return self.bn(o, last_bn, ACT_RELU, res)
+
+
+EXPANSION = {'BASIC': 1, 'BOTTLENECK': 4}
+
+
+def hrnet_plan(extra, num_joints):
+    P = Plan(3)
+    x = P.conv_bn(0, 'conv1', 'bn1', 64, 3, 2, 1, ACT_RELU)
+    x = P.conv_bn(x, 'conv2', 'bn2', 64, 3, 2, 1, ACT_RELU)
+    for k in range(4):
+        x = P.block('BOTTLENECK', x, 'layer1.%d' % k, 64)
+    cur = [x]
+    for st in (2, 3, 4):
+        cfg = extra['STAGE%d' % st]
+        kind = cfg['BLOCK']
+        widths = [c * EXPANSION[kind] for c in cfg['NUM_CHANNELS']]
+        nb = cfg['NUM_BRANCHES']
+        assert nb == len(widths) == len(cfg['NUM_BLOCKS'])
+        tp = 'transition%d' % (st - 1)
+        nxt = []
+        for i in range(nb):                               # pose_hrnet.py:323-356 + :433-452
+            if i < len(cur):
+                if P.ch[cur[i]] != widths[i]:
+                    nxt.append(P.conv_bn(cur[i], '%s.%d.0' % (tp, i), '%s.%d.1' % (tp, i),
+                                         widths[i], 3, 1, 1, ACT_RELU))
+                else:
+                    nxt.append(cur[i])
+            else:
+                t, n = cur[-1], i + 1 - len(cur)
+                for j in range(n):
+                    co = widths[i] if j == n - 1 else P.ch[cur[-1]]
+                    t = P.conv_bn(t, '%s.%d.%d.0' % (tp, i, j), '%s.%d.%d.1' % (tp, i, j), co, 3, 2, 1, ACT_RELU)
+                nxt.append(t)
+        cur = nxt
+        nmod = cfg['NUM_MODULES']
+        for m in range(nmod):
+            mp = 'stage%d.%d' % (st, m)
+            multi = not (st == 4 and m == nmod - 1)       # :405-408
+            for b in range(nb):
+                for k in range(cfg['NUM_BLOCKS'][b]):
+                    cur[b] = P.block(kind, cur[b], '%s.branches.%d.%d' % (mp, b, k), cfg['NUM_CHANNELS'][b])
+            if nb == 1:
+                continue
+            fused = []
+            for i in range(nb if multi else 1):           # :196-232, :254-265
+                srcs, shifts = [], []
+                for j in range(nb):
+                    fp = '%s.fuse_layers.%d.%d' % (mp, i, j)
+                    if j == i:
+                        srcs.append(cur[j]); shifts.append(0)
+                    elif j > i:
+                        srcs.append(P.conv_bn(cur[j], fp + '.0', fp + '.1', P.ch[cur[i]], 1, 1, 0, ACT_NONE))
+                        shifts.append(j - i)
+                    else:
+                        t = cur[j]
+                        for k in range(i - j):
+                            last = k == i - j - 1
+                            t = P.conv_bn(t, '%s.%d.0' % (fp, k), '%s.%d.1' % (fp, k),
+                                          P.ch[cur[i]] if last else P.ch[cur[j]], 3, 2, 1,
+                                          ACT_NONE if last else ACT_RELU)
+                        srcs.append(t); shifts.append(0)
+                fused.append(P.fuse(srcs, shifts, ACT_RELU))
+            cur = fused
+    k = extra['FINAL_CONV_KERNEL']
+    P.out = P.conv(cur[0], 'final_layer', num_joints, k, 1, 1 if k == 3 else 0, bias=True)
+    return P
+
+
+RESNET_SPEC = {18: ('BASIC', [2, 2, 2, 2]), 34: ('BASIC', [3, 4, 6, 3]), 50: ('BOTTLENECK', [3, 4, 6, 3]),
+               101: ('BOTTLENECK', [3, 4, 23, 3]), 152: ('BOTTLENECK', [3, 8, 36, 3])}
+
+
+def resnet_plan(extra, num_joints):
+    kind, layers = RESNET_SPEC[extra['NUM_LAYERS']]
+    P = Plan(3)
+    x = P.conv_bn(0, 'conv1', 'bn1', 64, 7, 2, 3, ACT_RELU)
+    x = P.maxpool(x)
+    for li, n in enumerate(layers):
+        for k in range(n):
+            x = P.block(kind, x, 'layer%d.%d' % (li + 1, k), 64 * 2 ** li, 2 if (k == 0 and li > 0) else 1)
+    for i in range(extra['NUM_DECONV_LAYERS']):           # pose_resnet.py:145-191
+        kk = extra['NUM_DECONV_KERNELS'][i]
+        if kk != 4:
+            raise NotImplementedError('only 4x4 stride-2 deconv heads are on the hot path')
+        x = P.deconv(x, 'deconv_layers.%d' % (3 * i), extra['NUM_DECONV_FILTERS'][i], 4, 2, 1,
+                     bias=bool(extra.get('DECONV_WITH_BIAS', False)))
+        x = P.bn(x, 'deconv_layers.%d' % (3 * i + 1), ACT_RELU)
+    k = extra['FINAL_CONV_KERNEL']
+    P.out = P.conv(x, 'final_layer', num_joints, k, 1, 1 if k == 3 else 0, bias=True)
+    return P
+
+
+def unet_plan(input_nc, output_nc, num_downs, ngf=64):
+    """U-Net with the reference's quirks folded into fused steps: the in-place LeakyReLU that
+    also feeds the skip (Unet_generator.py:42,61,69,83) becomes norm+leaky producing the skip
+    tensor; the parent's in-place ReLU on the concatenation becomes cat+relu."""
+    inner = [ngf, ngf * 2, ngf * 4, ngf * 8] + [ngf * 8] * (num_downs - 4)
+    P = Plan(input_nc)
+    pre = ['model']
+    for i in range(1, num_downs):
+        pre.append(pre[-1] + ('.model.1' if i == 1 else '.model.3'))
+
+    def names(i):
+        if i == 0:
+            return pre[0] + '.model.0', pre[0] + '.model.3'
+        if i == num_downs - 1:
+            return pre[i] + '.model.1', pre[i] + '.model.3'
+        return pre[i] + '.model.1', pre[i] + '.model.5'
+
+    def level(i, a):
+        """a = LeakyReLU'd input of block i (i >= 1); returns ReLU(cat([a, up-branch]))."""
+        dn, un = names(i)
+        d = P.conv(a, dn, inner[i], 4, 2, 1, bias=True)
+        if i == num_downs - 1:
+            r = P.act(d, ACT_RELU)
+        else:
+            r = level(i + 1, P.inorm(d, ACT_LEAKY))
+        u = P.inorm(P.deconv(r, un, P.ch[a], 4, 2, 1, bias=True), ACT_NONE)
+        return P.catact(a, u, ACT_RELU)
+
+    dn, un = names(0)
+    d = P.conv(0, dn, inner[0], 4, 2, 1, bias=True)
+    r = level(1, P.act(d, ACT_LEAKY))
+    P.out = P.deconv(r, un, output_nc, 4, 2, 1, bias=True)
+    return P
+
+
+# ---------------------------------------------------------------------------------------------
+class PlanNet(nn.Module):
+    """nn.Module whose parameters/buffers are registered under the reference's state-dict
+    keys and whose forward interprets a Plan with the HIP ops."""
+
+    def __init__(self, plan):
+        super().__init__()
+        self.plan = plan
+        for name, shape, kind in plan.params:
+            self._register(name, nn.Parameter(self._default_init(shape, kind)), False)
+        for name, shape, kind in plan.buffers:
+            if kind == 'nbt':
+                t = torch.zeros((), dtype=torch.int64)
+            else:
+                t = torch.zeros(shape) if kind == 'rm' else torch.ones(shape)
+            self._register(name, t, True)
+        self._last_use = {}
+        for idx, st in enumerate(plan.steps):
+            for s in self._srcs(st):
+                self._last_use[s] = idx
+        self._cache = None
+
+    @staticmethod
+    def _default_init(shape, kind):
+        """torch.nn defaults (kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in)); BN (1, 0))."""
+        if kind in ('conv', 'deconv'):
+            fan_in = shape[1] * shape[2] * shape[3]
+            bound = 1.0 / math.sqrt(fan_in)
+            w = torch.empty(shape).uniform_(-bound, bound)
+            return w.contiguous(memory_format=torch.channels_last)
+        if kind.startswith('bias'):
+            bound = 1.0 / math.sqrt(int(kind.split(':')[1]))
+            return torch.empty(shape).uniform_(-bound, bound)
+        return torch.ones(shape) if kind == 'bn_w' else torch.zeros(shape)
+
+    def _register(self, dotted, tensor, is_buffer):
+        mod = self
+        parts = dotted.split('.')
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        if is_buffer:
+            mod.register_buffer(parts[-1], tensor)
+        else:
+            mod.register_parameter(parts[-1], tensor)
+
+    @staticmethod
+    def _srcs(st):
+        k = st[0]
+        if k in ('conv', 'deconv'):
+            return [st[2]]
+        if k == 'bn':
+            return [st[2]] + ([st[4]] if st[4] is not None else [])
+        if k in ('inorm', 'act', 'maxpool'):
+            return [st[1]]
+        if k == 'catact':
+            return [st[1], st[2]]
+        if k == 'fuse':
+            return list(st[1])
+        raise ValueError(k)
+
+    def _apply(self, fn, *a, **kw):
+        r = super()._apply(fn, *a, **kw)
+        self._cache = None
+        for p in self.parameters():                       # keep conv weights [O][R][S][I] in memory
+            if p.dim() == 4 and not p.is_contiguous(memory_format=torch.channels_last):
+                p.data = p.data.contiguous(memory_format=torch.channels_last)
+        return r
+
+    def _tensors(self):
+        if self._cache is None:
+            d = dict(self.named_parameters())
+            d.update(dict(self.named_buffers()))
+            self._cache = d
+        return self._cache
+
+    def load_state_dict(self, *a, **kw):
+        r = super().load_state_dict(*a, **kw)
+        self._cache = None
+        return r
+
+    def forward(self, x):
+        T = self._tensors()
+        train = self.training
+        slots = [None] * len(self.plan.ch)
+        slots[0] = x
+        out_slot = self.plan.out
+        for idx, st in enumerate(self.plan.steps):
+            k = st[0]
+            if k == 'conv':
+                _, name, s, d, stride, pad, hb = st
+                slots[d] = ops.conv2d(slots[s], T[name + '.weight'], T[name + '.bias'] if hb else None, stride, pad)
+            elif k == 'deconv':
+                _, name, s, d, stride, pad, hb = st
+                slots[d] = ops.conv_transpose2d(slots[s], T[name + '.weight'],
+                                                T[name + '.bias'] if hb else None, stride, pad)
+            elif k == 'bn':
+                _, name, s, d, res, act = st
+                slots[d] = ops.batch_norm(slots[s], T[name + '.weight'], T[name + '.bias'],
+                                          T[name + '.running_mean'], T[name + '.running_var'],
+                                          T[name + '.num_batches_tracked'],
+                                          slots[res] if res is not None else None, act, train,
+                                          BN_MOMENTUM, BN_EPS)
+            elif k == 'inorm':
+                slots[st[2]] = ops.instance_norm(slots[st[1]], st[3], 1e-5)
+            elif k == 'act':
+                slots[st[2]] = ops.activation(slots[st[1]], st[3])
+            elif k == 'catact':
+                slots[st[3]] = ops.cat_act(slots[st[1]], slots[st[2]], st[4])
+            elif k == 'fuse':
+                slots[st[3]] = ops.fuse_sum([slots[s] for s in st[1]], st[2], st[4])
+            elif k == 'maxpool':
+                slots[st[2]] = ops.max_pool3x3s2(slots[st[1]])
+            for s in self._srcs(st):                      # drop dead activations early
+                if self._last_use[s] == idx and s != out_slot:
+                    slots[s] = None
+        return slots[out_slot]

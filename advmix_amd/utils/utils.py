@@ -1,0 +1,167 @@
+"""Mirror of the hot-path pieces of lib/utils/utils.py: ``get_optimizer`` (:78-94, Adam with
+lr only) backed by ONE flat-buffer HIP Adam kernel instead of 878 per-tensor launches, and
+``save_checkpoint`` (:97-108)."""
+import ctypes
+import os
+
+import torch
+
+from .._lib import call
+
+
+def _ceil4(n):
+    return (n + 3) // 4 * 4
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr) semantics (betas (0.9, 0.999), eps 1e-8, no weight decay).
+
+    On first use every parameter is re-pointed into one flat fp32 buffer (16-byte aligned
+    slots, conv weights keep their channels_last strides) and ``p.grad`` into a parallel flat
+    gradient buffer that the backward kernels accumulate into.  ``step()`` is a single kernel
+    over the flat buffers; lr / betas / eps and the step counter live in device memory so a
+    captured HIP graph replays correctly.  ``zero_grad()`` zero-fills (never sets to None)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
+        self._flat = None
+        if all(p.is_cuda for p in self._params()):
+            self._ensure_flat()
+
+    # ---- flat storage ---------------------------------------------------------------------
+    def _params(self):
+        return [p for g in self.param_groups for p in g['params']]
+
+    @staticmethod
+    def _view(flat, off, p):
+        n = p.numel()
+        if p.dim() == 4:
+            O, I, R, S = p.shape
+            return flat[off:off + n].view(O, R, S, I).permute(0, 3, 1, 2)
+        return flat[off:off + n].view(p.shape)
+
+    def _ensure_flat(self):
+        if self._flat is not None:
+            return
+        ps = self._params()
+        dev = ps[0].device
+        if dev.type != 'cuda':
+            raise RuntimeError('FlatAdam needs CUDA parameters: move the model to the GPU before '
+                               'calling get_optimizer (there is no CPU fallback)')
+        total = sum(_ceil4(p.numel()) for p in ps)
+        fp = torch.zeros(total, device=dev, dtype=torch.float32)
+        fg = torch.zeros(total, device=dev, dtype=torch.float32)
+        off = 0
+        self._offsets = []
+        with torch.no_grad():
+            for p in ps:
+                if p.dtype != torch.float32:
+                    raise TypeError('FlatAdam handles fp32 parameters only')
+                if p.dim() == 4 and not p.is_contiguous(memory_format=torch.channels_last):
+                    p.data = p.data.contiguous(memory_format=torch.channels_last)
+                v = self._view(fp, off, p)
+                v.copy_(p.data)
+                old_grad = p.grad
+                p.data = v
+                g = self._view(fg, off, p)
+                if old_grad is not None:
+                    g.copy_(old_grad)
+                p.grad = g
+                self._offsets.append(off)
+                off += _ceil4(p.numel())
+        self._flat = (fp, fg, torch.zeros_like(fp), torch.zeros_like(fp))
+        g0 = self.param_groups[0]
+        self._hyper = torch.tensor([g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps']],
+                                   device=dev, dtype=torch.float32)
+        self._hyper_host = (g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'])
+        self._step = torch.zeros((), device=dev, dtype=torch.int64)
+
+    @property
+    def flat_params(self):
+        self._ensure_flat()
+        return self._flat[0]
+
+    @property
+    def flat_grads(self):
+        self._ensure_flat()
+        return self._flat[1]
+
+    def sync_hyper(self):
+        """Push lr/betas/eps to the device if a scheduler changed them (host-side, not captured)."""
+        self._ensure_flat()
+        g0 = self.param_groups[0]
+        cur = (g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'])
+        if cur != self._hyper_host:
+            self._hyper.copy_(torch.tensor(cur, dtype=torch.float32))
+            self._hyper_host = cur
+
+    # ---- torch.optim API ------------------------------------------------------------------
+    def zero_grad(self, set_to_none=False):
+        self._ensure_flat()
+        fg = self._flat[1]
+        call('advmix_fill', ctypes.c_void_p(fg.data_ptr()), 0.0, fg.numel(),
+             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    @torch.no_grad()
+    def step(self, closure=None, sync_hyper=True):
+        self._ensure_flat()
+        if sync_hyper and not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper()
+        fp, fg, m, v = self._flat
+        P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+        call('advmix_adam', P(fp), P(fg), P(m), P(v), fp.numel(), P(self._hyper), P(self._step),
+             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    def state_dict(self):
+        self._ensure_flat()
+        ps = self._params()
+        step = float(self._step.item())
+        state = {}
+        for i, (p, off) in enumerate(zip(ps, self._offsets)):
+            state[i] = {'step': torch.tensor(step),
+                        'exp_avg': self._view(self._flat[2], off, p).detach().clone(),
+                        'exp_avg_sq': self._view(self._flat[3], off, p).detach().clone()}
+        groups = [dict((k, v) for k, v in g.items() if k != 'params') for g in self.param_groups]
+        for g in groups:
+            g['params'] = list(range(len(ps)))
+        return {'state': state, 'param_groups': groups}
+
+    def load_state_dict(self, sd):
+        self._ensure_flat()
+        ps = self._params()
+        for k, v in sd['param_groups'][0].items():
+            if k != 'params':
+                self.param_groups[0][k] = v
+        step = 0
+        with torch.no_grad():
+            for i, (p, off) in enumerate(zip(ps, self._offsets)):
+                st = sd['state'].get(i) or sd['state'].get(str(i))
+                if st is None:
+                    continue
+                self._view(self._flat[2], off, p).copy_(st['exp_avg'])
+                self._view(self._flat[3], off, p).copy_(st['exp_avg_sq'])
+                step = max(step, int(float(st['step'])))
+        self._step.fill_(step)
+        self.sync_hyper()
+
+
+def get_optimizer(cfg, model):
+    """lib/utils/utils.py:78-94.  Only the Adam branch is on the hot path (every shipped
+    experiment uses it); the SGD branch is handed to torch.optim unchanged."""
+    if cfg.TRAIN.OPTIMIZER == 'adam':
+        return FlatAdam(model.parameters(), lr=cfg.TRAIN.LR)
+    if cfg.TRAIN.OPTIMIZER == 'sgd':
+        raise NotImplementedError('TRAIN.OPTIMIZER sgd is not on the MI355X hot path; use adam')
+    return None
+
+
+def save_checkpoint(states, is_best, output_dir, filename='checkpoint.pth', suffix=''):
+    """lib/utils/utils.py:97-108."""
+    if suffix != '':
+        torch.save(states, os.path.join(output_dir, filename[:-4] + '_' + suffix + '.pth'))
+        if is_best and 'state_dict' in states:
+            torch.save(states['best_state_dict'], os.path.join(output_dir, 'model_best_{}.pth'.format(suffix)))
+    else:
+        torch.save(states, os.path.join(output_dir, filename))
+        if is_best and 'state_dict' in states:
+            torch.save(states['best_state_dict'], os.path.join(output_dir, 'model_best.pth'))

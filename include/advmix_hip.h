@@ -71,7 +71,8 @@ int advmix_bias_grad(const float* dy, float* db, int64_t rows, int C, void* stre
 /* ---- normalisation: replaces nn.BatchNorm2d (train / eval, pose_hrnet.py:34 etc.) and
  * nn.InstanceNorm2d(affine=False) (Unet_generator.py:19,43,45).  groups = 1 -> BatchNorm
  * over all N*H*W rows; groups = N -> InstanceNorm over H*W rows of each image.
- * Statistics are reduced in fp64 from fp32 block partials (deterministic, no atomics).
+ * Statistics are accumulated and reduced in fp64 (deterministic block partials, no atomics):
+ * E[x^2]-E[x]^2 needs twice the input precision when |mean| >> std.
  * ws: workspace of advmix_norm_ws_bytes(groups, C) bytes. */
 int64_t advmix_norm_ws_bytes(int groups, int C);
 /* batch statistics -> mean[g,C], invstd[g,C]; if running_mean != NULL updates running stats

@@ -53,8 +53,12 @@ def mix_views(inputs, logits):
 
 def advmix_step(net, extra, D, G, T, optD, optG, inputs, target, tw,
                 alpha=0.1, adv_loss_weight=1.0, use_target_weight=True,
-                unet_kw=None, want=None):
-    """Returns dict(loss_D, loss_G, out1, out2, teacher, tmp, avg_acc, ...)."""
+                unet_kw=None, after_D_step=None):
+    """Returns dict(loss_D, loss_G, out1, out2, teacher, tmp, avg_acc, ...).
+    ``after_D_step`` (test hook, not reference behaviour): called right after the D update so a
+    parity test can overwrite D with the device path's updated weights ("teacher forcing"):
+    Adam's first steps are ~lr*sign(g), so elements whose gradient is rounding noise move in
+    implementation-dependent directions and an unforced comparison measures that, not kernels."""
     unet_kw = unet_kw or {}
     dn, gn = optD.names, optG.names
     _set_grad(G, gn, True)
@@ -70,6 +74,8 @@ def advmix_step(net, extra, D, G, T, optD, optG, inputs, target, tw,
     loss_D = l_hm * (1 - alpha) + l_kd * alpha                           # :151-153
     gD = torch.autograd.grad(loss_D, [D[k] for k in dn], allow_unused=True)
     optD.step(gD)                                                        # :154-155
+    if after_D_step is not None:
+        after_D_step()
 
     _set_grad(D, dn, False)                                              # :158
     out2 = posenet_forward(net, D, tmp, extra, True)                     # :160 (updated D)

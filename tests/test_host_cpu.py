@@ -1,0 +1,115 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the
+header declares, the model mirrors register exactly the reference's state-dict keys/shapes,
+config loading, the flat gradient all-reduce over gloo (world_size 2)."""
+import json
+import os
+import re
+import subprocess
+import sys
+import types
+
+import pytest
+import torch
+
+from helpers import gold_json
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    import advmix_amd._lib as L
+    hdr = open(os.path.join(ROOT, 'include', 'advmix_hip.h')).read()
+    names = set(re.findall(r'\b(advmix_[a-z0-9_]+)\s*\(', hdr))
+    assert len(names) >= 28
+    for n in names:
+        assert hasattr(L.lib, n), n
+    assert names - {'advmix_norm_ws_bytes'} == set(L.SIGNATURES), (names ^ set(L.SIGNATURES))
+    assert L.lib.advmix_version() == 1
+    assert L.lib.advmix_norm_ws_bytes(1, 64) == 1024 * 2 * 64 * 8 + 2 * 64 * 4
+
+
+def _cfg(net, extra, J):
+    from advmix_amd.config import CfgNode
+    return CfgNode({'MODEL': {'NAME': net, 'EXTRA': extra, 'NUM_JOINTS': J, 'INIT_WEIGHTS': True, 'PRETRAINED': ''}})
+
+
+def test_model_mirrors_register_reference_keys():
+    from oracle import configs
+    from advmix_amd import models
+    ref = gold_json('state_dict_keys.json')
+    for tag, net, extra, J in (('hrnet_w32', 'pose_hrnet', configs.HRNET_W32, 17),
+                               ('hrnet_w48', 'pose_hrnet', configs.HRNET_W48, 17),
+                               ('resnet50', 'pose_resnet', configs.RES50, 17),
+                               ('hrnet_tiny', 'pose_hrnet', configs.HRNET_TINY, 5),
+                               ('resnet18_tiny', 'pose_resnet', configs.RES18_TINY, 5)):
+        m = getattr(models, net).get_pose_net(_cfg(net, extra, J), is_train=True)
+        mine = {k: list(v.shape) for k, v in m.state_dict().items()}
+        assert mine == {k: s for k, s in ref[tag]}, tag
+        for p in m.parameters():
+            if p.dim() == 4:
+                assert p.is_contiguous(memory_format=torch.channels_last)
+    for d in (5, 6):
+        g = models.Unet_generator.UnetGenerator(9, 3, d)
+        assert [[k, list(v.shape)] for k, v in g.state_dict().items()] == ref['unet%d' % d]
+    w = dict(m.named_parameters())['conv1.weight']
+    assert abs(float(w.detach().std()) - 0.001) < 3e-4           # init_weights: N(0, 1e-3)
+
+
+def test_state_dict_roundtrip_with_reference_layout():
+    from oracle import configs, detinit
+    from oracle.posenet import posenet_spec
+    from advmix_amd import models
+    m = models.pose_hrnet.get_pose_net(_cfg('pose_hrnet', configs.HRNET_TINY, 5), is_train=False)
+    sd = detinit.fill_state_dict(posenet_spec('pose_hrnet', configs.HRNET_TINY, 5))
+    m.load_state_dict(sd, strict=True)
+    out = m.state_dict()
+    for k, v in sd.items():
+        assert torch.equal(out[k].contiguous(), v), k
+    w = m.get_parameter('stage2.0.branches.0.0.conv1.weight')
+    assert w.is_contiguous(memory_format=torch.channels_last) and w.shape[1] == 8
+
+
+def test_config_loader_reads_yaml_like_yacs(tmp_path):
+    from advmix_amd.config import cfg, update_config
+    y = tmp_path / 'e.yaml'
+    y.write_text("GPUS: (0,1,2,3)\nMODEL:\n  NAME: pose_resnet\n  EXTRA:\n    NUM_LAYERS: 50\n"
+                 "TRAIN:\n  LR: 0.001\n  LR_STEP:\n  - 90\n  - 120\n")
+    c = cfg.clone()
+    update_config(c, types.SimpleNamespace(cfg=str(y), opts=['TRAIN.LR', '0.01', 'MODEL.NUM_JOINTS', '16']))
+    assert c.GPUS == (0, 1, 2, 3) and c.TRAIN.LR == 0.01 and c.MODEL.EXTRA.NUM_LAYERS == 50
+    assert c['MODEL']['NUM_JOINTS'] == 16 and c.TRAIN.LR_STEP == [90, 120]
+    with pytest.raises(AttributeError):
+        c.TRAIN.LR = 1.0                                         # frozen
+    with pytest.raises(KeyError):
+        c2 = cfg.clone()
+        c2.merge_from_list(['TRAIN.NOPE', '1'])
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from advmix_amd.dp import GradSync
+rank = int(os.environ['RANK'])
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ['MASTER_PORT'],
+                        rank=rank, world_size=2)
+gs = GradSync(bucket_mb=0.001)                 # 262 elements / bucket -> many buckets
+flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+gs.all_reduce_mean(flat)
+ok = torch.allclose(flat, torch.arange(1000, dtype=torch.float32) * 1.5)
+class Opt: flat_grads = torch.full((77,), float(rank))
+o = Opt(); gs.sync(o)
+ok = ok and torch.allclose(o.flat_grads, torch.full((77,), 0.5))
+dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+'''
+
+
+def test_grad_sync_two_ranks_gloo(tmp_path):
+    script = tmp_path / 'w.py'
+    script.write_text(_WORKER % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29611')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
+    for p in procs:
+        assert p.wait(timeout=120) == 0

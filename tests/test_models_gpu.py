@@ -1,0 +1,216 @@
+"""Whole-network and whole-step parity on a real MI355X: the HIP path (through the C ABI)
+against the CPU oracle on the same seeded inputs, and against the reference-generated golden
+vectors.  Tolerance 1e-3 abs + 1e-3 rel (north_star: heatmaps/loss within 1e-3 fp32)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import CASES, gold_json, gold_npz, build_states, checksum_close   # noqa: E402
+from smoke_step import (product_models, assert_close, run_smoke, assert_grads,      # noqa: E402
+                        pull_params, match_fraction)
+
+
+def _f64_grads(net, extra, D, names, x, tgt, tw, B, J):
+    """fp64 re-run of the oracle (loss restated in double; oracle.loss casts to float)."""
+    import torch.nn.functional as F
+    from oracle.posenet import posenet_forward
+    P = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in D.items()}
+    for k in names:
+        P[k].requires_grad_(True)
+    xx = x.double().clone().requires_grad_(True)
+    y = posenet_forward(net, P, xx, extra, True)
+    w_ = tw.double().reshape(B, J, 1, 1)
+    d = y * w_ - tgt.double() * w_
+    l = (F.smooth_l1_loss(d, torch.zeros_like(d), reduction='none').mean(dim=(0, 2, 3)) * 0.5).sum() / J
+    g = torch.autograd.grad(l, [P[k] for k in names] + [xx])
+    return dict(zip(names + ['x'], g))
+
+
+@pytest.mark.parametrize('tag', list(CASES))
+def test_forward_backward_vs_oracle_and_golden(tag):
+    from oracle.posenet import posenet_forward, calibrate, trainable
+    from oracle.unet import unet_forward
+    from oracle.loss import joints_loss
+    from oracle.synth import synth_batch, strided
+    from oracle import detinit
+    from advmix_amd import ops
+    from advmix_amd.core.loss import JointsMSELoss
+    net, extra, J, B, H, W, _ = CASES[tag]
+    g = gold_npz('forward.npz')
+    D, T, G = build_states(net, extra, J)
+    views, tgt, tw = synth_batch(tag, B, J, H, W)
+    calibrate(net, D, views[2], extra)
+    cfg, mD, mG, _ = product_models(net, extra, J, D, T, G)
+
+    mD.eval()                                             # eval-mode (teacher-style) forward
+    with torch.no_grad():
+        ye = mD(views[0].cuda())
+        ye_ref = posenet_forward(net, D, views[0], extra, False)
+    assert_close('eval out', ye, ye_ref)
+    gs = max(1.0, float(ye_ref.abs().max()))
+    assert float(np.abs(strided(ye.cpu().contiguous()) - g[tag + '.eval_out']).max()) <= 1e-3 * gs
+
+    mD.train()                                            # train-mode forward + full backward
+    x = views[1].cuda().requires_grad_(True)
+    yt = mD(x)
+    loss = JointsMSELoss(True)(yt, tgt.cuda(), tw.cuda())
+    loss.backward()
+    names = trainable(D)
+    g64 = _f64_grads(net, extra, D, names, views[1], tgt, tw, B, J)
+    for k in names:
+        D[k].requires_grad_(True)
+    xr = views[1].clone().requires_grad_(True)
+    yr = posenet_forward(net, D, xr, extra, True)
+    lr = joints_loss(yr, tgt, tw, True)
+    g32 = dict(zip(names + ['x'], torch.autograd.grad(lr, [D[k] for k in names] + [xr])))
+    assert_close('train out', yt, yr)
+    ts = max(1.0, float(yr.abs().max()))
+    assert float(np.abs(strided(yt.detach().cpu().contiguous()) - g[tag + '.train_out']).max()) <= 1e-3 * ts
+    assert_close('loss', loss.detach(), lr.detach(), 1e-4)
+    assert_close('loss vs golden', [float(loss.detach())], g[tag + '.loss'], 1e-4)
+    got = {k: p.grad.detach().cpu() for k, p in mD.named_parameters()}
+    got['x'] = x.grad.cpu()
+    stats = assert_grads('D grads', names + ['x'], got, g32, g64)
+    print(tag, 'D-grad median rel err hip %.2e fp32-oracle %.2e outliers %d' % stats)
+    sd = mD.state_dict()
+    for k in D:
+        if k.endswith(('running_mean', 'running_var')):
+            assert_close(k, sd[k], D[k].detach())
+        if k.endswith('num_batches_tracked'):
+            assert int(sd[k]) == int(D[k])
+
+    for k in G:                                           # generator forward/backward
+        G[k].requires_grad_(True)
+    gi = ops.cat_views([v.cuda().contiguous() for v in views])
+    lg = mG(gi)
+    lg_ref = unet_forward(G, torch.cat(views, 1))
+    assert_close('unet out', lg, lg_ref)
+    assert float(np.abs(strided(lg.detach().cpu().contiguous()) - g[tag + '.unet_out']).max()) <= \
+        1e-3 * max(1.0, float(lg_ref.abs().max()))
+    proj = detinit.normal(tag + '.gproj', lg_ref.shape)
+    (lg * proj.cuda()).sum().backward()
+    gg32 = dict(zip(G, torch.autograd.grad((lg_ref * proj).sum(), list(G.values()))))
+    G64 = {k: v.detach().double().requires_grad_(True) for k, v in G.items()}
+    lg64 = unet_forward(G64, torch.cat(views, 1).double())
+    gg64 = dict(zip(G, torch.autograd.grad((lg64 * proj.double()).sum(), list(G64.values()))))
+    gmax = max(float(v.abs().max()) for v in gg64.values())
+    # conv biases that feed an InstanceNorm have an exactly-zero true gradient: compare those
+    # against the network's gradient scale instead of their own (pure rounding noise)
+    live = [k for k in G if float(gg64[k].abs().max()) > 1e-4 * gmax]
+    gotG = {k: p.grad.detach().cpu() for k, p in mG.named_parameters()}
+    stats = assert_grads('G grads', live, gotG, gg32, gg64)
+    for k in G:
+        if k not in live:
+            assert float(gotG[k].abs().max()) <= 1e-3 * gmax, k
+    print(tag, 'G-grad median rel err hip %.2e fp32-oracle %.2e outliers %d' % stats)
+
+
+@pytest.mark.parametrize('tag', list(CASES))
+def test_advmix_and_plain_steps_vs_oracle_and_golden(tag):
+    """Reference lr (1e-3), teacher-forced: after each device-side update the oracle adopts the
+    device weights, so every compared quantity is computed from identical parameters."""
+    from oracle.posenet import calibrate, trainable
+    from oracle.step import Adam, advmix_step as ostep, plain_step as oplain
+    from oracle.synth import synth_batch, strided
+    from advmix_amd.core.function import advmix_step, plain_step
+    from advmix_amd.core.loss import JointsMSELoss
+    from advmix_amd.utils.utils import get_optimizer
+    net, extra, J, B, H, W, iters = CASES[tag]
+    g = gold_npz('advmix_steps.npz')
+    meta = gold_json('advmix_checksums.json')[tag]
+    D, T, G = build_states(net, extra, J, salt=10)
+    calib = synth_batch(tag + '.calib', B, J, H, W)[0][0]
+    calibrate(net, T, calib, extra)
+    calibrate(net, D, calib, extra)
+    cfg, mD, mG, mT = product_models(net, extra, J, D, T, G)
+    optD, optG = get_optimizer(cfg, mD), get_optimizer(cfg, mG)
+    oD, oG = Adam(D, trainable(D)), Adam(G, list(G))
+    crit = JointsMSELoss(True)
+    args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
+    mD.train(); mG.train(); mT.eval()
+    fracs = []
+    for it in range(iters):
+        v, t, w = synth_batch('%s.it%d' % (tag, it), B, J, H, W)
+        before = {k: p.detach().clone() for k, p in mD.named_parameters()}
+        loss_D, out = advmix_step(args, mD, mG, mT, crit, optD, optG,
+                                  [x.cuda().contiguous() for x in v], t.cuda(), w.cuda())
+
+        # Adam step 1 is lr*sign(g): identical to 1e-6 except where g is rounding noise; later
+        # steps are lr*m/sqrt(v): continuous in g, so they agree to (grad rel. error) * lr
+        atol = 1e-6 if it == 0 else 1e-4
+
+        def force():
+            fracs.append(match_fraction(mD, D, atol))     # oracle's own update vs the device's
+            pull_params(mD, D)
+        ref = ostep(net, extra, D, G, T, oD, oG, v, t, w, alpha=0.1, after_D_step=force)
+        fracs.append(match_fraction(mG, G, atol))
+        pull_params(mG, G)
+        assert_close('loss_D', loss_D, ref['loss_D'])
+        assert_close('out2', out, ref['out2'])
+        if it == 0:                                       # golden: the reference's own numbers
+            want = g[tag + '.losses'][0]
+            assert_close('loss_D vs golden', [float(loss_D)], [0.9 * want[0] + 0.1 * want[1]])
+            for k, p in mD.named_parameters():            # Adam step 1 moves every element by <= lr
+                assert float((p.detach() - before[k]).abs().max()) <= 1e-3 * 1.001, k
+        # gradients left in the flat buffers: D grads from the D step, G grads from the G step
+        gD = {k: p.grad.detach().cpu() for k, p in mD.named_parameters()}
+        mh = np.median([float((gD[k] - ref['gD'][k]).abs().max()) / (float(ref['gD'][k].abs().max()) + 1e-30)
+                        for k in ref['gD']])
+        assert mh <= 0.15, ('median D-grad error vs fp32 oracle', mh)
+    sd = mD.state_dict()
+    assert int(sd['bn1.num_batches_tracked']) == meta['nbt']       # calib + 2 forwards / iteration
+    for k in D:
+        if k.endswith(('running_mean', 'running_var')):
+            assert_close(k, sd[k], D[k].detach())
+    assert min(fracs[:2]) >= 0.95 and min(fracs) >= 0.9, fracs
+    assert all(not p.requires_grad for p in mD.parameters())       # function.py:158 leaves D frozen
+    print(tag, 'element match fractions after each update', ['%.4f' % f for f in fracs])
+
+    D, _, _ = build_states(net, extra, J, salt=20)        # plain (non-AdvMix) loop, function.py:30-95
+    calibrate(net, D, calib, extra)
+    cfg, mD, _, _ = product_models(net, extra, J, D, T, G)
+    optD, oD = get_optimizer(cfg, mD), Adam(D, trainable(D))
+    mD.train()
+    for it in range(2):
+        v, t, w = synth_batch('%s.plain%d' % (tag, it), B, J, H, W)
+        loss, out = plain_step(mD, crit, optD, v[0].cuda(), t.cuda(), w.cuda())
+        ref = oplain(net, extra, D, oD, v[0], t, w)
+        assert match_fraction(mD, D, 1e-6 if it == 0 else 1e-4) >= 0.9
+        pull_params(mD, D)
+        assert_close('plain loss', loss, ref['loss'])
+        assert_close('plain out', out, ref['out'])
+        if it == 0:
+            assert_close('plain loss vs golden', [float(loss)], [g[tag + '.plain_losses'][0]])
+
+
+def test_smoke_entry():
+    run_smoke('hrnet_tiny', iters=2)
+    run_smoke('resnet18_tiny', iters=1)
+
+
+def test_nms_mirror_matches_reference_semantics():
+    from advmix_amd.nms import nms as pn
+    from oracle import nms as onms
+    g = gold_json('nms.json')
+    for name, c in g['box'].items():
+        d = np.array(c['dets'], np.float32) if c['dets'] is not None else np.load(
+            __import__('os').path.join(__import__('helpers').GOLD, 'nms_dets_%s.npy' % name))
+        assert [int(i) for i in pn.nms(d, c['thresh'])] == c['keep'], name
+        assert [int(i) for i in pn.gpu_nms(d, c['thresh'])] == c['keep'], name
+        assert [int(i) for i in pn.cpu_nms(d, c['thresh'])] == c['keep'], name
+    d = np.array([[0, 0, 9, 9, 0.9], [5, 0, 14, 9, 0.8]], np.float32)
+    th = float(np.float32(50.0) / np.float32(150.0))
+    for thr in (th, float(np.nextafter(th, 1.0)), float(np.nextafter(th, 0.0)), 0.3333, 0.5):   # Python floats
+        assert [int(i) for i in pn.nms(d, thr)] == onms.py_nms(d, thr), thr
+        assert [int(i) for i in pn.gpu_nms(d, thr)] == onms.gpu_nms(d, thr), thr
+        assert [int(i) for i in pn.cpu_nms(d, thr)] == onms.cpu_nms(d, thr), thr
+    assert pn.nms(d[:0], 0.5) == [] and pn.gpu_nms(d[:0], 0.5) == []
+    for name, c in g['oks'].items():
+        k = np.array(c['kpts'])
+        db = [{'score': s, 'keypoints': kk, 'area': a} for s, kk, a in zip(c['score'], k, c['area'])]
+        assert [int(i) for i in pn.oks_nms(db, c['thresh'])] == c['keep'], name
+        assert [int(i) for i in pn.soft_oks_nms(db, c['thresh'])] == c['soft_keep'], name

@@ -164,6 +164,31 @@ def test_batch_norm_train(case):
     check('eval', ye, yer)
 
 
+@pytest.mark.parametrize('ratio', [1.0, 30.0, 1000.0])
+def test_norm_statistics_survive_large_mean(ratio):
+    """|mean|/std up to 1e3: E[x^2]-E[x]^2 must not lose the variance (fp64 accumulation)."""
+    ops = _ops()
+    d = dev()
+    B, C, H, W = 2, 16, 12, 10
+    x = rnd(B, C, H, W, seed=17) * 0.01 + rnd(1, C, 1, 1, seed=18).sign() * 0.01 * ratio
+    x = x.float().double()                               # the fp32-representable input
+    for inorm in (False, True):
+        xr = x.clone().requires_grad_(True)
+        yr = F.instance_norm(xr, eps=1e-5) if inorm else F.batch_norm(xr, None, None, None, None, True, 0.1, 1e-5)
+        dy = rnd(B, C, H, W, seed=19)
+        yr.backward(dy)
+        xg = cl(x).requires_grad_(True)
+        if inorm:
+            y = ops.instance_norm(xg, 0)
+        else:
+            y = ops.batch_norm(xg, torch.nn.Parameter(torch.ones(C, device=d)), torch.nn.Parameter(torch.zeros(C, device=d)),
+                               torch.zeros(C, device=d), torch.ones(C, device=d),
+                               torch.zeros((), dtype=torch.int64, device=d), None, 0, True)
+        check('y', y, yr, 2e-4)
+        y.backward(cl(dy))
+        check('dx', xg.grad, xr.grad, 5e-4)
+
+
 def test_batch_norm_frozen_params_input_grad_only():
     """G-step mode: D frozen (set_require_grad False) but BN still in train mode."""
     ops = _ops()

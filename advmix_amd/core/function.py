@@ -44,39 +44,50 @@ def plain_step(model, criterion, optimizer, input, target, target_weight, grad_s
     return loss.detach(), outputs.detach()
 
 
-def advmix_step(args, model, model_G, model_teacher, criterion, optimizer, optimizer_G,
-                inputs, target, target_weight, grad_sync=None):
-    """function.py:137-164, one batch.  ``inputs``: 3 contiguous NCHW fp32 CUDA views.
-    Returns (loss_D, output) with output = D(tmp) after the D update (the tensor the reference
-    feeds to ``accuracy``)."""
+def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, inputs, target, target_weight):
+    """function.py:137-154: G forward, softmax-mix, D forward on the detached mix, teacher forward,
+    heat-map + KD loss, D backward.  Leaves D's gradients in ``optimizer.flat_grads``."""
     G_input = ops.cat_views(inputs)                                       # :137
     logits = model_G(G_input)                                             # :138 (softmax fused below)
-
     set_require_grad(model, True)                                         # :140
     optimizer.zero_grad()
     tmp = ops.softmax_mix(logits, inputs)                                 # :138,142-144
-
     D_output_detach = model(tmp.detach())                                 # :146
     with torch.no_grad():
         teacher_output = model_teacher(inputs[0])                         # :148-149
-
     loss_D_hm = criterion(D_output_detach, target, target_weight)
     loss_D_kd = criterion(D_output_detach, teacher_output, target_weight)
     loss_D = loss_D_hm * (1 - args.alpha) + loss_D_kd * args.alpha        # :151-153
     loss_D.backward()
-    if grad_sync is not None:
-        grad_sync.sync(optimizer)
-    optimizer.step()                                                      # :155
+    return loss_D.detach(), tmp
 
+
+def advmix_phase_b(args, model, criterion, optimizer, optimizer_G, tmp, target, target_weight):
+    """function.py:155-163: D update, then the adversarial pass through the frozen, updated D."""
+    optimizer.step()                                                      # :155
     set_require_grad(model, False)                                        # :158
     optimizer_G.zero_grad()
     output = model(tmp)                                                   # :160
     loss_G = -criterion(output, target, target_weight) * args.adv_loss_weight
     loss_G.backward()
+    return output.detach()
+
+
+def advmix_step(args, model, model_G, model_teacher, criterion, optimizer, optimizer_G,
+                inputs, target, target_weight, grad_sync=None):
+    """function.py:137-164, one batch.  ``inputs``: 3 contiguous NCHW fp32 CUDA views.
+    Returns (loss_D, output) with output = D(tmp) after the D update (the tensor the reference
+    feeds to ``accuracy``).  The two all-reduces of the data-parallel design sit exactly where
+    the reference's optimizers consume the gradients."""
+    loss_D, tmp = advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer,
+                                 inputs, target, target_weight)
+    if grad_sync is not None:
+        grad_sync.sync(optimizer)
+    output = advmix_phase_b(args, model, criterion, optimizer, optimizer_G, tmp, target, target_weight)
     if grad_sync is not None:
         grad_sync.sync(optimizer_G)
     optimizer_G.step()                                                    # :164
-    return loss_D.detach(), output.detach()
+    return loss_D, output
 
 
 def _log(config, epoch, i, n, batch_time, data_time, losses, acc, bs, writer_dict):

@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int MAX_PARTIAL_BLOCKS = 1024;
+constexpr int MAX_PARTIAL_BLOCKS = 512;
 
 struct RowSplit { int nbg; int64_t rows_per_block; };
 
@@ -150,19 +150,31 @@ __global__ void norm_partial_scalar(const float* __restrict__ x, const float* __
     }
 }
 
-__global__ void norm_finalize_fwd(const double* __restrict__ partial, int nbg, int groups, int64_t Mg, int C,
-                                  float eps, float* __restrict__ mean, float* __restrict__ invstd,
-                                  float* running_mean, float* running_var, int64_t* nbt, float momentum) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 && nbt) *nbt += 1;
-    if (i >= groups * C) return;
-    int g = i / C, c = i - g * C;
-    double s = 0, ss = 0;
-    for (int b = 0; b < nbg; ++b) {
+// One wave per (group, channel): lanes stride over the block partials, then a wave reduction.
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partial, int nbg, int g, int c, int C,
+                                                int lane, double& s, double& ss) {
+    s = 0.0; ss = 0.0;
+    for (int b = lane; b < nbg; b += 64) {
         const double* pp = partial + ((int64_t)g * nbg + b) * 2 * C;
         s += pp[c];
         ss += pp[C + c];
     }
+    s = wave_sum_d(s);
+    ss = wave_sum_d(ss);
+}
+
+__global__ __launch_bounds__(256) void norm_finalize_fwd(const double* __restrict__ partial, int nbg, int groups,
+                                                         int64_t Mg, int C, float eps, float* __restrict__ mean,
+                                                         float* __restrict__ invstd, float* running_mean,
+                                                         float* running_var, int64_t* nbt, float momentum) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i == 0 && lane == 0 && nbt) *nbt += 1;
+    if (i >= groups * C) return;
+    const int g = i / C, c = i - g * C;
+    double s, ss;
+    reduce_partials(partial, nbg, g, c, C, lane, s, ss);
+    if (lane != 0) return;
     double m = s / (double)Mg;
     double var = ss / (double)Mg - m * m;
     if (var < 0) var = 0;
@@ -176,17 +188,16 @@ __global__ void norm_finalize_fwd(const double* __restrict__ partial, int nbg, i
 }
 
 // coef[g][0][C] = mean(g), coef[g][1][C] = mean(g*xhat); dgamma/dbeta += (groups == 1)
-__global__ void norm_finalize_bwd(const double* __restrict__ partial, int nbg, int groups, int64_t Mg, int C,
-                                  float* __restrict__ coef, float* dgamma, float* dbeta) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void norm_finalize_bwd(const double* __restrict__ partial, int nbg, int groups,
+                                                         int64_t Mg, int C, float* __restrict__ coef,
+                                                         float* dgamma, float* dbeta) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= groups * C) return;
-    int g = i / C, c = i - g * C;
-    double s = 0, ss = 0;
-    for (int b = 0; b < nbg; ++b) {
-        const double* pp = partial + ((int64_t)g * nbg + b) * 2 * C;
-        s += pp[c];
-        ss += pp[C + c];
-    }
+    const int g = i / C, c = i - g * C;
+    double s, ss;
+    reduce_partials(partial, nbg, g, c, C, lane, s, ss);
+    if (lane != 0) return;
     coef[((int64_t)g * 2) * C + c] = (float)(s / (double)Mg);
     coef[((int64_t)g * 2 + 1) * C + c] = (float)(ss / (double)Mg);
     if (dbeta) dbeta[c] += (float)s;
@@ -305,7 +316,7 @@ extern "C" int advmix_norm_stats(const float* x, int groups, int64_t Mg, int C, 
     else
         hipLaunchKernelGGL((norm_partial_scalar<0>), g, dim3(256), 0, st, x, nullptr, nullptr, 0, nullptr, nullptr,
                            partial, Mg, C, sp.rows_per_block, 0);
-    hipLaunchKernelGGL(norm_finalize_fwd, dim3(cdiv((int64_t)groups * C, 256)), dim3(256), 0, st, partial, sp.nbg,
+    hipLaunchKernelGGL(norm_finalize_fwd, dim3(cdiv((int64_t)groups * C, 4)), dim3(256), 0, st, partial, sp.nbg,
                        groups, Mg, C, eps, mean, invstd, running_mean, running_var, nbt, momentum);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
@@ -360,7 +371,7 @@ extern "C" int advmix_norm_bwd(const float* dy, const float* y, int ldy, const f
     else
         hipLaunchKernelGGL((norm_partial_scalar<1>), g, dim3(256), 0, st, x, dy, y, ldy, mean, invstd, partial, Mg, C,
                            sp.rows_per_block, act);
-    hipLaunchKernelGGL(norm_finalize_bwd, dim3(cdiv((int64_t)groups * C, 256)), dim3(256), 0, st, partial, sp.nbg,
+    hipLaunchKernelGGL(norm_finalize_bwd, dim3(cdiv((int64_t)groups * C, 4)), dim3(256), 0, st, partial, sp.nbg,
                        groups, Mg, C, coef, dgamma, dbeta);
     int64_t rows = (int64_t)groups * Mg;
     if (vec)

@@ -1,0 +1,67 @@
+"""HIP-graph execution of the AdvMix step.
+
+HRNet-W32's step is ~9,000 kernel launches (293 convs + 292 BNs per pass, 3 forward and 2
+backward passes); driven eagerly from Python it is launch-bound.  The step has static shapes,
+so it is captured ONCE into HIP graphs (hipStreamBeginCapture via torch.cuda.CUDAGraph - every
+kernel in libadvmix_hip.so is capture-safe: no allocation, no sync) and replayed per batch.
+
+With data parallelism the step is cut into three graphs at the two points where gradients are
+exchanged (see dp.GradSync): [G fwd, mix, D fwd, T fwd, losses, D bwd] -> all-reduce(D grads)
+-> [Adam(D), D fwd, loss, bwd through D into G] -> all-reduce(G grads) -> [Adam(G)].
+The RCCL calls stay outside the graphs.  The autograd tape recorded while capturing graph 1
+is consumed while capturing graph 2; all three share one memory pool."""
+import torch
+
+from .core.function import advmix_phase_a, advmix_phase_b, advmix_step
+
+
+class AdvMixGraphRunner:
+    def __init__(self, args, model, model_G, model_teacher, criterion, optimizer, optimizer_G,
+                 inputs, target, target_weight, grad_sync=None, warmup=2):
+        self.opt, self.optG, self.sync = optimizer, optimizer_G, grad_sync
+        dev = inputs[0].device
+        # static input buffers: new batches are copied into these
+        self.inputs = [v.clone() for v in inputs]
+        self.target, self.tw = target.clone(), target_weight.clone()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                     # eager warm-up off the default stream
+            for _ in range(warmup):
+                advmix_step(args, model, model_G, model_teacher, criterion, optimizer, optimizer_G,
+                            self.inputs, self.target, self.tw, grad_sync)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        optimizer.sync_hyper()
+        optimizer_G.sync_hyper()
+        self.g1, self.g2, self.g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g1):
+            self.loss_D, tmp = advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer,
+                                              self.inputs, self.target, self.tw)
+        pool = self.g1.pool()
+        with torch.cuda.graph(self.g2, pool=pool):
+            self.output = advmix_phase_b(args, model, criterion, optimizer, optimizer_G, tmp,
+                                         self.target, self.tw)
+        del tmp
+        with torch.cuda.graph(self.g3, pool=pool):
+            optimizer_G.step(sync_hyper=False)
+        torch.cuda.synchronize(dev)
+
+    def load_batch(self, inputs, target, target_weight):
+        for d, s in zip(self.inputs, inputs):
+            d.copy_(s, non_blocking=True)
+        self.target.copy_(target, non_blocking=True)
+        self.tw.copy_(target_weight, non_blocking=True)
+
+    def step(self):
+        """Replay one AdvMix step on the current static batch. Returns (loss_D, output) views
+        of graph-owned tensors (valid until the next replay)."""
+        self.opt.sync_hyper()
+        self.optG.sync_hyper()
+        self.g1.replay()
+        if self.sync is not None:
+            self.sync.sync(self.opt)
+        self.g2.replay()
+        if self.sync is not None:
+            self.sync.sync(self.optG)
+        self.g3.replay()
+        return self.loss_D, self.output

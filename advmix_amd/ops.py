@@ -1,14 +1,21 @@
-"""torch.autograd.Function wrappers over the C ABI (include/advmix_hip.h).
+"""Autograd layer over the C ABI (include/advmix_hip.h).
 
-PyTorch is plumbing here: device memory (caching allocator), the current HIP
-stream and the autograd tape.  All arithmetic runs in libadvmix_hip.so.
+PyTorch is plumbing here: device memory (caching allocator), HIP streams and the autograd
+tape.  All arithmetic runs in libadvmix_hip.so.
 
-Tensors are logical NCHW with channels_last strides, i.e. dense NHWC in HBM.
-Parameter gradients are ACCUMULATED by the kernels straight into ``param.grad``
-(a view of the optimizer's flat gradient buffer once ``FlatAdam`` owns the
-model); the Functions return None for them.  ``ctx.needs_input_grad`` carries
-the reference's three gradient modes (full / input-only after
-``set_require_grad(model, False)`` / none), lib/core/function.py:98-104,140,158.
+Tensors are logical NCHW with channels_last strides, i.e. dense NHWC in HBM.  Parameter
+gradients are ACCUMULATED by the kernels straight into ``param.grad`` (a view of the
+optimizer's flat gradient buffer once ``FlatAdam`` owns the model); autograd sees None for
+them.  ``needs_input_grad`` carries the reference's three gradient modes (full / input-only
+after ``set_require_grad(model, False)`` / none), lib/core/function.py:98-104,140,158.
+
+Every op is a *member* (a pair of plain functions ``fwd``/``bwd`` taking a raw HIP stream);
+``GroupFn`` is the single autograd.Function.  A group runs its members CONCURRENTLY on forked
+HIP streams and joins before returning: HRNet's 2-4 resolution branches, its fuse convs and
+the residual downsample paths are independent, and individually the low-resolution ones only
+launch 96-192 workgroups on a 256-CU chip.  All memory is allocated on the caller's stream
+(allocation is host-side), the side streams only carry kernels between the fork and the join,
+so the pattern is safe for the caching allocator and legal inside HIP-graph capture.
 """
 import ctypes
 
@@ -18,14 +25,26 @@ from ._lib import call, lib
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 _CL = torch.channels_last
+MAX_LANES = 8
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
 def _st():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _p(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+_KEEP = []      # temporaries created while a group's lanes are in flight; dropped after the join
+
+
+def keep(t):
+    """A tensor freed before the lanes join could be handed by the caching allocator (which only
+    orders reuse on the CALLER's stream) to the next member while a side-lane kernel still reads
+    it - so every temporary lives until GroupFn has joined."""
+    _KEEP.append(t)
+    return t
 
 
 def nhwc(x):
@@ -36,7 +55,7 @@ def nhwc(x):
     if x.dim() != 4:
         raise ValueError('expected a 4-D NCHW tensor')
     if not x.is_contiguous(memory_format=_CL):
-        x = x.contiguous(memory_format=_CL)
+        x = keep(x.contiguous(memory_format=_CL))
     return x
 
 
@@ -44,29 +63,42 @@ def empty_nhwc(B, C, H, W, device):
     return torch.empty((B, H, W, C), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
 
 
-def _grad_buf(p):
+def _grad_buf(p, st):
+    """param.grad, created on demand.  The zero-fill runs on the MEMBER's stream ``st``: a torch
+    zeros_() would be enqueued on the caller's stream and race with a side lane's accumulation."""
     if p.grad is None:
-        p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
+        g = torch.empty_like(p, memory_format=torch.preserve_format)
+        call('advmix_fill', _p(g), 0.0, g.numel(), st)
+        p.grad = g
     return p.grad
 
 
 _ws_cache = {}
+WS_BYTES = 48 << 20      # fixed per-lane scratch: norm partials need <= 512*2*C*8 B (C = 2048: 16.8 MB)
 
 
-def _workspace(device, nbytes):
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+def _workspace(device, nbytes, lane):
+    """Per-(device, lane) scratch of fixed size, allocated once (never re-allocated while another
+    lane might still be using the old one).  Lanes never share scratch; within a lane kernels
+    are stream-ordered."""
+    if nbytes > WS_BYTES:
+        raise ValueError('norm workspace of %d bytes exceeds the per-lane scratch (%d)' % (nbytes, WS_BYTES))
+    key = (device.index, lane)
     w = _ws_cache.get(key)
-    if w is None or w.numel() * 4 < nbytes:
-        w = torch.empty((nbytes + 3) // 4 + 1024, device=device, dtype=torch.float32)
+    if w is None:
+        w = torch.empty(WS_BYTES // 4, device=device, dtype=torch.float32)
         _ws_cache[key] = w
     return w
 
 
-def _wt(w, A, T, B):
-    """[A][T][B] -> [B][T][A] weight re-layout for the transposed-gather kernel."""
-    out = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
-    call('advmix_transpose_w', _p(w), _p(out), A, T, B, _st())
-    return out
+_lane_streams = {}
+
+
+def _lanes(device, n):
+    ss = _lane_streams.setdefault(device.index, [])
+    while len(ss) < n:
+        ss.append(torch.cuda.Stream(device=device))
+    return ss[:n]
 
 
 def _check_w(w):
@@ -74,12 +106,25 @@ def _check_w(w):
         raise ValueError('conv weights must be channels_last ([O][R][S][I] in memory)')
 
 
-# ---------------------------------------------------------------------------------------------
-class ConvFn(torch.autograd.Function):
-    """nn.Conv2d (square stride / padding, dilation 1, groups 1)."""
+def _wt(st, w, A, T, B):
+    """[A][T][B] -> [B][T][A] weight re-layout for the transposed-gather kernel."""
+    out = keep(torch.empty(w.numel(), device=w.device, dtype=torch.float32))
+    call('advmix_transpose_w', _p(w), _p(out), A, T, B, st)
+    return out
+
+
+# =============================================================================================
+# members: fwd(st, lane, tensors, meta, needs) -> (outputs, saved, extra)
+#          bwd(st, lane, saved, extra, meta, grads, needs) -> input grads (aligned with tensors)
+# =============================================================================================
+class Conv:
+    NHWC = (0,)      # inputs made dense NHWC BEFORE the lanes fork (None = all)
+    """nn.Conv2d (square stride / padding, dilation 1, groups 1).  tensors = (x, w, bias|None)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad):
+    def fwd(st, lane, t, meta, needs):
+        x, w, bias = t
+        stride, pad = meta
         x = nhwc(x)
         _check_w(w)
         B, Ci, Hi, Wi = x.shape
@@ -88,241 +133,234 @@ class ConvFn(torch.autograd.Function):
         Wo = (Wi + 2 * pad - S) // stride + 1
         y = empty_nhwc(B, Co, Ho, Wo, x.device)
         call('advmix_conv_fwd', _p(x), _p(w), _p(bias), _p(y), B, Hi, Wi, Ci, Ho, Wo, Co, R, S,
-             stride, pad, _st())
-        ctx.save_for_backward(x, w, bias)
-        ctx.geom = (stride, pad)
-        return y
+             stride, pad, st)
+        return (y,), (x, w, bias), None
 
     @staticmethod
-    def backward(ctx, dy):
-        x, w, bias = ctx.saved_tensors
-        stride, pad = ctx.geom
-        dy = nhwc(dy)
+    def bwd(st, lane, saved, extra, meta, grads, needs):
+        x, w, bias = saved
+        stride, pad = meta
+        dy = nhwc(grads[0])
         B, Ci, Hi, Wi = x.shape
         Co, _, R, S = w.shape
         Ho, Wo = dy.shape[2], dy.shape[3]
         dx = None
-        if ctx.needs_input_grad[0]:
-            wt = _wt(w, Co, R * S, Ci)
+        if needs[0]:
+            wt = _wt(st, w, Co, R * S, Ci)
             dx = empty_nhwc(B, Ci, Hi, Wi, x.device)
             call('advmix_conv_tr', _p(dy), _p(wt), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
-                 stride, pad, _st())
-        if ctx.needs_input_grad[1]:
-            call('advmix_conv_wgrad', _p(dy), _p(x), _p(_grad_buf(w)), B, Ho, Wo, Co, Hi, Wi, Ci,
-                 R, S, stride, pad, _st())
-        if bias is not None and ctx.needs_input_grad[2]:
-            call('advmix_bias_grad', _p(dy), _p(_grad_buf(bias)), B * Ho * Wo, Co, _st())
-        return dx, None, None, None, None
+                 stride, pad, st)
+        if needs[1]:
+            call('advmix_conv_wgrad', _p(dy), _p(x), _p(_grad_buf(w, st)), B, Ho, Wo, Co, Hi, Wi, Ci,
+                 R, S, stride, pad, st)
+        if bias is not None and needs[2]:
+            call('advmix_bias_grad', _p(dy), _p(_grad_buf(bias, st)), B * Ho * Wo, Co, st)
+        return dx, None, None
 
 
-class DeconvFn(torch.autograd.Function):
+class Deconv:
+    NHWC = (0,)      # inputs made dense NHWC BEFORE the lanes fork (None = all)
     """nn.ConvTranspose2d (output_padding 0); weight logical [Cin, Cout, R, S]."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad):
+    def fwd(st, lane, t, meta, needs):
+        x, w, bias = t
+        stride, pad = meta
         x = nhwc(x)
         _check_w(w)
         B, Ci, Hi, Wi = x.shape
         _, Co, R, S = w.shape
         Ho = (Hi - 1) * stride - 2 * pad + R
         Wo = (Wi - 1) * stride - 2 * pad + S
-        wt = _wt(w, Ci, R * S, Co)                        # [Co][R][S][Ci]
+        wt = _wt(st, w, Ci, R * S, Co)                    # [Co][R][S][Ci]
         y = empty_nhwc(B, Co, Ho, Wo, x.device)
         call('advmix_conv_tr', _p(x), _p(wt), _p(bias), _p(y), B, Hi, Wi, Ci, Ho, Wo, Co, R, S,
-             stride, pad, _st())
-        ctx.save_for_backward(x, w, bias)
-        ctx.geom = (stride, pad)
-        return y
+             stride, pad, st)
+        return (y,), (x, w, bias), None
 
     @staticmethod
-    def backward(ctx, dy):
-        x, w, bias = ctx.saved_tensors
-        stride, pad = ctx.geom
-        dy = nhwc(dy)
+    def bwd(st, lane, saved, extra, meta, grads, needs):
+        x, w, bias = saved
+        stride, pad = meta
+        dy = nhwc(grads[0])
         B, Ci, Hi, Wi = x.shape
         _, Co, R, S = w.shape
         Ho, Wo = dy.shape[2], dy.shape[3]
         dx = None
-        if ctx.needs_input_grad[0]:
+        if needs[0]:
             dx = empty_nhwc(B, Ci, Hi, Wi, x.device)
             call('advmix_conv_fwd', _p(dy), _p(w), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
-                 stride, pad, _st())
-        if ctx.needs_input_grad[1]:
-            call('advmix_conv_wgrad', _p(x), _p(dy), _p(_grad_buf(w)), B, Hi, Wi, Ci, Ho, Wo, Co,
-                 R, S, stride, pad, _st())
-        if bias is not None and ctx.needs_input_grad[2]:
-            call('advmix_bias_grad', _p(dy), _p(_grad_buf(bias)), B * Ho * Wo, Co, _st())
-        return dx, None, None, None, None
+                 stride, pad, st)
+        if needs[1]:
+            call('advmix_conv_wgrad', _p(x), _p(dy), _p(_grad_buf(w, st)), B, Hi, Wi, Ci, Ho, Wo, Co,
+                 R, S, stride, pad, st)
+        if bias is not None and needs[2]:
+            call('advmix_bias_grad', _p(dy), _p(_grad_buf(bias, st)), B * Ho * Wo, Co, st)
+        return dx, None, None
 
 
-# ---------------------------------------------------------------------------------------------
-class BatchNormFn(torch.autograd.Function):
-    """y = act(BN(x) + residual).  training: batch stats + running-stat update
-    (momentum, unbiased var, num_batches_tracked += 1); eval: running stats."""
+class BatchNorm:
+    NHWC = (0, 6)      # inputs made dense NHWC BEFORE the lanes fork (None = all)
+    """y = act(BN(x) + residual).  tensors = (x, gamma, beta, rmean, rvar, nbt, residual|None);
+    meta = (act, training, momentum, eps).  training: batch stats + running-stat update."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, nbt, residual, act, training, momentum, eps):
+    def fwd(st, lane, t, meta, needs):
+        x, gamma, beta, rmean, rvar, nbt, residual = t
+        act, training, momentum, eps = meta
         x = nhwc(x)
         B, C, H, W = x.shape
         rows = B * H * W
         res = nhwc(residual) if residual is not None else None
         y = empty_nhwc(B, C, H, W, x.device)
-        ctx.training = training
         if not training:
             call('advmix_bn_eval', _p(x), _p(gamma), _p(beta), _p(rmean), _p(rvar), eps, _p(res),
-                 _p(y), rows, C, act, _st())
-            return y
+                 _p(y), rows, C, act, st)
+            return (y,), (), None
         mean = torch.empty(C, device=x.device, dtype=torch.float32)
         invstd = torch.empty(C, device=x.device, dtype=torch.float32)
-        ws = _workspace(x.device, lib.advmix_norm_ws_bytes(1, C))
+        ws = _workspace(x.device, lib.advmix_norm_ws_bytes(1, C), lane)
         call('advmix_norm_stats', _p(x), 1, rows, C, eps, _p(mean), _p(invstd), _p(rmean), _p(rvar),
-             _p(nbt), momentum, _p(ws), _st())
+             _p(nbt), momentum, _p(ws), st)
         call('advmix_norm_apply', _p(x), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), _p(y),
-             C, 1, rows, C, act, _st())
-        ctx.save_for_backward(x, y, mean, invstd, gamma, beta)
-        ctx.act = act
-        ctx.has_res = residual is not None
-        return y
+             C, 1, rows, C, act, st)
+        return (y,), (x, y, mean, invstd, gamma, beta), residual is not None
 
     @staticmethod
-    def backward(ctx, dy):
-        if not ctx.training:
+    def bwd(st, lane, saved, has_res, meta, grads, needs):
+        act, training = meta[0], meta[1]
+        if not training:
             raise RuntimeError('advmix_amd: backward through eval-mode BatchNorm is not on the hot path')
-        x, y, mean, invstd, gamma, beta = ctx.saved_tensors
-        dy = nhwc(dy)
+        x, y, mean, invstd, gamma, beta = saved
+        dy = nhwc(grads[0])
         B, C, H, W = x.shape
         rows = B * H * W
-        act = ctx.act
-        need_res = ctx.has_res and ctx.needs_input_grad[6]
+        need_res = has_res and needs[6]
         dx = empty_nhwc(B, C, H, W, x.device)
         dres = None
         if need_res:
             dres = dy if act == ACT_NONE else empty_nhwc(B, C, H, W, x.device)
-        ws = _workspace(x.device, lib.advmix_norm_ws_bytes(1, C))
-        dg = _grad_buf(gamma) if ctx.needs_input_grad[1] else None
-        db = _grad_buf(beta) if ctx.needs_input_grad[2] else None
+        ws = _workspace(x.device, lib.advmix_norm_ws_bytes(1, C), lane)
+        dg = _grad_buf(gamma, st) if needs[1] else None
+        db = _grad_buf(beta, st) if needs[2] else None
         call('advmix_norm_bwd', _p(dy), _p(y), C, _p(x), _p(mean), _p(invstd), _p(gamma), _p(dx),
              _p(dres) if (need_res and act != ACT_NONE) else None, _p(dg), _p(db), 1, rows, C, act,
-             _p(ws), _st())
-        return dx, None, None, None, None, None, dres, None, None, None, None
+             _p(ws), st)
+        return dx, None, None, None, None, None, dres
 
 
-class InstanceNormFn(torch.autograd.Function):
-    """y = act(InstanceNorm2d(x)) with affine=False, no running stats, eps 1e-5."""
+class InstanceNorm:
+    NHWC = (0,)      # inputs made dense NHWC BEFORE the lanes fork (None = all)
+    """y = act(InstanceNorm2d(x)), affine=False, no running stats.  meta = (act, eps)."""
 
     @staticmethod
-    def forward(ctx, x, act, eps):
-        x = nhwc(x)
+    def fwd(st, lane, t, meta, needs):
+        x = nhwc(t[0])
+        act, eps = meta
         B, C, H, W = x.shape
         mean = torch.empty(B * C, device=x.device, dtype=torch.float32)
         invstd = torch.empty(B * C, device=x.device, dtype=torch.float32)
-        ws = _workspace(x.device, lib.advmix_norm_ws_bytes(B, C))
+        ws = _workspace(x.device, lib.advmix_norm_ws_bytes(B, C), lane)
         y = empty_nhwc(B, C, H, W, x.device)
         call('advmix_norm_stats', _p(x), B, H * W, C, eps, _p(mean), _p(invstd), None, None, None,
-             0.0, _p(ws), _st())
+             0.0, _p(ws), st)
         call('advmix_norm_apply', _p(x), _p(mean), _p(invstd), None, None, None, _p(y), C, B, H * W,
-             C, act, _st())
-        ctx.save_for_backward(x, y, mean, invstd)
-        ctx.act = act
-        return y
+             C, act, st)
+        return (y,), (x, y, mean, invstd), None
 
     @staticmethod
-    def backward(ctx, dy):
-        x, y, mean, invstd = ctx.saved_tensors
-        dy = nhwc(dy)
+    def bwd(st, lane, saved, extra, meta, grads, needs):
+        x, y, mean, invstd = saved
+        dy = nhwc(grads[0])
         B, C, H, W = x.shape
         dx = empty_nhwc(B, C, H, W, x.device)
-        ws = _workspace(x.device, lib.advmix_norm_ws_bytes(B, C))
+        ws = _workspace(x.device, lib.advmix_norm_ws_bytes(B, C), lane)
         call('advmix_norm_bwd', _p(dy), _p(y), C, _p(x), _p(mean), _p(invstd), None, _p(dx), None,
-             None, None, B, H * W, C, ctx.act, _p(ws), _st())
-        return dx, None, None
+             None, None, B, H * W, C, meta[0], _p(ws), st)
+        return (dx,)
 
 
-# ---------------------------------------------------------------------------------------------
-class ActFn(torch.autograd.Function):
+class Act:
+    NHWC = (0,)      # inputs made dense NHWC BEFORE the lanes fork (None = all)
     @staticmethod
-    def forward(ctx, x, act):
-        x = nhwc(x)
+    def fwd(st, lane, t, meta, needs):
+        x = nhwc(t[0])
         B, C, H, W = x.shape
         y = empty_nhwc(B, C, H, W, x.device)
-        call('advmix_act_copy', _p(x), C, _p(y), C, B * H * W, C, act, _st())
-        ctx.save_for_backward(y)
-        ctx.act = act
-        return y
+        call('advmix_act_copy', _p(x), C, _p(y), C, B * H * W, C, meta, st)
+        return (y,), (y,), None
 
     @staticmethod
-    def backward(ctx, dy):
-        (y,) = ctx.saved_tensors
-        dy = nhwc(dy)
+    def bwd(st, lane, saved, extra, meta, grads, needs):
+        (y,) = saved
+        dy = nhwc(grads[0])
         B, C, H, W = y.shape
         dx = empty_nhwc(B, C, H, W, y.device)
-        call('advmix_act_bwd', _p(dy), C, _p(y), C, _p(dx), C, B * H * W, C, ctx.act, _st())
-        return dx, None
+        call('advmix_act_bwd', _p(dy), C, _p(y), C, _p(dx), C, B * H * W, C, meta, st)
+        return (dx,)
 
 
-class CatActFn(torch.autograd.Function):
+class CatAct:
+    NHWC = (0, 1)      # inputs made dense NHWC BEFORE the lanes fork (None = all)
     """y = act(cat([a, b], dim=1))  (Unet_generator.py:83 followed by the parent's uprelu)."""
 
     @staticmethod
-    def forward(ctx, a, b, act):
-        a, b = nhwc(a), nhwc(b)
+    def fwd(st, lane, t, meta, needs):
+        a, b = nhwc(t[0]), nhwc(t[1])
         B, Ca, H, W = a.shape
         Cb = b.shape[1]
         C = Ca + Cb
         y = empty_nhwc(B, C, H, W, a.device)
         rows = B * H * W
         base = y.data_ptr()
-        call('advmix_act_copy', _p(a), Ca, ctypes.c_void_p(base), C, rows, Ca, act, _st())
-        call('advmix_act_copy', _p(b), Cb, ctypes.c_void_p(base + 4 * Ca), C, rows, Cb, act, _st())
-        ctx.save_for_backward(y)
-        ctx.meta = (Ca, Cb, act)
-        return y
+        call('advmix_act_copy', _p(a), Ca, ctypes.c_void_p(base), C, rows, Ca, meta, st)
+        call('advmix_act_copy', _p(b), Cb, ctypes.c_void_p(base + 4 * Ca), C, rows, Cb, meta, st)
+        return (y,), (y,), (Ca, Cb)
 
     @staticmethod
-    def backward(ctx, dy):
-        (y,) = ctx.saved_tensors
-        Ca, Cb, act = ctx.meta
-        dy = nhwc(dy)
+    def bwd(st, lane, saved, extra, meta, grads, needs):
+        (y,) = saved
+        Ca, Cb = extra
+        dy = nhwc(grads[0])
         B, C, H, W = y.shape
         rows = B * H * W
-        da = empty_nhwc(B, Ca, H, W, y.device) if ctx.needs_input_grad[0] else None
-        db = empty_nhwc(B, Cb, H, W, y.device) if ctx.needs_input_grad[1] else None
+        da = empty_nhwc(B, Ca, H, W, y.device) if needs[0] else None
+        db = empty_nhwc(B, Cb, H, W, y.device) if needs[1] else None
         if da is not None:
-            call('advmix_act_bwd', _p(dy), C, _p(y), C, _p(da), Ca, rows, Ca, act, _st())
+            call('advmix_act_bwd', _p(dy), C, _p(y), C, _p(da), Ca, rows, Ca, meta, st)
         if db is not None:
             call('advmix_act_bwd', ctypes.c_void_p(dy.data_ptr() + 4 * Ca), C,
-                 ctypes.c_void_p(y.data_ptr() + 4 * Ca), C, _p(db), Cb, rows, Cb, act, _st())
-        return da, db, None
+                 ctypes.c_void_p(y.data_ptr() + 4 * Ca), C, _p(db), Cb, rows, Cb, meta, st)
+        return da, db
 
 
-class FuseSumFn(torch.autograd.Function):
-    """y = act(sum_j nearest_up_{2^shift_j}(in_j))  (pose_hrnet.py:206,254-265)."""
+class FuseSum:
+    NHWC = None      # inputs made dense NHWC BEFORE the lanes fork (None = all)
+    """y = act(sum_j nearest_up_{2^shift_j}(in_j))  (pose_hrnet.py:206,254-265). meta=(act, shifts)."""
 
     @staticmethod
-    def forward(ctx, act, shifts, *ins):
-        ins = [nhwc(t) for t in ins]
+    def fwd(st, lane, t, meta, needs):
+        act, shifts = meta
+        ins = [nhwc(v) for v in t]
         n = len(ins)
-        j0 = shifts.index(0)
-        B, C, H, W = ins[j0].shape
+        B, C, H, W = ins[shifts.index(0)].shape
         y = empty_nhwc(B, C, H, W, ins[0].device)
-        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ins])
+        ptrs = (ctypes.c_void_p * n)(*[v.data_ptr() for v in ins])
         sh = (ctypes.c_int * n)(*shifts)
-        call('advmix_fuse_sum', ptrs, sh, n, _p(y), B, H, W, C, act, _st())
-        ctx.save_for_backward(y)
-        ctx.meta = (act, tuple(shifts))
-        return y
+        call('advmix_fuse_sum', ptrs, sh, n, _p(y), B, H, W, C, act, st)
+        return (y,), (y,), None
 
     @staticmethod
-    def backward(ctx, dy):
-        (y,) = ctx.saved_tensors
-        act, shifts = ctx.meta
-        dy = nhwc(dy)
+    def bwd(st, lane, saved, extra, meta, grads, needs):
+        (y,) = saved
+        act, shifts = meta
+        dy = nhwc(grads[0])
         B, C, H, W = y.shape
         n = len(shifts)
-        g = empty_nhwc(B, C, H, W, y.device)
+        g = keep(empty_nhwc(B, C, H, W, y.device))
         outs = []
         for j, s in enumerate(shifts):
-            if not ctx.needs_input_grad[2 + j]:
+            if not needs[j]:
                 outs.append(None)
             elif s == 0:
                 outs.append(g)
@@ -331,40 +369,229 @@ class FuseSumFn(torch.autograd.Function):
         ptrs = (ctypes.c_void_p * n)(*[(o.data_ptr() if (o is not None and s > 0) else None)
                                       for o, s in zip(outs, shifts)])
         sh = (ctypes.c_int * n)(*shifts)
-        call('advmix_fuse_sum_bwd', _p(dy), _p(y), _p(g), ptrs, sh, n, B, H, W, C, act, _st())
-        return (None, None) + tuple(outs)
+        call('advmix_fuse_sum_bwd', _p(dy), _p(y), _p(g), ptrs, sh, n, B, H, W, C, act, st)
+        return tuple(outs)
 
 
-class MaxPoolFn(torch.autograd.Function):
+class MaxPool:
+    NHWC = (0,)      # inputs made dense NHWC BEFORE the lanes fork (None = all)
     """nn.MaxPool2d(kernel_size=3, stride=2, padding=1)  (pose_resnet.py:115)."""
 
     @staticmethod
-    def forward(ctx, x):
-        x = nhwc(x)
+    def fwd(st, lane, t, meta, needs):
+        x = nhwc(t[0])
         B, C, H, W = x.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         y = empty_nhwc(B, C, Ho, Wo, x.device)
         idx = torch.empty(B * Ho * Wo * C, device=x.device, dtype=torch.uint8)
-        call('advmix_maxpool3x3s2', _p(x), _p(y), _p(idx), B, H, W, C, Ho, Wo, _st())
-        ctx.save_for_backward(idx)
-        ctx.shape = (B, C, H, W, Ho, Wo)
-        return y
+        call('advmix_maxpool3x3s2', _p(x), _p(y), _p(idx), B, H, W, C, Ho, Wo, st)
+        return (y,), (idx,), (B, C, H, W, Ho, Wo)
 
     @staticmethod
-    def backward(ctx, dy):
-        (idx,) = ctx.saved_tensors
-        B, C, H, W, Ho, Wo = ctx.shape
-        dy = nhwc(dy)
+    def bwd(st, lane, saved, extra, meta, grads, needs):
+        (idx,) = saved
+        B, C, H, W, Ho, Wo = extra
+        dy = nhwc(grads[0])
         dx = empty_nhwc(B, C, H, W, dy.device)
-        call('advmix_maxpool3x3s2_bwd', _p(dy), _p(idx), _p(dx), B, H, W, C, Ho, Wo, _st())
-        return dx
+        call('advmix_maxpool3x3s2_bwd', _p(dy), _p(idx), _p(dx), B, H, W, C, Ho, Wo, st)
+        return (dx,)
 
 
-# ---------------------------------------------------------------------------------------------
 def _nchw3(v):
     if v.dim() != 4 or v.shape[1] != 3 or not v.is_contiguous() or v.dtype != torch.float32 or not v.is_cuda:
         raise ValueError('views must be contiguous NCHW fp32 CUDA tensors [B,3,H,W]')
     return v
+
+
+class Mix:
+    NHWC = (0,)      # inputs made dense NHWC BEFORE the lanes fork (None = all)
+    """tmp = sum_k views[k] * softmax(logits, 1)[:, k:k+1]  (function.py:138-144)."""
+
+    @staticmethod
+    def fwd(st, lane, t, meta, needs):
+        logits = nhwc(t[0])
+        v0, v1, v2 = _nchw3(t[1]), _nchw3(t[2]), _nchw3(t[3])
+        B, _, H, W = v0.shape
+        tmp = empty_nhwc(B, 3, H, W, v0.device)
+        call('advmix_mix_fwd', _p(v0), _p(v1), _p(v2), _p(logits), _p(tmp), B, H, W, st)
+        return (tmp,), (logits, v0, v1, v2), None
+
+    @staticmethod
+    def bwd(st, lane, saved, extra, meta, grads, needs):
+        logits, v0, v1, v2 = saved
+        dtmp = nhwc(grads[0])
+        B, _, H, W = v0.shape
+        dl = empty_nhwc(B, 3, H, W, v0.device)
+        call('advmix_mix_bwd', _p(v0), _p(v1), _p(v2), _p(logits), _p(dtmp), _p(dl), B, H, W, st)
+        return dl, None, None, None
+
+
+class JointsLoss:
+    NHWC = (0,)      # inputs made dense NHWC BEFORE the lanes fork (None = all)
+    """JointsMSELoss.forward (lib/core/loss.py:25-65); fused forward + gradient.
+    tensors = (pred, target, tw|None); meta = (use_tw, mse)."""
+
+    @staticmethod
+    def fwd(st, lane, t, meta, needs):
+        pred, target, tw = t
+        use_tw, mse = meta
+        pred = nhwc(pred)
+        B, J, H, W = pred.shape
+        if target.shape != pred.shape:
+            raise ValueError('target shape %s != output shape %s' % (tuple(target.shape), tuple(pred.shape)))
+        target = keep(target.float())
+        if target.is_contiguous():
+            t_nhwc = 0
+        elif target.is_contiguous(memory_format=_CL):
+            t_nhwc = 1
+        else:
+            target, t_nhwc = keep(target.contiguous()), 0
+        w = keep(tw.float().reshape(B, J).contiguous()) if use_tw else None
+        loss = torch.empty((), device=pred.device, dtype=torch.float32)
+        call('advmix_fill', _p(loss), 0.0, 1, st)
+        grad = empty_nhwc(B, J, H, W, pred.device) if needs[0] else None
+        call('advmix_joints_loss', _p(pred), _p(target), t_nhwc, _p(w), _p(loss), _p(grad), 1.0,
+             B, J, H * W, 1 if mse else 0, st)
+        return (loss,), ((grad,) if needs[0] else ()), None
+
+    @staticmethod
+    def bwd(st, lane, saved, extra, meta, grads, needs):
+        (grad,) = saved
+        out = torch.empty_like(grad, memory_format=torch.preserve_format)
+        dl = keep(grads[0].float().contiguous())
+        call('advmix_scale_dev', _p(out), _p(grad), _p(dl), 1.0, grad.numel(), st)
+        return out, None, None
+
+
+# =============================================================================================
+class GroupFn(torch.autograd.Function):
+    """Runs a list of independent members; member i on lane i % MAX_LANES (lane 0 = the
+    caller's stream).  Inputs/outputs are the members' tensors, flattened."""
+
+    @staticmethod
+    def forward(ctx, members, *flat):
+        dev = next(t for t in flat if t is not None).device
+        n = len(members)
+        cur = torch.cuda.current_stream(dev)
+        nl = min(n, MAX_LANES)
+        # layout conversions are torch kernels on the caller's stream: do them BEFORE the fork so
+        # no side lane can start ahead of a copy it depends on
+        flat = list(flat)
+        pos = 0
+        for op, cnt, meta in members:
+            for k in (range(cnt) if op.NHWC is None else op.NHWC):
+                if flat[pos + k] is not None:
+                    flat[pos + k] = nhwc(flat[pos + k])
+            pos += cnt
+        side = _lanes(dev, nl - 1)
+        for s in side:
+            s.wait_stream(cur)
+        handles = [ctypes.c_void_p(cur.cuda_stream)] + [ctypes.c_void_p(s.cuda_stream) for s in side]
+        outs, saved, spans, extras = [], [], [], []
+        pos = 0
+        needs_all = ctx.needs_input_grad[1:]
+        for i, (op, cnt, meta) in enumerate(members):
+            t = flat[pos:pos + cnt]
+            o, sv, ex = op.fwd(handles[i % nl], i % nl, t, meta, needs_all[pos:pos + cnt])
+            spans.append((pos, cnt, len(outs), len(o), len(saved), len(sv)))
+            outs += list(o)
+            saved += list(sv)
+            extras.append(ex)
+            pos += cnt
+        for s in side:
+            cur.wait_stream(s)
+        del _KEEP[:]
+        ctx.members, ctx.spans, ctx.extras = members, spans, extras
+        ctx.n_in = len(flat)
+        ctx.save_for_backward(*saved)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        saved = ctx.saved_tensors
+        dev = next(g for g in gouts if g is not None).device
+        members = ctx.members
+        nl = min(len(members), MAX_LANES)
+        cur = torch.cuda.current_stream(dev)
+        gouts = [nhwc(g) if (g is not None and g.dim() == 4) else g for g in gouts]   # before the fork
+        side = _lanes(dev, nl - 1)
+        for s in side:
+            s.wait_stream(cur)
+        handles = [ctypes.c_void_p(cur.cuda_stream)] + [ctypes.c_void_p(s.cuda_stream) for s in side]
+        grads = [None] * ctx.n_in
+        needs_all = ctx.needs_input_grad[1:]
+        for i, ((op, cnt, meta), (ipos, icnt, opos, ocnt, spos, scnt)) in enumerate(zip(members, ctx.spans)):
+            g = gouts[opos:opos + ocnt]
+            needs = needs_all[ipos:ipos + icnt]
+            if all(x is None for x in g) or not any(needs):
+                continue
+            r = op.bwd(handles[i % nl], i % nl, saved[spos:spos + scnt], ctx.extras[i], meta, g, needs)
+            grads[ipos:ipos + icnt] = list(r) + [None] * (icnt - len(r))
+        for s in side:
+            cur.wait_stream(s)
+        del _KEEP[:]
+        return (None,) + tuple(grads)
+
+
+def run_group(members):
+    """members: list of (op, tensors tuple, meta).  Returns a list of output tuples."""
+    flat, spec = [], []
+    for op, tensors, meta in members:
+        spec.append((op, len(tensors), meta))
+        flat += list(tensors)
+    outs = GroupFn.apply(spec, *flat)
+    res, pos = [], 0
+    for op, tensors, meta in members:
+        res.append(outs[pos])                              # every member has exactly one output
+        pos += 1
+    return res
+
+
+def _one(op, tensors, meta):
+    return run_group([(op, tuple(tensors), meta)])[0]
+
+
+# ---- functional spellings ---------------------------------------------------------------------
+def conv2d(x, w, bias=None, stride=1, pad=0):
+    return _one(Conv, (x, w, bias), (stride, pad))
+
+
+def conv_transpose2d(x, w, bias=None, stride=2, pad=1):
+    return _one(Deconv, (x, w, bias), (stride, pad))
+
+
+def batch_norm(x, gamma, beta, rmean, rvar, nbt, residual=None, act=ACT_NONE, training=True,
+               momentum=0.1, eps=1e-5):
+    return _one(BatchNorm, (x, gamma, beta, rmean, rvar, nbt, residual), (act, training, momentum, eps))
+
+
+def instance_norm(x, act=ACT_NONE, eps=1e-5):
+    return _one(InstanceNorm, (x,), (act, eps))
+
+
+def activation(x, act):
+    return _one(Act, (x,), act)
+
+
+def cat_act(a, b, act=ACT_NONE):
+    return _one(CatAct, (a, b), act)
+
+
+def fuse_sum(ins, shifts, act=ACT_RELU):
+    return _one(FuseSum, tuple(ins), (act, list(shifts)))
+
+
+def max_pool3x3s2(x):
+    return _one(MaxPool, (x,), None)
+
+
+def softmax_mix(logits, views):
+    return _one(Mix, (logits, views[0], views[1], views[2]), None)
+
+
+def joints_loss(pred, target, tw, use_target_weight=True, mse=False):
+    return _one(JointsLoss, (pred, target, tw), (use_target_weight, mse))
 
 
 def cat_views(views):
@@ -374,66 +601,6 @@ def cat_views(views):
     out = empty_nhwc(B, 9, H, W, v0.device)
     call('advmix_cat_views', _p(v0), _p(v1), _p(v2), _p(out), B, H, W, _st())
     return out
-
-
-class MixFn(torch.autograd.Function):
-    """tmp = sum_k views[k] * softmax(logits, 1)[:, k:k+1]  (function.py:138-144)."""
-
-    @staticmethod
-    def forward(ctx, logits, v0, v1, v2):
-        logits = nhwc(logits)
-        v0, v1, v2 = _nchw3(v0), _nchw3(v1), _nchw3(v2)
-        B, _, H, W = v0.shape
-        tmp = empty_nhwc(B, 3, H, W, v0.device)
-        call('advmix_mix_fwd', _p(v0), _p(v1), _p(v2), _p(logits), _p(tmp), B, H, W, _st())
-        ctx.save_for_backward(logits, v0, v1, v2)
-        return tmp
-
-    @staticmethod
-    def backward(ctx, dtmp):
-        logits, v0, v1, v2 = ctx.saved_tensors
-        dtmp = nhwc(dtmp)
-        B, _, H, W = v0.shape
-        dl = empty_nhwc(B, 3, H, W, v0.device)
-        call('advmix_mix_bwd', _p(v0), _p(v1), _p(v2), _p(logits), _p(dtmp), _p(dl), B, H, W, _st())
-        return dl, None, None, None
-
-
-class JointsLossFn(torch.autograd.Function):
-    """JointsMSELoss.forward (lib/core/loss.py:25-65); fused forward + gradient."""
-
-    @staticmethod
-    def forward(ctx, pred, target, tw, use_tw, mse):
-        pred = nhwc(pred)
-        B, J, H, W = pred.shape
-        if target.shape != pred.shape:
-            raise ValueError('target shape %s != output shape %s' % (tuple(target.shape), tuple(pred.shape)))
-        target = target.float()
-        if target.is_contiguous():
-            t_nhwc = 0
-        elif target.is_contiguous(memory_format=_CL):
-            t_nhwc = 1
-        else:
-            target, t_nhwc = target.contiguous(), 0
-        w = None
-        if use_tw:
-            w = tw.float().reshape(B, J).contiguous()
-        loss = torch.zeros((), device=pred.device, dtype=torch.float32)
-        need = ctx.needs_input_grad[0]
-        grad = empty_nhwc(B, J, H, W, pred.device) if need else None
-        call('advmix_joints_loss', _p(pred), _p(target), t_nhwc, _p(w), _p(loss), _p(grad), 1.0,
-             B, J, H * W, 1 if mse else 0, _st())
-        if need:
-            ctx.save_for_backward(grad)
-        return loss
-
-    @staticmethod
-    def backward(ctx, dl):
-        (grad,) = ctx.saved_tensors
-        out = torch.empty_like(grad, memory_format=torch.preserve_format)
-        dl = dl.float().contiguous()
-        call('advmix_scale_dev', _p(out), _p(grad), _p(dl), 1.0, grad.numel(), _st())
-        return out, None, None, None, None
 
 
 def heatmap_argmax(hm):
@@ -449,45 +616,3 @@ def heatmap_argmax(hm):
     mx = torch.empty((B, J), device=hm.device, dtype=torch.float32)
     call('advmix_heatmap_argmax', _p(hm), fmt, _p(idx), _p(mx), B, J, H * W, _st())
     return idx, mx
-
-
-# functional spellings used by the model mirror
-def conv2d(x, w, bias=None, stride=1, pad=0):
-    return ConvFn.apply(x, w, bias, stride, pad)
-
-
-def conv_transpose2d(x, w, bias=None, stride=2, pad=1):
-    return DeconvFn.apply(x, w, bias, stride, pad)
-
-
-def batch_norm(x, gamma, beta, rmean, rvar, nbt, residual=None, act=ACT_NONE, training=True,
-               momentum=0.1, eps=1e-5):
-    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, nbt, residual, act, training, momentum, eps)
-
-
-def instance_norm(x, act=ACT_NONE, eps=1e-5):
-    return InstanceNormFn.apply(x, act, eps)
-
-
-def activation(x, act):
-    return ActFn.apply(x, act)
-
-
-def cat_act(a, b, act=ACT_NONE):
-    return CatActFn.apply(a, b, act)
-
-
-def fuse_sum(ins, shifts, act=ACT_RELU):
-    return FuseSumFn.apply(act, list(shifts), *ins)
-
-
-def max_pool3x3s2(x):
-    return MaxPoolFn.apply(x)
-
-
-def softmax_mix(logits, views):
-    return MixFn.apply(logits, views[0], views[1], views[2])
-
-
-def joints_loss(pred, target, tw, use_target_weight=True, mse=False):
-    return JointsLossFn.apply(pred, target, tw, use_target_weight, mse)

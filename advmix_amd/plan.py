@@ -248,10 +248,20 @@ class PlanNet(nn.Module):
             else:
                 t = torch.zeros(shape) if kind == 'rm' else torch.ones(shape)
             self._register(name, t, True)
+        # ASAP levels: steps of one level are mutually independent (HRNet's branches, fuse convs,
+        # residual downsample paths) and are launched as ONE concurrent group
+        level = {0: 0}
+        groups = {}
+        for st in plan.steps:
+            lvl = 1 + max(level[s] for s in self._srcs(st))
+            level[self._dst(st)] = lvl
+            groups.setdefault(lvl, []).append(st)
+        self._levels = [groups[k] for k in sorted(groups)]
         self._last_use = {}
-        for idx, st in enumerate(plan.steps):
-            for s in self._srcs(st):
-                self._last_use[s] = idx
+        for li, sts in enumerate(self._levels):
+            for st in sts:
+                for s in self._srcs(st):
+                    self._last_use[s] = li
         self._cache = None
 
     @staticmethod
@@ -278,6 +288,13 @@ class PlanNet(nn.Module):
             mod.register_buffer(parts[-1], tensor)
         else:
             mod.register_parameter(parts[-1], tensor)
+
+    @staticmethod
+    def _dst(st):
+        k = st[0]
+        if k in ('conv', 'deconv', 'bn', 'catact', 'fuse'):
+            return st[3]
+        return st[2]                                       # inorm / act / maxpool
 
     @staticmethod
     def _srcs(st):
@@ -314,39 +331,42 @@ class PlanNet(nn.Module):
         self._cache = None
         return r
 
+    def _member(self, st, slots, T, train):
+        k = st[0]
+        if k in ('conv', 'deconv'):
+            _, name, s, d, stride, pad, hb = st
+            return (ops.Conv if k == 'conv' else ops.Deconv,
+                    (slots[s], T[name + '.weight'], T[name + '.bias'] if hb else None), (stride, pad))
+        if k == 'bn':
+            _, name, s, d, res, act = st
+            return (ops.BatchNorm,
+                    (slots[s], T[name + '.weight'], T[name + '.bias'], T[name + '.running_mean'],
+                     T[name + '.running_var'], T[name + '.num_batches_tracked'],
+                     slots[res] if res is not None else None), (act, train, BN_MOMENTUM, BN_EPS))
+        if k == 'inorm':
+            return (ops.InstanceNorm, (slots[st[1]],), (st[3], 1e-5))
+        if k == 'act':
+            return (ops.Act, (slots[st[1]],), st[3])
+        if k == 'catact':
+            return (ops.CatAct, (slots[st[1]], slots[st[2]]), st[4])
+        if k == 'fuse':
+            return (ops.FuseSum, tuple(slots[s] for s in st[1]), (st[4], list(st[2])))
+        if k == 'maxpool':
+            return (ops.MaxPool, (slots[st[1]],), None)
+        raise ValueError(k)
+
     def forward(self, x):
         T = self._tensors()
         train = self.training
         slots = [None] * len(self.plan.ch)
         slots[0] = x
         out_slot = self.plan.out
-        for idx, st in enumerate(self.plan.steps):
-            k = st[0]
-            if k == 'conv':
-                _, name, s, d, stride, pad, hb = st
-                slots[d] = ops.conv2d(slots[s], T[name + '.weight'], T[name + '.bias'] if hb else None, stride, pad)
-            elif k == 'deconv':
-                _, name, s, d, stride, pad, hb = st
-                slots[d] = ops.conv_transpose2d(slots[s], T[name + '.weight'],
-                                                T[name + '.bias'] if hb else None, stride, pad)
-            elif k == 'bn':
-                _, name, s, d, res, act = st
-                slots[d] = ops.batch_norm(slots[s], T[name + '.weight'], T[name + '.bias'],
-                                          T[name + '.running_mean'], T[name + '.running_var'],
-                                          T[name + '.num_batches_tracked'],
-                                          slots[res] if res is not None else None, act, train,
-                                          BN_MOMENTUM, BN_EPS)
-            elif k == 'inorm':
-                slots[st[2]] = ops.instance_norm(slots[st[1]], st[3], 1e-5)
-            elif k == 'act':
-                slots[st[2]] = ops.activation(slots[st[1]], st[3])
-            elif k == 'catact':
-                slots[st[3]] = ops.cat_act(slots[st[1]], slots[st[2]], st[4])
-            elif k == 'fuse':
-                slots[st[3]] = ops.fuse_sum([slots[s] for s in st[1]], st[2], st[4])
-            elif k == 'maxpool':
-                slots[st[2]] = ops.max_pool3x3s2(slots[st[1]])
-            for s in self._srcs(st):                      # drop dead activations early
-                if self._last_use[s] == idx and s != out_slot:
-                    slots[s] = None
+        for li, sts in enumerate(self._levels):
+            outs = ops.run_group([self._member(st, slots, T, train) for st in sts])
+            for st, o in zip(sts, outs):
+                slots[self._dst(st)] = o
+            for st in sts:                                 # drop dead activations early
+                for s in self._srcs(st):
+                    if self._last_use[s] == li and s != out_slot:
+                        slots[s] = None
         return slots[out_slot]

@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one full AdvMix train step (HRNet-W32 256x192, B=32 per
+GPU, synthetic inputs resident in HBM, random-init weights), fp32.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hrnet_w32|resnet50|hrnet_w48]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N ...` (one rank per GPU, RCCL); per-GPU work is fixed (weak scaling).  A "step" is the
+body of train_advmix's batch loop (lib/core/function.py:137-171): G fwd, softmax-mix, D step
+(heat-map + KD loss, backward, Adam), G step through the updated frozen D (backward, Adam),
+loss.item() and the PCK accuracy read-out - nothing is skipped inside the timed region.
+
+The JSON line also carries
+  roofline     - the dominant kernel (fp32-MFMA implicit-GEMM conv) timed live with HIP events:
+                 algorithmic FLOPs per launch / mean launch time vs the 157.3 TFLOP/s fp32 matrix peak
+  cpu_baseline - the CPU oracle (a restatement of the reference step, pinned to it by golden
+                 vectors) timed on this box's host cores on a bounded sample (B=4, a few steps).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+HRNET_STAGES = {
+    'hrnet_w32': (32, 64, 128, 256),
+    'hrnet_w48': (48, 96, 192, 384),
+}
+
+
+def hrnet_extra(widths):
+    ex = {'FINAL_CONV_KERNEL': 1, 'PRETRAINED_LAYERS': ['*']}
+    for i, (st, nmod) in enumerate(((2, 1), (3, 4), (4, 3))):
+        ex['STAGE%d' % st] = {'NUM_MODULES': nmod, 'NUM_BRANCHES': st, 'BLOCK': 'BASIC',
+                              'NUM_BLOCKS': [4] * st, 'NUM_CHANNELS': list(widths[:st]),
+                              'FUSE_METHOD': 'SUM'}
+    return ex
+
+
+WORKLOADS = {
+    # name: (MODEL.NAME, EXTRA, joints, H, W, unet downs, step GFLOP/img from SURVEY.md 8(d4))
+    'hrnet_w32': ('pose_hrnet', hrnet_extra(HRNET_STAGES['hrnet_w32']), 17, 256, 192, 6, 118.58),
+    'hrnet_w48': ('pose_hrnet', hrnet_extra(HRNET_STAGES['hrnet_w48']), 17, 384, 288, 5, 480.6),
+    'resnet50': ('pose_resnet', {'FINAL_CONV_KERNEL': 1, 'DECONV_WITH_BIAS': False, 'NUM_DECONV_LAYERS': 3,
+                                 'NUM_DECONV_FILTERS': [256, 256, 256], 'NUM_DECONV_KERNELS': [4, 4, 4],
+                                 'NUM_LAYERS': 50}, 17, 256, 192, 6, 91.77),
+}
+
+
+def synth(B, J, H, W, device, seed):
+    """3 N(0,1) views, Gaussian sigma=2 targets, weights in {0,1} (P=0.8)."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    views = [torch.randn(B, 3, H, W, generator=g).to(device) for _ in range(3)]
+    hh, ww = H // 4, W // 4
+    cx = torch.randint(0, ww, (B, J, 1, 1), generator=g).float()
+    cy = torch.randint(0, hh, (B, J, 1, 1), generator=g).float()
+    ys = torch.arange(hh).float().view(1, 1, hh, 1)
+    xs = torch.arange(ww).float().view(1, 1, 1, ww)
+    tgt = torch.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / 8.0)
+    tgt[tgt < 0.0111] = 0
+    tw = (torch.rand(B, J, 1, generator=g) < 0.8).float()
+    return views, tgt.to(device).contiguous(), tw.to(device)
+
+
+def build_models(workload, device):
+    from advmix_amd import models
+    from advmix_amd.config import CfgNode
+    from advmix_amd.core.loss import JointsMSELoss
+    from advmix_amd.utils.utils import get_optimizer
+    net, extra, J, H, W, downs, _ = WORKLOADS[workload]
+    cfg = CfgNode({'MODEL': {'NAME': net, 'EXTRA': extra, 'NUM_JOINTS': J, 'INIT_WEIGHTS': True, 'PRETRAINED': ''},
+                   'TRAIN': {'OPTIMIZER': 'adam', 'LR': 1e-3}, 'LOSS': {'USE_TARGET_WEIGHT': True}})
+    torch.manual_seed(1234)
+    mod = getattr(models, net)
+    D = mod.get_pose_net(cfg, is_train=True)                       # tools/train.py:60
+    T = mod.get_pose_net(cfg, is_train=False)
+    T.load_state_dict(D.state_dict())                              # copy.deepcopy(model), train.py:65
+    G = models.Unet_generator.UnetGenerator(9, 3, downs)           # train.py:67
+    D, T, G = D.to(device), T.to(device), G.to(device)
+    crit = JointsMSELoss(use_target_weight=True)
+    optD, optG = get_optimizer(cfg, D), get_optimizer(cfg, G)
+    D.train(); G.train(); T.eval()
+    return cfg, D, G, T, crit, optD, optG
+
+
+def time_dominant_kernel(B, device, iters=30):
+    """HIP-event timing of the dominant kernel: the 3x3 s1 32->32 conv on the 64x48 branch
+    (64 launches per HRNet-W32 forward; conv_igemm<128,32,fwd,vec>).  Events are recorded on the
+    stream the kernel is launched on (torch's current stream)."""
+    from advmix_amd import ops
+    x = torch.randn(B, 32, 64, 48, device=device).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter((torch.randn(32, 32, 3, 3, device=device) * 0.05).contiguous(memory_format=torch.channels_last),
+                           requires_grad=False)
+    with torch.no_grad():
+        for _ in range(5):
+            ops.conv2d(x, w, None, 1, 1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            ops.conv2d(x, w, None, 1, 1)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * B * 64 * 48 * 32 * 32 * 9
+    return {'bound': 'mfma', 'kernel': 'conv_igemm<128,32,fwd,vec4> 3x3 s1 32->32 @64x48',
+            'achieved': round(flops / (ms * 1e-3) / 1e12, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+            'us_per_launch': round(ms * 1e3, 2), 'algorithmic_gflop_per_launch': round(flops / 1e9, 3)}
+
+
+def cpu_baseline(workload, budget_s=25.0):
+    """The CPU oracle's AdvMix step on this host (bounded sample: B=4, >=1 warm-up + timed steps)."""
+    from oracle import detinit
+    from oracle.posenet import posenet_spec, trainable
+    from oracle.unet import unet_spec, unet_transposed_names
+    from oracle.step import Adam, advmix_step
+    from oracle.synth import synth_batch
+    net, extra, J, H, W, downs, _ = WORKLOADS[workload]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    detinit.mark_transposed(unet_transposed_names(9, 3, downs))
+    D = detinit.fill_state_dict(posenet_spec(net, extra, J))
+    T = {k: v.clone() for k, v in D.items()}
+    G = detinit.fill_state_dict(unet_spec(9, 3, downs), gain=0.5)
+    oD, oG = Adam(D, trainable(D)), Adam(G, list(G))
+    B = 4
+    v, t, w = synth_batch('bench.cpu', B, J, H, W)
+    kw = dict(unet_kw={'num_downs': downs})
+    advmix_step(net, extra, D, G, T, oD, oG, v, t, w, **kw)           # warm-up
+    n, t0 = 0, time.time()
+    while True:
+        advmix_step(net, extra, D, G, T, oD, oG, v, t, w, **kw)
+        n += 1
+        if time.time() - t0 > budget_s or n >= 10:
+            break
+    dt = time.time() - t0
+    return {'value': round(B * n / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%s AdvMix step, B=%d, %d timed steps after 1 warm-up, torch CPU fp32 oracle' % (workload, B, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='hrnet_w32', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU (TRAIN.BATCH_SIZE_PER_GPU)')
+    ap.add_argument('--exec', dest='exec_mode', default='graph', choices=['graph', 'eager'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus and world > 1:
+        raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    from advmix_amd.core.function import advmix_step
+    from advmix_amd.core.evaluate import accuracy
+    from advmix_amd.dp import GradSync
+    from advmix_amd.graph import AdvMixGraphRunner
+
+    net, extra, J, H, W, downs, gflop_img = WORKLOADS[a.workload]
+    cfg, D, G, T, crit, optD, optG = build_models(a.workload, device)
+    args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
+    views, tgt, tw = synth(a.batch, J, H, W, device, 1234 + rank)
+    sync = GradSync() if world > 1 else None
+
+    if a.exec_mode == 'graph':
+        runner = AdvMixGraphRunner(args, D, G, T, crit, optD, optG, views, tgt, tw, sync)
+
+        def one_step():
+            loss_D, out = runner.step()
+            lv = loss_D.item()                                         # function.py:167
+            _, avg_acc, cnt, _ = accuracy(out, runner.target)          # function.py:168
+            return lv, avg_acc
+    else:
+        def one_step():
+            loss_D, out = advmix_step(args, D, G, T, crit, optD, optG, views, tgt, tw, sync)
+            lv = loss_D.item()
+            _, avg_acc, cnt, _ = accuracy(out, tgt)
+            return lv, avg_acc
+
+    for _ in range(a.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        lv, acc = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if not (lv == lv):
+        raise SystemExit('loss is NaN')
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        value = a.batch * world * a.steps / dt
+        line = {
+            'metric': 'images/sec AdvMix train step (HRNet-W32 256x192)' if a.workload == 'hrnet_w32'
+            else 'images/sec AdvMix train step (%s)' % a.workload,
+            'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic (N(0,1) views, Gaussian targets), random-init weights',
+            'config': {'workload': '%s_%dx%d_advmix' % (a.workload, H, W), 'batch_per_gpu': a.batch,
+                       'global_batch': a.batch * world, 'generator': 'UnetGenerator(9,3,%d)' % downs,
+                       'parallelism': 'dp%d' % world, 'exec': 'hipgraph' if a.exec_mode == 'graph' else 'eager',
+                       'step_gflop_per_image': gflop_img},
+            'step_tflops_per_gpu': round(value / world * gflop_img / 1e3, 2),
+            'step_frac_of_fp32_mfma_peak': round(value / world * gflop_img / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
+            'last_loss_D': round(lv, 6),
+        }
+        if not a.no_roofline:
+            line['roofline'] = time_dominant_kernel(a.batch, device)
+        if world == 1 and not a.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(a.workload)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

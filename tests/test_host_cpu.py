@@ -25,7 +25,7 @@ def test_library_exports_every_header_symbol():
         assert hasattr(L.lib, n), n
     assert names - {'advmix_norm_ws_bytes'} == set(L.SIGNATURES), (names ^ set(L.SIGNATURES))
     assert L.lib.advmix_version() == 1
-    assert L.lib.advmix_norm_ws_bytes(1, 64) == 1024 * 2 * 64 * 8 + 2 * 64 * 4
+    assert L.lib.advmix_norm_ws_bytes(1, 64) == 512 * 2 * 64 * 8 + 2 * 64 * 4
 
 
 def _cfg(net, extra, J):

@@ -34,3 +34,8 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
+
+// conv_direct.hip: second-generation conv; returns -1 when the shape is not eligible
+int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const float* bias, float* y,
+                                int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
+                                int stride, int pad, int64_t Mmax, hipStream_t st);

@@ -1,0 +1,299 @@
+// Second-generation implicit-GEMM convolution for gfx950 (fp32 MFMA 32x32x2).
+//
+// What limited conv_igemm (rocprofv3 PMC, profiles/r01_pmc_conv32.txt): the MFMA pipe was 48 %
+// busy while waves sat 29 % of their life at barriers / s_waitcnt - every 16-deep k tile cost
+// two workgroup barriers and an LDS round trip for BOTH operands.  Here:
+//   * the activation operand never touches LDS: each lane loads its own MFMA A-fragment
+//     (row = output pixel, 4 consecutive channels = 16 B) straight from HBM/L2 into VGPRs with
+//     bounds-checked buffer loads - an out-of-image tap gets an out-of-range offset and the
+//     hardware returns 0.0f, so zero padding costs no select instructions;
+//   * loads for tap-chunk c+1 are issued before the MFMAs of chunk c (two named register sets,
+//     statically indexed), so a chunk's ~1000-2000 MFMA cycles cover the load latency;
+//     (a one-workgroup-per-CU persistent variant with cross-tile prefetch was measured and is
+//     SLOWER - 41.7 vs 26.2 us - one wave per SIMD cannot cover its own barrier/stage gaps);
+//   * only the weight chunk [BN][KC] is staged through LDS, double-buffered: ONE barrier per
+//     KC-deep chunk (16-32 MFMAs per wave) instead of two per 16-deep tile;
+//   * optional split over the K chunks (gridDim.z slices, fp32 atomics into a pre-zeroed
+//     output) for the low-resolution HRNet branches whose M x N tile grid is only 24-192
+//     workgroups on a 256-CU chip.
+// MODE 0 = forward gather (Conv2d fwd / ConvTranspose2d dgrad), MODE 1 = phase-decomposed
+// transposed gather (Conv2d dgrad / ConvTranspose2d fwd), exactly as conv_mfma.hip.
+#include "common.h"
+#include <stdlib.h>
+
+namespace direct {
+
+struct ConvD {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    int N, Hi, Wi, Ci;
+    int Ho, Wo, Co;
+    int R, S, stride, pad;
+    int xbytes, wbytes;     // buffer sizes for the hardware range check
+    int nsplit;             // K-chunk slices (gridDim.z = phases * nsplit)
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
+constexpr unsigned OOB = 0x80000000u;   // >= any buffer size we accept -> load returns 0
+
+template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT>
+__global__ __launch_bounds__(256) void conv_direct(ConvD p) {
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int KQ = KC / 8;                 // float4 k-groups per chunk (8 k each: 4 per lane half)
+    constexpr int LDB = KC + 4;
+    constexpr int BSL = (BN * KC / 4 + 255) / 256;
+
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDB];
+    __shared__ int4 taptab[64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wid / WN, wn = wid % WN;
+
+    int Hp, Wp, Th, Tw, rh = 0, rw = 0, phh = 0, phw = 0, zsl = blockIdx.z;
+    if (MODE == 0) {
+        Hp = p.Ho; Wp = p.Wo; Th = p.R; Tw = p.S;
+    } else {
+        const int phase = blockIdx.z / p.nsplit;
+        zsl = blockIdx.z - phase * p.nsplit;
+        rh = phase / p.stride; rw = phase % p.stride;
+        Hp = p.Ho > rh ? (p.Ho - rh + p.stride - 1) / p.stride : 0;
+        Wp = p.Wo > rw ? (p.Wo - rw + p.stride - 1) / p.stride : 0;
+        phh = (rh + p.pad) % p.stride; phw = (rw + p.pad) % p.stride;
+        Th = phh < p.R ? (p.R - phh + p.stride - 1) / p.stride : 0;
+        Tw = phw < p.S ? (p.S - phw + p.stride - 1) / p.stride : 0;
+    }
+    const int Mp = p.N * Hp * Wp;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= Mp) return;
+    const int ntaps = Th * Tw;
+    const int cpt = p.Ci / KC;                              // chunks per tap
+    const int nch_all = ntaps * cpt;
+    // this slice's chunk range
+    int ch_lo = 0, ch_hi = nch_all;
+    if (SPLIT) {
+        const int per = (nch_all + p.nsplit - 1) / p.nsplit;
+        ch_lo = zsl * per;
+        ch_hi = min(nch_all, ch_lo + per);
+        if (ch_lo >= ch_hi && !(zsl == 0)) return;          // empty slice (slice 0 still writes bias/zeros)
+    }
+    const int Kfull = p.R * p.S * p.Ci;
+
+    if (tid < ntaps) {
+        int4 t;
+        if (MODE == 0) {
+            t.x = tid / p.S; t.y = tid % p.S; t.z = tid * p.Ci;
+        } else {
+            int th = tid / Tw, tw = tid % Tw;
+            t.x = -th; t.y = -tw; t.z = ((phh + p.stride * th) * p.S + phw + p.stride * tw) * p.Ci;
+        }
+        t.w = 0;
+        taptab[tid] = t;
+    }
+
+    // ---- per-lane A rows -----------------------------------------------------------------
+    int a_nb[TM], a_h[TM], a_w[TM];
+    bool a_ok[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        int m = m0 + (wm * TM + t) * 32 + l31;
+        a_ok[t] = m < Mp;
+        int mm = a_ok[t] ? m : 0;
+        int n = mm / (Hp * Wp);
+        int rem = mm - n * (Hp * Wp);
+        int hi_ = rem / Wp, wi_ = rem - hi_ * Wp;
+        a_nb[t] = n * p.Hi * p.Wi;
+        if (MODE == 0) {
+            a_h[t] = hi_ * p.stride - p.pad;
+            a_w[t] = wi_ * p.stride - p.pad;
+        } else {
+            a_h[t] = (rh + hi_ * p.stride + p.pad - phh) / p.stride;
+            a_w[t] = (rw + wi_ * p.stride + p.pad - phw) / p.stride;
+        }
+    }
+    // ---- per-thread B staging slots --------------------------------------------------------
+    int b_row[BSL], b_k4[BSL];
+    unsigned b_off[BSL];
+#pragma unroll
+    for (int i = 0; i < BSL; ++i) {
+        int s = tid + 256 * i;
+        b_row[i] = s / (KC / 4);
+        b_k4[i] = (s % (KC / 4)) * 4;
+        bool ok = s < BN * KC / 4 && (n0 + b_row[i]) < p.Co;
+        b_off[i] = ok ? (unsigned)(((n0 + b_row[i]) * Kfull + b_k4[i]) * 4) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
+    __syncthreads();                                       // taptab visible
+
+    // Two named register sets (statically indexed): one being multiplied, one in flight.  A third
+    // set (two chunks of look-ahead) was measured and is NOT faster: 43.4 % vs 43.8 % on the
+    // 3x3 32->32 conv and 47 % vs 60 % on the 128x64 tile (130 VGPRs -> 2 waves/SIMD), i.e. the
+    // kernel is not bound by load latency per wave.
+    f32x4 A0[TM][KQ], A1[TM][KQ], Br[BSL];
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    // chunk cursor (of the chunk being ISSUED)
+    int tap = ch_lo / cpt;
+    int c0 = (ch_lo - tap * cpt) * KC;
+
+    auto issue = [&](f32x4 (&A)[TM][KQ]) {                 // loads of the chunk at (tap, c0)
+        const int4 tt = taptab[tap];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            int hi = a_h[t] + tt.x, wi = a_w[t] + tt.y;
+            bool ok = a_ok[t] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
+            unsigned off = ok ? (unsigned)(((a_nb[t] + hi * p.Wi + wi) * p.Ci + c0 + lh * 4) * 4) : OOB;
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) A[t][q] = bload(xr, off + q * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < BSL; ++i)
+            Br[i] = bload(wr, b_off[i] == OOB ? OOB : b_off[i] + (unsigned)((tt.z + c0) * 4));
+        c0 += KC;
+        if (c0 >= p.Ci) { c0 = 0; ++tap; }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < BSL; ++i)
+            if (tid + 256 * i < BN * KC / 4)
+                *reinterpret_cast<f32x4*>(&Bs[buf][b_row[i] * LDB + b_k4[i]]) = Br[i];
+    };
+    auto compute = [&](f32x4 (&A)[TM][KQ], int buf) {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            f32x4 b[TN];
+#pragma unroll
+            for (int u = 0; u < TN; ++u)
+                b[u] = *reinterpret_cast<const f32x4*>(&Bs[buf][((wn * TN + u) * 32 + l31) * LDB + q * 8 + lh * 4]);
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int u = 0; u < TN; ++u) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t][q][0], b[u][0], acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t][q][1], b[u][1], acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t][q][2], b[u][2], acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t][q][3], b[u][3], acc[t][u], 0, 0, 0);
+                }
+        }
+    };
+
+    const int nch = ch_hi - ch_lo;
+    if (nch > 0) {
+        issue(A0);
+        stage(0);
+        __syncthreads();
+        for (int ci = 0; ci < nch; ci += 2) {
+            // even chunk: multiply (A0, Bs[0]) while (A1, Br) of the next chunk are in flight
+            bool more = ci + 1 < nch;
+            if (more) issue(A1);
+            compute(A0, 0);
+            if (!more) break;
+            stage(1);
+            __syncthreads();
+            // odd chunk
+            more = ci + 2 < nch;
+            if (more) issue(A0);
+            compute(A1, 1);
+            if (more) { stage(0); __syncthreads(); }
+        }
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+        const int col = n0 + (wn * TN + u) * 32 + l31;
+        if (col >= p.Co) continue;
+        const float bv = (p.bias && (!SPLIT || zsl == 0)) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + (wm * TM + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= Mp) continue;
+                int64_t off;
+                if (MODE == 0) {
+                    off = (int64_t)m * p.Co + col;
+                } else {
+                    int n = m / (Hp * Wp);
+                    int rem = m - n * (Hp * Wp);
+                    int hi_ = rem / Wp, wi_ = rem - hi_ * Wp;
+                    off = ((int64_t)(n * p.Ho + rh + hi_ * p.stride) * p.Wo + rw + wi_ * p.stride) * p.Co + col;
+                }
+                if (SPLIT) atomicAdd(p.y + off, acc[t][u][r] + bv);
+                else p.y[off] = acc[t][u][r] + bv;
+            }
+        }
+    }
+}
+
+template <int MODE, int KC>
+int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
+    const int phases = MODE == 0 ? 1 : p.stride * p.stride;
+    const int maxtaps = MODE == 0 ? p.R * p.S : ((p.R + p.stride - 1) / p.stride) * ((p.S + p.stride - 1) / p.stride);
+    const int nch = maxtaps * (p.Ci / KC);
+#define LAUNCHD(TM_, TN_, WM_, WN_, SP_)                                                          \
+    do {                                                                                          \
+        dim3 g(cdiv(Mmax, 32 * TM_ * WM_), cdiv(p.Co, 32 * TN_ * WN_), phases * p.nsplit);        \
+        hipLaunchKernelGGL((conv_direct<TM_, TN_, WM_, WN_, KC, MODE, SP_>), g, dim3(256), 0, st, p); \
+    } while (0)
+    p.nsplit = 1;
+    if (p.Co <= 32) {
+        LAUNCHD(1, 1, 4, 1, false);                                        // 128 x 32
+    } else {
+        const int64_t b128 = (int64_t)cdiv(Mmax, 128) * cdiv(p.Co, 64) * phases;
+        if (b128 >= 512) {
+            LAUNCHD(1, 2, 4, 1, false);                                    // 128 x 64
+        } else {
+            const int64_t b64 = (int64_t)cdiv(Mmax, 64) * cdiv(p.Co, 64) * phases;
+            int ns = 1;
+            if (b64 < 256 && nch >= 8) {                                   // too few workgroups: split K
+                ns = (int)((512 + b64 - 1) / b64);
+                if (ns > nch / 4) ns = nch / 4;
+                if (ns > 8) ns = 8;
+                if (ns < 1) ns = 1;
+            }
+            if (ns > 1) {
+                p.nsplit = ns;
+                if (hipMemsetAsync(p.y, 0, (size_t)p.N * p.Ho * p.Wo * p.Co * sizeof(float), st) != hipSuccess)
+                    return ADVMIX_ELAUNCH;
+                LAUNCHD(1, 1, 2, 2, true);                                 // 64 x 64, K split + atomics
+            } else {
+                LAUNCHD(1, 1, 2, 2, false);                                // 64 x 64
+            }
+        }
+    }
+#undef LAUNCHD
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+}  // namespace direct
+
+// Returns -1 when the problem is not eligible (caller falls back to conv_igemm).
+int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const float* bias, float* y,
+                                int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
+                                int stride, int pad, int64_t Mmax, hipStream_t st) {
+    if (Ci % 16 != 0 || R * S > 64) return -1;
+    const int64_t xb = (int64_t)N * Hi * Wi * Ci * 4, wb = (int64_t)Co * R * S * Ci * 4;
+    if (xb >= 0x7fffffffLL || wb >= 0x7fffffffLL) return -1;
+    direct::ConvD p{x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, (int)xb, (int)wb, 1};
+    if (Ci % 32 == 0) return mode == 0 ? direct::launch<0, 32>(p, Mmax, st) : direct::launch<1, 32>(p, Mmax, st);
+    return mode == 0 ? direct::launch<0, 16>(p, Mmax, st) : direct::launch<1, 16>(p, Mmax, st);
+}

@@ -15,6 +15,7 @@
 // Replaces (reference): nn.Conv2d / nn.ConvTranspose2d in lib/models/pose_hrnet.py,
 // lib/models/pose_resnet.py, lib/models/Unet_generator.py (see include/advmix_hip.h).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -408,6 +409,15 @@ int launch_igemm(const ConvP& p, int64_t Mmax, hipStream_t st) {
     return ADVMIX_OK;
 }
 
+static bool use_direct() {
+    static int v = -1;                                   // ADVMIX_CONV=igemm forces the first-generation kernel (A/B runs)
+    if (v < 0) {
+        const char* e = getenv("ADVMIX_CONV");
+        v = (e && e[0] == 'i') ? 0 : 1;
+    }
+    return v == 1;
+}
+
 }  // namespace
 
 extern "C" int advmix_conv_fwd(const float* x, const float* w, const float* bias, float* y,
@@ -415,6 +425,11 @@ extern "C" int advmix_conv_fwd(const float* x, const float* w, const float* bias
                                int R, int S, int stride, int pad, void* stream) {
     if (!x || !w || !y || N <= 0 || Ci <= 0 || Co <= 0 || R * S > 64 || stride < 1) return ADVMIX_EINVAL;
     if (Ho != (Hi + 2 * pad - R) / stride + 1 || Wo != (Wi + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
+    if (use_direct()) {
+        int rc = advmix_conv_direct_dispatch(0, x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad,
+                                             (int64_t)N * Ho * Wo, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     ConvP p{x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad};
     return launch_igemm<0>(p, (int64_t)N * Ho * Wo, (hipStream_t)stream);
 }
@@ -426,8 +441,13 @@ extern "C" int advmix_conv_tr(const float* x, const float* wt, const float* bias
         return ADVMIX_EINVAL;
     // (Hb, Wb) must be a valid input size for a conv producing (Hs, Ws)
     if (Hs != (Hb + 2 * pad - R) / stride + 1 || Ws != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
-    ConvP p{x, wt, bias, y, N, Hs, Ws, Ck, Hb, Wb, Cn, R, S, stride, pad};
     int64_t Mmax = (int64_t)N * cdiv(Hb, stride) * cdiv(Wb, stride);
+    if (use_direct()) {
+        int rc = advmix_conv_direct_dispatch(1, x, wt, bias, y, N, Hs, Ws, Ck, Hb, Wb, Cn, R, S, stride, pad, Mmax,
+                                             (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
+    ConvP p{x, wt, bias, y, N, Hs, Ws, Ck, Hb, Wb, Cn, R, S, stride, pad};
     return launch_igemm<1>(p, Mmax, (hipStream_t)stream);
 }
 

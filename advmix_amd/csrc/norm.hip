@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void norm_partial(const float* __restrict__ x,
     const int64_t gend = (int64_t)(g + 1) * Mg;
     if (r1 > gend) r1 = gend;
     const int CV = C >> 2;
-    double* out = partial + ((int64_t)g * nbg + blk) * 2 * C;
+    double* out = partial + (int64_t)g * 2 * C * nbg + blk;      // [g][2][C][nbg]: element (k, c) at (k*C + c)*nbg
     const int tid = threadIdx.x;
     if (CV >= 256) {
         for (int cv = tid; cv < CV; cv += 256) {
@@ -89,7 +89,10 @@ __global__ __launch_bounds__(256) void norm_partial(const float* __restrict__ x,
             }
             for (int64_t r = r0; r < r1; ++r) accum4<KIND>(s0, s1, x, dy, y, r, ldy, C, cv * 4, mu, is, act);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { out[cv * 4 + e] = s0.v[e]; out[C + cv * 4 + e] = s1.v[e]; }
+            for (int e = 0; e < 4; ++e) {
+                out[(int64_t)(cv * 4 + e) * nbg] = s0.v[e];
+                out[(int64_t)(C + cv * 4 + e) * nbg] = s1.v[e];
+            }
         }
         return;
     }
@@ -118,7 +121,10 @@ __global__ __launch_bounds__(256) void norm_partial(const float* __restrict__ x,
     }
     if (rr == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { out[cv * 4 + e] = red[0][tid].v[e]; out[C + cv * 4 + e] = red[1][tid].v[e]; }
+        for (int e = 0; e < 4; ++e) {
+            out[(int64_t)(cv * 4 + e) * nbg] = red[0][tid].v[e];
+            out[(int64_t)(C + cv * 4 + e) * nbg] = red[1][tid].v[e];
+        }
     }
 }
 
@@ -133,7 +139,7 @@ __global__ void norm_partial_scalar(const float* __restrict__ x, const float* __
     int64_t r1 = r0 + rows_per_block;
     const int64_t gend = (int64_t)(g + 1) * Mg;
     if (r1 > gend) r1 = gend;
-    double* out = partial + ((int64_t)g * nbg + blk) * 2 * C;
+    double* out = partial + (int64_t)g * 2 * C * nbg + blk;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         double s0 = 0.0, s1 = 0.0;
         float mu = KIND ? mean[(int64_t)g * C + c] : 0.f, is = KIND ? invstd[(int64_t)g * C + c] : 0.f;
@@ -145,8 +151,8 @@ __global__ void norm_partial_scalar(const float* __restrict__ x, const float* __
                 s0 += (double)gg; s1 += (double)gg * (double)((xv - mu) * is);
             }
         }
-        out[c] = s0;
-        out[C + c] = s1;
+        out[(int64_t)c * nbg] = s0;
+        out[(int64_t)(C + c) * nbg] = s1;
     }
 }
 
@@ -154,10 +160,11 @@ __global__ void norm_partial_scalar(const float* __restrict__ x, const float* __
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partial, int nbg, int g, int c, int C,
                                                 int lane, double& s, double& ss) {
     s = 0.0; ss = 0.0;
+    const double* p0 = partial + ((int64_t)g * 2 * C + c) * nbg;
+    const double* p1 = partial + ((int64_t)g * 2 * C + C + c) * nbg;
     for (int b = lane; b < nbg; b += 64) {
-        const double* pp = partial + ((int64_t)g * nbg + b) * 2 * C;
-        s += pp[c];
-        ss += pp[C + c];
+        s += p0[b];
+        ss += p1[b];
     }
     s = wave_sum_d(s);
     ss = wave_sum_d(ss);
@@ -249,12 +256,22 @@ __global__ __launch_bounds__(256) void bn_eval_kernel(const float* __restrict__ 
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t r = i / CV;
         int c = (int)(i - r * CV) * V;
+        if (VEC) {
+            f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * C + c);
+            f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+            f32x4 m = *reinterpret_cast<const f32x4*>(rm + c), v = *reinterpret_cast<const f32x4*>(rv + c);
+            f32x4 o;
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            float is = 1.0f / sqrtf(rv[c + e] + eps);
-            float o = (x[r * C + c + e] - rm[c + e]) * is * gamma[c + e] + beta[c + e];
-            if (res) o += res[r * C + c + e];
-            y[r * C + c + e] = act_fwd(o, act);
+            for (int e = 0; e < 4; ++e) o[e] = (xv[e] - m[e]) * (1.0f / sqrtf(v[e] + eps)) * g[e] + bt[e];
+            if (res) o += *reinterpret_cast<const f32x4*>(res + r * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = act_fwd(o[e], act);
+            *reinterpret_cast<f32x4*>(y + r * C + c) = o;
+        } else {
+            float is = 1.0f / sqrtf(rv[c] + eps);
+            float o = (x[r * C + c] - rm[c]) * is * gamma[c] + beta[c];
+            if (res) o += res[r * C + c];
+            y[r * C + c] = act_fwd(o, act);
         }
     }
 }
@@ -275,16 +292,31 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(const float* __restrict__ 
         int64_t r = i / CV;
         int c = (int)(i - r * CV) * V;
         int64_t g = r / Mg;
+        if (VEC) {
+            f32x4 gg = *reinterpret_cast<const f32x4*>(dy + r * ldy + c);
+            if (act != ADVMIX_ACT_NONE) {
+                f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * ldy + c);
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            int cc = c + e;
-            float gg = dy[r * ldy + cc];
-            if (act != ADVMIX_ACT_NONE) gg *= act_grad(y[r * ldy + cc], act);
-            float is = invstd[g * C + cc];
-            float xh = (x[r * C + cc] - mean[g * C + cc]) * is;
-            float k = gamma ? gamma[cc] * is : is;
-            dx[r * C + cc] = k * (gg - coef[(g * 2) * C + cc] - xh * coef[(g * 2 + 1) * C + cc]);
-            if (dres) dres[r * C + cc] = gg;
+                for (int e = 0; e < 4; ++e) gg[e] *= act_grad(yv[e], act);
+            }
+            f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * C + c);
+            f32x4 is = *reinterpret_cast<const f32x4*>(invstd + g * C + c);
+            f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * C + c);
+            f32x4 c1 = *reinterpret_cast<const f32x4*>(coef + (g * 2) * C + c);
+            f32x4 c2 = *reinterpret_cast<const f32x4*>(coef + (g * 2 + 1) * C + c);
+            f32x4 k = is;
+            if (gamma) k = k * *reinterpret_cast<const f32x4*>(gamma + c);
+            f32x4 xh = (xv - mu) * is;
+            *reinterpret_cast<f32x4*>(dx + r * C + c) = k * (gg - c1 - xh * c2);
+            if (dres) *reinterpret_cast<f32x4*>(dres + r * C + c) = gg;
+        } else {
+            float gg = dy[r * ldy + c];
+            if (act != ADVMIX_ACT_NONE) gg *= act_grad(y[r * ldy + c], act);
+            float is = invstd[g * C + c];
+            float xh = (x[r * C + c] - mean[g * C + c]) * is;
+            float k = gamma ? gamma[c] * is : is;
+            dx[r * C + c] = k * (gg - coef[(g * 2) * C + c] - xh * coef[(g * 2 + 1) * C + c]);
+            if (dres) dres[r * C + c] = gg;
         }
     }
 }

@@ -92,60 +92,52 @@ def build_models(workload, device):
     return cfg, D, G, T, crit, optD, optG
 
 
-def time_dominant_kernel(B, device, iters=30):
+def time_dominant_kernel(B, device, iters=100):
     """HIP-event timing of the dominant kernel: the 3x3 s1 32->32 conv on the 64x48 branch
-    (64 launches per HRNet-W32 forward; conv_igemm<128,32,fwd,vec>).  Events are recorded on the
-    stream the kernel is launched on (torch's current stream)."""
-    from advmix_amd import ops
-    x = torch.randn(B, 32, 64, 48, device=device).contiguous(memory_format=torch.channels_last)
-    w = torch.nn.Parameter((torch.randn(32, 32, 3, 3, device=device) * 0.05).contiguous(memory_format=torch.channels_last),
-                           requires_grad=False)
-    with torch.no_grad():
-        for _ in range(5):
-            ops.conv2d(x, w, None, 1, 1)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(iters):
-            ops.conv2d(x, w, None, 1, 1)
-        e1.record()
-        torch.cuda.synchronize()
+    (64 launches per HRNet-W32 forward), launched back to back through the C ABI (ctypes adds
+    ~3 us of host time per call, below the kernel time, so the event average is the launch
+    duration).  Events are recorded on the stream the kernel is launched on."""
+    import ctypes
+    from advmix_amd._lib import call
+    x = torch.randn(B, 64, 48, 32, device=device)
+    w = torch.randn(32, 3, 3, 32, device=device) * 0.05
+    y = torch.empty(B, 64, 48, 32, device=device)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    run = lambda: call('advmix_conv_fwd', P(x), P(w), None, P(y), B, 64, 48, 32, 64, 48, 32, 3, 3, 1, 1, st)  # noqa: E731
+    for _ in range(10):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * B * 64 * 48 * 32 * 32 * 9
-    return {'bound': 'mfma', 'kernel': 'conv_igemm<128,32,fwd,vec4> 3x3 s1 32->32 @64x48',
+    return {'bound': 'mfma', 'kernel': 'conv_direct<1,1,4,1,32,fwd> 3x3 s1 32->32 @64x48 (128x32 tile)',
             'achieved': round(flops / (ms * 1e-3) / 1e12, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
             'us_per_launch': round(ms * 1e3, 2), 'algorithmic_gflop_per_launch': round(flops / 1e9, 3)}
 
 
-def cpu_baseline(workload, budget_s=25.0):
-    """The CPU oracle's AdvMix step on this host (bounded sample: B=4, >=1 warm-up + timed steps)."""
-    from oracle import detinit
-    from oracle.posenet import posenet_spec, trainable
-    from oracle.unet import unet_spec, unet_transposed_names
-    from oracle.step import Adam, advmix_step
-    from oracle.synth import synth_batch
-    net, extra, J, H, W, downs, _ = WORKLOADS[workload]
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    detinit.mark_transposed(unet_transposed_names(9, 3, downs))
-    D = detinit.fill_state_dict(posenet_spec(net, extra, J))
-    T = {k: v.clone() for k, v in D.items()}
-    G = detinit.fill_state_dict(unet_spec(9, 3, downs), gain=0.5)
-    oD, oG = Adam(D, trainable(D)), Adam(G, list(G))
-    B = 4
-    v, t, w = synth_batch('bench.cpu', B, J, H, W)
-    kw = dict(unet_kw={'num_downs': downs})
-    advmix_step(net, extra, D, G, T, oD, oG, v, t, w, **kw)           # warm-up
-    n, t0 = 0, time.time()
-    while True:
-        advmix_step(net, extra, D, G, T, oD, oG, v, t, w, **kw)
-        n += 1
-        if time.time() - t0 > budget_s or n >= 10:
-            break
-    dt = time.time() - t0
-    return {'value': round(B * n / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': '%s AdvMix step, B=%d, %d timed steps after 1 warm-up, torch CPU fp32 oracle' % (workload, B, n)}
+def cpu_baseline(workload, budget_s=25.0, hard_timeout_s=150.0):
+    """The CPU oracle's AdvMix step on this host (bounded sample: B=4, 1 warm-up + a few timed
+    steps), in a CPU-only child process with a hard timeout so the bench always finishes."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'cpu_bench.py'), workload, str(budget_s)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=hard_timeout_s, env=env, cwd=ROOT)
+        for ln in reversed(out.stdout.strip().splitlines()):
+            if ln.startswith('{'):
+                return json.loads(ln)
+        return {'value': None, 'unit': 'images/sec', 'cores': 0, 'kind': 'port',
+                'sample': 'cpu oracle failed: ' + (out.stderr.strip().splitlines() or ['?'])[-1][:200]}
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'unit': 'images/sec', 'cores': 0, 'kind': 'port',
+                'sample': 'cpu oracle exceeded the %.0fs hard timeout' % hard_timeout_s}
 
 
 def main():

@@ -1,0 +1,72 @@
+"""Time the CPU oracle's AdvMix step on the host cores (bench.py's cpu_baseline leg runs this
+in a child process with a hard timeout).  Test infrastructure; prints one JSON line."""
+import json
+import os
+import sys
+import time
+
+
+def effective_cpus(cap=32):
+    """CPUs this process may really use: affinity mask, cgroup quota and a cap (an OpenMP team
+    wider than the quota spins instead of working)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                    n = min(n, max(1, q // p))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, cap))
+
+
+def main():
+    workload, budget = sys.argv[1], float(sys.argv[2])
+    cores = effective_cpus()
+    os.environ.setdefault('OMP_NUM_THREADS', str(cores))
+    import torch
+    torch.set_num_threads(cores)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import detinit, configs
+    from oracle.posenet import posenet_spec, trainable
+    from oracle.unet import unet_spec, unet_transposed_names
+    from oracle.step import Adam, advmix_step
+    from oracle.synth import synth_batch
+    W = {'hrnet_w32': ('pose_hrnet', configs.HRNET_W32, 17, 256, 192, 6),
+         'hrnet_w48': ('pose_hrnet', configs.HRNET_W48, 17, 384, 288, 5),
+         'resnet50': ('pose_resnet', configs.RES50, 17, 256, 192, 6)}
+    net, extra, J, H, Wd, downs = W[workload]
+    detinit.mark_transposed(unet_transposed_names(9, 3, downs))
+    D = detinit.fill_state_dict(posenet_spec(net, extra, J))
+    T = {k: v.clone() for k, v in D.items()}
+    G = detinit.fill_state_dict(unet_spec(9, 3, downs), gain=0.5)
+    oD, oG = Adam(D, trainable(D)), Adam(G, list(G))
+    B = 4
+    v, t, w = synth_batch('bench.cpu', B, J, H, Wd)
+    kw = dict(unet_kw={'num_downs': downs})
+    t0 = time.time()
+    advmix_step(net, extra, D, G, T, oD, oG, v, t, w, **kw)           # warm-up
+    warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while n < 8 and (n == 0 or time.time() - t0 + warm < budget):
+        advmix_step(net, extra, D, G, T, oD, oG, v, t, w, **kw)
+        n += 1
+    dt = time.time() - t0
+    print(json.dumps({'value': round(B * n / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+                      'sample': '%s AdvMix step, B=%d, %d timed steps after 1 warm-up (%.1fs), torch CPU fp32 '
+                                'oracle, %d threads (os.cpu_count=%d)' % (workload, B, n, warm, cores,
+                                                                           os.cpu_count() or 0)}), flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Time one conv configuration through the C ABI directly (ctypes, ~3 us/call of host overhead,
+so the HIP-event average is the kernel's launch-to-launch time, not Python's).
+usage: microbench_conv.py B Ci H W Co k stride pad [mode=fwd|dgrad|wgrad] [iters]"""
+import ctypes, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from advmix_amd._lib import call
+
+B, Ci, H, W, Co, k, s, p = [int(v) for v in sys.argv[1:9]]
+mode = sys.argv[9] if len(sys.argv) > 9 else 'fwd'
+iters = int(sys.argv[10]) if len(sys.argv) > 10 else 50
+dev = torch.device('cuda:0')
+Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+x = torch.randn(B, H, W, Ci, device=dev)
+w = torch.randn(Co, k, k, Ci, device=dev) * 0.05
+wt = torch.randn(Ci, k, k, Co, device=dev) * 0.05
+y = torch.randn(B, Ho, Wo, Co, device=dev)
+dw = torch.zeros(Co, k, k, Ci, device=dev)
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+if mode == 'fwd':
+    run = lambda: call('advmix_conv_fwd', P(x), P(w), None, P(y), B, H, W, Ci, Ho, Wo, Co, k, k, s, p, st)
+elif mode == 'dgrad':
+    run = lambda: call('advmix_conv_tr', P(y), P(wt), None, P(x), B, Ho, Wo, Co, H, W, Ci, k, k, s, p, st)
+else:
+    run = lambda: call('advmix_conv_wgrad', P(y), P(x), P(dw), B, Ho, Wo, Co, H, W, Ci, k, k, s, p, st)
+for _ in range(5):
+    run()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(iters):
+    run()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / iters
+fl = 2.0 * B * Ho * Wo * Co * Ci * k * k
+print('%-5s B%d Ci%d %dx%d Co%d k%d s%d [%s]: %.1f us/launch  %.1f TFLOP/s (%.1f%% of 157.3)' % (
+    mode, B, Ci, H, W, Co, k, s, os.environ.get('ADVMIX_CONV', 'direct'), ms * 1e3, fl / ms / 1e9,
+    fl / ms / 1e9 / 157.3 * 100))

@@ -19,6 +19,7 @@ _p, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 # name -> argtypes, mirrors include/advmix_hip.h line by line
 SIGNATURES = {
     'advmix_version': [],
+    'advmix_set_option': [ctypes.c_char_p, _i],
     'advmix_conv_fwd': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_tr': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],

@@ -3,6 +3,8 @@
 // Reference sites: lib/core/function.py:137-144; lib/core/loss.py:25-65;
 // lib/core/inference.py:22-49; lib/utils/utils.py:89-92 (torch.optim.Adam defaults).
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -164,7 +166,31 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 }  // namespace
 
+AdvmixOpts& advmix_opts() {
+    static AdvmixOpts o = [] {
+        AdvmixOpts d{1, 1, 512, 256};
+        const char* e;
+        if ((e = getenv("ADVMIX_CONV")) && e[0] == 'i') d.direct = 0;
+        if ((e = getenv("ADVMIX_CONV3")) && e[0] == '0') d.conv3 = 0;
+        if ((e = getenv("ADVMIX_CONV3_MIN_ITEMS"))) d.conv3_min_items = atoi(e);
+        if ((e = getenv("ADVMIX_CONV3_GRID"))) d.conv3_grid = atoi(e);
+        return d;
+    }();
+    return o;
+}
+
 extern "C" int advmix_version(void) { return 1; }
+
+extern "C" int advmix_set_option(const char* name, int value) {
+    if (!name) return ADVMIX_EINVAL;
+    AdvmixOpts& o = advmix_opts();
+    if (!strcmp(name, "direct")) o.direct = value;
+    else if (!strcmp(name, "conv3")) o.conv3 = value;
+    else if (!strcmp(name, "conv3_min_items")) o.conv3_min_items = value;
+    else if (!strcmp(name, "conv3_grid")) o.conv3_grid = value > 0 ? value : 256;
+    else return ADVMIX_EINVAL;
+    return ADVMIX_OK;
+}
 
 extern "C" int advmix_cat_views(const float* v0, const float* v1, const float* v2, float* out, int N, int H, int W,
                                 void* stream) {

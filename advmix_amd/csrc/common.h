@@ -39,3 +39,16 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const float* bias, float* y,
                                 int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
                                 int stride, int pad, int64_t Mmax, hipStream_t st);
+
+// conv3x3_lds.hip: LDS-resident-patch 3x3/s1/p1 conv (flip = 1: its input gradient); -1 = not eligible
+int advmix_conv3x3_lds_dispatch(int flip, const float* x, const float* w, const float* bias, float* y, int N, int H,
+                                int W, int Ci, int Co, hipStream_t st);
+
+// runtime-tunable dispatch options (advmix_set_option / ADVMIX_* environment at first use)
+struct AdvmixOpts {
+    int direct;            // 1: conv_direct / conv3x3_lds allowed, 0: first-generation conv_igemm only
+    int conv3;             // 1: LDS-patch 3x3 kernel allowed
+    int conv3_min_items;   // minimum (tile x chunk) items before the persistent 3x3 kernel is used
+    int conv3_grid;        // persistent workgroups (256 = one per CU)
+};
+AdvmixOpts& advmix_opts();

@@ -409,14 +409,7 @@ int launch_igemm(const ConvP& p, int64_t Mmax, hipStream_t st) {
     return ADVMIX_OK;
 }
 
-static bool use_direct() {
-    static int v = -1;                                   // ADVMIX_CONV=igemm forces the first-generation kernel (A/B runs)
-    if (v < 0) {
-        const char* e = getenv("ADVMIX_CONV");
-        v = (e && e[0] == 'i') ? 0 : 1;
-    }
-    return v == 1;
-}
+static bool use_direct() { return advmix_opts().direct != 0; }
 
 }  // namespace
 
@@ -425,6 +418,10 @@ extern "C" int advmix_conv_fwd(const float* x, const float* w, const float* bias
                                int R, int S, int stride, int pad, void* stream) {
     if (!x || !w || !y || N <= 0 || Ci <= 0 || Co <= 0 || R * S > 64 || stride < 1) return ADVMIX_EINVAL;
     if (Ho != (Hi + 2 * pad - R) / stride + 1 || Wo != (Wi + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
+    if (use_direct() && R == 3 && S == 3 && stride == 1 && pad == 1) {
+        int rc = advmix_conv3x3_lds_dispatch(0, x, w, bias, y, N, Hi, Wi, Ci, Co, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     if (use_direct()) {
         int rc = advmix_conv_direct_dispatch(0, x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad,
                                              (int64_t)N * Ho * Wo, (hipStream_t)stream);
@@ -442,6 +439,11 @@ extern "C" int advmix_conv_tr(const float* x, const float* wt, const float* bias
     // (Hb, Wb) must be a valid input size for a conv producing (Hs, Ws)
     if (Hs != (Hb + 2 * pad - R) / stride + 1 || Ws != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
     int64_t Mmax = (int64_t)N * cdiv(Hb, stride) * cdiv(Wb, stride);
+    if (use_direct() && R == 3 && S == 3 && stride == 1 && pad == 1) {
+        // the adjoint of a 3x3/s1/p1 conv is the same conv on dY with mirrored taps
+        int rc = advmix_conv3x3_lds_dispatch(1, x, wt, bias, y, N, Hs, Ws, Ck, Cn, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     if (use_direct()) {
         int rc = advmix_conv_direct_dispatch(1, x, wt, bias, y, N, Hs, Ws, Ck, Hb, Wb, Cn, R, S, stride, pad, Mmax,
                                              (hipStream_t)stream);

@@ -35,6 +35,9 @@ extern "C" {
 #define ADVMIX_ACT_LEAKY02 2   /* LeakyReLU(0.2), lib/models/Unet_generator.py:42 */
 
 int advmix_version(void);
+/* dispatch knobs for A/B runs and tests: "direct" (0 = first-generation conv only), "conv3" (LDS-patch 3x3
+ * kernel on/off), "conv3_min_items", "conv3_grid".  Unknown name -> ADVMIX_EINVAL. */
+int advmix_set_option(const char* name, int value);
 
 /* ---- convolution family: replaces nn.Conv2d / nn.ConvTranspose2d forward+backward
  * (lib/models/pose_hrnet.py:22-25,65-71,200-232,323-349,411-417;

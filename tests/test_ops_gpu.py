@@ -54,11 +54,28 @@ CONV_CASES = [
     (2, 256, 8, 6, 256, 3, 1, 1, False),
     (2, 512, 6, 4, 512, 4, 2, 1, True),
     (2, 40, 7, 5, 72, 3, 1, 1, True),
+    (2, 64, 20, 24, 48, 3, 1, 1, True),     # LDS-patch kernel: 2 channel chunks, ragged tiles, Co % 32 != 0
+    (1, 32, 9, 17, 32, 3, 1, 1, False),
+    (2, 96, 16, 16, 64, 3, 1, 1, False),
 ]
 
 
+@pytest.fixture(params=['auto', 'lds3x3', 'direct', 'igemm'])
+def conv_path(request):
+    """Force each generation of the conv kernels in turn (advmix_set_option)."""
+    from advmix_amd._lib import call
+    cfg = {'auto': (1, 1, 512), 'lds3x3': (1, 1, 1), 'direct': (1, 0, 512), 'igemm': (0, 0, 512)}[request.param]
+    call('advmix_set_option', b'direct', cfg[0])
+    call('advmix_set_option', b'conv3', cfg[1])
+    call('advmix_set_option', b'conv3_min_items', cfg[2])
+    yield request.param
+    call('advmix_set_option', b'direct', 1)
+    call('advmix_set_option', b'conv3', 1)
+    call('advmix_set_option', b'conv3_min_items', 512)
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv2d_fwd_dgrad_wgrad(case):
+def test_conv2d_fwd_dgrad_wgrad(case, conv_path):
     ops = _ops()
     B, Ci, H, W, Co, k, s, p, hb = case
     x = rnd(B, Ci, H, W, seed=1)

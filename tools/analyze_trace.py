@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 kernel_trace.csv: busy fraction, concurrency, per-kernel totals for the
+steady-state tail of the run.  usage: analyze_trace.py <kernel_trace.csv> [tail_fraction]"""
+import collections, csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
+ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows)
+t0, t1 = ev[0][0], max(e[1] for e in ev)
+cut = t0 + int((t1 - t0) * (1 - frac))
+sel = [e for e in ev if e[0] >= cut]
+span = max(e[1] for e in sel) - sel[0][0]
+busy, cs, ce = 0, sel[0][0], sel[0][1]
+for s, e, _ in sel[1:]:
+    if s > ce:
+        busy += ce - cs; cs, ce = s, e
+    else:
+        ce = max(ce, e)
+busy += ce - cs
+tot = sum(e[1] - e[0] for e in sel)
+print('window %.1f ms  busy(union) %.1f ms (%.1f%%)  sum of kernels %.1f ms  (avg concurrency %.2f)  launches %d' % (
+    span / 1e6, busy / 1e6, 100 * busy / span, tot / 1e6, tot / busy, len(sel)))
+agg = collections.defaultdict(lambda: [0, 0])
+for s, e, n in sel:
+    n = n.replace('(anonymous namespace)::', '').replace('void ', '')
+    n = n.split('(')[0][:80]
+    agg[n][0] += e - s; agg[n][1] += 1
+for n, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:30]:
+    print('%6.2f%%  calls %6d  avg %8.1f us  %s' % (100 * d / tot, c, d / c / 1e3, n))

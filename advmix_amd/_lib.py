@@ -22,6 +22,7 @@ SIGNATURES = {
     'advmix_set_option': [ctypes.c_char_p, _i],
     'advmix_conv_fwd': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_tr': [_p, _p, _p, _p] + [_i] * 11 + [_p],
+    'advmix_conv_tr_w': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],
     'advmix_transpose_w': [_p, _p, _i, _i, _i, _p],
     'advmix_bias_grad': [_p, _p, _l, _i, _p],

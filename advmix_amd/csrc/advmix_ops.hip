@@ -168,10 +168,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 AdvmixOpts& advmix_opts() {
     static AdvmixOpts o = [] {
-        AdvmixOpts d{1, 1, 512, 256};
+        // conv3 (LDS-patch persistent 3x3) is opt-in: alone it wins on 128->128 @16x12 (28.7 vs 34.9 us)
+        // but one 135-KB-LDS workgroup per CU blocks the concurrent lanes: 89.9 vs 86.3 ms per AdvMix step
+        AdvmixOpts d{1, 0, 512, 256};
         const char* e;
         if ((e = getenv("ADVMIX_CONV")) && e[0] == 'i') d.direct = 0;
-        if ((e = getenv("ADVMIX_CONV3")) && e[0] == '0') d.conv3 = 0;
+        if ((e = getenv("ADVMIX_CONV3"))) d.conv3 = e[0] != '0';
         if ((e = getenv("ADVMIX_CONV3_MIN_ITEMS"))) d.conv3_min_items = atoi(e);
         if ((e = getenv("ADVMIX_CONV3_GRID"))) d.conv3_grid = atoi(e);
         return d;

@@ -38,7 +38,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // conv_direct.hip: second-generation conv; returns -1 when the shape is not eligible
 int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const float* bias, float* y,
                                 int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
-                                int stride, int pad, int64_t Mmax, hipStream_t st);
+                                int stride, int pad, int64_t Mmax, hipStream_t st, int bt = 0);
 
 // conv3x3_lds.hip: LDS-resident-patch 3x3/s1/p1 conv (flip = 1: its input gradient); -1 = not eligible
 int advmix_conv3x3_lds_dispatch(int flip, const float* x, const float* w, const float* bias, float* y, int N, int H,

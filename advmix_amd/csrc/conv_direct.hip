@@ -44,7 +44,10 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 
 constexpr unsigned OOB = 0x80000000u;   // >= any buffer size we accept -> load returns 0
 
-template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT>
+// BT: the weight operand is given k-major, w[Ck][R][S][Cn] (a Conv2d's own [Co][R][S][Ci] seen from its
+// input gradient, a ConvTranspose2d's own [Ci][R][S][Co] seen from its forward): a thread loads 4
+// consecutive n of one k and scatters them into the [n][k] LDS image, so no re-layout kernel is needed.
+template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT>
 __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
             int th = tid / Tw, tw = tid % Tw;
             t.x = -th; t.y = -tw; t.z = ((phh + p.stride * th) * p.S + phw + p.stride * tw) * p.Ci;
         }
-        t.w = 0;
+        t.w = t.z / p.Ci;                                   // r*S + s (BT addressing)
         taptab[tid] = t;
     }
 
@@ -127,10 +130,17 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
 #pragma unroll
     for (int i = 0; i < BSL; ++i) {
         int s = tid + 256 * i;
-        b_row[i] = s / (KC / 4);
-        b_k4[i] = (s % (KC / 4)) * 4;
-        bool ok = s < BN * KC / 4 && (n0 + b_row[i]) < p.Co;
-        b_off[i] = ok ? (unsigned)(((n0 + b_row[i]) * Kfull + b_k4[i]) * 4) : OOB;
+        if (!BT) {
+            b_row[i] = s / (KC / 4);                        // n
+            b_k4[i] = (s % (KC / 4)) * 4;                   // k (4 consecutive)
+            bool ok = s < BN * KC / 4 && (n0 + b_row[i]) < p.Co;
+            b_off[i] = ok ? (unsigned)(((n0 + b_row[i]) * Kfull + b_k4[i]) * 4) : OOB;
+        } else {
+            b_k4[i] = s / (BN / 4);                         // k (one)
+            b_row[i] = (s % (BN / 4)) * 4;                  // n (4 consecutive; Co % 4 == 0 is checked on the host)
+            bool ok = s < BN * KC / 4 && (n0 + b_row[i]) < p.Co;
+            b_off[i] = ok ? (unsigned)((b_k4[i] * p.R * p.S * p.Co + n0 + b_row[i]) * 4) : OOB;
+        }
     }
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
@@ -165,15 +175,23 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
         }
 #pragma unroll
         for (int i = 0; i < BSL; ++i)
-            Br[i] = bload(wr, b_off[i] == OOB ? OOB : b_off[i] + (unsigned)((tt.z + c0) * 4));
+            Br[i] = bload(wr, b_off[i] == OOB ? OOB
+                              : b_off[i] + (BT ? (unsigned)(((c0 * p.R * p.S + tt.w) * p.Co) * 4)
+                                             : (unsigned)((tt.z + c0) * 4)));
         c0 += KC;
         if (c0 >= p.Ci) { c0 = 0; ++tap; }
     };
     auto stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < BSL; ++i)
-            if (tid + 256 * i < BN * KC / 4)
-                *reinterpret_cast<f32x4*>(&Bs[buf][b_row[i] * LDB + b_k4[i]]) = Br[i];
+            if (tid + 256 * i < BN * KC / 4) {
+                if (!BT) {
+                    *reinterpret_cast<f32x4*>(&Bs[buf][b_row[i] * LDB + b_k4[i]]) = Br[i];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Bs[buf][(b_row[i] + e) * LDB + b_k4[i]] = Br[i][e];
+                }
+            }
     };
     auto compute = [&](f32x4 (&A)[TM][KQ], int buf) {
 #pragma unroll
@@ -243,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     }
 }
 
-template <int MODE, int KC>
+template <int MODE, int KC, bool BT>
 int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
     const int phases = MODE == 0 ? 1 : p.stride * p.stride;
     const int maxtaps = MODE == 0 ? p.R * p.S : ((p.R + p.stride - 1) / p.stride) * ((p.S + p.stride - 1) / p.stride);
@@ -251,7 +269,7 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
 #define LAUNCHD(TM_, TN_, WM_, WN_, SP_)                                                          \
     do {                                                                                          \
         dim3 g(cdiv(Mmax, 32 * TM_ * WM_), cdiv(p.Co, 32 * TN_ * WN_), phases * p.nsplit);        \
-        hipLaunchKernelGGL((conv_direct<TM_, TN_, WM_, WN_, KC, MODE, SP_>), g, dim3(256), 0, st, p); \
+        hipLaunchKernelGGL((conv_direct<TM_, TN_, WM_, WN_, KC, MODE, SP_, BT>), g, dim3(256), 0, st, p); \
     } while (0)
     p.nsplit = 1;
     if (p.Co <= 32) {
@@ -287,13 +305,17 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
 }  // namespace direct
 
 // Returns -1 when the problem is not eligible (caller falls back to conv_igemm).
+// bt != 0 (mode 1 only): w is k-major [Ci(k)][R][S][Co(n)] instead of [Co][R][S][Ci].
 int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const float* bias, float* y,
                                 int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
-                                int stride, int pad, int64_t Mmax, hipStream_t st) {
+                                int stride, int pad, int64_t Mmax, hipStream_t st, int bt) {
     if (Ci % 16 != 0 || R * S > 64) return -1;
+    if (bt && (mode != 1 || Co % 4 != 0)) return -1;
     const int64_t xb = (int64_t)N * Hi * Wi * Ci * 4, wb = (int64_t)Co * R * S * Ci * 4;
     if (xb >= 0x7fffffffLL || wb >= 0x7fffffffLL) return -1;
     direct::ConvD p{x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, (int)xb, (int)wb, 1};
-    if (Ci % 32 == 0) return mode == 0 ? direct::launch<0, 32>(p, Mmax, st) : direct::launch<1, 32>(p, Mmax, st);
-    return mode == 0 ? direct::launch<0, 16>(p, Mmax, st) : direct::launch<1, 16>(p, Mmax, st);
+    if (bt) return Ci % 32 == 0 ? direct::launch<1, 32, true>(p, Mmax, st) : direct::launch<1, 16, true>(p, Mmax, st);
+    if (Ci % 32 == 0)
+        return mode == 0 ? direct::launch<0, 32, false>(p, Mmax, st) : direct::launch<1, 32, false>(p, Mmax, st);
+    return mode == 0 ? direct::launch<0, 16, false>(p, Mmax, st) : direct::launch<1, 16, false>(p, Mmax, st);
 }

@@ -506,3 +506,15 @@ extern "C" int advmix_bias_grad(const float* dy, float* db, int64_t rows, int C,
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }
+
+extern "C" int advmix_conv_tr_w(const float* x, const float* w, const float* bias, float* y,
+                                int N, int Hs, int Ws, int Ck, int Hb, int Wb, int Cn,
+                                int R, int S, int stride, int pad, void* stream) {
+    if (!x || !w || !y || N <= 0 || Ck <= 0 || Cn <= 0 || stride < 1 || stride > 8) return ADVMIX_EINVAL;
+    if (Hs != (Hb + 2 * pad - R) / stride + 1 || Ws != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
+    if (!use_direct()) return ADVMIX_EINVAL;
+    int64_t Mmax = (int64_t)N * cdiv(Hb, stride) * cdiv(Wb, stride);
+    int rc = advmix_conv_direct_dispatch(1, x, w, bias, y, N, Hs, Ws, Ck, Hb, Wb, Cn, R, S, stride, pad, Mmax,
+                                         (hipStream_t)stream, 1);
+    return rc < 0 ? ADVMIX_EINVAL : rc;
+}

@@ -25,7 +25,7 @@ from ._lib import call, lib
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 _CL = torch.channels_last
-MAX_LANES = 8
+MAX_LANES = int(__import__('os').environ.get('ADVMIX_LANES', '3'))   # concurrent HIP streams per launch group
 
 
 def _p(t):
@@ -86,9 +86,15 @@ def _workspace(device, nbytes, lane):
     key = (device.index, lane)
     w = _ws_cache.get(key)
     if w is None:
-        w = torch.empty(WS_BYTES // 4, device=device, dtype=torch.float32)
+        w = torch.zeros(WS_BYTES // 4, device=device, dtype=torch.float32)   # ticket words start at 0
         _ws_cache[key] = w
     return w
+
+
+def _ensure_workspaces(device, n):
+    """Create (and zero) the scratch of lanes 0..n-1 on the CALLER's stream, before any fork."""
+    for lane in range(n):
+        _workspace(device, 0, lane)
 
 
 _lane_streams = {}
@@ -99,6 +105,21 @@ def _lanes(device, n):
     while len(ss) < n:
         ss.append(torch.cuda.Stream(device=device))
     return ss[:n]
+
+
+_DIRECT = {'ok': __import__('os').environ.get('ADVMIX_BT', '1') != '0'}
+
+
+def _direct_ok():
+    """False while a test forces the first-generation conv (advmix_set_option('direct', 0))."""
+    return _DIRECT['ok']
+
+
+def set_option(name, value):
+    """advmix_set_option plus the Python-side dispatch it implies."""
+    call('advmix_set_option', name.encode(), int(value))
+    if name == 'direct':
+        _DIRECT['ok'] = bool(value)
 
 
 def _check_w(w):
@@ -146,10 +167,14 @@ class Conv:
         Ho, Wo = dy.shape[2], dy.shape[3]
         dx = None
         if needs[0]:
-            wt = _wt(st, w, Co, R * S, Ci)
             dx = empty_nhwc(B, Ci, Hi, Wi, x.device)
-            call('advmix_conv_tr', _p(dy), _p(wt), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
-                 stride, pad, st)
+            if Co % 16 == 0 and Ci % 4 == 0 and _direct_ok():      # weights consumed in their own layout
+                call('advmix_conv_tr_w', _p(dy), _p(w), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
+                     stride, pad, st)
+            else:
+                wt = _wt(st, w, Co, R * S, Ci)
+                call('advmix_conv_tr', _p(dy), _p(wt), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
+                     stride, pad, st)
         if needs[1]:
             call('advmix_conv_wgrad', _p(dy), _p(x), _p(_grad_buf(w, st)), B, Ho, Wo, Co, Hi, Wi, Ci,
                  R, S, stride, pad, st)
@@ -172,10 +197,14 @@ class Deconv:
         _, Co, R, S = w.shape
         Ho = (Hi - 1) * stride - 2 * pad + R
         Wo = (Wi - 1) * stride - 2 * pad + S
-        wt = _wt(st, w, Ci, R * S, Co)                    # [Co][R][S][Ci]
         y = empty_nhwc(B, Co, Ho, Wo, x.device)
-        call('advmix_conv_tr', _p(x), _p(wt), _p(bias), _p(y), B, Hi, Wi, Ci, Ho, Wo, Co, R, S,
-             stride, pad, st)
+        if Ci % 16 == 0 and Co % 4 == 0 and _direct_ok():
+            call('advmix_conv_tr_w', _p(x), _p(w), _p(bias), _p(y), B, Hi, Wi, Ci, Ho, Wo, Co, R, S,
+                 stride, pad, st)
+        else:
+            wt = _wt(st, w, Ci, R * S, Co)                # [Co][R][S][Ci]
+            call('advmix_conv_tr', _p(x), _p(wt), _p(bias), _p(y), B, Hi, Wi, Ci, Ho, Wo, Co, R, S,
+                 stride, pad, st)
         return (y,), (x, w, bias), None
 
     @staticmethod
@@ -483,16 +512,21 @@ class GroupFn(torch.autograd.Function):
                 if flat[pos + k] is not None:
                     flat[pos + k] = nhwc(flat[pos + k])
             pos += cnt
+        _ensure_workspaces(dev, nl)
         side = _lanes(dev, nl - 1)
         for s in side:
             s.wait_stream(cur)
         handles = [ctypes.c_void_p(cur.cuda_stream)] + [ctypes.c_void_p(s.cuda_stream) for s in side]
-        outs, saved, spans, extras = [], [], [], []
+        outs, saved, spans, extras, nondiff = [], [], [], [], []
         pos = 0
         needs_all = ctx.needs_input_grad[1:]
         for i, (op, cnt, meta) in enumerate(members):
             t = flat[pos:pos + cnt]
-            o, sv, ex = op.fwd(handles[i % nl], i % nl, t, meta, needs_all[pos:pos + cnt])
+            needs = needs_all[pos:pos + cnt]
+            o, sv, ex = op.fwd(handles[i % nl], i % nl, t, meta, needs)
+            if not any(needs):                             # frozen member (e.g. the teacher riding along):
+                sv = ()                                    # nothing to differentiate, keep nothing alive
+                nondiff += list(o)
             spans.append((pos, cnt, len(outs), len(o), len(saved), len(sv)))
             outs += list(o)
             saved += list(sv)
@@ -505,6 +539,8 @@ class GroupFn(torch.autograd.Function):
         ctx.n_in = len(flat)
         ctx.save_for_backward(*saved)
         ctx.set_materialize_grads(False)
+        if nondiff:
+            ctx.mark_non_differentiable(*nondiff)
         return tuple(outs)
 
     @staticmethod
@@ -515,6 +551,7 @@ class GroupFn(torch.autograd.Function):
         nl = min(len(members), MAX_LANES)
         cur = torch.cuda.current_stream(dev)
         gouts = [nhwc(g) if (g is not None and g.dim() == 4) else g for g in gouts]   # before the fork
+        _ensure_workspaces(dev, nl)
         side = _lanes(dev, nl - 1)
         for s in side:
             s.wait_stream(cur)

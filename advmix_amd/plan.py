@@ -355,18 +355,44 @@ class PlanNet(nn.Module):
             return (ops.MaxPool, (slots[st[1]],), None)
         raise ValueError(k)
 
+    def begin(self, x):
+        """Start a level-by-level execution (see PlanRun)."""
+        return PlanRun(self, x)
+
     def forward(self, x):
-        T = self._tensors()
-        train = self.training
-        slots = [None] * len(self.plan.ch)
-        slots[0] = x
-        out_slot = self.plan.out
-        for li, sts in enumerate(self._levels):
-            outs = ops.run_group([self._member(st, slots, T, train) for st in sts])
-            for st, o in zip(sts, outs):
-                slots[self._dst(st)] = o
-            for st in sts:                                 # drop dead activations early
-                for s in self._srcs(st):
-                    if self._last_use[s] == li and s != out_slot:
-                        slots[s] = None
-        return slots[out_slot]
+        run = self.begin(x)
+        while not run.done:
+            run.consume(ops.run_group(run.members()))
+        return run.result
+
+
+class PlanRun:
+    """One in-flight forward of a PlanNet, advanced one level (= one concurrent launch group)
+    at a time."""
+
+    def __init__(self, net, x):
+        self.net, self.T, self.train = net, net._tensors(), net.training
+        self.slots = [None] * len(net.plan.ch)
+        self.slots[0] = x
+        self.li = 0
+
+    @property
+    def done(self):
+        return self.li >= len(self.net._levels)
+
+    def members(self):
+        return [self.net._member(st, self.slots, self.T, self.train) for st in self.net._levels[self.li]]
+
+    def consume(self, outs):
+        net, sts = self.net, self.net._levels[self.li]
+        for st, o in zip(sts, outs):
+            self.slots[net._dst(st)] = o
+        for st in sts:                                     # drop dead activations early
+            for s in net._srcs(st):
+                if net._last_use[s] == self.li and s != net.plan.out:
+                    self.slots[s] = None
+        self.li += 1
+
+    @property
+    def result(self):
+        return self.slots[self.net.plan.out]

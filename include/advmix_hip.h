@@ -58,6 +58,13 @@ int advmix_conv_tr(const float* x, const float* wt, const float* bias, float* y,
                    int N, int Hs, int Ws, int Ck, int Hb, int Wb, int Cn,
                    int R, int S, int stride, int pad, void* stream);
 
+/* Same operation with the weight in its OWN layout, w[Ck][R][S][Cn] (a Conv2d's [Co][R][S][Ci] for its input
+ * gradient, a ConvTranspose2d's [Ci][R][S][Co] for its forward): no advmix_transpose_w needed.  Supported
+ * when Ck % 16 == 0 and Cn % 4 == 0 (returns ADVMIX_EINVAL otherwise: re-layout and call advmix_conv_tr). */
+int advmix_conv_tr_w(const float* x, const float* w, const float* bias, float* y,
+                     int N, int Hs, int Ws, int Ck, int Hb, int Wb, int Cn,
+                     int R, int S, int stride, int pad, void* stream);
+
 /* dw[Ca][R][S][Cb] += sum_p a[p, Ca] * b[gather(p,r,s), Cb]   (fp32 atomics, split over pixels)
  * a: [N,Ha,Wa,Ca] at the conv's OUTPUT resolution, b: [N,Hb,Wb,Cb] at its INPUT resolution.
  * Conv2d: a = dY, b = X.   ConvTranspose2d: a = X, b = dY (gives [Cin][R][S][Cout]). */

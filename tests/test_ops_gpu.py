@@ -63,15 +63,15 @@ CONV_CASES = [
 @pytest.fixture(params=['auto', 'lds3x3', 'direct', 'igemm'])
 def conv_path(request):
     """Force each generation of the conv kernels in turn (advmix_set_option)."""
-    from advmix_amd._lib import call
-    cfg = {'auto': (1, 1, 512), 'lds3x3': (1, 1, 1), 'direct': (1, 0, 512), 'igemm': (0, 0, 512)}[request.param]
-    call('advmix_set_option', b'direct', cfg[0])
-    call('advmix_set_option', b'conv3', cfg[1])
-    call('advmix_set_option', b'conv3_min_items', cfg[2])
+    from advmix_amd.ops import set_option
+    cfg = {'auto': (1, 0, 512), 'lds3x3': (1, 1, 1), 'direct': (1, 0, 512), 'igemm': (0, 0, 512)}[request.param]
+    set_option('direct', cfg[0])
+    set_option('conv3', cfg[1])
+    set_option('conv3_min_items', cfg[2])
     yield request.param
-    call('advmix_set_option', b'direct', 1)
-    call('advmix_set_option', b'conv3', 1)
-    call('advmix_set_option', b'conv3_min_items', 512)
+    set_option('direct', 1)
+    set_option('conv3', 0)
+    set_option('conv3_min_items', 512)
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
@@ -110,7 +110,7 @@ DECONV_CASES = [
 
 
 @pytest.mark.parametrize('case', DECONV_CASES)
-def test_conv_transpose2d(case):
+def test_conv_transpose2d(case, conv_path):
     ops = _ops()
     B, Ci, H, W, Co, hb = case
     x = rnd(B, Ci, H, W, seed=5)
@@ -135,7 +135,7 @@ def test_conv_transpose2d(case):
 
 @pytest.mark.parametrize('case', [(4, 32, 16, 12, 1, True), (2, 64, 9, 7, 1, False), (2, 256, 8, 6, 0, True),
                                   (2, 2048, 4, 3, 1, False), (3, 48, 5, 5, 1, True), (8, 32, 64, 48, 1, True),
-                                  (2, 6, 5, 5, 1, True)])
+                                  (2, 6, 5, 5, 1, True), (32, 32, 64, 48, 1, True)])
 def test_batch_norm_train(case):
     ops = _ops()
     B, C, H, W, act, has_res = case

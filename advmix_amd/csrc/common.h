@@ -50,5 +50,10 @@ struct AdvmixOpts {
     int conv3;             // 1: LDS-patch 3x3 kernel allowed
     int conv3_min_items;   // minimum (tile x chunk) items before the persistent 3x3 kernel is used
     int conv3_grid;        // persistent workgroups (256 = one per CU)
+    int wgrad_direct;      // 1: register-fragment wgrad kernel allowed
 };
 AdvmixOpts& advmix_opts();
+
+// wgrad_direct.hip: both operands loaded in fragment layout; -1 = not eligible
+int advmix_wgrad_direct_dispatch(const float* a, const float* b, float* dw, int N, int Ha, int Wa, int Ca, int Hb,
+                                 int Wb, int Cb, int R, int S, int stride, int pad, hipStream_t st);

@@ -458,6 +458,10 @@ extern "C" int advmix_conv_wgrad(const float* a, const float* b, float* dw,
                                  int R, int S, int stride, int pad, void* stream) {
     if (!a || !b || !dw || N <= 0 || Ca <= 0 || Cb <= 0 || stride < 1) return ADVMIX_EINVAL;
     if (Ha != (Hb + 2 * pad - R) / stride + 1 || Wa != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
+    {
+        int rc = advmix_wgrad_direct_dispatch(a, b, dw, N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     WgP p{a, b, dw, N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad, 0};
     const int64_t P = (int64_t)N * Ha * Wa;
     const int Ntot = R * S * Cb;

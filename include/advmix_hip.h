@@ -36,7 +36,7 @@ extern "C" {
 
 int advmix_version(void);
 /* dispatch knobs for A/B runs and tests: "direct" (0 = first-generation conv only), "conv3" (LDS-patch 3x3
- * kernel on/off), "conv3_min_items", "conv3_grid".  Unknown name -> ADVMIX_EINVAL. */
+ * kernel on/off), "conv3_min_items", "conv3_grid", "wgrad_direct".  Unknown name -> ADVMIX_EINVAL. */
 int advmix_set_option(const char* name, int value);
 
 /* ---- convolution family: replaces nn.Conv2d / nn.ConvTranspose2d forward+backward

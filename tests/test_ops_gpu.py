@@ -65,11 +65,13 @@ def conv_path(request):
     """Force each generation of the conv kernels in turn (advmix_set_option)."""
     from advmix_amd.ops import set_option
     cfg = {'auto': (1, 0, 512), 'lds3x3': (1, 1, 1), 'direct': (1, 0, 512), 'igemm': (0, 0, 512)}[request.param]
+    set_option('wgrad_direct', {'igemm': 0, 'auto': 1}.get(request.param, 2))   # 2 = force where eligible
     set_option('direct', cfg[0])
     set_option('conv3', cfg[1])
     set_option('conv3_min_items', cfg[2])
     yield request.param
     set_option('direct', 1)
+    set_option('wgrad_direct', 1)
     set_option('conv3', 0)
     set_option('conv3_min_items', 512)
 

@@ -116,9 +116,17 @@ def time_dominant_kernel(B, device, iters=100):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * B * 64 * 48 * 32 * 32 * 9
+    # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2
+    # on gfx950 + WRITE_SIZE, tools/pmc_conv.sh + tools/summarize_pmc.py); measured at B = 32
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_conv32_direct.json')
+    if B == 32 and os.path.exists(pmc):
+        with open(pmc) as f:
+            traffic = round(json.load(f)['hbm_bytes_per_launch'])
     return {'bound': 'mfma', 'kernel': 'conv_direct<1,1,4,1,32,fwd> 3x3 s1 32->32 @64x48 (128x32 tile)',
             'achieved': round(flops / (ms * 1e-3) / 1e12, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+            'frac': round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
+            'traffic_unit': 'HBM bytes per launch (PMC, corrected); algorithmic = 25.2e6',
             'us_per_launch': round(ms * 1e3, 2), 'algorithmic_gflop_per_launch': round(flops / 1e9, 3)}
 
 

@@ -21,6 +21,8 @@ SIGNATURES = {
     'advmix_version': [],
     'advmix_set_option': [ctypes.c_char_p, _i],
     'advmix_conv_fwd': [_p, _p, _p, _p] + [_i] * 11 + [_p],
+    'advmix_conv_fwd_ex': [_p, _p, _p, _p] + [_i] * 11 + [_p, _p, _p, _p, _f, _p, _i, _p, _p, _p],
+    'advmix_norm_finalize': [_p, _i, _l, _i, _f, _p, _p, _p, _p, _p, _f, _p],
     'advmix_conv_tr': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_tr_w': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],

@@ -35,10 +35,20 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// conv_direct.hip: second-generation conv; returns -1 when the shape is not eligible
+// optional fused conv epilogue (forward gather only)
+struct ConvEpi {
+    const float *gamma, *beta, *rm, *rv;   // eval-mode BatchNorm (all four or none)
+    const float* res;                      // residual added after BN
+    float eps;
+    int act;
+    double* stats;                         // out: [2][Co][nbg] column (sum, sumsq) of the RAW conv output
+};
+// conv_direct.hip: second-generation conv; returns -1 when the shape is not eligible, -2 when only the
+// fused epilogue is unavailable
 int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const float* bias, float* y,
                                 int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
-                                int stride, int pad, int64_t Mmax, hipStream_t st, int bt = 0);
+                                int stride, int pad, int64_t Mmax, hipStream_t st, int bt = 0,
+                                const ConvEpi* epi = nullptr, int* stats_nbg = nullptr);
 
 // conv3x3_lds.hip: LDS-resident-patch 3x3/s1/p1 conv (flip = 1: its input gradient); -1 = not eligible
 int advmix_conv3x3_lds_dispatch(int flip, const float* x, const float* w, const float* bias, float* y, int N, int H,

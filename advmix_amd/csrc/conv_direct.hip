@@ -33,6 +33,13 @@ struct ConvD {
     int R, S, stride, pad;
     int xbytes, wbytes;     // buffer sizes for the hardware range check
     int nsplit;             // K-chunk slices (gridDim.z = phases * nsplit)
+    // optional fused epilogue (MODE 0, no K split): eval-mode BatchNorm + residual + activation, and/or
+    // per-wave column sums of the raw conv output for a following train-mode BatchNorm
+    const float *bn_gamma, *bn_beta, *bn_rm, *bn_rv, *res;
+    float bn_eps;
+    int act;
+    double* stats;          // [2][Co][stats_nbg]: (sum, sum of squares) per 32*TM-row wave slab
+    int stats_nbg;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -237,14 +244,21 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
 #pragma unroll
     for (int u = 0; u < TN; ++u) {
         const int col = n0 + (wn * TN + u) * 32 + l31;
-        if (col >= p.Co) continue;
-        const float bv = (p.bias && (!SPLIT || zsl == 0)) ? p.bias[col] : 0.f;
+        const bool cvalid = col < p.Co;
+        const float bv = (cvalid && p.bias && (!SPLIT || zsl == 0)) ? p.bias[col] : 0.f;
+        float bn_is = 1.f, bn_g = 1.f, bn_b = 0.f, bn_m = 0.f;
+        const bool bn = !SPLIT && MODE == 0 && p.bn_gamma != nullptr;
+        if (bn && cvalid) {
+            bn_is = 1.0f / sqrtf(p.bn_rv[col] + p.bn_eps);
+            bn_g = p.bn_gamma[col]; bn_b = p.bn_beta[col]; bn_m = p.bn_rm[col];
+        }
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int m = m0 + (wm * TM + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= Mp) continue;
+                if (m >= Mp || !cvalid) continue;
                 int64_t off;
                 if (MODE == 0) {
                     off = (int64_t)m * p.Co + col;
@@ -254,8 +268,25 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
                     int hi_ = rem / Wp, wi_ = rem - hi_ * Wp;
                     off = ((int64_t)(n * p.Ho + rh + hi_ * p.stride) * p.Wo + rw + wi_ * p.stride) * p.Co + col;
                 }
-                if (SPLIT) atomicAdd(p.y + off, acc[t][u][r] + bv);
-                else p.y[off] = acc[t][u][r] + bv;
+                float v = acc[t][u][r] + bv;
+                if (SPLIT) { atomicAdd(p.y + off, v); continue; }
+                if (MODE == 0) {
+                    s1 += v;
+                    s2 += v * v;
+                    if (bn) v = (v - bn_m) * bn_is * bn_g + bn_b;
+                    if (p.res) v += p.res[off];
+                    v = act_fwd(v, p.act);
+                }
+                p.y[off] = v;
+            }
+        }
+        if (!SPLIT && MODE == 0 && p.stats) {              // wave-uniform branch: every lane shuffles
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lh == 0 && cvalid) {
+                const int pb = blockIdx.x * WM + wm;
+                p.stats[(int64_t)col * p.stats_nbg + pb] = (double)s1;
+                p.stats[((int64_t)p.Co + col) * p.stats_nbg + pb] = (double)s2;
             }
         }
     }
@@ -273,10 +304,12 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
     } while (0)
     p.nsplit = 1;
     if (p.Co <= 32) {
+        p.stats_nbg = cdiv(Mmax, 128) * 4;
         LAUNCHD(1, 1, 4, 1, false);                                        // 128 x 32
     } else {
         const int64_t b128 = (int64_t)cdiv(Mmax, 128) * cdiv(p.Co, 64) * phases;
         if (b128 >= 512) {
+            p.stats_nbg = cdiv(Mmax, 128) * 4;
             LAUNCHD(1, 2, 4, 1, false);                                    // 128 x 64
         } else {
             const int64_t b64 = (int64_t)cdiv(Mmax, 64) * cdiv(p.Co, 64) * phases;
@@ -287,12 +320,14 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
                 if (ns > 8) ns = 8;
                 if (ns < 1) ns = 1;
             }
+            if (ns > 1 && (p.bn_gamma || p.res || p.act || p.stats)) return -2;   // fused epilogue needs whole-K tiles
             if (ns > 1) {
                 p.nsplit = ns;
                 if (hipMemsetAsync(p.y, 0, (size_t)p.N * p.Ho * p.Wo * p.Co * sizeof(float), st) != hipSuccess)
                     return ADVMIX_ELAUNCH;
                 LAUNCHD(1, 1, 2, 2, true);                                 // 64 x 64, K split + atomics
             } else {
+                p.stats_nbg = cdiv(Mmax, 64) * 2;
                 LAUNCHD(1, 1, 2, 2, false);                                // 64 x 64
             }
         }
@@ -304,18 +339,30 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
 
 }  // namespace direct
 
-// Returns -1 when the problem is not eligible (caller falls back to conv_igemm).
+// Returns -1 when the problem is not eligible (caller falls back to conv_igemm), -2 when only the fused
+// epilogue is not available for this shape (K-split configuration).
 // bt != 0 (mode 1 only): w is k-major [Ci(k)][R][S][Co(n)] instead of [Co][R][S][Ci].
 int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const float* bias, float* y,
                                 int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
-                                int stride, int pad, int64_t Mmax, hipStream_t st, int bt) {
+                                int stride, int pad, int64_t Mmax, hipStream_t st, int bt, const ConvEpi* epi,
+                                int* stats_nbg) {
     if (Ci % 16 != 0 || R * S > 64) return -1;
     if (bt && (mode != 1 || Co % 4 != 0)) return -1;
+    if (epi && mode != 0) return -2;
     const int64_t xb = (int64_t)N * Hi * Wi * Ci * 4, wb = (int64_t)Co * R * S * Ci * 4;
     if (xb >= 0x7fffffffLL || wb >= 0x7fffffffLL) return -1;
-    direct::ConvD p{x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, (int)xb, (int)wb, 1};
-    if (bt) return Ci % 32 == 0 ? direct::launch<1, 32, true>(p, Mmax, st) : direct::launch<1, 16, true>(p, Mmax, st);
-    if (Ci % 32 == 0)
-        return mode == 0 ? direct::launch<0, 32, false>(p, Mmax, st) : direct::launch<1, 32, false>(p, Mmax, st);
-    return mode == 0 ? direct::launch<0, 16, false>(p, Mmax, st) : direct::launch<1, 16, false>(p, Mmax, st);
+    direct::ConvD p{x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, (int)xb, (int)wb, 1,
+                    nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0};
+    if (epi) {
+        p.bn_gamma = epi->gamma; p.bn_beta = epi->beta; p.bn_rm = epi->rm; p.bn_rv = epi->rv; p.res = epi->res;
+        p.bn_eps = epi->eps; p.act = epi->act; p.stats = epi->stats;
+    }
+    int rc;
+    if (bt) rc = Ci % 32 == 0 ? direct::launch<1, 32, true>(p, Mmax, st) : direct::launch<1, 16, true>(p, Mmax, st);
+    else if (Ci % 32 == 0)
+        rc = mode == 0 ? direct::launch<0, 32, false>(p, Mmax, st) : direct::launch<1, 32, false>(p, Mmax, st);
+    else
+        rc = mode == 0 ? direct::launch<0, 16, false>(p, Mmax, st) : direct::launch<1, 16, false>(p, Mmax, st);
+    if (stats_nbg) *stats_nbg = p.stats_nbg;
+    return rc;
 }

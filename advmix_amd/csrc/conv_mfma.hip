@@ -522,3 +522,22 @@ extern "C" int advmix_conv_tr_w(const float* x, const float* w, const float* bia
                                          (hipStream_t)stream, 1);
     return rc < 0 ? ADVMIX_EINVAL : rc;
 }
+
+// Conv2d forward with a fused epilogue (conv_direct only): eval-mode BatchNorm + residual + activation,
+// and/or per-slab column statistics of the raw output for a following train-mode BatchNorm.
+extern "C" int advmix_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y,
+                                  int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
+                                  int R, int S, int stride, int pad,
+                                  const float* bn_gamma, const float* bn_beta, const float* bn_rm, const float* bn_rv,
+                                  float bn_eps, const float* residual, int act, double* stats, int* stats_nbg,
+                                  void* stream) {
+    if (!x || !w || !y || N <= 0 || Ci <= 0 || Co <= 0 || stride < 1) return ADVMIX_EINVAL;
+    if (Ho != (Hi + 2 * pad - R) / stride + 1 || Wo != (Wi + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
+    if ((bn_gamma != nullptr) != (bn_beta && bn_rm && bn_rv)) return ADVMIX_EINVAL;
+    if (stats && !stats_nbg) return ADVMIX_EINVAL;
+    if (!use_direct()) return ADVMIX_EINVAL;
+    ConvEpi e{bn_gamma, bn_beta, bn_rm, bn_rv, residual, bn_eps, act, stats};
+    int rc = advmix_conv_direct_dispatch(0, x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad,
+                                         (int64_t)N * Ho * Wo, (hipStream_t)stream, 0, &e, stats_nbg);
+    return rc < 0 ? ADVMIX_EINVAL : rc;
+}

@@ -357,6 +357,16 @@ extern "C" int advmix_norm_stats(const float* x, int groups, int64_t Mg, int C, 
     return ADVMIX_OK;
 }
 
+extern "C" int advmix_norm_finalize(const double* partial, int nbg, int64_t rows, int C, float eps, float* mean,
+                                    float* invstd, float* running_mean, float* running_var, int64_t* nbt,
+                                    float momentum, void* stream) {
+    if (!partial || nbg <= 0 || rows <= 0 || C <= 0 || !mean || !invstd) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(norm_finalize_fwd, dim3(cdiv((int64_t)C, 4)), dim3(256), 0, (hipStream_t)stream, partial, nbg,
+                       1, rows, C, eps, mean, invstd, running_mean, running_var, nbt, momentum);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
 extern "C" int advmix_norm_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
                                  const float* beta, const float* residual, float* y, int ldy, int groups,
                                  int64_t Mg, int C, int act, void* stream) {

@@ -278,6 +278,100 @@ class BatchNorm:
         return dx, None, None, None, None, None, dres
 
 
+class ConvBN:
+    """conv (bias-free) -> BatchNorm -> (+residual) -> activation as ONE member (pose_hrnet.py:41-57).
+    tensors = (x, w, gamma, beta, rmean, rvar, nbt, residual|None); meta = (stride, pad, act, training,
+    momentum, eps).  eval: a single launch (BN folded into the conv epilogue).  training: the conv epilogue
+    also emits the per-slab column sums, so the statistics pass over the conv output disappears
+    (conv -> finalize -> apply).  Shapes the fused epilogue does not serve fall back to the separate kernels."""
+    NHWC = (0, 7)
+
+    @staticmethod
+    def fwd(st, lane, t, meta, needs):
+        x, w, gamma, beta, rmean, rvar, nbt, residual = t
+        stride, pad, act, training, momentum, eps = meta
+        x = nhwc(x)
+        _check_w(w)
+        res = nhwc(residual) if residual is not None else None
+        B, Ci, Hi, Wi = x.shape
+        Co, _, R, S = w.shape
+        Ho = (Hi + 2 * pad - R) // stride + 1
+        Wo = (Wi + 2 * pad - S) // stride + 1
+        rows = B * Ho * Wo
+        geom = (B, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad)
+        y = empty_nhwc(B, Co, Ho, Wo, x.device)
+        fused_ok = _direct_ok() and Ci % 16 == 0
+        if not training:
+            rc = lib.advmix_conv_fwd_ex(_p(x), _p(w), None, _p(y), *geom, _p(gamma), _p(beta), _p(rmean),
+                                        _p(rvar), eps, _p(res), act, None, None, st) if fused_ok else 1
+            if rc == 1:                                     # not served by the fused epilogue
+                c = keep(empty_nhwc(B, Co, Ho, Wo, x.device))
+                call('advmix_conv_fwd', _p(x), _p(w), None, _p(c), *geom, st)
+                call('advmix_bn_eval', _p(c), _p(gamma), _p(beta), _p(rmean), _p(rvar), eps, _p(res),
+                     _p(y), rows, Co, act, st)
+            elif rc != 0:
+                raise RuntimeError('advmix_conv_fwd_ex failed: %d' % rc)
+            return (y,), (), None
+        c = empty_nhwc(B, Co, Ho, Wo, x.device)
+        mean = torch.empty(Co, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(Co, device=x.device, dtype=torch.float32)
+        ws = _workspace(x.device, lib.advmix_norm_ws_bytes(1, Co), lane)
+        rc = 1
+        if fused_ok and rows * Co // 2 + 4096 <= WS_BYTES:
+            nbg = ctypes.c_int(0)
+            rc = lib.advmix_conv_fwd_ex(_p(x), _p(w), None, _p(c), *geom, None, None, None, None, 0.0, None, 0,
+                                        _p(ws), ctypes.byref(nbg), st)
+            if rc == 0:
+                call('advmix_norm_finalize', _p(ws), nbg.value, rows, Co, eps, _p(mean), _p(invstd), _p(rmean),
+                     _p(rvar), _p(nbt), momentum, st)
+            elif rc != 1:
+                raise RuntimeError('advmix_conv_fwd_ex failed: %d' % rc)
+        if rc == 1:
+            call('advmix_conv_fwd', _p(x), _p(w), None, _p(c), *geom, st)
+            call('advmix_norm_stats', _p(c), 1, rows, Co, eps, _p(mean), _p(invstd), _p(rmean), _p(rvar),
+                 _p(nbt), momentum, _p(ws), st)
+        call('advmix_norm_apply', _p(c), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), _p(y),
+             Co, 1, rows, Co, act, st)
+        return (y,), (x, w, c, y, mean, invstd, gamma, beta), residual is not None
+
+    @staticmethod
+    def bwd(st, lane, saved, has_res, meta, grads, needs):
+        stride, pad, act, training = meta[0], meta[1], meta[2], meta[3]
+        if not training:
+            raise RuntimeError('advmix_amd: backward through eval-mode BatchNorm is not on the hot path')
+        x, w, c, y, mean, invstd, gamma, beta = saved
+        dy = nhwc(grads[0])
+        B, Ci, Hi, Wi = x.shape
+        Co, _, R, S = w.shape
+        Ho, Wo = y.shape[2], y.shape[3]
+        rows = B * Ho * Wo
+        need_res = has_res and needs[7]
+        dc = keep(empty_nhwc(B, Co, Ho, Wo, x.device))
+        dres = None
+        if need_res:
+            dres = dy if act == ACT_NONE else empty_nhwc(B, Co, Ho, Wo, x.device)
+        ws = _workspace(x.device, lib.advmix_norm_ws_bytes(1, Co), lane)
+        dg = _grad_buf(gamma, st) if needs[2] else None
+        db = _grad_buf(beta, st) if needs[3] else None
+        call('advmix_norm_bwd', _p(dy), _p(y), Co, _p(c), _p(mean), _p(invstd), _p(gamma), _p(dc),
+             _p(dres) if (need_res and act != ACT_NONE) else None, _p(dg), _p(db), 1, rows, Co, act,
+             _p(ws), st)
+        dx = None
+        if needs[0]:
+            dx = empty_nhwc(B, Ci, Hi, Wi, x.device)
+            if Co % 16 == 0 and Ci % 4 == 0 and _direct_ok():
+                call('advmix_conv_tr_w', _p(dc), _p(w), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
+                     stride, pad, st)
+            else:
+                wt = _wt(st, w, Co, R * S, Ci)
+                call('advmix_conv_tr', _p(dc), _p(wt), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
+                     stride, pad, st)
+        if needs[1]:
+            call('advmix_conv_wgrad', _p(dc), _p(x), _p(_grad_buf(w, st)), B, Ho, Wo, Co, Hi, Wi, Ci,
+                 R, S, stride, pad, st)
+        return dx, None, None, None, None, None, None, dres
+
+
 class InstanceNorm:
     NHWC = (0,)      # inputs made dense NHWC BEFORE the lanes fork (None = all)
     """y = act(InstanceNorm2d(x)), affine=False, no running stats.  meta = (act, eps)."""
@@ -601,6 +695,11 @@ def conv_transpose2d(x, w, bias=None, stride=2, pad=1):
 def batch_norm(x, gamma, beta, rmean, rvar, nbt, residual=None, act=ACT_NONE, training=True,
                momentum=0.1, eps=1e-5):
     return _one(BatchNorm, (x, gamma, beta, rmean, rvar, nbt, residual), (act, training, momentum, eps))
+
+
+def conv_bn(x, w, gamma, beta, rmean, rvar, nbt, residual=None, stride=1, pad=0, act=ACT_NONE, training=True,
+            momentum=0.1, eps=1e-5):
+    return _one(ConvBN, (x, w, gamma, beta, rmean, rvar, nbt, residual), (stride, pad, act, training, momentum, eps))
 
 
 def instance_norm(x, act=ACT_NONE, eps=1e-5):

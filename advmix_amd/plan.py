@@ -248,11 +248,14 @@ class PlanNet(nn.Module):
             else:
                 t = torch.zeros(shape) if kind == 'rm' else torch.ones(shape)
             self._register(name, t, True)
+        # conv -> BatchNorm pairs become one fused member (ops.ConvBN) when the conv has no bias and its
+        # output feeds only that BatchNorm
+        steps = self._fuse_conv_bn(plan.steps)
         # ASAP levels: steps of one level are mutually independent (HRNet's branches, fuse convs,
         # residual downsample paths) and are launched as ONE concurrent group
         level = {0: 0}
         groups = {}
-        for st in plan.steps:
+        for st in steps:
             lvl = 1 + max(level[s] for s in self._srcs(st))
             level[self._dst(st)] = lvl
             groups.setdefault(lvl, []).append(st)
@@ -289,9 +292,50 @@ class PlanNet(nn.Module):
         else:
             mod.register_parameter(parts[-1], tensor)
 
+    @classmethod
+    def _fuse_conv_bn(cls, steps):
+        uses = {}
+        for st in steps:
+            for s in cls._srcs(st):
+                uses[s] = uses.get(s, 0) + 1
+        bn_of = {st[2]: st for st in steps if st[0] == 'bn'}          # conv-output slot -> its bn step
+        out, fused_bn = [], set()
+        for st in steps:
+            if st[0] == 'conv' and not st[6] and uses.get(st[3], 0) == 1 and st[3] in bn_of:
+                _, cname, x, y, stride, pad, _hb = st
+                _, bname, _y, z, res, act = bn_of[y]
+                out.append(('convbn', cname, bname, x, z, stride, pad, res, act))
+                fused_bn.add(bname)
+            elif st[0] == 'bn' and st[1] in fused_bn:
+                continue
+            else:
+                out.append(st)
+        # a fused step sits where its conv was; a residual produced later in program order (the
+        # downsample path) is still earlier in LEVEL order, which is all the scheduler uses
+        return cls._toposort(out)
+
+    @classmethod
+    def _toposort(cls, steps):
+        ready, done, out = {0}, set(), []
+        pending = list(steps)
+        while pending:
+            rest = []
+            for st in pending:
+                if all(s in ready for s in cls._srcs(st)):
+                    out.append(st)
+                    ready.add(cls._dst(st))
+                else:
+                    rest.append(st)
+            if len(rest) == len(pending):
+                raise RuntimeError('plan has a dependency cycle')
+            pending = rest
+        return out
+
     @staticmethod
     def _dst(st):
         k = st[0]
+        if k == 'convbn':
+            return st[4]
         if k in ('conv', 'deconv', 'bn', 'catact', 'fuse'):
             return st[3]
         return st[2]                                       # inorm / act / maxpool
@@ -299,6 +343,8 @@ class PlanNet(nn.Module):
     @staticmethod
     def _srcs(st):
         k = st[0]
+        if k == 'convbn':
+            return [st[3]] + ([st[7]] if st[7] is not None else [])
         if k in ('conv', 'deconv'):
             return [st[2]]
         if k == 'bn':
@@ -333,6 +379,13 @@ class PlanNet(nn.Module):
 
     def _member(self, st, slots, T, train):
         k = st[0]
+        if k == 'convbn':
+            _, cname, bname, s, d, stride, pad, res, act = st
+            return (ops.ConvBN,
+                    (slots[s], T[cname + '.weight'], T[bname + '.weight'], T[bname + '.bias'],
+                     T[bname + '.running_mean'], T[bname + '.running_var'], T[bname + '.num_batches_tracked'],
+                     slots[res] if res is not None else None),
+                    (stride, pad, act, train, BN_MOMENTUM, BN_EPS))
         if k in ('conv', 'deconv'):
             _, name, s, d, stride, pad, hb = st
             return (ops.Conv if k == 'conv' else ops.Deconv,

@@ -50,6 +50,19 @@ int advmix_conv_fwd(const float* x, const float* w, const float* bias, float* y,
                     int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
                     int R, int S, int stride, int pad, void* stream);
 
+/* Conv2d forward with a fused epilogue.  Eval-mode BatchNorm (bn_* all non-NULL or all NULL): y =
+ * act((conv + bias - rm) / sqrt(rv + eps) * gamma + beta + residual).  stats != NULL: additionally writes
+ * per-slab column sums of the RAW conv output, stats[2][Co][*stats_nbg] (double), in the layout
+ * advmix_norm_finalize consumes, so a following train-mode BatchNorm needs no statistics pass.  Returns
+ * ADVMIX_EINVAL when the shape is served by a kernel without the fused epilogue (Cin % 16 != 0, K-split
+ * small-M configurations): call advmix_conv_fwd and the separate norm kernels instead.
+ * (pose_hrnet.py:41-57: conv -> bn -> (+residual) -> relu.) */
+int advmix_conv_fwd_ex(const float* x, const float* w, const float* bias, float* y,
+                       int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
+                       int R, int S, int stride, int pad,
+                       const float* bn_gamma, const float* bn_beta, const float* bn_rm, const float* bn_rv,
+                       float bn_eps, const float* residual, int act, double* stats, int* stats_nbg, void* stream);
+
 /* "transposed gather": y[N,Hb,Wb,Cn] = sum_{r,s,c} x[N,(h+p-r)/s,(w+p-s)/s,c] * wt[Cn][R][S][Ck]
  * for the taps where the division is exact and in range (phase-decomposed: no zero work).
  * Conv2d input-gradient (x = dY, wt = transposed weight [Ci][R][S][Co]) and
@@ -90,6 +103,10 @@ int64_t advmix_norm_ws_bytes(int groups, int C);
 int advmix_norm_stats(const float* x, int groups, int64_t rows_per_group, int C, float eps,
                       float* mean, float* invstd, float* running_mean, float* running_var,
                       int64_t* num_batches_tracked, float momentum, void* ws, void* stream);
+/* groups == 1 statistics from partial sums produced elsewhere (advmix_conv_fwd_ex): partial[2][C][nbg]. */
+int advmix_norm_finalize(const double* partial, int nbg, int64_t rows, int C, float eps, float* mean,
+                         float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                         float momentum, void* stream);
 /* y = act((x - mean)*invstd*gamma + beta + residual); gamma/beta/residual may be NULL.
  * y rows have stride ldy floats (>= C) so the result can land in a channel slice. */
 int advmix_norm_apply(const float* x, const float* mean, const float* invstd,

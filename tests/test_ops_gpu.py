@@ -37,6 +37,18 @@ def check(name, got, ref, tol=1e-4):
     assert err <= tol * scale, '%s: max err %.3e vs scale %.3e (rel %.3e)' % (name, err, scale, err / scale)
 
 
+def check_l2(name, got, ref, tol=1e-3):
+    """Relative L2 error.  Used for gradients that pass through a ReLU computed on the device: a
+    pre-activation within rounding of 0 may take the other branch than the float64 reference, which
+    moves a handful of elements by O(1) (max-abs blows up) but not the norm."""
+    got = got.detach().double().cpu()
+    ref = ref.detach().double()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    rel = float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+    frac = float(((got - ref).abs() > 1e-3 * ref.abs().max()).double().mean())
+    assert rel <= tol and frac <= 1e-3, '%s: rel L2 %.3e, %.2e of elements off' % (name, rel, frac)
+
+
 CONV_CASES = [
     # B, Ci, H, W, Co, k, stride, pad, bias
     (2, 32, 16, 12, 32, 3, 1, 1, False),
@@ -206,6 +218,58 @@ def test_norm_statistics_survive_large_mean(ratio):
         check('y', y, yr, 2e-4)
         y.backward(cl(dy))
         check('dx', xg.grad, xr.grad, 5e-4)
+
+
+@pytest.mark.parametrize('case', [
+    # B, Ci, H, W, Co, k, stride, pad, act, has_res
+    (8, 32, 64, 48, 32, 3, 1, 1, 1, True),      # fused epilogue, 128x32 tiles
+    (8, 64, 32, 24, 64, 3, 1, 1, 1, False),     # 64x64 tiles
+    (4, 256, 16, 12, 64, 1, 1, 0, 0, False),
+    (2, 256, 8, 6, 256, 3, 1, 1, 1, True),      # K-split shape: falls back to the separate kernels
+    (2, 3, 32, 24, 64, 3, 2, 1, 1, False),      # Cin = 3: first-generation conv + separate norm
+    (3, 48, 20, 12, 96, 3, 2, 1, 1, False),
+])
+def test_conv_bn_fused_member(case):
+    ops = _ops()
+    d = dev()
+    B, Ci, H, W, Co, k, s_, p_, act, has_res = case
+    x = rnd(B, Ci, H, W, seed=101)
+    w = rnd(Co, Ci, k, k, seed=102, scale=(Ci * k * k) ** -0.5)
+    g, bt = rnd(Co, seed=103) * 0.2 + 1, rnd(Co, seed=104) * 0.3
+    rm, rv = rnd(Co, seed=105) * 0.1, rnd(Co, seed=106).abs() + 0.5
+    Ho, Wo = (H + 2 * p_ - k) // s_ + 1, (W + 2 * p_ - k) // s_ + 1
+    res = rnd(B, Co, Ho, Wo, seed=107) if has_res else None
+    for training in (True, False):
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        gr, br = g.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+        rr = res.clone().requires_grad_(True) if has_res else None
+        rmr, rvr = rm.clone(), rv.clone()
+        yr = F.batch_norm(F.conv2d(xr, wr, None, s_, p_), rmr, rvr, gr, br, training, 0.1, 1e-5)
+        if has_res:
+            yr = yr + rr
+        if act:
+            yr = F.relu(yr)
+        xg = cl(x).requires_grad_(True)
+        wg = torch.nn.Parameter(cl(w))
+        gg, bg = torch.nn.Parameter(g.float().to(d)), torch.nn.Parameter(bt.float().to(d))
+        rmg, rvg = rm.float().to(d), rv.float().to(d)
+        nbt = torch.zeros((), dtype=torch.int64, device=d)
+        rg = cl(res).requires_grad_(True) if has_res else None
+        y = ops.conv_bn(xg, wg, gg, bg, rmg, rvg, nbt, rg, s_, p_, act, training, 0.1, 1e-5)
+        check('y train=%s' % training, y, yr, 2e-4)
+        if training:
+            check('running_mean', rmg, rmr, 2e-4)
+            check('running_var', rvg, rvr, 2e-4)
+            assert int(nbt) == 1
+            dy = rnd(B, Co, Ho, Wo, seed=108)
+            yr.backward(dy)
+            y.backward(cl(dy))
+            check_l2('dx', xg.grad, xr.grad)
+            check_l2('dw', wg.grad, wr.grad)
+            check_l2('dgamma', gg.grad, gr.grad)
+            check_l2('dbeta', bg.grad, br.grad)
+            if has_res:
+                check_l2('dres', rg.grad, rr.grad)
 
 
 def test_batch_norm_frozen_params_input_grad_only():

@@ -35,6 +35,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+#define ADVMIX_STAT_SLOTS 64
 // optional fused conv epilogue (forward gather only)
 struct ConvEpi {
     const float *gamma, *beta, *rm, *rv;   // eval-mode BatchNorm (all four or none)

@@ -38,8 +38,8 @@ struct ConvD {
     const float *bn_gamma, *bn_beta, *bn_rm, *bn_rv, *res;
     float bn_eps;
     int act;
-    double* stats;          // [2][Co][stats_nbg]: (sum, sum of squares) per 32*TM-row wave slab
-    int stats_nbg;
+    double* stats;          // [2][Co][stats_nbg]: (sum, sum of squares), wave slabs folded onto
+    int stats_nbg;          // stats_nbg (= STAT_SLOTS) slots with fp64 atomics; must be zero on entry
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -284,9 +284,11 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (lh == 0 && cvalid) {
-                const int pb = blockIdx.x * WM + wm;
-                p.stats[(int64_t)col * p.stats_nbg + pb] = (double)s1;
-                p.stats[((int64_t)p.Co + col) * p.stats_nbg + pb] = (double)s2;
+                // 3072 wave slabs on the dominant shape would make the finalize kernel read 1.5 MB; fold
+                // them onto a few slots instead (~200K fp64 atomics per launch = ~1 us of atomic pipe)
+                const int pb = (blockIdx.x * WM + wm) % p.stats_nbg;
+                atomicAdd(p.stats + (int64_t)col * p.stats_nbg + pb, (double)s1);
+                atomicAdd(p.stats + ((int64_t)p.Co + col) * p.stats_nbg + pb, (double)s2);
             }
         }
     }
@@ -303,13 +305,12 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
         hipLaunchKernelGGL((conv_direct<TM_, TN_, WM_, WN_, KC, MODE, SP_, BT>), g, dim3(256), 0, st, p); \
     } while (0)
     p.nsplit = 1;
+    p.stats_nbg = ADVMIX_STAT_SLOTS;
     if (p.Co <= 32) {
-        p.stats_nbg = cdiv(Mmax, 128) * 4;
         LAUNCHD(1, 1, 4, 1, false);                                        // 128 x 32
     } else {
         const int64_t b128 = (int64_t)cdiv(Mmax, 128) * cdiv(p.Co, 64) * phases;
         if (b128 >= 512) {
-            p.stats_nbg = cdiv(Mmax, 128) * 4;
             LAUNCHD(1, 2, 4, 1, false);                                    // 128 x 64
         } else {
             const int64_t b64 = (int64_t)cdiv(Mmax, 64) * cdiv(p.Co, 64) * phases;
@@ -327,7 +328,6 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
                     return ADVMIX_ELAUNCH;
                 LAUNCHD(1, 1, 2, 2, true);                                 // 64 x 64, K split + atomics
             } else {
-                p.stats_nbg = cdiv(Mmax, 64) * 2;
                 LAUNCHD(1, 1, 2, 2, false);                                // 64 x 64
             }
         }

@@ -176,7 +176,8 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
 __global__ __launch_bounds__(256) void norm_finalize_fwd(const double* __restrict__ partial, int nbg, int groups,
                                                          int64_t Mg, int C, float eps, float* __restrict__ mean,
                                                          float* __restrict__ invstd, float* running_mean,
-                                                         float* running_var, int64_t* nbt, float momentum) {
+                                                         float* running_var, int64_t* nbt, float momentum,
+                                                         double* zero_after) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i == 0 && lane == 0 && nbt) *nbt += 1;
@@ -184,6 +185,12 @@ __global__ __launch_bounds__(256) void norm_finalize_fwd(const double* __restric
     const int g = i / C, c = i - g * C;
     double s, ss;
     reduce_partials(partial, nbg, g, c, C, lane, s, ss);
+    if (zero_after) {                                    // atomically accumulated slots: leave them clean
+        for (int b = lane; b < nbg; b += 64) {
+            zero_after[((int64_t)g * 2 * C + c) * nbg + b] = 0.0;
+            zero_after[((int64_t)g * 2 * C + C + c) * nbg + b] = 0.0;
+        }
+    }
     if (lane != 0) return;
     double m = s / (double)Mg;
     double var = ss / (double)Mg - m * m;
@@ -352,17 +359,18 @@ extern "C" int advmix_norm_stats(const float* x, int groups, int64_t Mg, int C, 
         hipLaunchKernelGGL((norm_partial_scalar<0>), g, dim3(256), 0, st, x, nullptr, nullptr, 0, nullptr, nullptr,
                            partial, Mg, C, sp.rows_per_block, 0);
     hipLaunchKernelGGL(norm_finalize_fwd, dim3(cdiv((int64_t)groups * C, 4)), dim3(256), 0, st, partial, sp.nbg,
-                       groups, Mg, C, eps, mean, invstd, running_mean, running_var, nbt, momentum);
+                       groups, Mg, C, eps, mean, invstd, running_mean, running_var, nbt, momentum, (double*)nullptr);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }
 
-extern "C" int advmix_norm_finalize(const double* partial, int nbg, int64_t rows, int C, float eps, float* mean,
+extern "C" int advmix_norm_finalize(double* partial, int nbg, int64_t rows, int C, float eps, float* mean,
                                     float* invstd, float* running_mean, float* running_var, int64_t* nbt,
                                     float momentum, void* stream) {
     if (!partial || nbg <= 0 || rows <= 0 || C <= 0 || !mean || !invstd) return ADVMIX_EINVAL;
-    hipLaunchKernelGGL(norm_finalize_fwd, dim3(cdiv((int64_t)C, 4)), dim3(256), 0, (hipStream_t)stream, partial, nbg,
-                       1, rows, C, eps, mean, invstd, running_mean, running_var, nbt, momentum);
+    hipLaunchKernelGGL(norm_finalize_fwd, dim3(cdiv((int64_t)C, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)partial, nbg, 1, rows, C, eps, mean, invstd, running_mean, running_var, nbt,
+                       momentum, partial);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }

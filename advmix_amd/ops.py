@@ -75,13 +75,15 @@ def _grad_buf(p, st):
 
 _ws_cache = {}
 WS_BYTES = 48 << 20      # fixed per-lane scratch: norm partials need <= 512*2*C*8 B (C = 2048: 16.8 MB)
+STAT_OFF = 40 << 20      # last 8 MB: zero-initialised fp64 slots the fused conv epilogue accumulates into
+STAT_SLOTS = 64          # (= ADVMIX_STAT_SLOTS); advmix_norm_finalize leaves them zero again
 
 
 def _workspace(device, nbytes, lane):
     """Per-(device, lane) scratch of fixed size, allocated once (never re-allocated while another
     lane might still be using the old one).  Lanes never share scratch; within a lane kernels
     are stream-ordered."""
-    if nbytes > WS_BYTES:
+    if nbytes > STAT_OFF:
         raise ValueError('norm workspace of %d bytes exceeds the per-lane scratch (%d)' % (nbytes, WS_BYTES))
     key = (device.index, lane)
     w = _ws_cache.get(key)
@@ -317,12 +319,13 @@ class ConvBN:
         invstd = torch.empty(Co, device=x.device, dtype=torch.float32)
         ws = _workspace(x.device, lib.advmix_norm_ws_bytes(1, Co), lane)
         rc = 1
-        if fused_ok and rows * Co // 2 + 4096 <= WS_BYTES:
+        if fused_ok and 2 * Co * STAT_SLOTS * 8 <= WS_BYTES - STAT_OFF:
             nbg = ctypes.c_int(0)
+            slots = ctypes.c_void_p(ws.data_ptr() + STAT_OFF)
             rc = lib.advmix_conv_fwd_ex(_p(x), _p(w), None, _p(c), *geom, None, None, None, None, 0.0, None, 0,
-                                        _p(ws), ctypes.byref(nbg), st)
+                                        slots, ctypes.byref(nbg), st)
             if rc == 0:
-                call('advmix_norm_finalize', _p(ws), nbg.value, rows, Co, eps, _p(mean), _p(invstd), _p(rmean),
+                call('advmix_norm_finalize', slots, nbg.value, rows, Co, eps, _p(mean), _p(invstd), _p(rmean),
                      _p(rvar), _p(nbt), momentum, st)
             elif rc != 1:
                 raise RuntimeError('advmix_conv_fwd_ex failed: %d' % rc)

@@ -52,8 +52,9 @@ int advmix_conv_fwd(const float* x, const float* w, const float* bias, float* y,
 
 /* Conv2d forward with a fused epilogue.  Eval-mode BatchNorm (bn_* all non-NULL or all NULL): y =
  * act((conv + bias - rm) / sqrt(rv + eps) * gamma + beta + residual).  stats != NULL: additionally writes
- * per-slab column sums of the RAW conv output, stats[2][Co][*stats_nbg] (double), in the layout
- * advmix_norm_finalize consumes, so a following train-mode BatchNorm needs no statistics pass.  Returns
+ * column sums of the RAW conv output, ACCUMULATED with fp64 atomics into stats[2][Co][*stats_nbg] (the buffer
+ * must be zero on entry; advmix_norm_finalize consumes it and leaves it zero), so a following train-mode
+ * BatchNorm needs no statistics pass.  Returns
  * ADVMIX_EINVAL when the shape is served by a kernel without the fused epilogue (Cin % 16 != 0, K-split
  * small-M configurations): call advmix_conv_fwd and the separate norm kernels instead.
  * (pose_hrnet.py:41-57: conv -> bn -> (+residual) -> relu.) */
@@ -103,8 +104,8 @@ int64_t advmix_norm_ws_bytes(int groups, int C);
 int advmix_norm_stats(const float* x, int groups, int64_t rows_per_group, int C, float eps,
                       float* mean, float* invstd, float* running_mean, float* running_var,
                       int64_t* num_batches_tracked, float momentum, void* ws, void* stream);
-/* groups == 1 statistics from partial sums produced elsewhere (advmix_conv_fwd_ex): partial[2][C][nbg]. */
-int advmix_norm_finalize(const double* partial, int nbg, int64_t rows, int C, float eps, float* mean,
+/* groups == 1 statistics from the sums accumulated by advmix_conv_fwd_ex: partial[2][C][nbg]; zeroes them. */
+int advmix_norm_finalize(double* partial, int nbg, int64_t rows, int C, float eps, float* mean,
                          float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                          float momentum, void* stream);
 /* y = act((x - mean)*invstd*gamma + beta + residual); gamma/beta/residual may be NULL.

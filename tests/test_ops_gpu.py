@@ -37,18 +37,6 @@ def check(name, got, ref, tol=1e-4):
     assert err <= tol * scale, '%s: max err %.3e vs scale %.3e (rel %.3e)' % (name, err, scale, err / scale)
 
 
-def check_l2(name, got, ref, tol=1e-3):
-    """Relative L2 error.  Used for gradients that pass through a ReLU computed on the device: a
-    pre-activation within rounding of 0 may take the other branch than the float64 reference, which
-    moves a handful of elements by O(1) (max-abs blows up) but not the norm."""
-    got = got.detach().double().cpu()
-    ref = ref.detach().double()
-    assert got.shape == ref.shape, (name, got.shape, ref.shape)
-    rel = float((got - ref).norm() / ref.norm().clamp_min(1e-30))
-    frac = float(((got - ref).abs() > 1e-3 * ref.abs().max()).double().mean())
-    assert rel <= tol and frac <= 1e-3, '%s: rel L2 %.3e, %.2e of elements off' % (name, rel, frac)
-
-
 CONV_CASES = [
     # B, Ci, H, W, Co, k, stride, pad, bias
     (2, 32, 16, 12, 32, 3, 1, 1, False),
@@ -244,11 +232,10 @@ def test_conv_bn_fused_member(case):
         gr, br = g.clone().requires_grad_(True), bt.clone().requires_grad_(True)
         rr = res.clone().requires_grad_(True) if has_res else None
         rmr, rvr = rm.clone(), rv.clone()
-        yr = F.batch_norm(F.conv2d(xr, wr, None, s_, p_), rmr, rvr, gr, br, training, 0.1, 1e-5)
+        pre = F.batch_norm(F.conv2d(xr, wr, None, s_, p_), rmr, rvr, gr, br, training, 0.1, 1e-5)
         if has_res:
-            yr = yr + rr
-        if act:
-            yr = F.relu(yr)
+            pre = pre + rr
+        yr = F.relu(pre) if act else pre
         xg = cl(x).requires_grad_(True)
         wg = torch.nn.Parameter(cl(w))
         gg, bg = torch.nn.Parameter(g.float().to(d)), torch.nn.Parameter(bt.float().to(d))
@@ -262,14 +249,17 @@ def test_conv_bn_fused_member(case):
             check('running_var', rvg, rvr, 2e-4)
             assert int(nbt) == 1
             dy = rnd(B, Co, Ho, Wo, seed=108)
-            yr.backward(dy)
+            # differentiate the reference through the DEVICE's ReLU mask: a pre-activation within
+            # rounding of 0 may land on the other side than in float64, which is not a kernel error
+            mask = (y.detach().cpu() > 0).double() if act else 1.0
+            (pre * mask).backward(dy)
             y.backward(cl(dy))
-            check_l2('dx', xg.grad, xr.grad)
-            check_l2('dw', wg.grad, wr.grad)
-            check_l2('dgamma', gg.grad, gr.grad)
-            check_l2('dbeta', bg.grad, br.grad)
+            check('dx', xg.grad, xr.grad, 5e-4)
+            check('dw', wg.grad, wr.grad, 5e-4)
+            check('dgamma', gg.grad, gr.grad, 5e-4)
+            check('dbeta', bg.grad, br.grad, 5e-4)
             if has_res:
-                check_l2('dres', rg.grad, rr.grad)
+                check('dres', rg.grad, rr.grad)
 
 
 def test_batch_norm_frozen_params_input_grad_only():

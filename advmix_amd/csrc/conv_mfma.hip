@@ -374,14 +374,29 @@ __global__ void transpose_w_kernel(const float* __restrict__ in, float* __restri
     }
 }
 
-__global__ void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int64_t rows, int C,
-                                 int64_t rows_per_block) {
-    int64_t r0 = blockIdx.x * rows_per_block;
-    int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+// db[c] += sum over rows of dy[rows, C]: 256 threads = RP row-lanes x Cp columns, LDS tree over the
+// row-lanes, one atomic per column per block (coalesced 4-byte lanes along c).
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db,
+                                                        int64_t rows, int C, int64_t rows_per_block) {
+    __shared__ float red[256];
+    const int Cp = C < 256 ? C : 256;
+    const int RP = 256 / Cp;
+    const int tid = threadIdx.x, rr = tid / Cp, cc = tid - rr * Cp;
+    const int64_t r0 = blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (int cbase = 0; cbase < C; cbase += Cp) {
+        const int c = cbase + cc;
         float s = 0.f;
-        for (int64_t r = r0; r < r1; ++r) s += dy[r * C + c];
-        atomicAdd(db + c, s);
+        if (rr < RP && c < C)
+            for (int64_t r = r0 + rr; r < r1; r += RP) s += dy[r * C + c];
+        red[tid] = s;
+        __syncthreads();
+        for (int step = 1; step < RP; step <<= 1) {
+            if (rr < RP && (rr % (2 * step)) == 0 && rr + step < RP) red[tid] += red[tid + step * Cp];
+            __syncthreads();
+        }
+        if (rr == 0 && c < C) atomicAdd(db + c, red[tid]);
+        __syncthreads();
     }
 }
 
@@ -503,8 +518,8 @@ extern "C" int advmix_transpose_w(const float* in, float* out, int A, int T, int
 
 extern "C" int advmix_bias_grad(const float* dy, float* db, int64_t rows, int C, void* stream) {
     if (!dy || !db || rows <= 0 || C <= 0) return ADVMIX_EINVAL;
-    int64_t rpb = (rows + 511) / 512;
-    if (rpb < 64) rpb = 64;
+    int64_t rpb = (rows + 1023) / 1024;
+    if (rpb < 32) rpb = 32;
     int blocks = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(bias_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, db, rows, C, rpb);
     ADVMIX_CHECK_LAUNCH();

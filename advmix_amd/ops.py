@@ -25,7 +25,7 @@ from ._lib import call, lib
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 _CL = torch.channels_last
-MAX_LANES = int(__import__('os').environ.get('ADVMIX_LANES', '3'))   # concurrent HIP streams per launch group
+MAX_LANES = int(__import__('os').environ.get('ADVMIX_LANES', '4'))   # concurrent HIP streams per launch group
 
 
 def _p(t):

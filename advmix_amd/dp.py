@@ -13,10 +13,11 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, bucket_mb=64, group=None):
+    def __init__(self, bucket_mb=64, group=None, force=False):
         self.group = group
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.force = force          # run the collectives even with one rank (single-GPU test of the path)
         self._side = None
 
     def _side_stream(self, device):
@@ -28,7 +29,7 @@ class GradSync:
         """Average ``flat`` (1-D fp32) over ranks in place.  On CUDA the bucketed collectives
         run on a side HIP stream (so bucket k+1 overlaps the scaling of bucket k) and the
         current stream waits for them before the optimizer reads the buffer."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         n = flat.numel()
         if flat.is_cuda:

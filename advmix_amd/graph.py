@@ -34,15 +34,17 @@ class AdvMixGraphRunner:
         optimizer.sync_hyper()
         optimizer_G.sync_hyper()
         self.g1, self.g2, self.g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g1):
+        # thread_local: only this thread launches work; RCCL's watchdog thread may query events meanwhile
+        mode = dict(capture_error_mode='thread_local')
+        with torch.cuda.graph(self.g1, **mode):
             self.loss_D, tmp = advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer,
                                               self.inputs, self.target, self.tw)
         pool = self.g1.pool()
-        with torch.cuda.graph(self.g2, pool=pool):
+        with torch.cuda.graph(self.g2, pool=pool, **mode):
             self.output = advmix_phase_b(args, model, criterion, optimizer, optimizer_G, tmp,
                                          self.target, self.tw)
         del tmp
-        with torch.cuda.graph(self.g3, pool=pool):
+        with torch.cuda.graph(self.g3, pool=pool, **mode):
             optimizer_G.step(sync_hyper=False)
         torch.cuda.synchronize(dev)
 

@@ -174,8 +174,10 @@ def main():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    if world > 1:
+    force_sync = os.environ.get('ADVMIX_FORCE_SYNC') == '1'     # exercise the RCCL path with a single rank
+    if world > 1 or force_sync:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29555')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from advmix_amd.core.function import advmix_step
@@ -187,7 +189,7 @@ def main():
     cfg, D, G, T, crit, optD, optG = build_models(a.workload, device)
     args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
     views, tgt, tw = synth(a.batch, J, H, W, device, 1234 + rank)
-    sync = GradSync() if world > 1 else None
+    sync = GradSync(force=force_sync) if (world > 1 or force_sync) else None
 
     if a.exec_mode == 'graph':
         runner = AdvMixGraphRunner(args, D, G, T, crit, optD, optG, views, tgt, tw, sync)
@@ -223,6 +225,7 @@ def main():
     if not (lv == lv):
         raise SystemExit('loss is NaN')
 
+    line = None
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = a.batch * world * a.steps / dt
@@ -244,10 +247,20 @@ def main():
             line['roofline'] = time_dominant_kernel(a.batch, device)
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(a.workload)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+
+
+    if world > 1 or force_sync:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio; flush it first so the JSON line is the LAST line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':

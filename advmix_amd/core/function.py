@@ -1,5 +1,5 @@
-"""Mirror of the training half of lib/core/function.py: ``train`` (:30-95),
-``set_require_grad`` (:98-104), ``train_advmix`` (:107-197), ``AverageMeter`` (:383-398) with
+"""Mirror of lib/core/function.py: ``train`` (:30-95), ``set_require_grad`` (:98-104),
+``train_advmix`` (:107-197), ``validate`` (:200-358), ``AverageMeter`` (:383-398) with
 identical signatures.  The per-batch bodies are factored into ``plain_step`` / ``advmix_step``
 so bench.py, the HIP-graph runner and the loops share one implementation.
 
@@ -11,10 +11,12 @@ import logging
 import os
 import time
 
+import numpy as np
 import torch
 
 from .. import ops
 from .evaluate import accuracy
+from .inference import get_final_preds
 
 logger = logging.getLogger(__name__)
 
@@ -155,6 +157,111 @@ def train_advmix(config, args, train_loader, models, criterion, optimizers, epoc
         end = time.time()
         if i % config.PRINT_FREQ == 0:
             _log(config, epoch, i, n, batch_time, data_time, losses, acc, inputs[0].size(0), writer_dict)
+
+
+def validate_batch(config, model, criterion, input, target, target_weight, flip_pairs):
+    """function.py:223-276 for one batch, entirely on the device: eval forward, optional flip test
+    (flipped forward, flip-back + joint swap + SHIFT_HEATMAP + average as ONE kernel), loss.
+    Returns (output [B,J,H,W] CUDA tensor, loss 0-dim tensor)."""
+    with torch.no_grad():
+        input = _cuda(input).float().contiguous()
+        output = model(input)                                                            # :230
+        if isinstance(output, list):
+            output = output[-1]
+        if config.TEST.FLIP_TEST:
+            output_flipped = model(ops.flip_w(input))                                    # :241-242
+            if isinstance(output_flipped, list):
+                output_flipped = output_flipped[-1]
+            output = ops.flip_merge(output, output_flipped, flip_pairs,
+                                    shift=bool(config.TEST.SHIFT_HEATMAP))               # :249-261
+        loss = criterion(output, target, target_weight)                                  # :269
+    return output, loss
+
+
+def validate(config, args, val_loader, val_dataset, model, criterion, output_dir,
+             tb_log_dir, writer_dict=None, cpu=False):
+    """function.py:200-358.  Same bookkeeping (all_preds [N,J,3], all_boxes [N,6], image paths, the
+    ``val_dataset.evaluate`` call, markdown table, tensorboard scalars); the heat-maps never leave the
+    GPU - per batch only the loss scalar, [B,J] argmax indices (accuracy) and [B,J,3] predictions do."""
+    if cpu:
+        raise RuntimeError('advmix_amd: validate() has no CPU path (the reference\'s cpu=True debug mode)')
+    batch_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter()
+    model.eval()
+    num_samples = len(val_dataset)
+    all_preds = np.zeros((num_samples, config.MODEL.NUM_JOINTS, 3), dtype=np.float32)
+    all_boxes = np.zeros((num_samples, 6))
+    image_path, filenames, imgnums = [], [], []
+    idx = 0
+    end = time.time()
+    time_gpu = 0.
+    n_batches = 0
+    for i, (input, target, target_weight, meta) in enumerate(val_loader):
+        if isinstance(target, (list, tuple)):
+            target = target[0]                                                           # :264
+        target = _cuda(target)
+        target_weight = _cuda(target_weight)
+        torch.cuda.synchronize()
+        infer_start = time.time()
+        output, loss = validate_batch(config, model, criterion, input, target, target_weight,
+                                      val_dataset.flip_pairs)
+        torch.cuda.synchronize()
+        time_gpu += time.time() - infer_start
+        num_images = input.size(0)
+        losses.update(loss.item(), num_images)
+        _, avg_acc, cnt, pred = accuracy(output, target, args=None, cfg=config)          # :274
+        acc.update(avg_acc, cnt)
+        batch_time.update(time.time() - end)
+        end = time.time()
+
+        c = np.asarray(meta['center'], dtype=np.float32) if not torch.is_tensor(meta['center']) \
+            else meta['center'].numpy()
+        s = np.asarray(meta['scale'], dtype=np.float32) if not torch.is_tensor(meta['scale']) \
+            else meta['scale'].numpy()
+        score = np.asarray(meta['score']) if not torch.is_tensor(meta['score']) else meta['score'].numpy()
+        preds, maxvals = get_final_preds(config, args, output, c, s)                     # :286-287
+        all_preds[idx:idx + num_images, :, 0:2] = preds[:, :, 0:2]
+        all_preds[idx:idx + num_images, :, 2:3] = maxvals
+        all_boxes[idx:idx + num_images, 0:2] = c[:, 0:2]
+        all_boxes[idx:idx + num_images, 2:4] = s[:, 0:2]
+        all_boxes[idx:idx + num_images, 4] = np.prod(s * 200, 1)
+        all_boxes[idx:idx + num_images, 5] = score
+        image_path.extend(meta['image'])
+        idx += num_images
+        n_batches += 1
+        if i % config.PRINT_FREQ == 0:
+            logger.info('Test: [{0}/{1}]\t'
+                        'Time {batch_time.val:.3f} ({batch_time.avg:.3f})\t'
+                        'Loss {loss.val:.4f} ({loss.avg:.4f})\t'
+                        'Accuracy {acc.val:.3f} ({acc.avg:.3f})'.format(
+                            i, len(val_loader) if hasattr(val_loader, '__len__') else -1,
+                            batch_time=batch_time, loss=losses, acc=acc))
+    logger.info('=> The average inference time is : %s', time_gpu / max(n_batches, 1))
+
+    name_values, perf_indicator = val_dataset.evaluate(
+        config, all_preds, output_dir, all_boxes, image_path, filenames, imgnums)
+    model_name = config.MODEL.NAME
+    for name_value in (name_values if isinstance(name_values, list) else [name_values]):
+        _print_name_value(name_value, model_name)
+    if writer_dict:
+        writer = writer_dict['writer']
+        global_steps = writer_dict['valid_global_steps']
+        writer.add_scalar('valid_loss', losses.avg, global_steps)
+        writer.add_scalar('valid_acc', acc.avg, global_steps)
+        for name_value in (name_values if isinstance(name_values, list) else [name_values]):
+            writer.add_scalars('valid', dict(name_value), global_steps)
+        writer_dict['valid_global_steps'] = global_steps + 1
+    validate.last = {'loss': losses.avg, 'acc': acc.avg}        # for callers that want the meters
+    return name_values, perf_indicator
+
+
+def _print_name_value(name_value, full_arch_name):
+    """function.py:363-380: one markdown table row per metric set."""
+    names, values = list(name_value.keys()), list(name_value.values())
+    logger.info('| Arch ' + ' '.join('| {}'.format(n) for n in names) + ' |')
+    logger.info('|---' * (len(names) + 1) + '|')
+    if len(full_arch_name) > 15:
+        full_arch_name = full_arch_name[:8] + '...'
+    logger.info('| ' + full_arch_name + ' ' + ' '.join('| {:.3f}'.format(v) for v in values) + ' |')
 
 
 class AverageMeter(object):

@@ -755,3 +755,74 @@ def heatmap_argmax(hm):
     mx = torch.empty((B, J), device=hm.device, dtype=torch.float32)
     call('advmix_heatmap_argmax', _p(hm), fmt, _p(idx), _p(mx), B, J, H * W, _st())
     return idx, mx
+
+
+# ---- validate(): flip test and final predictions ---------------------------------------------
+
+def _dense_layout(t):
+    """(tensor, nhwc flag) for a logical-NCHW fp32 CUDA tensor that is dense in NCHW or NHWC memory."""
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4:
+        raise TypeError('needs a 4-D fp32 CUDA tensor')
+    if t.is_contiguous():
+        return t, 0
+    return nhwc(t), 1
+
+
+def flip_w(x, channels_last=True):
+    """``x.flip(3)`` (function.py:241) of a dense NCHW batch, written straight into the layout the
+    networks consume (NHWC when ``channels_last``)."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+        raise TypeError('flip_w needs a 4-D fp32 CUDA tensor')
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    y = empty_nhwc(B, C, H, W, x.device) if channels_last else torch.empty_like(x)
+    call('advmix_flip_w', _p(x), _p(y), B, C, H, W, 1 if channels_last else 0, _st())
+    return y
+
+
+_partner_cache = {}
+
+
+def flip_partner(flip_pairs, J, device):
+    """int32 [J] permutation of ``flip_back``'s pairwise swaps (transforms.py:36-39), cached per device."""
+    key = (tuple(tuple(int(v) for v in p) for p in flip_pairs), J, device.index)
+    t = _partner_cache.get(key)
+    if t is None:
+        perm = list(range(J))
+        for a, b in key[0]:                      # sequential swaps, exactly like the reference loop
+            perm[a], perm[b] = perm[b], perm[a]
+        t = torch.tensor(perm, dtype=torch.int32, device=device)
+        _partner_cache[key] = t
+    return t
+
+
+def flip_merge(output, output_flipped, flip_pairs, shift, merge=True):
+    """Flip-test merge on the device: ``(output + shift(flip_back(output_flipped))) * 0.5``
+    (function.py:249-261); ``merge=False`` returns the flipped-back (and shifted) maps alone."""
+    of, fmt = _dense_layout(output_flipped.detach())
+    B, J, H, W = of.shape
+    o = None
+    if merge:
+        o = output.detach()
+        o = nhwc(o) if fmt else o.contiguous()
+        if o.shape != of.shape:
+            raise ValueError('flip_merge: shape mismatch')
+    y = empty_nhwc(B, J, H, W, of.device) if fmt else torch.empty_like(of)
+    call('advmix_flip_merge', _p(o), _p(of), _p(flip_partner(flip_pairs, J, of.device)), _p(y), B, J, H, W, fmt,
+         1 if shift else 0, _st())
+    return y
+
+
+def final_preds(hm, center, scale, post_process):
+    """Device ``get_final_preds`` (inference.py:52-95): returns (coords [B,J,2] heat-map space,
+    preds [B,J,2] image space, maxvals [B,J]) as CUDA tensors.  center/scale: [B,2] (any float dtype/host)."""
+    hm, fmt = _dense_layout(hm.detach())
+    B, J, H, W = hm.shape
+    c = torch.as_tensor(center, dtype=torch.float32).reshape(B, 2).to(hm.device).contiguous()
+    s = torch.as_tensor(scale, dtype=torch.float32).reshape(B, 2).to(hm.device).contiguous()
+    coords = torch.empty((B, J, 2), device=hm.device, dtype=torch.float32)
+    preds = torch.empty((B, J, 2), device=hm.device, dtype=torch.float32)
+    mx = torch.empty((B, J), device=hm.device, dtype=torch.float32)
+    call('advmix_final_preds', _p(hm), fmt, _p(c), _p(s), B, J, H, W, 1 if post_process else 0, _p(coords),
+         _p(preds), _p(mx), _st())
+    return coords, preds, mx

@@ -179,6 +179,23 @@ int advmix_adam(float* p, const float* g, float* m, float* v, int64_t n, const f
                 int64_t* step, void* stream);
 int advmix_fill(float* p, float value, int64_t n, void* stream);
 
+/* ---- validate(): flip test and final predictions ----------------------------------------
+ * Replace the numpy round trips of lib/core/function.py:240-261,285-287, lib/utils/transforms.py:16-41,57-107
+ * and lib/core/inference.py:52-95. */
+/* y = x.flip(3).  x dense NCHW [B,C,H,W]; y dense NCHW (y_nhwc = 0) or NHWC (1). */
+int advmix_flip_w(const float* x, float* y, int B, int C, int H, int W, int y_nhwc, void* stream);
+/* F = flip_back(flipped, pairs) (W reversed, joint j <- partner[j]); if shift, F[..., 1:] = F[..., :-1];
+ * y = out ? (out + F) * 0.5f : F.  All four [B,J,H,W] in the same dense layout (nhwc 0/1); partner[J] int32
+ * on the device. */
+int advmix_flip_merge(const float* out, const float* flipped, const int32_t* partner, float* y,
+                      int B, int J, int H, int W, int nhwc, int shift, void* stream);
+/* get_final_preds: per (b, j) first-occurrence argmax, maxvals[B*J], optional +-0.25 px shift (post_process),
+ * heat-map coordinates coords[B*J*2] (optional, may be NULL) and image coordinates preds[B*J*2] through the
+ * inverse crop transform of center[B*2] / scale[B*2] (device fp32, scale in units of 200 px). */
+int advmix_final_preds(const float* hm, int nhwc, const float* center, const float* scale,
+                       int B, int J, int H, int W, int post_process,
+                       float* coords, float* preds, float* maxvals, void* stream);
+
 /* ---- lib/nms: nms_kernel.cu:33-77 (bitmask) + :90-143 (host greedy) */
 /* device bitmask only: boxes_dev [n,5] sorted by score desc -> mask_dev [n, ceil(n/64)] uint64 */
 int advmix_nms_mask(const float* boxes_dev, int n, float thresh, uint64_t* mask_dev, void* stream);

@@ -26,7 +26,7 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 from oracle import detinit, configs                       # noqa: E402
 from oracle.posenet import posenet_spec                   # noqa: E402
 from oracle.unet import unet_spec, unet_transposed_names  # noqa: E402
-from oracle.synth import synth_batch, strided, checksum   # noqa: E402
+from oracle.synth import synth_batch, strided, checksum, synth_heatmaps, synth_boxes   # noqa: E402
 
 
 class AD(dict):
@@ -284,12 +284,141 @@ def gen_nms(M):
         json.dump({'box': box, 'oks': oks}, f)
 
 
+COCO_PAIRS = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]       # coco.py:71-72 (data)
+
+
+def gen_validate(M):
+    """Validation path from the REAL reference: get_final_preds / flip_back on synthetic maps,
+    the ``validate`` loop on tiny + full nets, COCODataset.evaluate's rescoring + OKS-NMS.  The one missing
+    third-party piece, cv2.getAffineTransform, is the restatement in oracle/validate.py (see its header)."""
+    from oracle import validate as ov
+    sys.modules['cv2'].getAffineTransform = ov.cv_get_affine_transform
+    import utils.transforms as T
+    T.cv2 = sys.modules['cv2']
+    inf, fn = M['core.inference'], M['core.function']
+    torch.cuda.synchronize = lambda *a, **k: None
+    res, meta = {}, {}
+
+    # (1) get_final_preds on synthetic maps
+    for i, (B, J, H, W) in enumerate([(4, 17, 64, 48), (3, 5, 16, 16), (2, 17, 96, 72)]):
+        hm = synth_heatmaps('val.hm%d' % i, B, J, H, W)
+        c, s, _ = synth_boxes('val.box%d' % i, B)
+        for pp in (0, 1):
+            cfg = AD.wrap({'TEST': {'POST_PROCESS': bool(pp)}, 'MODEL': {'IMAGE_SIZE': [W * 4, H * 4]}})
+            preds, maxvals = inf.get_final_preds(cfg, None, hm.copy(), c, s)
+            res['fp%d.pp%d.preds' % (i, pp)] = preds
+            res['fp%d.pp%d.maxvals' % (i, pp)] = maxvals
+        meta['fp%d' % i] = [B, J, H, W]
+
+    # (2) flip_back
+    for i, (B, J, H, W, pairs) in enumerate([(2, 17, 16, 12, COCO_PAIRS), (3, 5, 8, 8, [[0, 3], [1, 2]])]):
+        x = detinit.normal('val.fb%d' % i, (B, J, H, W), 1.0).numpy()
+        res['fb%d' % i] = T.flip_back(x.copy(), pairs)
+        meta['fb%d' % i] = {'shape': [B, J, H, W], 'pairs': pairs}
+
+    # (3) the validate loop
+    for tag, net, extra, J, B, H, W, pairs in (
+            ('hrnet_tiny', 'pose_hrnet', configs.HRNET_TINY, 5, 3, 64, 64, [[0, 3], [1, 2]]),
+            ('resnet18_tiny', 'pose_resnet', configs.RES18_TINY, 5, 3, 64, 64, [[0, 3], [1, 2]]),
+            ('hrnet_w32', 'pose_hrnet', configs.HRNET_W32, 17, 2, 256, 192, COCO_PAIRS)):
+        for mode, (flip, shift, pp) in (('plain', (False, False, False)), ('flip', (True, True, True))):
+            cfg, D, _, _ = build_ref_models(M, net, extra, J, 6, salt=30)
+            calibrate_ref(D, synth_batch(tag + '.valcalib', B, J, H, W)[0][0])
+            cfg['TEST'] = AD(FLIP_TEST=flip, SHIFT_HEATMAP=shift, POST_PROCESS=pp)
+            cfg['MODEL']['IMAGE_SIZE'] = [W, H]
+            cfg['PRINT_FREQ'] = 10 ** 9
+            batches, paths = [], []
+            for it in range(2):
+                v, t, w = synth_batch('%s.val%d' % (tag, it), B, J, H, W)
+                c, s, score = synth_boxes('%s.valbox%d' % (tag, it), B)
+                names = ['img/%012d.jpg' % (100 + (it * B + k) // 2) for k in range(B)]
+                batches.append((v[0], [t, t], w, {'center': torch.from_numpy(c), 'scale': torch.from_numpy(s),
+                                                  'score': torch.from_numpy(score), 'image': names}))
+            seen = {}
+
+            class DS:
+                flip_pairs = pairs
+
+                def __len__(self):
+                    return 2 * B
+
+                def evaluate(self, cfg_, preds, out_dir, all_boxes, img_path, *a, **k):
+                    seen['preds'], seen['boxes'], seen['paths'] = preds.copy(), all_boxes.copy(), list(img_path)
+                    return {'AP': 0.0}, 0.0
+
+            crit = Rec(M['core.loss'].JointsMSELoss(True))
+            outs = []
+            inner = crit.fn
+
+            def rec_out(o, t, w, inner=inner, outs=outs):
+                outs.append(o.detach().clone())
+                return inner(o, t, w)
+            crit.fn = rec_out
+            scal = {}
+            wd = {'writer': types.SimpleNamespace(add_scalar=lambda k, v, g: scal.__setitem__(k, float(v)),
+                                                  add_scalars=lambda *a, **k: None),
+                  'valid_global_steps': 0}
+            fn.save_debug_images = lambda *a, **k: None
+            fn._tocuda = lambda x: x
+            fn.validate(cfg, None, batches, DS(), D, crit, '/tmp', '/tmp', wd)
+            key = '%s.%s' % (tag, mode)
+            res[key + '.all_preds'] = seen['preds']
+            res[key + '.all_boxes'] = seen['boxes']
+            res[key + '.losses'] = np.array(crit.vals)
+            for it in range(2):
+                res['%s.out%d' % (key, it)] = strided(outs[it], 2048)
+            meta[key] = {'loss_avg': scal['valid_loss'], 'acc_avg': scal['valid_acc'], 'paths': seen['paths'],
+                         'B': B, 'pairs': pairs}
+            print('validate', key, crit.vals, scal, flush=True)
+
+    # (4) COCODataset.evaluate: rescoring + OKS-NMS (coco.py:318-371), constructor bypassed
+    for m, attrs in (('pycocotools', {}), ('pycocotools.coco', {'COCO': None}),
+                     ('pycocotools.cocoeval', {'COCOeval': None}), ('json_tricks', {}),
+                     ('imagecorruptions', {'corrupt': None, 'get_corruption_names': None})):
+        mod = types.ModuleType(m)
+        for k, v in attrs.items():
+            setattr(mod, k, v)
+        sys.modules.setdefault(m, mod)
+    pkg = types.ModuleType('dataset')
+    pkg.__path__ = [os.path.join(REF, 'lib', 'dataset')]
+    sys.modules['dataset'] = pkg
+    import dataset.coco as rc
+    for i, (N, per_img, soft, in_vis, oks_thre) in enumerate([(24, 6, False, 0.2, 0.6), (24, 6, True, 0.2, 0.6),
+                                                             (9, 3, False, 0.0, 0.5)]):
+        J = 17
+        base = detinit.uniform('val.oks%d.base' % i, (N // per_img, J, 2)).numpy() * 200 + 50
+        jit = detinit.normal('val.oks%d.jit' % i, (N, J, 2), 3.0).numpy()
+        kp = np.zeros((N, J, 3), dtype=np.float32)
+        kp[:, :, 0:2] = base[np.arange(N) // per_img] + jit
+        kp[:, :, 2] = detinit.uniform('val.oks%d.conf' % i, (N, J)).numpy()
+        boxes = np.zeros((N, 6))
+        boxes[:, 4] = detinit.uniform('val.oks%d.area' % i, (N,)).numpy().astype(np.float64) * 20000 + 5000
+        boxes[:, 5] = detinit.uniform('val.oks%d.score' % i, (N,)).numpy().astype(np.float64)
+        paths = ['img/%012d.jpg' % (7 + n // per_img) for n in range(N)]
+        ds = object.__new__(rc.COCODataset)
+        ds.test_robust, ds.corruption_type, ds.image_set = False, 'clean', 'test-dev2017'
+        ds.num_joints, ds.in_vis_thre, ds.oks_thre, ds.soft_nms = J, in_vis, oks_thre, soft
+        got = {}
+        ds._write_coco_keypoint_results = lambda kpts, f, got=got: got.__setitem__('k', kpts)
+        ds.evaluate(AD(RANK=0), kp.copy(), '/tmp/advmix_golden_eval', boxes.copy(), paths)
+        kept = []
+        for img_kpts in got['k']:
+            for person in img_kpts:
+                row = int(np.where((kp == person['keypoints']).all(axis=(1, 2)))[0][0])
+                kept.append([int(person['image']), row, float(person['score'])])
+        res['oks%d.kept' % i] = np.array(kept, dtype=np.float64)
+        meta['oks%d' % i] = {'N': N, 'per_img': per_img, 'soft': soft, 'in_vis': in_vis, 'oks_thre': oks_thre}
+    np.savez_compressed(os.path.join(OUT, 'validate.npz'), **res)
+    with open(os.path.join(OUT, 'validate.json'), 'w') as f:
+        json.dump(meta, f)
+
+
 def main():
     logging.basicConfig(level=logging.WARNING)
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     M = import_reference()
-    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix']
+    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate']
     for w in which:
         globals()['gen_' + w](M)
         print('done', w, flush=True)

@@ -113,3 +113,34 @@ def test_grad_sync_two_ranks_gloo(tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
     for p in procs:
         assert p.wait(timeout=120) == 0
+
+
+def test_coco_rescore_is_the_reference_running_sum():
+    """dataset.coco.rescore (vectorised over persons) == the per-person float32 running sum of
+    coco.py:340-353 as restated by the oracle - bit for bit, including persons with no confident joint."""
+    import numpy as np
+    from advmix_amd.dataset.coco import rescore, image_index, COCO_FLIP_PAIRS
+    rng = np.random.default_rng(5)
+    preds = rng.random((40, 17, 3)).astype(np.float32)
+    preds[3, :, 2] = 0.0                                 # nobody above the threshold
+    box = rng.random(40)
+    for thr in (0.0, 0.2, 0.95):
+        got = rescore(preds, box, thr)
+        for n in range(40):
+            acc, cnt = 0, 0
+            for j in range(17):
+                t = preds[n][j][2]
+                if t > thr:
+                    acc, cnt = acc + t, cnt + 1
+            if cnt:
+                acc = acc / cnt
+            assert got[n] == acc * box[n], (thr, n)
+    assert image_index('images/val2017/000000397133.jpg') == 397133
+    assert len(COCO_FLIP_PAIRS) == 8
+
+
+def test_flip_partner_is_the_sequential_pair_swap():
+    import torch
+    from advmix_amd import ops
+    p = ops.flip_partner([[1, 2], [3, 4]], 6, torch.device('cpu'))
+    assert p.tolist() == [0, 2, 1, 4, 3, 5] and p.dtype == torch.int32

@@ -214,3 +214,117 @@ def test_nms_mirror_matches_reference_semantics():
         db = [{'score': s, 'keypoints': kk, 'area': a} for s, kk, a in zip(c['score'], k, c['area'])]
         assert [int(i) for i in pn.oks_nms(db, c['thresh'])] == c['keep'], name
         assert [int(i) for i in pn.soft_oks_nms(db, c['thresh'])] == c['soft_keep'], name
+
+
+# ---- validate() ------------------------------------------------------------------------------
+
+VAL_CASES = {
+    'hrnet_tiny': ('pose_hrnet', 'HRNET_TINY', 5, 3, 64, 64),
+    'resnet18_tiny': ('pose_resnet', 'RES18_TINY', 5, 3, 64, 64),
+    'hrnet_w32': ('pose_hrnet', 'HRNET_W32', 17, 2, 256, 192),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(VAL_CASES))
+@pytest.mark.parametrize('mode', ['plain', 'flip'])
+def test_validate_loop_matches_reference_fixture(tag, mode):
+    """The product ``validate`` (device flip test + device get_final_preds) on the batches the REAL
+    reference's ``validate`` was run on: merged heat-maps / losses within 1e-3, all_boxes exact,
+    maxvals within 1e-3, coordinates equal wherever the argmax did not flip on an fp32 near-tie, and
+    - exactly - equal to the oracle's get_final_preds applied to the product's own heat-maps."""
+    from oracle import configs, validate as oval
+    from oracle.posenet import calibrate
+    from oracle.synth import synth_batch, synth_boxes, strided
+    from helpers import gold_npz, gold_json, build_states
+    from smoke_step import product_models, assert_close
+    from advmix_amd.core.function import validate
+    from advmix_amd.core.loss import JointsMSELoss
+    net, ename, J, B, H, W = VAL_CASES[tag]
+    extra = getattr(configs, ename)
+    g, meta = gold_npz('validate.npz'), gold_json('validate.json')
+    key = '%s.%s' % (tag, mode)
+    m = meta[key]
+    flip = mode == 'flip'
+    D_sd, T_sd, G_sd = build_states(net, extra, J, salt=30)
+    calibrate(net, D_sd, synth_batch(tag + '.valcalib', B, J, H, W)[0][0], extra)
+    cfg, D, _, _ = product_models(net, extra, J, D_sd, T_sd, G_sd)
+    cfg.defrost() if hasattr(cfg, 'defrost') else None
+    cfg['TEST'] = type(cfg)({'FLIP_TEST': flip, 'SHIFT_HEATMAP': flip, 'POST_PROCESS': flip})
+    cfg['PRINT_FREQ'] = 10 ** 9
+    batches, boxes = [], []
+    for it in range(2):
+        v, t, w = synth_batch('%s.val%d' % (tag, it), B, J, H, W)
+        c, s, score = synth_boxes('%s.valbox%d' % (tag, it), B)
+        names = ['img/%012d.jpg' % (100 + (it * B + k) // 2) for k in range(B)]
+        batches.append((v[0], [t, t], w, {'center': torch.from_numpy(c), 'scale': torch.from_numpy(s),
+                                          'score': torch.from_numpy(score), 'image': names}))
+        boxes.append((c, s))
+    seen, outs, losses = {}, [], []
+
+    class DS:
+        flip_pairs = m['pairs']
+
+        def __len__(self):
+            return 2 * B
+
+        def evaluate(self, cfg_, preds, out_dir, all_boxes, img_path, *a, **k):
+            seen.update(preds=preds.copy(), boxes=all_boxes.copy(), paths=list(img_path))
+            return {'AP': 0.0}, 0.0
+
+    crit = JointsMSELoss(True).cuda()
+
+    def rec(o, t, w):
+        outs.append(o.detach().clone())
+        v = crit(o, t, w)
+        losses.append(float(v))
+        return v
+    validate(cfg, None, batches, DS(), D, rec, '/tmp', '/tmp', None)
+    assert seen['paths'] == m['paths']
+    assert np.array_equal(seen['boxes'], g[key + '.all_boxes'])
+    for it in range(2):
+        assert_close('%s merged heat-map %d' % (key, it), strided(outs[it].contiguous(), 2048),
+                     g['%s.out%d' % (key, it)])
+    assert_close(key + ' losses', np.array(losses), g[key + '.losses'])
+    assert abs(validate.last['loss'] - m['loss_avg']) <= 1e-3 * max(1.0, abs(m['loss_avg']))
+    want = g[key + '.all_preds']
+    assert_close(key + ' maxvals', seen['preds'][:, :, 2], want[:, :, 2])
+    same = np.abs(seen['preds'][:, :, 0:2] - want[:, :, 0:2]).max(axis=2) <= 1e-3
+    assert same.mean() >= 0.9, same.mean()
+    # exact post-processing parity on the product's own heat-maps
+    for it in range(2):
+        c, s = boxes[it]
+        p, mv, _ = oval.get_final_preds(outs[it].contiguous().cpu().numpy(), c, s, flip)
+        got = seen['preds'][it * B:(it + 1) * B]
+        assert np.array_equal(got[:, :, 2:3], mv)
+        ulp = np.spacing(np.abs(p).astype(np.float32))
+        assert (np.abs(got[:, :, 0:2].astype(np.float64) - p) <= ulp).all()
+
+
+def test_coco_rescoring_and_oks_nms_match_reference_fixture():
+    """advmix_amd.dataset.coco.rescore_and_nms (device OKS matrix) against COCODataset.evaluate's kept
+    persons and scores recorded from the real reference."""
+    from oracle import detinit
+    from helpers import gold_npz, gold_json
+    from advmix_amd.dataset.coco import rescore_and_nms
+    g, meta = gold_npz('validate.npz'), gold_json('validate.json')
+    for i in range(3):
+        m = meta['oks%d' % i]
+        N, per_img, J = m['N'], m['per_img'], 17
+        base = detinit.uniform('val.oks%d.base' % i, (N // per_img, J, 2)).numpy() * 200 + 50
+        jit = detinit.normal('val.oks%d.jit' % i, (N, J, 2), 3.0).numpy()
+        kp = np.zeros((N, J, 3), dtype=np.float32)
+        kp[:, :, 0:2] = base[np.arange(N) // per_img] + jit
+        kp[:, :, 2] = detinit.uniform('val.oks%d.conf' % i, (N, J)).numpy()
+        boxes = np.zeros((N, 6))
+        boxes[:, 4] = detinit.uniform('val.oks%d.area' % i, (N,)).numpy().astype(np.float64) * 20000 + 5000
+        boxes[:, 5] = detinit.uniform('val.oks%d.score' % i, (N,)).numpy().astype(np.float64)
+        paths = ['img/%012d.jpg' % (7 + n // per_img) for n in range(N)]
+        kept = rescore_and_nms(kp, boxes, paths, J, m['in_vis'], m['oks_thre'], m['soft'])
+        flat = []
+        for persons in kept:
+            for person in persons:
+                row = int(np.where((kp == person['keypoints']).all(axis=(1, 2)))[0][0])
+                flat.append((int(person['image']), row, float(person['score'])))
+        want = g['oks%d.kept' % i]
+        assert [(a, b) for a, b, _ in flat] == [(int(a), int(b)) for a, b, _ in want], i
+        assert np.allclose([f[2] for f in flat], want[:, 2], rtol=1e-12, atol=0)

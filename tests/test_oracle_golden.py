@@ -164,3 +164,117 @@ def test_advmix_and_plain_steps_match_reference(tag):
         r = plain_step(net, extra, D, optD, v[0], t, w)
         close([float(r['loss'])], [g[tag + '.plain_losses'][it]], 1e-4, 1e-3)
     checksum_close(checksum(D, meta['plain_D'].keys()), meta['plain_D'])
+
+
+# ---- validation path: oracle/validate.py against the real reference's outputs ----------------
+
+from oracle import validate as oval                                   # noqa: E402
+from oracle.synth import synth_heatmaps, synth_boxes                  # noqa: E402
+
+VAL_CASES = {
+    'hrnet_tiny': ('pose_hrnet', configs.HRNET_TINY, 5, 3, 64, 64),
+    'resnet18_tiny': ('pose_resnet', configs.RES18_TINY, 5, 3, 64, 64),
+    'hrnet_w32': ('pose_hrnet', configs.HRNET_W32, 17, 2, 256, 192),
+}
+
+
+def test_final_preds_and_flip_back_match_reference():
+    g, meta = gold_npz('validate.npz'), gold_json('validate.json')
+    for i in range(3):
+        B, J, H, W = meta['fp%d' % i]
+        hm = synth_heatmaps('val.hm%d' % i, B, J, H, W)
+        c, s, _ = synth_boxes('val.box%d' % i, B)
+        for pp in (0, 1):
+            preds, maxvals, _ = oval.get_final_preds(hm.copy(), c, s, bool(pp))
+            assert preds.dtype == np.float32
+            assert np.array_equal(preds, g['fp%d.pp%d.preds' % (i, pp)]), (i, pp)
+            assert np.array_equal(maxvals, g['fp%d.pp%d.maxvals' % (i, pp)])
+        assert (g['fp%d.pp1.preds' % i] != g['fp%d.pp0.preds' % i]).any()          # the shift did something
+    for i in range(2):
+        m = meta['fb%d' % i]
+        x = detinit.normal('val.fb%d' % i, tuple(m['shape']), 1.0).numpy()
+        assert np.array_equal(oval.flip_back(x, m['pairs']), g['fb%d' % i])
+
+
+def device_formula_preds(coords, center, scale, W, H):
+    """numpy statement of the closed form advmix_final_preds evaluates on the device (postproc.hip):
+    with rot = 0 the three-point affine is axis-aligned, so the 6x6 solve collapses to two slopes."""
+    f32, f64 = np.float32, np.float64
+    out = np.zeros(coords.shape, dtype=np.float32)
+    for b in range(coords.shape[0]):
+        cx, cy = f32(center[b, 0]), f32(center[b, 1])
+        sw = f32(scale[b, 0]) * f32(200.0)
+        cy1 = f32(f64(cy) + f64(sw * f32(-0.5)))
+        d = f32(cy - cy1)
+        s2x = f32(cx + (-d))
+        hw, hh = f64(W) * 0.5, f64(H) * 0.5
+        mx, my = (f64(cx) - f64(s2x)) / hw, (f64(cy) - f64(cy1)) / hw
+        tx, ty = f64(cx) - mx * hw, f64(cy) - my * hh
+        out[b, :, 0] = (mx * coords[b, :, 0].astype(f64) + tx).astype(f32)
+        out[b, :, 1] = (my * coords[b, :, 1].astype(f64) + ty).astype(f32)
+    return out
+
+
+def test_device_affine_closed_form_equals_the_three_point_solve():
+    g, meta = gold_npz('validate.npz'), gold_json('validate.json')
+    for i in range(3):
+        B, J, H, W = meta['fp%d' % i]
+        hm = synth_heatmaps('val.hm%d' % i, B, J, H, W)
+        c, s, _ = synth_boxes('val.box%d' % i, B)
+        _, _, coords = oval.get_final_preds(hm.copy(), c, s, True)
+        want = g['fp%d.pp1.preds' % i]
+        got = device_formula_preds(coords, c, s, W, H)
+        ulp = np.spacing(np.abs(want).astype(np.float32))
+        assert (np.abs(got.astype(np.float64) - want) <= ulp).all()                # at most 1 float32 ulp
+        assert (got == want).mean() > 0.98
+
+
+@pytest.mark.parametrize('tag', sorted(VAL_CASES))
+@pytest.mark.parametrize('mode', ['plain', 'flip'])
+def test_validate_loop_matches_reference(tag, mode):
+    net, extra, J, B, H, W = VAL_CASES[tag]
+    g, meta = gold_npz('validate.npz'), gold_json('validate.json')
+    key = '%s.%s' % (tag, mode)
+    m = meta[key]
+    flip = mode == 'flip'
+    D, _, _ = build_states(net, extra, J, salt=30)
+    calibrate(net, D, synth_batch(tag + '.valcalib', B, J, H, W)[0][0], extra)
+    outs, cs, ss, scores, losses = [], [], [], [], []
+    for it in range(2):
+        v, t, w = synth_batch('%s.val%d' % (tag, it), B, J, H, W)
+        c, s, score = synth_boxes('%s.valbox%d' % (tag, it), B)
+        out, loss, _, _ = oval.validate_batch(net, extra, D, v[0], t, w, m['pairs'], flip, flip)
+        close(strided(torch.from_numpy(out), 2048), g['%s.out%d' % (key, it)], 1e-4, 1e-3)
+        outs.append(out); cs.append(c); ss.append(s); scores.append(score); losses.append(loss)
+    close(losses, g[key + '.losses'], 1e-5, 1e-4)
+    assert abs(np.mean(losses) - m['loss_avg']) <= 1e-4 * max(1.0, abs(m['loss_avg']))
+    all_preds, all_boxes = oval.collect(np.concatenate(outs), np.concatenate(cs), np.concatenate(ss),
+                                        np.concatenate(scores), flip)
+    assert np.array_equal(all_boxes, g[key + '.all_boxes'])
+    want = g[key + '.all_preds']
+    close(all_preds[:, :, 2], want[:, :, 2], 1e-4, 1e-3)
+    same = np.abs(all_preds[:, :, 0:2] - want[:, :, 0:2]).max(axis=2) <= 1e-3
+    assert same.mean() >= 0.9, same.mean()        # an argmax may flip on a near-tie between two fp32 forwards
+
+
+def test_rescoring_and_oks_nms_match_reference():
+    g, meta = gold_npz('validate.npz'), gold_json('validate.json')
+    for i in range(3):
+        m = meta['oks%d' % i]
+        N, per_img, J = m['N'], m['per_img'], 17
+        base = detinit.uniform('val.oks%d.base' % i, (N // per_img, J, 2)).numpy() * 200 + 50
+        jit = detinit.normal('val.oks%d.jit' % i, (N, J, 2), 3.0).numpy()
+        kp = np.zeros((N, J, 3), dtype=np.float32)
+        kp[:, :, 0:2] = base[np.arange(N) // per_img] + jit
+        kp[:, :, 2] = detinit.uniform('val.oks%d.conf' % i, (N, J)).numpy()
+        boxes = np.zeros((N, 6))
+        boxes[:, 4] = detinit.uniform('val.oks%d.area' % i, (N,)).numpy().astype(np.float64) * 20000 + 5000
+        boxes[:, 5] = detinit.uniform('val.oks%d.score' % i, (N,)).numpy().astype(np.float64)
+        ids = [7 + n // per_img for n in range(N)]
+        got = oval.rescore_and_nms(kp, boxes, ids, m['in_vis'], m['oks_thre'], m['soft'])
+        flat = [[img, row, sc] for img, kept in got for row, sc in kept]
+        want = g['oks%d.kept' % i]
+        assert len(flat) == len(want) and 0 < len(flat) <= N, (i, len(flat), len(want))
+        assert m['soft'] or len(flat) < N          # hard NMS suppressed someone; soft NMS only re-orders (<= 20 kept)
+        assert [(int(a), int(b)) for a, b, _ in flat] == [(int(a), int(b)) for a, b, _ in want]
+        assert np.allclose([f[2] for f in flat], want[:, 2], rtol=1e-12, atol=0)

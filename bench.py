@@ -134,11 +134,125 @@ def time_dominant_kernel(B, device, iters=100):
             'us_per_launch': round(ms * 1e3, 2), 'algorithmic_gflop_per_launch': round(flops / 1e9, 3)}
 
 
-def cpu_baseline(workload, budget_s=25.0, hard_timeout_s=150.0):
+def time_eval_conv(B, device, iters=100):
+    """Dominant kernel of the validation path: the same 3x3 s1 32->32 conv with the eval-mode BatchNorm +
+    ReLU folded into its epilogue (one launch per conv+bn+relu)."""
+    import ctypes
+    from advmix_amd._lib import call
+    x = torch.randn(B, 64, 48, 32, device=device)
+    w = torch.randn(32, 3, 3, 32, device=device) * 0.05
+    y = torch.empty(B, 64, 48, 32, device=device)
+    g, b, rm = (torch.randn(32, device=device) for _ in range(3))
+    rv = torch.rand(32, device=device) + 0.5
+    P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    run = lambda: call('advmix_conv_fwd_ex', P(x), P(w), None, P(y), B, 64, 48, 32, 64, 48, 32, 3, 3, 1, 1,  # noqa: E731
+                       P(g), P(b), P(rm), P(rv), 1e-5, None, 1, None, None, st)
+    for _ in range(10):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * B * 64 * 48 * 32 * 32 * 9
+    return {'bound': 'mfma', 'kernel': 'conv_direct<1,1,4,1,32,fwd,epilogue=BN-eval+ReLU> 3x3 s1 32->32 @64x48',
+            'achieved': round(flops / (ms * 1e-3) / 1e12, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+            'us_per_launch': round(ms * 1e3, 2), 'algorithmic_gflop_per_launch': round(flops / 1e9, 3)}
+
+
+def bench_validate(a, device, rank, world):
+    """--path validate: images/sec of the validate() batch body (function.py:223-300) with the COCO test
+    settings of the experiment YAMLs (FLIP_TEST, SHIFT_HEATMAP, POST_PROCESS): two eval forwards, the
+    fused flip-back/shift/average kernel, loss.item(), PCK accuracy, device get_final_preds + its D2H."""
+    import numpy as np
+    from advmix_amd.core.function import validate_batch
+    from advmix_amd.core.evaluate import accuracy
+    from advmix_amd.core.inference import get_final_preds
+    from advmix_amd.dataset.coco import COCO_FLIP_PAIRS
+    from advmix_amd.config import CfgNode
+    net, extra, J, H, W, downs, _ = WORKLOADS[a.workload]
+    cfg, D, G, T, crit, optD, optG = build_models(a.workload, device)
+    cfg['TEST'] = CfgNode({'FLIP_TEST': True, 'SHIFT_HEATMAP': True, 'POST_PROCESS': True})
+    D.eval()
+    views, tgt, tw = synth(a.batch, J, H, W, device, 1234 + rank)
+    rng = np.random.default_rng(7 + rank)
+    center = (rng.random((a.batch, 2)) * [600, 440] + 20).astype(np.float32)
+    sw = (rng.random(a.batch) * 2.5 + 0.4).astype(np.float32)
+    scale = np.stack([sw, sw / np.float32(0.75)], 1)
+    graph = None
+    if a.exec_mode == 'graph':
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                validate_batch(cfg, D, crit, views[0], tgt, tw, COCO_FLIP_PAIRS)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            g_out, g_loss = validate_batch(cfg, D, crit, views[0], tgt, tw, COCO_FLIP_PAIRS)
+
+    def one_batch():
+        if graph is not None:
+            graph.replay()
+            out, loss = g_out, g_loss
+        else:
+            out, loss = validate_batch(cfg, D, crit, views[0], tgt, tw, COCO_FLIP_PAIRS)
+        lv = loss.item()
+        accuracy(out, tgt)
+        preds, maxvals = get_final_preds(cfg, None, out, center, scale)
+        return lv, preds
+
+    import torch.distributed as dist
+    for _ in range(a.warmup):
+        one_batch()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        lv, preds = one_batch()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank != 0:
+        return None
+    fwd_gflop = {'hrnet_w32': 15.290, 'hrnet_w48': 70.613, 'resnet50': 10.853}[a.workload]     # SURVEY 2.4
+    value = a.batch * world * a.steps / dt
+    line = {'metric': 'images/sec validate batch, flip test (%s)' % a.workload, 'value': round(value, 2),
+            'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic (N(0,1) images, Gaussian targets, random boxes), random-init weights',
+            'config': {'workload': '%s_%dx%d_validate_flip' % (a.workload, H, W), 'batch_per_gpu': a.batch,
+                       'global_batch': a.batch * world, 'parallelism': 'dp%d' % world,
+                       'exec': 'hipgraph' if graph is not None else 'eager',
+                       'batch_gflop_per_image': 2 * fwd_gflop},
+            'step_tflops_per_gpu': round(value / world * 2 * fwd_gflop / 1e3, 2),
+            'step_frac_of_fp32_mfma_peak': round(value / world * 2 * fwd_gflop / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
+            'last_loss': round(lv, 6)}
+    if not a.no_roofline:
+        line['roofline'] = time_eval_conv(a.batch, device)
+    if world == 1 and not a.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(a.workload, path='validate')
+    return line
+
+
+def cpu_baseline(workload, budget_s=25.0, hard_timeout_s=150.0, path='train'):
     """The CPU oracle's AdvMix step on this host (bounded sample: B=4, 1 warm-up + a few timed
     steps), in a CPU-only child process with a hard timeout so the bench always finishes."""
     import subprocess
-    cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'cpu_bench.py'), workload, str(budget_s)]
+    cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'cpu_bench.py'), workload, str(budget_s), path]
     env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=hard_timeout_s, env=env, cwd=ROOT)
@@ -160,6 +274,8 @@ def main():
     ap.add_argument('--workload', default='hrnet_w32', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=32, help='images per GPU (TRAIN.BATCH_SIZE_PER_GPU)')
     ap.add_argument('--exec', dest='exec_mode', default='graph', choices=['graph', 'eager'])
+    ap.add_argument('--path', default='train', choices=['train', 'validate'],
+                    help='train = the headline AdvMix step; validate = the validate() batch body (SURVEY 8 f1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     a = ap.parse_args()
@@ -179,6 +295,16 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29555')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    if a.path == 'validate':
+        line = bench_validate(a, device, rank, world)
+        if world > 1 or force_sync:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            sys.stdout.flush()
+            print(json.dumps(line), flush=True)
+        return
 
     from advmix_amd.core.function import advmix_step
     from advmix_amd.core.evaluate import accuracy

@@ -30,6 +30,41 @@ def effective_cpus(cap=32):
     return max(1, min(n, cap))
 
 
+def validate_main(workload, budget, cores):
+    """One validate batch (function.py:223-300, FLIP_TEST/SHIFT_HEATMAP/POST_PROCESS on) on the host."""
+    import numpy as np
+    from oracle import detinit, configs
+    from oracle.posenet import posenet_spec, calibrate
+    from oracle.synth import synth_batch, synth_boxes
+    from oracle import validate as ov
+    W = {'hrnet_w32': ('pose_hrnet', configs.HRNET_W32, 17, 256, 192),
+         'hrnet_w48': ('pose_hrnet', configs.HRNET_W48, 17, 384, 288),
+         'resnet50': ('pose_resnet', configs.RES50, 17, 256, 192)}
+    net, extra, J, H, Wd = W[workload]
+    D = detinit.fill_state_dict(posenet_spec(net, extra, J))
+    B = 8
+    v, t, w = synth_batch('bench.cpu.val', B, J, H, Wd)
+    c, s, score = synth_boxes('bench.cpu.valbox', B)
+    calibrate(net, D, v[0], extra)
+    pairs = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]
+
+    def batch():
+        out, loss, _, _ = ov.validate_batch(net, extra, D, v[0], t, w, pairs, True, True)
+        ov.collect(out, c, s, score, True)
+    t0 = time.time()
+    batch()
+    warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while n < 16 and (n == 0 or time.time() - t0 + warm < budget):
+        batch()
+        n += 1
+    dt = time.time() - t0
+    print(json.dumps({'value': round(B * n / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+                      'sample': '%s validate batch (flip test + final preds), B=%d, %d timed batches after 1 warm-up '
+                                '(%.1fs), torch CPU fp32 + numpy oracle, %d threads (os.cpu_count=%d)' % (
+                                    workload, B, n, warm, cores, os.cpu_count() or 0)}), flush=True)
+
+
 def main():
     workload, budget = sys.argv[1], float(sys.argv[2])
     cores = effective_cpus()
@@ -37,6 +72,8 @@ def main():
     import torch
     torch.set_num_threads(cores)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if len(sys.argv) > 3 and sys.argv[3] == 'validate':
+        return validate_main(workload, budget, cores)
     from oracle import detinit, configs
     from oracle.posenet import posenet_spec, trainable
     from oracle.unet import unet_spec, unet_transposed_names

@@ -40,6 +40,7 @@ SIGNATURES = {
     'advmix_maxpool3x3s2_bwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'advmix_scale_dev': [_p, _p, _p, _f, _l, _p],
     'advmix_axpy': [_p, _p, _f, _l, _p],
+    'advmix_add': [_p, _p, _p, _l, _p],
     'advmix_cat_views': [_p, _p, _p, _p, _i, _i, _i, _p],
     'advmix_mix_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     'advmix_mix_bwd': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],

@@ -62,6 +62,7 @@ struct AdvmixOpts {
     int conv3_min_items;   // minimum (tile x chunk) items before the persistent 3x3 kernel is used
     int conv3_grid;        // persistent workgroups (256 = one per CU)
     int wgrad_direct;      // 1: register-fragment wgrad kernel allowed
+    int mfma16;            // 1: conv_direct uses the 16x16x4 MFMA shape (16 pixel rows x 64 B per fragment load)
 };
 AdvmixOpts& advmix_opts();
 

@@ -54,11 +54,37 @@ constexpr unsigned OOB = 0x80000000u;   // >= any buffer size we accept -> load 
 // BT: the weight operand is given k-major, w[Ck][R][S][Cn] (a Conv2d's own [Co][R][S][Ci] seen from its
 // input gradient, a ConvTranspose2d's own [Ci][R][S][Co] seen from its forward): a thread loads 4
 // consecutive n of one k and scatters them into the [n][k] LDS image, so no re-layout kernel is needed.
-template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT, bool EPI>
+// MR = rows of the MFMA shape: 32 -> v_mfma_f32_32x32x2 (lane: row l%32, k-lane l/32 of 2; a fragment load
+// touches 32 pixel rows x 32 B), 16 -> v_mfma_f32_16x16x4 (row l%16, k-lane l/16 of 4; 16 pixel rows x 64 B per
+// load, i.e. half as many cache lines per instruction at the same MFMA rate).  A 32x32 wave tile is NSUB x NSUB
+// MFMA tiles.
+template <int MR> struct MfmaShape;
+template <> struct MfmaShape<32> {
+    typedef f32x16 acc_t;
+    static constexpr int NR = 16;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
+};
+template <> struct MfmaShape<16> {
+    typedef f32x4 acc_t;
+    static constexpr int NR = 4;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int r, int lk) { return 4 * lk + r; }
+};
+
+template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT, bool EPI, int MR>
 __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     static_assert(WM * WN == 4, "4 waves");
+    typedef MfmaShape<MR> MS;
+    constexpr int NSUB = 32 / MR;              // MFMA tiles per 32 rows / 32 columns
+    constexpr int KL = 64 / MR;                // k-lanes: lanes that hold different k of the same row
+    constexpr int RM = TM * NSUB, RN = TN * NSUB;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr int KQ = KC / 8;                 // float4 k-groups per chunk (8 k each: 4 per lane half)
+    constexpr int KQ = KC / (4 * KL);          // float4 k-groups per chunk (4 k per k-lane each)
     constexpr int LDB = KC + 4;
     constexpr int BSL = (BN * KC / 4 + 255) / 256;
 
@@ -67,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
+    const int l31 = lane % MR, lh = lane / MR;             // row within the MFMA tile, k-lane
     const int wm = wid / WN, wn = wid % WN;
 
     int Hp, Wp, Th, Tw, rh = 0, rw = 0, phh = 0, phw = 0, zsl = blockIdx.z;
@@ -112,11 +138,11 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     }
 
     // ---- per-lane A rows -----------------------------------------------------------------
-    int a_nb[TM], a_h[TM], a_w[TM];
-    bool a_ok[TM];
+    int a_nb[RM], a_h[RM], a_w[RM];
+    bool a_ok[RM];
 #pragma unroll
-    for (int t = 0; t < TM; ++t) {
-        int m = m0 + (wm * TM + t) * 32 + l31;
+    for (int t = 0; t < RM; ++t) {
+        int m = m0 + wm * TM * 32 + t * MR + l31;
         a_ok[t] = m < Mp;
         int mm = a_ok[t] ? m : 0;
         int n = mm / (Hp * Wp);
@@ -157,28 +183,28 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     // set (two chunks of look-ahead) was measured and is NOT faster: 43.4 % vs 43.8 % on the
     // 3x3 32->32 conv and 47 % vs 60 % on the 128x64 tile (130 VGPRs -> 2 waves/SIMD), i.e. the
     // kernel is not bound by load latency per wave.
-    f32x4 A0[TM][KQ], A1[TM][KQ], Br[BSL];
-    f32x16 acc[TM][TN];
+    f32x4 A0[RM][KQ], A1[RM][KQ], Br[BSL];
+    typename MS::acc_t acc[RM][RN];
 #pragma unroll
-    for (int t = 0; t < TM; ++t)
+    for (int t = 0; t < RM; ++t)
 #pragma unroll
-        for (int u = 0; u < TN; ++u)
+        for (int u = 0; u < RN; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+            for (int r = 0; r < MS::NR; ++r) acc[t][u][r] = 0.f;
 
     // chunk cursor (of the chunk being ISSUED)
     int tap = ch_lo / cpt;
     int c0 = (ch_lo - tap * cpt) * KC;
 
-    auto issue = [&](f32x4 (&A)[TM][KQ]) {                 // loads of the chunk at (tap, c0)
+    auto issue = [&](f32x4 (&A)[RM][KQ]) {                 // loads of the chunk at (tap, c0)
         const int4 tt = taptab[tap];
 #pragma unroll
-        for (int t = 0; t < TM; ++t) {
+        for (int t = 0; t < RM; ++t) {
             int hi = a_h[t] + tt.x, wi = a_w[t] + tt.y;
             bool ok = a_ok[t] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
             unsigned off = ok ? (unsigned)(((a_nb[t] + hi * p.Wi + wi) * p.Ci + c0 + lh * 4) * 4) : OOB;
 #pragma unroll
-            for (int q = 0; q < KQ; ++q) A[t][q] = bload(xr, off + q * 32);
+            for (int q = 0; q < KQ; ++q) A[t][q] = bload(xr, off + q * (16 * KL));
         }
 #pragma unroll
         for (int i = 0; i < BSL; ++i)
@@ -200,22 +226,20 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
                 }
             }
     };
-    auto compute = [&](f32x4 (&A)[TM][KQ], int buf) {
+    auto compute = [&](f32x4 (&A)[RM][KQ], int buf) {
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
-            f32x4 b[TN];
+            f32x4 b[RN];
 #pragma unroll
-            for (int u = 0; u < TN; ++u)
-                b[u] = *reinterpret_cast<const f32x4*>(&Bs[buf][((wn * TN + u) * 32 + l31) * LDB + q * 8 + lh * 4]);
+            for (int u = 0; u < RN; ++u)
+                b[u] = *reinterpret_cast<const f32x4*>(
+                    &Bs[buf][(wn * TN * 32 + u * MR + l31) * LDB + q * (4 * KL) + lh * 4]);
 #pragma unroll
-            for (int t = 0; t < TM; ++t)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int u = 0; u < TN; ++u) {
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t][q][0], b[u][0], acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t][q][1], b[u][1], acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t][q][2], b[u][2], acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t][q][3], b[u][3], acc[t][u], 0, 0, 0);
-                }
+                for (int t = 0; t < RM; ++t)
+#pragma unroll
+                    for (int u = 0; u < RN; ++u) acc[t][u] = MS::mma(A[t][q][j], b[u][j], acc[t][u]);
         }
     };
 
@@ -242,8 +266,8 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
 
     // ---- epilogue -----------------------------------------------------------------------------
 #pragma unroll
-    for (int u = 0; u < TN; ++u) {
-        const int col = n0 + (wn * TN + u) * 32 + l31;
+    for (int u = 0; u < RN; ++u) {
+        const int col = n0 + wn * TN * 32 + u * MR + l31;
         const bool cvalid = col < p.Co;
         const float bv = (cvalid && p.bias && (!SPLIT || zsl == 0)) ? p.bias[col] : 0.f;
         float bn_is = 1.f, bn_g = 1.f, bn_b = 0.f, bn_m = 0.f;
@@ -254,10 +278,10 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
         }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int t = 0; t < TM; ++t) {
+        for (int t = 0; t < RM; ++t) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = m0 + (wm * TM + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            for (int r = 0; r < MS::NR; ++r) {
+                int m = m0 + wm * TM * 32 + t * MR + MS::row(r, lh);
                 if (m >= Mp || !cvalid) continue;
                 int64_t off;
                 if (MODE == 0) {
@@ -281,8 +305,11 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
             }
         }
         if (EPI && p.stats) {                               // wave-uniform branch: every lane shuffles
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
+#pragma unroll
+            for (int o = MR; o < 64; o <<= 1) {             // lanes of the same column differ in the k-lane bits
+                s1 += __shfl_xor(s1, o, 64);
+                s2 += __shfl_xor(s2, o, 64);
+            }
             if (lh == 0 && cvalid) {
                 // 3072 wave slabs on the dominant shape would make the finalize kernel read 1.5 MB; fold
                 // them onto a few slots instead (~200K fp64 atomics per launch = ~1 us of atomic pipe)
@@ -294,7 +321,7 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     }
 }
 
-template <int MODE, int KC, bool BT, bool EPI>
+template <int MODE, int KC, bool BT, bool EPI, int MR>
 int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
     static_assert(!EPI || (MODE == 0 && !BT), "fused epilogue: forward gather only");
     const int phases = MODE == 0 ? 1 : p.stride * p.stride;
@@ -303,7 +330,7 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
 #define LAUNCHD(TM_, TN_, WM_, WN_, SP_)                                                          \
     do {                                                                                          \
         dim3 g(cdiv(Mmax, 32 * TM_ * WM_), cdiv(p.Co, 32 * TN_ * WN_), phases * p.nsplit);        \
-        hipLaunchKernelGGL((conv_direct<TM_, TN_, WM_, WN_, KC, MODE, SP_, BT, (EPI && !SP_)>), g, dim3(256), 0, st, p); \
+        hipLaunchKernelGGL((conv_direct<TM_, TN_, WM_, WN_, KC, MODE, SP_, BT, (EPI && !SP_), MR>), g, dim3(256), 0, st, p); \
     } while (0)
     p.nsplit = 1;
     p.stats_nbg = ADVMIX_STAT_SLOTS;
@@ -359,14 +386,19 @@ int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const 
         p.bn_eps = epi->eps; p.act = epi->act; p.stats = epi->stats;
     }
     int rc;
+#define LAUNCH_KC(MODE_, BT_, EPI_, MR_)                                                        \
+    (Ci % 32 == 0 ? direct::launch<MODE_, 32, BT_, EPI_, MR_>(p, Mmax, st) : direct::launch<MODE_, 16, BT_, EPI_, MR_>(p, Mmax, st))
+#define LAUNCH_MR(MODE_, BT_, EPI_) (advmix_opts().mfma16 ? LAUNCH_KC(MODE_, BT_, EPI_, 16) : LAUNCH_KC(MODE_, BT_, EPI_, 32))
     if (bt)
-        rc = Ci % 32 == 0 ? direct::launch<1, 32, true, false>(p, Mmax, st) : direct::launch<1, 16, true, false>(p, Mmax, st);
+        rc = LAUNCH_MR(1, true, false);
     else if (mode == 1)
-        rc = Ci % 32 == 0 ? direct::launch<1, 32, false, false>(p, Mmax, st) : direct::launch<1, 16, false, false>(p, Mmax, st);
+        rc = LAUNCH_MR(1, false, false);
     else if (epi)
-        rc = Ci % 32 == 0 ? direct::launch<0, 32, false, true>(p, Mmax, st) : direct::launch<0, 16, false, true>(p, Mmax, st);
+        rc = LAUNCH_MR(0, false, true);
     else
-        rc = Ci % 32 == 0 ? direct::launch<0, 32, false, false>(p, Mmax, st) : direct::launch<0, 16, false, false>(p, Mmax, st);
+        rc = LAUNCH_MR(0, false, false);
+#undef LAUNCH_MR
+#undef LAUNCH_KC
     if (stats_nbg) *stats_nbg = p.stats_nbg;
     return rc;
 }

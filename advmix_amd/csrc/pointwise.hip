@@ -177,6 +177,20 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ a, const 
         a[i] += alpha * b[i];
 }
 
+// out = a + b, 4 floats per thread when n % 4 == 0 (gradient fan-in inside a launch chain)
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, int64_t n, int vec) {
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+            reinterpret_cast<f32x4*>(out)[i] =
+                reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+    } else {
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            out[i] = a[i] + b[i];
+    }
+}
+
 __global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                         const float* __restrict__ s_dev, float s_host, int64_t n) {
     const float s = (s_dev ? *s_dev : 1.0f) * s_host;
@@ -278,6 +292,16 @@ extern "C" int advmix_axpy(float* a, const float* b, float alpha, int64_t n, voi
     if (!a || !b || n < 0) return ADVMIX_EINVAL;
     if (n == 0) return ADVMIX_OK;
     hipLaunchKernelGGL(axpy_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, n);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    if (!a || !b || !out || n < 0) return ADVMIX_EINVAL;
+    if (n == 0) return ADVMIX_OK;
+    const int vec = (n % 4 == 0) && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0);
+    hipLaunchKernelGGL(add_kernel, dim3(stream_blocks(vec ? n / 4 : n)), dim3(256), 0, (hipStream_t)stream, a, b, out,
+                       n, vec);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }

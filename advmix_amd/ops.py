@@ -589,6 +589,83 @@ class JointsLoss:
         return out, None, None
 
 
+def _add(st, a, b):
+    """a + b for two dense tensors of identical layout, on the member's stream (gradient fan-in
+    inside a Chain; a torch add would run on the caller's stream)."""
+    if a.shape != b.shape or a.stride() != b.stride():
+        raise RuntimeError('advmix_amd: gradient fan-in of differently laid out tensors')
+    out = keep(torch.empty_like(a, memory_format=torch.preserve_format))
+    call('advmix_add', _p(a), _p(b), _p(out), a.numel(), st)
+    return out
+
+
+class Chain:
+    """A dependent run of members executed back to back on ONE lane: an HRNet branch with its fuse
+    convolutions, a bottleneck stack, a whole U-Net.  Inside a chain nothing waits for the other
+    lanes, so branches drift apart and one branch's tiny kernels (norm finalize, fuse sums) overlap
+    another's convolutions; the level-synchronous schedule (one group per plan level) joined all
+    lanes after every conv+BN instead.
+
+    tensors = (external slot tensors..., then every other tensor of every sub-member)
+    meta    = (subs, ext_slots, out_slots); subs[i] = (op, refs, sub_meta, dst_slot) with refs[j] =
+              ('s', slot) | ('i', flat index into tensors) | None for the sub-member's j-th tensor.
+    The sub-members are the ordinary member classes; their gradients w.r.t. a slot that has several
+    consumers are summed here (``advmix_add``), which is what autograd's fan-in adds did before."""
+
+    @staticmethod
+    def NHWC(meta):
+        return tuple(range(len(meta[1])))
+
+    @staticmethod
+    def n_out(meta):
+        return len(meta[2])
+
+    @staticmethod
+    def fwd(st, lane, t, meta, needs):
+        subs, ext_slots, out_slots = meta
+        val = {s_: t[i] for i, s_ in enumerate(ext_slots)}
+        need = {s_: bool(needs[i]) for i, s_ in enumerate(ext_slots)}
+        saved, rec = [], []
+        for op, refs, smeta, dst in subs:
+            tin = tuple(None if r is None else (val[r[1]] if r[0] == 's' else t[r[1]]) for r in refs)
+            nin = tuple(False if r is None else (need[r[1]] if r[0] == 's' else bool(needs[r[1]])) for r in refs)
+            o, sv, ex = op.fwd(st, lane, tin, smeta, nin)
+            wants = any(nin)
+            if not wants:
+                sv = ()
+            keep(o[0])                                     # an intermediate nobody saved must outlive the lanes
+            val[dst], need[dst] = o[0], wants
+            rec.append((len(saved), len(sv), ex, nin))
+            saved += list(sv)
+        return tuple(val[s_] for s_ in out_slots), tuple(saved), rec
+
+    @staticmethod
+    def bwd(st, lane, saved, rec, meta, grads, needs):
+        subs, ext_slots, out_slots = meta
+        grad = {}
+        for s_, g in zip(out_slots, grads):
+            if g is not None:
+                grad[s_] = g if s_ not in grad else _add(st, grad[s_], g)
+        flat = [None] * len(needs)
+        for (op, refs, smeta, dst), (sp, sc, ex, nin) in zip(reversed(subs), reversed(rec)):
+            go = grad.pop(dst, None)
+            if go is None or not any(nin):
+                continue
+            r = op.bwd(st, lane, saved[sp:sp + sc], ex, smeta, [go], nin)
+            for ref, g in zip(refs, r):
+                if g is None or ref is None:
+                    continue
+                keep(g)
+                if ref[0] == 's':
+                    grad[ref[1]] = g if ref[1] not in grad else _add(st, grad[ref[1]], g)
+                else:
+                    flat[ref[1]] = g if flat[ref[1]] is None else _add(st, flat[ref[1]], g)
+        for i, s_ in enumerate(ext_slots):
+            if needs[i]:
+                flat[i] = grad.get(s_)
+        return flat
+
+
 # =============================================================================================
 class GroupFn(torch.autograd.Function):
     """Runs a list of independent members; member i on lane i % MAX_LANES (lane 0 = the
@@ -605,7 +682,8 @@ class GroupFn(torch.autograd.Function):
         flat = list(flat)
         pos = 0
         for op, cnt, meta in members:
-            for k in (range(cnt) if op.NHWC is None else op.NHWC):
+            idx = op.NHWC(meta) if callable(op.NHWC) else op.NHWC
+            for k in (range(cnt) if idx is None else idx):
                 if flat[pos + k] is not None:
                     flat[pos + k] = nhwc(flat[pos + k])
             pos += cnt
@@ -669,7 +747,8 @@ class GroupFn(torch.autograd.Function):
 
 
 def run_group(members):
-    """members: list of (op, tensors tuple, meta).  Returns a list of output tuples."""
+    """members: list of (op, tensors tuple, meta).  Returns one entry per member: its output
+    tensor, or for a Chain the tuple of its output slots."""
     flat, spec = [], []
     for op, tensors, meta in members:
         spec.append((op, len(tensors), meta))
@@ -677,8 +756,13 @@ def run_group(members):
     outs = GroupFn.apply(spec, *flat)
     res, pos = [], 0
     for op, tensors, meta in members:
-        res.append(outs[pos])                              # every member has exactly one output
-        pos += 1
+        if hasattr(op, 'n_out'):                           # a Chain returns the tuple of its output slots
+            n = op.n_out(meta)
+            res.append(tuple(outs[pos:pos + n]))
+            pos += n
+        else:
+            res.append(outs[pos])
+            pos += 1
     return res
 
 

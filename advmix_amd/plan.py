@@ -10,6 +10,7 @@ Builders below restate the topologies of lib/models/pose_hrnet.py:274-460,
 lib/models/pose_resnet.py:103-207 and lib/models/Unet_generator.py:13-112.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -28,10 +29,13 @@ class Plan:
         self.steps = []
         self.ch = [in_channels]   # channels per slot; slot 0 is the input
         self.out = None
+        self.tag = None           # launch-chain label given to the steps created next (None = standalone)
+        self.slot_tag = [None]    # per slot: the label of the step that produces it
 
     # -- slot helpers ------------------------------------------------------------------
     def _new(self, c):
         self.ch.append(c)
+        self.slot_tag.append(self.tag)
         return len(self.ch) - 1
 
     def conv(self, x, name, cout, k, stride, pad, bias=False):
@@ -112,6 +116,10 @@ EXPANSION = {'BASIC': 1, 'BOTTLENECK': 4}
 
 def hrnet_plan(extra, num_joints):
     P = Plan(3)
+    # Launch chains (see PlanNet): the stem is one chain; inside a stage, chain (module m, branch b) is
+    # [fuse sum that produced the branch input, the branch's blocks, the fuse convolutions that read the
+    # branch output] - everything a branch does between two exchanges with the other branches.
+    P.tag = 'stem'
     x = P.conv_bn(0, 'conv1', 'bn1', 64, 3, 2, 1, ACT_RELU)
     x = P.conv_bn(x, 'conv2', 'bn2', 64, 3, 2, 1, ACT_RELU)
     for k in range(4):
@@ -126,6 +134,7 @@ def hrnet_plan(extra, num_joints):
         tp = 'transition%d' % (st - 1)
         nxt = []
         for i in range(nb):                               # pose_hrnet.py:323-356 + :433-452
+            P.tag = 's%d.m0.b%d' % (st, i)
             if i < len(cur):
                 if P.ch[cur[i]] != widths[i]:
                     nxt.append(P.conv_bn(cur[i], '%s.%d.0' % (tp, i), '%s.%d.1' % (tp, i),
@@ -144,6 +153,7 @@ def hrnet_plan(extra, num_joints):
             mp = 'stage%d.%d' % (st, m)
             multi = not (st == 4 and m == nmod - 1)       # :405-408
             for b in range(nb):
+                P.tag = 's%d.m%d.b%d' % (st, m, b)
                 for k in range(cfg['NUM_BLOCKS'][b]):
                     cur[b] = P.block(kind, cur[b], '%s.branches.%d.%d' % (mp, b, k), cfg['NUM_CHANNELS'][b])
             if nb == 1:
@@ -153,6 +163,7 @@ def hrnet_plan(extra, num_joints):
                 srcs, shifts = [], []
                 for j in range(nb):
                     fp = '%s.fuse_layers.%d.%d' % (mp, i, j)
+                    P.tag = 's%d.m%d.b%d' % (st, m, j)     # fuse convs ride at the tail of their SOURCE branch
                     if j == i:
                         srcs.append(cur[j]); shifts.append(0)
                     elif j > i:
@@ -166,8 +177,12 @@ def hrnet_plan(extra, num_joints):
                                           P.ch[cur[i]] if last else P.ch[cur[j]], 3, 2, 1,
                                           ACT_NONE if last else ACT_RELU)
                         srcs.append(t); shifts.append(0)
+                # the sum opens the next module's chain of branch i; at a stage boundary it stands alone so
+                # that the new branch's transition does not have to wait for a whole sibling chain
+                P.tag = ('s%d.m%d.b%d' % (st, m + 1, i)) if m + 1 < nmod else ('head' if st == 4 else None)
                 fused.append(P.fuse(srcs, shifts, ACT_RELU))
             cur = fused
+    P.tag = 'head'
     k = extra['FINAL_CONV_KERNEL']
     P.out = P.conv(cur[0], 'final_layer', num_joints, k, 1, 1 if k == 3 else 0, bias=True)
     return P
@@ -180,6 +195,7 @@ RESNET_SPEC = {18: ('BASIC', [2, 2, 2, 2]), 34: ('BASIC', [3, 4, 6, 3]), 50: ('B
 def resnet_plan(extra, num_joints):
     kind, layers = RESNET_SPEC[extra['NUM_LAYERS']]
     P = Plan(3)
+    P.tag = 'all'                                          # a sequential network: one launch chain
     x = P.conv_bn(0, 'conv1', 'bn1', 64, 7, 2, 3, ACT_RELU)
     x = P.maxpool(x)
     for li, n in enumerate(layers):
@@ -203,6 +219,7 @@ def unet_plan(input_nc, output_nc, num_downs, ngf=64):
     tensor; the parent's in-place ReLU on the concatenation becomes cat+relu."""
     inner = [ngf, ngf * 2, ngf * 4, ngf * 8] + [ngf * 8] * (num_downs - 4)
     P = Plan(input_nc)
+    P.tag = 'all'                                          # a sequential network: one launch chain
     pre = ['model']
     for i in range(1, num_downs):
         pre.append(pre[-1] + ('.model.1' if i == 1 else '.model.3'))
@@ -233,6 +250,33 @@ def unet_plan(input_nc, output_nc, num_downs, ngf=64):
 
 
 # ---------------------------------------------------------------------------------------------
+CHAINS = os.environ.get('ADVMIX_CHAINS', '1') != '0'
+
+
+class _Slot:
+    def __init__(self, slot):
+        self.slot = slot
+
+
+class _SlotRefs:
+    """Stands in for the slot table while a chain's static description is built."""
+
+    def __getitem__(self, s):
+        return _Slot(s)
+
+
+class _Name:
+    def __init__(self, name):
+        self.name = name
+
+
+class _NameRefs:
+    """Stands in for the parameter table: records which named tensor a sub-member wants."""
+
+    def __getitem__(self, n):
+        return _Name(n)
+
+
 class PlanNet(nn.Module):
     """nn.Module whose parameters/buffers are registered under the reference's state-dict
     keys and whose forward interprets a Plan with the HIP ops."""
@@ -251,13 +295,17 @@ class PlanNet(nn.Module):
         # conv -> BatchNorm pairs become one fused member (ops.ConvBN) when the conv has no bias and its
         # output feeds only that BatchNorm
         steps = self._fuse_conv_bn(plan.steps)
-        # ASAP levels: steps of one level are mutually independent (HRNet's branches, fuse convs,
-        # residual downsample paths) and are launched as ONE concurrent group
+        # Launch chains: dependent runs of steps that execute back to back on one lane (ops.Chain).
+        # Chains of one level are mutually independent (HRNet's branches with their fuse convolutions)
+        # and are launched as ONE concurrent group; lanes only join between levels (once per HRNet
+        # module instead of once per conv+BN).  ADVMIX_CHAINS=0 restores one step per chain.
+        steps = self._build_chains(steps, plan.out, plan.slot_tag) if CHAINS else steps
         level = {0: 0}
         groups = {}
         for st in steps:
             lvl = 1 + max(level[s] for s in self._srcs(st))
-            level[self._dst(st)] = lvl
+            for d in self._dsts(st):
+                level[d] = lvl
             groups.setdefault(lvl, []).append(st)
         self._levels = [groups[k] for k in sorted(groups)]
         self._last_use = {}
@@ -266,6 +314,7 @@ class PlanNet(nn.Module):
                 for s in self._srcs(st):
                     self._last_use[s] = li
         self._cache = None
+        self._chain_meta = {}
 
     @staticmethod
     def _default_init(shape, kind):
@@ -315,6 +364,41 @@ class PlanNet(nn.Module):
         return cls._toposort(out)
 
     @classmethod
+    def _build_chains(cls, steps, out_slot, slot_tag):
+        """Contract the steps that carry the same chain label (given by the plan builder) into one
+        ('chain', steps, external source slots, output slots) super-step.  The contracted graph must
+        stay acyclic (``_toposort`` raises otherwise); levels are then taken over super-steps."""
+        by_tag, chains = {}, []                            # chains: [None, [steps]] in first-step order
+        for st in steps:
+            tag = slot_tag[cls._dst(st)]
+            if tag is None or tag not in by_tag:
+                chains.append([None, [st]])
+                if tag is not None:
+                    by_tag[tag] = len(chains) - 1
+            else:
+                chains[by_tag[tag]][1].append(st)
+        consumers = {}
+        for ci, (_, sts) in enumerate(chains):
+            for st in sts:
+                for s in cls._srcs(st):
+                    consumers.setdefault(s, set()).add(ci)
+        out = []
+        for ci, (_, sts) in enumerate(chains):
+            if len(sts) == 1:
+                out.append(sts[0])
+                continue
+            made = [cls._dst(st) for st in sts]
+            ext, seen = [], set(made)
+            for st in sts:
+                for s in cls._srcs(st):
+                    if s not in seen:
+                        seen.add(s)
+                        ext.append(s)
+            outs = [d for d in made if d == out_slot or (consumers.get(d, set()) - {ci})]
+            out.append(('chain', tuple(sts), tuple(ext), tuple(outs)))
+        return cls._toposort(out)
+
+    @classmethod
     def _toposort(cls, steps):
         ready, done, out = {0}, set(), []
         pending = list(steps)
@@ -323,7 +407,7 @@ class PlanNet(nn.Module):
             for st in pending:
                 if all(s in ready for s in cls._srcs(st)):
                     out.append(st)
-                    ready.add(cls._dst(st))
+                    ready.update(cls._dsts(st))
                 else:
                     rest.append(st)
             if len(rest) == len(pending):
@@ -340,9 +424,15 @@ class PlanNet(nn.Module):
             return st[3]
         return st[2]                                       # inorm / act / maxpool
 
+    @classmethod
+    def _dsts(cls, st):
+        return list(st[3]) if st[0] == 'chain' else [cls._dst(st)]
+
     @staticmethod
     def _srcs(st):
         k = st[0]
+        if k == 'chain':
+            return list(st[2])
         if k == 'convbn':
             return [st[3]] + ([st[7]] if st[7] is not None else [])
         if k in ('conv', 'deconv'):
@@ -377,8 +467,36 @@ class PlanNet(nn.Module):
         self._cache = None
         return r
 
+    def _chain_member(self, st, slots, T, train):
+        """ops.Chain member of a ('chain', steps, ext_slots, out_slots) super-step.  The static part
+        (which tensor of which sub-member is a slot, which a parameter) is built once per mode."""
+        key = (id(st), train)
+        cached = self._chain_meta.get(key)
+        if cached is None:
+            _, sts, ext, outs = st
+            ref = _SlotRefs()
+            subs, names = [], []
+            for sub in sts:
+                op, tensors, meta = self._member(sub, ref, _NameRefs(), train)
+                refs = []
+                for t in tensors:
+                    if t is None:
+                        refs.append(None)
+                    elif isinstance(t, _Slot):
+                        refs.append(('s', t.slot))
+                    else:
+                        refs.append(('i', len(ext) + len(names)))
+                        names.append(t.name)
+                subs.append((op, tuple(refs), meta, self._dst(sub)))
+            cached = ((tuple(subs), tuple(ext), tuple(outs)), tuple(names))
+            self._chain_meta[key] = cached
+        meta, names = cached
+        return (ops.Chain, tuple(slots[s] for s in meta[1]) + tuple(T[n] for n in names), meta)
+
     def _member(self, st, slots, T, train):
         k = st[0]
+        if k == 'chain':
+            return self._chain_member(st, slots, T, train)
         if k == 'convbn':
             _, cname, bname, s, d, stride, pad, res, act = st
             return (ops.ConvBN,
@@ -439,7 +557,11 @@ class PlanRun:
     def consume(self, outs):
         net, sts = self.net, self.net._levels[self.li]
         for st, o in zip(sts, outs):
-            self.slots[net._dst(st)] = o
+            if st[0] == 'chain':
+                for d, t in zip(st[3], o):
+                    self.slots[d] = t
+            else:
+                self.slots[net._dst(st)] = o
         for st in sts:                                     # drop dead activations early
             for s in net._srcs(st):
                 if net._last_use[s] == self.li and s != net.plan.out:

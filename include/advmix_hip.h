@@ -149,6 +149,8 @@ int advmix_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int 
 int advmix_scale_dev(float* y, const float* x, const float* s_dev, float s_host, int64_t n, void* stream);
 /* a += alpha * b (n floats) */
 int advmix_axpy(float* a, const float* b, float alpha, int64_t n, void* stream);
+/* out = a + b (n floats, no aliasing): gradient fan-in of a tensor with two consumers */
+int advmix_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 
 /* ---- AdvMix glue: lib/core/function.py:137-144 (cat + softmax-mix), lib/core/loss.py:25-65,
  * lib/core/inference.py:22-49 (argmax), lib/utils/utils.py:89-92 (Adam) */

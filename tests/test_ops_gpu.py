@@ -60,16 +60,19 @@ CONV_CASES = [
 ]
 
 
-@pytest.fixture(params=['auto', 'lds3x3', 'direct', 'igemm'])
+@pytest.fixture(params=['auto', 'lds3x3', 'direct', 'direct16', 'igemm'])
 def conv_path(request):
     """Force each generation of the conv kernels in turn (advmix_set_option)."""
     from advmix_amd.ops import set_option
-    cfg = {'auto': (1, 0, 512), 'lds3x3': (1, 1, 1), 'direct': (1, 0, 512), 'igemm': (0, 0, 512)}[request.param]
+    cfg = {'auto': (1, 0, 512), 'lds3x3': (1, 1, 1), 'direct': (1, 0, 512), 'direct16': (1, 0, 512),
+           'igemm': (0, 0, 512)}[request.param]
     set_option('wgrad_direct', {'igemm': 0, 'auto': 1}.get(request.param, 2))   # 2 = force where eligible
     set_option('direct', cfg[0])
     set_option('conv3', cfg[1])
     set_option('conv3_min_items', cfg[2])
+    set_option('mfma16', 1 if request.param == 'direct16' else 0)      # 16x16x4 MFMA shape in conv_direct
     yield request.param
+    set_option('mfma16', 0)
     set_option('direct', 1)
     set_option('wgrad_direct', 1)
     set_option('conv3', 0)

@@ -6,8 +6,11 @@ raises at import, and every op raises on a non-zero status.
 import ctypes
 import os
 
+import torch  # noqa: F401  - FIRST: torch carries its own libamdhip64; loading ours before it would bind
+#               the kernels to a second HIP runtime instance and every launch on a torch stream fails
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, 'libadvmix_hip.so')
+SO_PATH = os.environ.get('ADVMIX_SO') or os.path.join(_HERE, 'libadvmix_hip.so')   # ADVMIX_SO: debug builds (tools/)
 
 if not os.path.exists(SO_PATH):
     raise ImportError('advmix_amd: %s not found - build it with `python -m advmix_amd.build` '

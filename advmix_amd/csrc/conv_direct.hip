@@ -204,17 +204,29 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
             bool ok = a_ok[t] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
             unsigned off = ok ? (unsigned)(((a_nb[t] + hi * p.Wi + wi) * p.Ci + c0 + lh * 4) * 4) : OOB;
 #pragma unroll
-            for (int q = 0; q < KQ; ++q) A[t][q] = bload(xr, off + q * (16 * KL));
+            for (int q = 0; q < KQ; ++q) {
+#if defined(CD_DBG) && (CD_DBG & 1)                  /* throughput experiments (tools/conv_limiter.sh): no A loads */
+                float fv = __builtin_bit_cast(float, off + q);
+                A[t][q] = f32x4{fv, fv, fv, fv};
+#else
+                A[t][q] = bload(xr, off + q * (16 * KL));
+#endif
+            }
         }
+#if !(defined(CD_DBG) && (CD_DBG & 2))
 #pragma unroll
         for (int i = 0; i < BSL; ++i)
             Br[i] = bload(wr, b_off[i] == OOB ? OOB
                               : b_off[i] + (BT ? (unsigned)(((c0 * p.R * p.S + tt.w) * p.Co) * 4)
                                              : (unsigned)((tt.z + c0) * 4)));
+#endif
         c0 += KC;
         if (c0 >= p.Ci) { c0 = 0; ++tap; }
     };
     auto stage = [&](int buf) {
+#if defined(CD_DBG) && (CD_DBG & 2)                  /* no weight staging at all */
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < BSL; ++i)
             if (tid + 256 * i < BN * KC / 4) {
@@ -231,9 +243,15 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
         for (int q = 0; q < KQ; ++q) {
             f32x4 b[RN];
 #pragma unroll
-            for (int u = 0; u < RN; ++u)
+            for (int u = 0; u < RN; ++u) {
+#if defined(CD_DBG) && (CD_DBG & 2)
+                float fb = __builtin_bit_cast(float, (unsigned)(buf + q + u + lane));
+                b[u] = f32x4{fb, fb, fb, fb};
+#else
                 b[u] = *reinterpret_cast<const f32x4*>(
                     &Bs[buf][(wn * TN * 32 + u * MR + l31) * LDB + q * (4 * KL) + lh * 4]);
+#endif
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -255,12 +273,18 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
             compute(A0, 0);
             if (!more) break;
             stage(1);
+#if !(defined(CD_DBG) && (CD_DBG & 2))
             __syncthreads();
+#endif
             // odd chunk
             more = ci + 2 < nch;
             if (more) issue(A0);
             compute(A1, 1);
+#if defined(CD_DBG) && (CD_DBG & 2)
+            if (more) stage(0);
+#else
             if (more) { stage(0); __syncthreads(); }
+#endif
         }
     }
 
@@ -293,6 +317,9 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
                     off = ((int64_t)(n * p.Ho + rh + hi_ * p.stride) * p.Wo + rw + wi_ * p.stride) * p.Co + col;
                 }
                 float v = acc[t][u][r] + bv;
+#if defined(CD_DBG) && (CD_DBG & 4)                  /* no output stores (kept alive by an impossible value) */
+                if (v != 123456.789f) continue;
+#endif
                 if (SPLIT) { atomicAdd(p.y + off, v); continue; }
                 if (EPI) {
                     s1 += v;

@@ -92,6 +92,25 @@ def build_models(workload, device):
     return cfg, D, G, T, crit, optD, optG
 
 
+def _event_time(run, iters, reps=5):
+    """Median over ``reps`` HIP-event measurements of ``iters`` back-to-back launches (ms per launch);
+    events are recorded on the stream the kernels are launched on (torch's current stream)."""
+    for _ in range(20):
+        run()
+    vals = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        vals.append(e0.elapsed_time(e1) / iters)
+    vals.sort()
+    return vals[len(vals) // 2], vals
+
+
 def time_dominant_kernel(B, device, iters=100):
     """HIP-event timing of the dominant kernel: the 3x3 s1 32->32 conv on the 64x48 branch
     (64 launches per HRNet-W32 forward), launched back to back through the C ABI (ctypes adds
@@ -109,16 +128,7 @@ def time_dominant_kernel(B, device, iters=100):
     # the variant the training step launches: conv + per-channel sums for the following BatchNorm
     run = lambda: call('advmix_conv_fwd_ex', P(x), P(w), None, P(y), B, 64, 48, 32, 64, 48, 32, 3, 3, 1, 1,  # noqa: E731
                        None, None, None, None, 0.0, None, 0, P(slots), ctypes.byref(nbg), st)
-    for _ in range(10):
-        run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    ms, runs = _event_time(run, iters)
     flops = 2.0 * B * 64 * 48 * 32 * 32 * 9
     # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2
     # on gfx950 + WRITE_SIZE, tools/pmc_conv.sh + tools/summarize_pmc.py); measured at B = 32
@@ -131,7 +141,8 @@ def time_dominant_kernel(B, device, iters=100):
             'achieved': round(flops / (ms * 1e-3) / 1e12, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
             'traffic_unit': 'HBM bytes per launch (PMC, corrected); algorithmic = 25.2e6',
-            'us_per_launch': round(ms * 1e3, 2), 'algorithmic_gflop_per_launch': round(flops / 1e9, 3)}
+            'us_per_launch': round(ms * 1e3, 2), 'us_per_launch_runs': [round(v * 1e3, 2) for v in runs],
+            'algorithmic_gflop_per_launch': round(flops / 1e9, 3)}
 
 
 def time_eval_conv(B, device, iters=100):
@@ -148,21 +159,13 @@ def time_eval_conv(B, device, iters=100):
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     run = lambda: call('advmix_conv_fwd_ex', P(x), P(w), None, P(y), B, 64, 48, 32, 64, 48, 32, 3, 3, 1, 1,  # noqa: E731
                        P(g), P(b), P(rm), P(rv), 1e-5, None, 1, None, None, st)
-    for _ in range(10):
-        run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    ms, runs = _event_time(run, iters)
     flops = 2.0 * B * 64 * 48 * 32 * 32 * 9
     return {'bound': 'mfma', 'kernel': 'conv_direct<1,1,4,1,32,fwd,epilogue=BN-eval+ReLU> 3x3 s1 32->32 @64x48',
             'achieved': round(flops / (ms * 1e-3) / 1e12, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
-            'us_per_launch': round(ms * 1e3, 2), 'algorithmic_gflop_per_launch': round(flops / 1e9, 3)}
+            'us_per_launch': round(ms * 1e3, 2), 'us_per_launch_runs': [round(v * 1e3, 2) for v in runs],
+            'algorithmic_gflop_per_launch': round(flops / 1e9, 3)}
 
 
 def bench_validate(a, device, rank, world):

@@ -26,3 +26,25 @@ for s, e, n in sel:
     agg[n][0] += e - s; agg[n][1] += 1
 for n, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:30]:
     print('%6.2f%%  calls %6d  avg %8.1f us  %s' % (100 * d / tot, c, d / c / 1e3, n))
+
+# concurrency histogram: share of the window with exactly k kernels in flight, and how much of the
+# window has no MFMA (conv / wgrad) kernel in flight at all
+pts = []
+for s, e, n in sel:
+    heavy = ('conv_direct' in n) or ('conv_wgrad' in n) or ('wgrad_direct' in n) or ('conv_igemm' in n)
+    pts.append((s, 1, heavy)); pts.append((e, -1, heavy))
+pts.sort()
+hist = collections.defaultdict(int)
+k = h = 0
+no_heavy = 0
+prev = pts[0][0]
+for t, d, heavy in pts:
+    hist[k] += t - prev
+    if h == 0 and k > 0:
+        no_heavy += t - prev
+    prev = t
+    k += d
+    if heavy:
+        h += d
+print('kernels in flight: ' + '  '.join('%d: %.1f%%' % (kk, 100 * v / span) for kk, v in sorted(hist.items()) if v > 0.002 * span))
+print('time with kernels in flight but no conv/wgrad kernel among them: %.1f%% of the window' % (100 * no_heavy / span))

@@ -289,6 +289,11 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     }
 
     // ---- epilogue -----------------------------------------------------------------------------
+    // BN column sums: the WM waves that share a column meet in LDS (the weight buffer is free now), so a
+    // workgroup issues ONE pair of fp64 atomics per column instead of one per wave
+    float* sred = &Bs[0][0];                               // [2][WM][BN]
+    const bool stats = EPI && p.stats != nullptr;          // uniform over the grid
+    if (stats) __syncthreads();                            // every wave is done reading Bs
 #pragma unroll
     for (int u = 0; u < RN; ++u) {
         const int col = n0 + wn * TN * 32 + u * MR + l31;
@@ -331,19 +336,33 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
                 p.y[off] = v;
             }
         }
-        if (EPI && p.stats) {                               // wave-uniform branch: every lane shuffles
+        if (stats) {                                        // wave-uniform branch: every lane shuffles
 #pragma unroll
             for (int o = MR; o < 64; o <<= 1) {             // lanes of the same column differ in the k-lane bits
                 s1 += __shfl_xor(s1, o, 64);
                 s2 += __shfl_xor(s2, o, 64);
             }
-            if (lh == 0 && cvalid) {
-                // 3072 wave slabs on the dominant shape would make the finalize kernel read 1.5 MB; fold
-                // them onto a few slots instead (~200K fp64 atomics per launch = ~1 us of atomic pipe)
-                const int pb = (blockIdx.x * WM + wm) % p.stats_nbg;
-                atomicAdd(p.stats + (int64_t)col * p.stats_nbg + pb, (double)s1);
-                atomicAdd(p.stats + ((int64_t)p.Co + col) * p.stats_nbg + pb, (double)s2);
+            if (lh == 0) {
+                const int cb = wn * TN * 32 + u * MR + l31;
+                sred[wm * BN + cb] = s1;
+                sred[(WM + wm) * BN + cb] = s2;
             }
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.Co) {
+            double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < WM; ++k) {
+                d1 += (double)sred[k * BN + tid];
+                d2 += (double)sred[(WM + k) * BN + tid];
+            }
+            // the per-workgroup sums are folded onto stats_nbg slots per column (768 workgroups on the
+            // dominant shape -> 12 atomics per address), which norm_finalize reduces and re-zeroes
+            const int pb = blockIdx.x % p.stats_nbg;
+            atomicAdd(p.stats + (int64_t)(n0 + tid) * p.stats_nbg + pb, d1);
+            atomicAdd(p.stats + ((int64_t)p.Co + n0 + tid) * p.stats_nbg + pb, d2);
         }
     }
 }

@@ -468,6 +468,13 @@ extern "C" int advmix_conv_tr(const float* x, const float* wt, const float* bias
     return launch_igemm<1>(p, Mmax, (hipStream_t)stream);
 }
 
+// workgroups a wgrad launch aims for (output tiles x pixel slices); every slice adds its partial tile with
+// fp32 atomics, so this trades parallelism against atomic traffic (ADVMIX_WGRAD_BLOCKS to experiment)
+static int wgrad_target_blocks() {
+    static int v = [] { const char* e = getenv("ADVMIX_WGRAD_BLOCKS"); int t = e ? atoi(e) : 1024; return t > 0 ? t : 1024; }();
+    return v;
+}
+
 extern "C" int advmix_conv_wgrad(const float* a, const float* b, float* dw,
                                  int N, int Ha, int Wa, int Ca, int Hb, int Wb, int Cb,
                                  int R, int S, int stride, int pad, void* stream) {
@@ -485,7 +492,7 @@ extern "C" int advmix_conv_wgrad(const float* a, const float* b, float* dw,
 #define LAUNCHW(WM_, WN_, V_)                                                             \
     do {                                                                                  \
         int tiles = cdiv(Ca, 32 * WM_) * cdiv(Ntot, 32 * WN_);                            \
-        int64_t ns = 1024 / tiles;                                                        \
+        int64_t ns = wgrad_target_blocks() / tiles;                                       \
         if (ns < 1) ns = 1;                                                               \
         int64_t maxs = (P + 63) / 64;                                                     \
         if (ns > maxs) ns = maxs;                                                         \

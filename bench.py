@@ -133,7 +133,7 @@ def time_dominant_kernel(B, device, iters=100):
     # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2
     # on gfx950 + WRITE_SIZE, tools/pmc_conv.sh + tools/summarize_pmc.py); measured at B = 32
     traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_conv32_direct.json')
+    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_conv32_epi.json')      # the same kernel variant (conv + BN sums)
     if B == 32 and os.path.exists(pmc):
         with open(pmc) as f:
             traffic = round(json.load(f)['hbm_bytes_per_launch'])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time one conv configuration through the C ABI directly (ctypes, ~3 us/call of host overhead,
 so the HIP-event average is the kernel's launch-to-launch time, not Python's).
-usage: microbench_conv.py B Ci H W Co k stride pad [mode=fwd|dgrad|wgrad] [iters]"""
+usage: microbench_conv.py B Ci H W Co k stride pad [mode=fwd|fwd_stats|dgrad|wgrad] [iters]"""
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,7 +19,12 @@ y = torch.randn(B, Ho, Wo, Co, device=dev)
 dw = torch.zeros(Co, k, k, Ci, device=dev)
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-if mode == 'fwd':
+if mode == 'fwd_stats':      # the variant the training step launches: conv + BN column sums in the epilogue
+    slots = torch.zeros(2 * Co * 64, device=dev, dtype=torch.float64)
+    nbg = ctypes.c_int(0)
+    run = lambda: call('advmix_conv_fwd_ex', P(x), P(w), None, P(y), B, H, W, Ci, Ho, Wo, Co, k, k, s, p,
+                       None, None, None, None, 0.0, None, 0, P(slots), ctypes.byref(nbg), st)
+elif mode == 'fwd':
     run = lambda: call('advmix_conv_fwd', P(x), P(w), None, P(y), B, H, W, Ci, Ho, Wo, Co, k, k, s, p, st)
 elif mode == 'dgrad':
     run = lambda: call('advmix_conv_tr', P(y), P(wt), None, P(x), B, Ho, Wo, Co, H, W, Ci, k, k, s, p, st)

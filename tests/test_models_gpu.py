@@ -328,3 +328,43 @@ def test_coco_rescoring_and_oks_nms_match_reference_fixture():
         want = g['oks%d.kept' % i]
         assert [(a, b) for a, b, _ in flat] == [(int(a), int(b)) for a, b, _ in want], i
         assert np.allclose([f[2] for f in flat], want[:, 2], rtol=1e-12, atol=0)
+
+
+def test_launch_chains_equal_the_level_schedule(monkeypatch):
+    """Scheduling only: the chain schedule (ops.Chain members, 12 levels for an HRNet) and the one-step-per-member
+    schedule launch the same kernels on the same data.  Results agree to rounding, not bit for bit: K-split
+    convolutions and the BN column sums accumulate with atomics (order varies run to run in either schedule),
+    and gradient fan-in sums associate differently."""
+    from oracle import configs
+    from oracle.synth import synth_batch
+    from advmix_amd import plan as plan_mod
+    from advmix_amd.core.loss import JointsMSELoss
+    net, extra, J, B, H, W = 'pose_hrnet', configs.HRNET_TINY, 5, 2, 64, 64
+    D_sd, T_sd, G_sd = build_states(net, extra, J, salt=40)
+    v, t, w = synth_batch('chains.check', B, J, H, W)
+    res = {}
+    for chains in (True, False):
+        monkeypatch.setattr(plan_mod, 'CHAINS', chains)
+        cfg, D, G, _ = product_models(net, extra, J, D_sd, T_sd, G_sd)
+        kinds = {st[0] for lv in D._levels for st in lv}
+        assert ('chain' in kinds) == chains
+        D.train()
+        x = v[0].cuda().requires_grad_(True)
+        out = D(x)
+        loss = JointsMSELoss(True).cuda()(out, t.cuda(), w.cuda())
+        loss.backward()
+        g_out = G(torch.cat(v, 1).cuda())
+        res[chains] = (out.detach().cpu(), x.grad.detach().cpu(), g_out.detach().cpu(),
+                       {k: p.grad.detach().cpu() for k, p in D.named_parameters()},
+                       {k: b.detach().cpu().clone() for k, b in D.named_buffers()}, len(D._levels))
+    a, b = res[True], res[False]
+    assert a[5] < b[5] / 3                                  # far fewer joins
+    for i in (0, 2):
+        assert float((a[i] - b[i]).abs().max()) <= 1e-5 * max(1.0, float(b[i].abs().max()))
+    for k in a[4]:                                          # BN running statistics
+        assert float((a[4][k].double() - b[4][k].double()).abs().max()) <= 1e-5 * max(1.0, float(b[4][k].double().abs().max())), k
+    scale = float(b[1].abs().max())
+    assert float((a[1] - b[1]).abs().max()) <= 1e-3 * scale    # rounding differences amplified through train-mode BN
+    for k in a[3]:
+        s = float(b[3][k].abs().max()) + 1e-12
+        assert float((a[3][k] - b[3][k]).abs().max()) <= 1e-3 * s + 1e-9, k

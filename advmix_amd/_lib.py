@@ -51,6 +51,8 @@ SIGNATURES = {
     'advmix_heatmap_argmax': [_p, _i, _p, _p, _i, _i, _i, _p],
     'advmix_adam': [_p, _p, _p, _p, _l, _p, _p, _p],
     'advmix_fill': [_p, _f, _l, _p],
+    'advmix_make_views': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    'advmix_render_targets': [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'advmix_flip_w': [_p, _p, _i, _i, _i, _i, _i, _p],
     'advmix_flip_merge': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'advmix_final_preds': [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],

@@ -1,0 +1,117 @@
+// Device side of the three-view input pipeline (HBM-bound, a few microseconds per batch).
+// Reference sites: tools/train.py:116-126 (ToTensor + Normalize), lib/dataset/advaug.py:111-170 (grid_aug,
+// called with use_h = use_w = True, rotate = 1, offset = False, mode = 1: advaug.py:189-202),
+// lib/dataset/JointsDataset.py:412-491 (generate_target, gaussian branch).
+// The loader keeps what needs the CPU (image decode, cv2 warp, PIL AutoAugment, the numpy RNG draws) and
+// hands over ONE uint8 crop (+ the AutoAugment uint8 crop) per sample instead of three float32 tensors:
+// 12x fewer PCIe bytes, and the normalisation / GridMask / target rendering leave the worker processes.
+#include "common.h"
+
+namespace {
+
+static int stream_blocks(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+// 1 where grid_aug's mask (mode = 1, i.e. 1 - mask) keeps the pixel: on a row stripe or on a column stripe.
+// Stripes live on the 1.5x canvas (hh x ww), the image is its centre crop (advaug.py:116-146).
+__device__ __forceinline__ bool grid_keep(int y, int x, int H, int W, int d, int l, int st_h, int st_w) {
+    const int hh = (int)(1.5 * H), ww = (int)(1.5 * W);
+    const int Y = y + (hh - H) / 2, X = x + (ww - W) / 2;
+    bool row = false, col = false;
+    int q = Y - st_h;
+    if (q >= 0) { int i = q / d; row = i < hh / d && q - i * d < l; }
+    q = X - st_w;
+    if (q >= 0) { int i = q / d; col = i < ww / d && q - i * d < l; }
+    return row || col;
+}
+
+// base / aug: uint8 [B][H][W][3]; views: float32 NCHW [B][3][H][W].
+// v = (u8 / 255 - mean) / std in float32, each step rounded like torchvision's ToTensor + Normalize.
+__global__ __launch_bounds__(256) void make_views_kernel(const uint8_t* __restrict__ base,
+                                                         const uint8_t* __restrict__ aug,
+                                                         const int32_t* __restrict__ grid, float m0, float m1, float m2,
+                                                         float s0, float s1, float s2, float* __restrict__ v0,
+                                                         float* __restrict__ v1, float* __restrict__ v2, int B, int H,
+                                                         int W) {
+    const int64_t HW = (int64_t)H * W, total = (int64_t)B * HW;
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW, p = i - b * HW;
+        const int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
+        float keep = 1.0f;
+        if (grid) {
+            const int d = grid[b * 4];
+            if (d > 0) keep = grid_keep(y, x, H, W, d, grid[b * 4 + 1], grid[b * 4 + 2], grid[b * 4 + 3]) ? 1.0f : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int64_t o = (b * 3 + c) * HW + p;
+            const float n = __fdiv_rn(__fdiv_rn((float)base[i * 3 + c], 255.0f) - mean[c], sd[c]);
+            v0[o] = n;
+            if (v2) v2[o] = n * keep;                        // a product, like the reference (keeps -0.0)
+            if (v1) v1[o] = aug ? __fdiv_rn(__fdiv_rn((float)aug[i * 3 + c], 255.0f) - mean[c], sd[c]) : n;
+        }
+    }
+}
+
+// One workgroup per (b, j): heat-map [Hh][Wh] with the 13x13 (2*tmp+1) patch g centred on the joint, or zeros.
+__global__ __launch_bounds__(256) void render_targets_kernel(const double* __restrict__ joints,
+                                                             const double* __restrict__ vis,
+                                                             const int32_t* __restrict__ grid,
+                                                             const float* __restrict__ g, int tmp,
+                                                             const float* __restrict__ jw, float* __restrict__ target,
+                                                             float* __restrict__ tw, double* __restrict__ vis_out,
+                                                             int J, int H, int W, int Hh, int Wh) {
+    const int64_t bj = blockIdx.x;
+    const int64_t b = bj / J;
+    const int j = (int)(bj - b * J);
+    const double jx = joints[bj * 3], jy = joints[bj * 3 + 1];
+    double v0 = vis[bj * 3], v1 = vis[bj * 3 + 1];
+    if (grid && grid[b * 4] > 0) {                          // advaug.py:159-168: joints under the mask turn invisible
+        int tx = (int)jx, ty = (int)jy;
+        tx = min(tx, W - 1); tx = max(tx, 0);
+        ty = min(ty, H - 1); ty = max(ty, 0);
+        if (!grid_keep(ty, tx, H, W, grid[b * 4], grid[b * 4 + 1], grid[b * 4 + 2], grid[b * 4 + 3])) { v0 = 0.0; v1 = 0.0; }
+    }
+    if (vis_out && threadIdx.x == 0) { vis_out[bj * 3] = v0; vis_out[bj * 3 + 1] = v1; vis_out[bj * 3 + 2] = vis[bj * 3 + 2]; }
+    float w = (float)v0;                                     // target_weight[:, 0] = joints_vis[:, 0]
+    const double fsx = (double)W / (double)Wh, fsy = (double)H / (double)Hh;      // feat_stride
+    const int mu_x = (int)(jx / fsx + 0.5), mu_y = (int)(jy / fsy + 0.5);
+    const int ulx = mu_x - tmp, uly = mu_y - tmp, brx = mu_x + tmp + 1, bry = mu_y + tmp + 1;
+    if (ulx >= Wh || uly >= Hh || brx < 0 || bry < 0) w = 0.f;
+    const bool draw = w > 0.5f;
+    const int size = 2 * tmp + 1;
+    float* t = target + bj * (int64_t)Hh * Wh;
+    for (int p = threadIdx.x; p < Hh * Wh; p += blockDim.x) {
+        const int y = p / Wh, x = p - y * Wh;
+        const int gy = y - uly, gx = x - ulx;
+        t[p] = (draw && gy >= 0 && gy < size && gx >= 0 && gx < size) ? g[gy * size + gx] : 0.f;
+    }
+    if (threadIdx.x == 0) tw[bj] = jw ? w * jw[j] : w;
+}
+
+}  // namespace
+
+extern "C" int advmix_make_views(const uint8_t* base, const uint8_t* aug, const int32_t* grid, const float* mean,
+                                 const float* std_, float* v0, float* v1, float* v2, int B, int H, int W,
+                                 void* stream) {
+    if (!base || !mean || !std_ || !v0 || B <= 0 || H <= 0 || W <= 0) return ADVMIX_EINVAL;
+    const int64_t total = (int64_t)B * H * W;
+    hipLaunchKernelGGL(make_views_kernel, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, base, aug,
+                       grid, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], v0, v1, v2, B, H, W);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_render_targets(const double* joints, const double* vis, const int32_t* grid, const float* g,
+                                     int tmp_size, const float* joints_weight, float* target, float* target_weight,
+                                     double* vis_out, int B, int J, int H, int W, int Hh, int Wh, void* stream) {
+    if (!joints || !vis || !g || !target || !target_weight || B <= 0 || J <= 0 || tmp_size < 0) return ADVMIX_EINVAL;
+    if (H <= 0 || W <= 0 || Hh <= 0 || Wh <= 0) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(render_targets_kernel, dim3(B * J), dim3(256), 0, (hipStream_t)stream, joints, vis, grid, g,
+                       tmp_size, joints_weight, target, target_weight, vis_out, J, H, W, Hh, Wh);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}

@@ -181,6 +181,21 @@ int advmix_adam(float* p, const float* g, float* m, float* v, int64_t n, const f
                 int64_t* step, void* stream);
 int advmix_fill(float* p, float value, int64_t n, void* stream);
 
+/* ---- three-view input pipeline on the device -------------------------------------------------
+ * Replace tools/train.py:116-126 (ToTensor + Normalize), lib/dataset/advaug.py:111-170 (GridMask as
+ * MixCombine calls it) and lib/dataset/JointsDataset.py:412-491 (gaussian target rendering). */
+/* base, aug: uint8 [B][H][W][3] device crops (aug may be NULL -> v1 = v0); grid: int32 [B][4] = (d, l, st_h,
+ * st_w) of grid_aug's draws, d <= 0 = this sample keeps its image, NULL = no GridMask at all; mean, std_: 3 HOST
+ * floats each.  v0 (clean), v1 (AutoAugment), v2 (GridMask; v1 / v2 may be NULL): float32 NCHW [B][3][H][W]. */
+int advmix_make_views(const uint8_t* base, const uint8_t* aug, const int32_t* grid, const float* mean,
+                      const float* std_, float* v0, float* v1, float* v2, int B, int H, int W, void* stream);
+/* joints, vis: float64 [B][J][3] in input-image pixels; g: the (2*tmp_size+1)^2 float32 gaussian patch;
+ * grid (optional) applies GridMask's visibility rule first; joints_weight (optional) [J].
+ * target [B][J][Hh][Wh], target_weight [B][J], vis_out (optional) [B][J][3]. */
+int advmix_render_targets(const double* joints, const double* vis, const int32_t* grid, const float* g,
+                          int tmp_size, const float* joints_weight, float* target, float* target_weight,
+                          double* vis_out, int B, int J, int H, int W, int Hh, int Wh, void* stream);
+
 /* ---- validate(): flip test and final predictions ----------------------------------------
  * Replace the numpy round trips of lib/core/function.py:240-261,285-287, lib/utils/transforms.py:16-41,57-107
  * and lib/core/inference.py:52-95. */

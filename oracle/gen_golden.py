@@ -413,12 +413,70 @@ def gen_validate(M):
         json.dump(meta, f)
 
 
+INPUT_CASES = [('small', 4, 5, 64, 48, 16, 12), ('coco', 3, 17, 256, 192, 64, 48), ('w48', 2, 17, 384, 288, 96, 72)]
+
+
+def gen_inputpipe(M):
+    """Input pipeline from the REAL reference: ``grid_aug`` as MixCombine calls it and
+    ``JointsDataset.generate_target`` (constructor bypassed).  ToTensor + Normalize is torchvision (absent):
+    the images fed to grid_aug come from oracle.inputpipe.to_tensor_normalize (see its header)."""
+    from oracle import inputpipe as ip
+    for m, attrs in (('pycocotools', {}), ('pycocotools.coco', {'COCO': None}),
+                     ('pycocotools.cocoeval', {'COCOeval': None}), ('json_tricks', {}),
+                     ('imagecorruptions', {'corrupt': None, 'get_corruption_names': None})):
+        mod = types.ModuleType(m)
+        for k, v in attrs.items():
+            setattr(mod, k, v)
+        sys.modules.setdefault(m, mod)
+    pkg = types.ModuleType('dataset')
+    pkg.__path__ = [os.path.join(REF, 'lib', 'dataset')]
+    sys.modules.setdefault('dataset', pkg)
+    import dataset.advaug as adv
+    import dataset.JointsDataset as jd
+    res, meta = {}, {}
+    for tag, B, J, H, W, Hh, Wh in INPUT_CASES:
+        base, aug, jt, vis = ip.synth_samples('inp.' + tag, B, J, H, W)
+        draws = []
+        for b in range(B):
+            img = ip.to_tensor_normalize(base[b])
+            np.random.seed(1000 + 17 * b + H)
+            state = np.random.get_state()
+            out, _, vis_out, rec = adv.grid_aug(AD(joints_num=J), img.clone(), jt[b].copy(), vis[b].copy(), True, True,
+                                                1, False, 0.5, 1, 0.7, {})
+            np.random.set_state(state)                      # replay the draws through the restatement
+            draws.append(ip.grid_draws(H, W, 0.5, 0.7, 1, np.random))
+            kept = (out != 0)[0].numpy() if draws[-1] is not None else np.ones((H, W), bool)
+            res['%s.mask%d' % (tag, b)] = np.packbits(kept)
+            res['%s.vis%d' % (tag, b)] = np.asarray(vis_out)
+            fake = types.SimpleNamespace(num_joints=J, heatmap_size=np.array([Wh, Hh]), image_size=np.array([W, H]),
+                                         sigma=2, target_type='gaussian', use_different_joints_weight=False,
+                                         joints_weight=1)
+            for name, vv in (('clean', vis[b]), ('grid', np.asarray(vis_out))):
+                tgt, tw = jd.JointsDataset.generate_target(fake, jt[b].copy(), vv.copy())
+                res['%s.%s.target%d' % (tag, name, b)] = tgt[0]
+                res['%s.%s.tw%d' % (tag, name, b)] = tw
+        meta[tag] = {'draws': draws, 'masked': int(sum(d is not None for d in draws))}
+        print('inputpipe', tag, meta[tag], flush=True)
+    # different joints weights (JointsDataset.py:488-489)
+    tag, B, J, H, W, Hh, Wh = INPUT_CASES[1]
+    base, aug, jt, vis = ip.synth_samples('inp.' + tag, B, J, H, W)
+    jw = np.array([1., 1., 1., 1., 1., 1., 1., 1.2, 1.2, 1.5, 1.5, 1., 1., 1.2, 1.2, 1.5, 1.5],
+                  dtype=np.float32).reshape((J, 1))          # coco.py:74-80 (data)
+    fake = types.SimpleNamespace(num_joints=J, heatmap_size=np.array([Wh, Hh]), image_size=np.array([W, H]),
+                                 sigma=2, target_type='gaussian', use_different_joints_weight=True, joints_weight=jw)
+    _, tw = jd.JointsDataset.generate_target(fake, jt[0].copy(), vis[0].copy())
+    res['coco.jw.tw0'] = tw
+    np.savez_compressed(os.path.join(OUT, 'inputpipe.npz'), **res)
+    with open(os.path.join(OUT, 'inputpipe.json'), 'w') as f:
+        json.dump(meta, f)
+
+
 def main():
     logging.basicConfig(level=logging.WARNING)
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     M = import_reference()
-    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate']
+    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe']
     for w in which:
         globals()['gen_' + w](M)
         print('done', w, flush=True)

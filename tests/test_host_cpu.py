@@ -144,3 +144,21 @@ def test_flip_partner_is_the_sequential_pair_swap():
     from advmix_amd import ops
     p = ops.flip_partner([[1, 2], [3, 4]], 6, torch.device('cpu'))
     assert p.tolist() == [0, 2, 1, 4, 3, 5] and p.dtype == torch.int32
+
+
+def test_grid_params_replays_the_reference_draws():
+    """dataset.advaug.grid_params consumes numpy's global RNG exactly like grid_aug (advaug.py:112-140): same
+    seeds -> the draws recorded from the real reference, and the stream position afterwards is the same."""
+    import json, os
+    import numpy as np
+    from advmix_amd.dataset.advaug import grid_params
+    from advmix_amd.dataset.JointsDataset import gaussian_patch
+    meta = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'inputpipe.json')))
+    for tag, B, H, W in (('small', 4, 64, 48), ('coco', 3, 256, 192), ('w48', 2, 384, 288)):
+        for b in range(B):
+            np.random.seed(1000 + 17 * b + H)
+            got = grid_params(H, W, 0.5, 0.7, 1, np.random)
+            want = meta[tag]['draws'][b]
+            assert (got is None and want is None) or list(got) == want, (tag, b, got, want)
+    g, tmp = gaussian_patch(2)
+    assert g.shape == (13, 13) and tmp == 6 and g[6, 6] == 1.0 and g.dtype == np.float32

@@ -539,3 +539,64 @@ def test_final_preds_vs_reference_fixture(nhwc):
     p, m = get_final_preds(cfg, None, _layout(torch.from_numpy(hm), nhwc), c, s)
     assert p.dtype == np.float32 and p.shape == (B, J, 2) and m.shape == (B, J, 1)
     assert np.array_equal(p, got) and np.array_equal(m, wmax)
+
+
+# ---- input pipeline kernels ------------------------------------------------------------------
+
+INPUT_CASES = [('small', 4, 5, 64, 48, 16, 12), ('coco', 3, 17, 256, 192, 64, 48), ('w48', 2, 17, 384, 288, 96, 72)]
+
+
+def test_make_views_bit_exact_vs_oracle_and_reference_mask():
+    """ToTensor + Normalize + GridMask on the device: bit-identical to the CPU restatement (torch fp32 ops) and
+    to the mask the REAL grid_aug produced for the same numpy RNG draws."""
+    from oracle import inputpipe as oip
+    from helpers import gold_npz, gold_json
+    from advmix_amd.dataset.advaug import make_views, pack_grid, grid_params
+    g, meta = gold_npz('inputpipe.npz'), gold_json('inputpipe.json')
+    for tag, B, J, H, W, Hh, Wh in INPUT_CASES:
+        base, aug, jt, vis = oip.synth_samples('inp.' + tag, B, J, H, W)
+        params = []
+        for b in range(B):
+            np.random.seed(1000 + 17 * b + H)
+            params.append(grid_params(H, W, 0.5, 0.7, 1, np.random))
+        grid = pack_grid(params, dev())
+        v0, v1, v2 = make_views(torch.from_numpy(base).to(dev()), torch.from_numpy(aug).to(dev()), grid)
+        for b in range(B):
+            want0 = oip.to_tensor_normalize(base[b])
+            assert torch.equal(v0[b].cpu(), want0), (tag, b)
+            assert torch.equal(v1[b].cpu(), oip.to_tensor_normalize(aug[b]))
+            kept = np.unpackbits(g['%s.mask%d' % (tag, b)])[:H * W].reshape(H, W).astype(np.float32)
+            assert torch.equal(v2[b].cpu(), want0 * torch.from_numpy(kept)), (tag, b)
+    # no AutoAugment crop, no GridMask table: three copies of the clean view
+    a, b_, c = make_views(torch.from_numpy(base).to(dev()))
+    assert torch.equal(a, b_) and torch.equal(a, c)
+
+
+def test_render_targets_bit_exact_vs_reference():
+    """Heat-map targets / target weights (and GridMask's visibility rule) on the device against the REAL
+    JointsDataset.generate_target / grid_aug outputs."""
+    from oracle import inputpipe as oip
+    from helpers import gold_npz, gold_json
+    from advmix_amd.dataset.advaug import pack_grid, grid_params
+    from advmix_amd.dataset.JointsDataset import TargetRenderer
+    g = gold_npz('inputpipe.npz')
+    for tag, B, J, H, W, Hh, Wh in INPUT_CASES:
+        base, aug, jt, vis = oip.synth_samples('inp.' + tag, B, J, H, W)
+        params = []
+        for b in range(B):
+            np.random.seed(1000 + 17 * b + H)
+            params.append(grid_params(H, W, 0.5, 0.7, 1, np.random))
+        r = TargetRenderer((W, H), (Wh, Hh), 2, device=dev())
+        tgt, tw = r.render(jt, vis)
+        tgt_g, tw_g, vis_g = r.render(jt, vis, pack_grid(params, dev()))
+        for b in range(B):
+            assert np.array_equal(tgt[b].cpu().numpy(), g['%s.clean.target%d' % (tag, b)]), (tag, b)
+            assert np.array_equal(tw[b].cpu().numpy(), g['%s.clean.tw%d' % (tag, b)])
+            assert np.array_equal(vis_g[b].cpu().numpy(), g['%s.vis%d' % (tag, b)])
+            assert np.array_equal(tgt_g[b].cpu().numpy(), g['%s.grid.target%d' % (tag, b)])
+            assert np.array_equal(tw_g[b].cpu().numpy(), g['%s.grid.tw%d' % (tag, b)])
+        assert float(tw.sum()) > 0 and float(tgt.max()) == 1.0
+    jw = np.array([1., 1., 1., 1., 1., 1., 1., 1.2, 1.2, 1.5, 1.5, 1., 1., 1.2, 1.2, 1.5, 1.5], np.float32)
+    base, aug, jt, vis = oip.synth_samples('inp.coco', 3, 17, 256, 192)
+    _, tw = TargetRenderer((192, 256), (48, 64), 2, joints_weight=jw, device=dev()).render(jt, vis)
+    assert np.array_equal(tw[0].cpu().numpy(), g['coco.jw.tw0'])

@@ -278,3 +278,40 @@ def test_rescoring_and_oks_nms_match_reference():
         assert m['soft'] or len(flat) < N          # hard NMS suppressed someone; soft NMS only re-orders (<= 20 kept)
         assert [(int(a), int(b)) for a, b, _ in flat] == [(int(a), int(b)) for a, b, _ in want]
         assert np.allclose([f[2] for f in flat], want[:, 2], rtol=1e-12, atol=0)
+
+
+# ---- input pipeline: oracle/inputpipe.py against the real grid_aug / generate_target ----------
+
+from oracle import inputpipe as oip                                    # noqa: E402
+
+INPUT_CASES = [('small', 4, 5, 64, 48, 16, 12), ('coco', 3, 17, 256, 192, 64, 48), ('w48', 2, 17, 384, 288, 96, 72)]
+
+
+def test_gridmask_and_targets_match_reference():
+    g, meta = gold_npz('inputpipe.npz'), gold_json('inputpipe.json')
+    for tag, B, J, H, W, Hh, Wh in INPUT_CASES:
+        base, aug, jt, vis = oip.synth_samples('inp.' + tag, B, J, H, W)
+        assert meta[tag]['masked'] >= 1
+        for b in range(B):
+            np.random.seed(1000 + 17 * b + H)
+            draws = oip.grid_draws(H, W, 0.5, 0.7, 1, np.random)
+            want = meta[tag]['draws'][b]
+            assert (draws is None and want is None) or list(draws) == want
+            img = oip.to_tensor_normalize(base[b])
+            out, vis_out, mask = oip.grid_aug(img, jt[b], vis[b], draws, J)
+            kept = np.unpackbits(g['%s.mask%d' % (tag, b)])[:H * W].reshape(H, W).astype(bool)
+            if draws is None:
+                assert kept.all() and torch.equal(out, img)
+            else:
+                assert np.array_equal(mask.astype(bool), kept)
+                assert torch.equal(out, img * torch.from_numpy(kept.astype(np.float32)))
+                assert 0.2 < kept.mean() < 0.95
+            assert np.array_equal(vis_out, g['%s.vis%d' % (tag, b)])
+            for name, vv in (('clean', vis[b]), ('grid', vis_out)):
+                tgt, tw = oip.generate_target(jt[b], vv, (W, H), (Wh, Hh), 2)
+                assert np.array_equal(tgt, g['%s.%s.target%d' % (tag, name, b)])
+                assert np.array_equal(tw, g['%s.%s.tw%d' % (tag, name, b)])
+    jw = np.array([1., 1., 1., 1., 1., 1., 1., 1.2, 1.2, 1.5, 1.5, 1., 1., 1.2, 1.2, 1.5, 1.5], np.float32).reshape(17, 1)
+    base, aug, jt, vis = oip.synth_samples('inp.coco', 3, 17, 256, 192)
+    _, tw = oip.generate_target(jt[0], vis[0], (192, 256), (48, 64), 2, jw)
+    assert np.array_equal(tw, g['coco.jw.tw0'])

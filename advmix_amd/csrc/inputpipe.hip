@@ -29,29 +29,58 @@ __device__ __forceinline__ bool grid_keep(int y, int x, int H, int W, int d, int
 
 // base / aug: uint8 [B][H][W][3]; views: float32 NCHW [B][3][H][W].
 // v = (u8 / 255 - mean) / std in float32, each step rounded like torchvision's ToTensor + Normalize.
+template <bool VEC>
 __global__ __launch_bounds__(256) void make_views_kernel(const uint8_t* __restrict__ base,
                                                          const uint8_t* __restrict__ aug,
                                                          const int32_t* __restrict__ grid, float m0, float m1, float m2,
                                                          float s0, float s1, float s2, float* __restrict__ v0,
                                                          float* __restrict__ v1, float* __restrict__ v2, int B, int H,
                                                          int W) {
-    const int64_t HW = (int64_t)H * W, total = (int64_t)B * HW;
+    constexpr int PX = VEC ? 4 : 1;                        // pixels per thread (W % 4 == 0: 12 B in, 9 x 16 B out)
+    const int64_t HW = (int64_t)H * W, total = (int64_t)B * HW / PX;
     const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t it = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; it < total; it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = it * PX;
         const int64_t b = i / HW, p = i - b * HW;
         const int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
-        float keep = 1.0f;
-        if (grid) {
-            const int d = grid[b * 4];
-            if (d > 0) keep = grid_keep(y, x, H, W, d, grid[b * 4 + 1], grid[b * 4 + 2], grid[b * 4 + 3]) ? 1.0f : 0.0f;
+        int d = 0, l = 0, sh = 0, sw = 0;
+        if (grid) { d = grid[b * 4]; l = grid[b * 4 + 1]; sh = grid[b * 4 + 2]; sw = grid[b * 4 + 3]; }
+        uint8_t ub[3 * PX], ua[3 * PX];
+        if (VEC) {
+            const uint32_t* pb = reinterpret_cast<const uint32_t*>(base + i * 3);
+            uint32_t w0 = pb[0], w1 = pb[1], w2 = pb[2];
+            __builtin_memcpy(ub, &w0, 4); __builtin_memcpy(ub + 4, &w1, 4); __builtin_memcpy(ub + 8, &w2, 4);
+            if (aug) {
+                const uint32_t* pa = reinterpret_cast<const uint32_t*>(aug + i * 3);
+                w0 = pa[0]; w1 = pa[1]; w2 = pa[2];
+                __builtin_memcpy(ua, &w0, 4); __builtin_memcpy(ua + 4, &w1, 4); __builtin_memcpy(ua + 8, &w2, 4);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { ub[c] = base[i * 3 + c]; if (aug) ua[c] = aug[i * 3 + c]; }
         }
+        float keep[PX];
+#pragma unroll
+        for (int k = 0; k < PX; ++k) keep[k] = (d > 0 && !grid_keep(y, x + k, H, W, d, l, sh, sw)) ? 0.0f : 1.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int64_t o = (b * 3 + c) * HW + p;
-            const float n = __fdiv_rn(__fdiv_rn((float)base[i * 3 + c], 255.0f) - mean[c], sd[c]);
-            v0[o] = n;
-            if (v2) v2[o] = n * keep;                        // a product, like the reference (keeps -0.0)
-            if (v1) v1[o] = aug ? __fdiv_rn(__fdiv_rn((float)aug[i * 3 + c], 255.0f) - mean[c], sd[c]) : n;
+            float n[PX], na[PX], ng[PX];
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                n[k] = __fdiv_rn(__fdiv_rn((float)ub[k * 3 + c], 255.0f) - mean[c], sd[c]);
+                na[k] = aug ? __fdiv_rn(__fdiv_rn((float)ua[k * 3 + c], 255.0f) - mean[c], sd[c]) : n[k];
+                ng[k] = n[k] * keep[k];                      // a product, like the reference (keeps -0.0)
+            }
+            if (VEC) {
+                *reinterpret_cast<f32x4*>(v0 + o) = f32x4{n[0], n[PX > 1 ? 1 : 0], n[PX > 2 ? 2 : 0], n[PX > 3 ? 3 : 0]};
+                if (v1) *reinterpret_cast<f32x4*>(v1 + o) = f32x4{na[0], na[PX > 1 ? 1 : 0], na[PX > 2 ? 2 : 0], na[PX > 3 ? 3 : 0]};
+                if (v2) *reinterpret_cast<f32x4*>(v2 + o) = f32x4{ng[0], ng[PX > 1 ? 1 : 0], ng[PX > 2 ? 2 : 0], ng[PX > 3 ? 3 : 0]};
+            } else {
+                v0[o] = n[0];
+                if (v1) v1[o] = na[0];
+                if (v2) v2[o] = ng[0];
+            }
         }
     }
 }
@@ -99,8 +128,14 @@ extern "C" int advmix_make_views(const uint8_t* base, const uint8_t* aug, const 
                                  void* stream) {
     if (!base || !mean || !std_ || !v0 || B <= 0 || H <= 0 || W <= 0) return ADVMIX_EINVAL;
     const int64_t total = (int64_t)B * H * W;
-    hipLaunchKernelGGL(make_views_kernel, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, base, aug,
-                       grid, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], v0, v1, v2, B, H, W);
+    const bool vec = W % 4 == 0 && (((uintptr_t)base | (uintptr_t)aug) & 3) == 0 &&
+                     (((uintptr_t)v0 | (uintptr_t)v1 | (uintptr_t)v2) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(make_views_kernel<true>, dim3(stream_blocks(total / 4)), dim3(256), 0, (hipStream_t)stream,
+                           base, aug, grid, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], v0, v1, v2, B, H, W);
+    else
+        hipLaunchKernelGGL(make_views_kernel<false>, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream,
+                           base, aug, grid, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], v0, v1, v2, B, H, W);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }

@@ -251,6 +251,63 @@ def bench_validate(a, device, rank, world):
     return line
 
 
+def bench_inputs(a, device, rank, world):
+    """--path inputs: images/sec of the device input pipeline: from the uint8 crops of one batch
+    (clean + AutoAugment) to the three normalised float views (GridMask on the third) and the gaussian
+    targets / target weights.  HBM-bound: 6 B read + 36 B written per pixel by the view kernel."""
+    import numpy as np
+    from advmix_amd.dataset.advaug import make_views, pack_grid, grid_params
+    from advmix_amd.dataset.JointsDataset import TargetRenderer
+    net, extra, J, H, W, downs, _ = WORKLOADS[a.workload]
+    rng = np.random.RandomState(99 + rank)
+    base = torch.from_numpy(rng.randint(0, 256, (a.batch, H, W, 3), dtype=np.uint8)).to(device)
+    aug = torch.from_numpy(rng.randint(0, 256, (a.batch, H, W, 3), dtype=np.uint8)).to(device)
+    grid = pack_grid([grid_params(H, W, rng=rng) for _ in range(a.batch)], device)
+    joints = np.zeros((a.batch, J, 3)); joints[:, :, 0] = rng.rand(a.batch, J) * W; joints[:, :, 1] = rng.rand(a.batch, J) * H
+    vis = np.zeros((a.batch, J, 3)); vis[:, :, :2] = (rng.rand(a.batch, J, 1) < 0.8)
+    jd, vd = torch.from_numpy(joints).to(device), torch.from_numpy(vis).to(device)
+    rend = TargetRenderer((W, H), (W // 4, H // 4), 2, device=device)
+
+    def one_batch():
+        views = make_views(base, aug, grid)
+        tgt, tw = rend.render(jd, vd)
+        return views, tgt, tw
+
+    for _ in range(a.warmup):
+        one_batch()
+    torch.cuda.synchronize()
+    steps = max(a.steps, 200)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_batch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank != 0:
+        return None
+    import ctypes
+    from advmix_amd._lib import call
+    v = [torch.empty((a.batch, 3, H, W), device=device) for _ in range(3)]
+    P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+    m = (ctypes.c_float * 3)(0.485, 0.456, 0.406); sd = (ctypes.c_float * 3)(0.229, 0.224, 0.225)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ms, runs = _event_time(lambda: call('advmix_make_views', P(base), P(aug), P(grid), ctypes.cast(m, ctypes.c_void_p),
+                                        ctypes.cast(sd, ctypes.c_void_p), P(v[0]), P(v[1]), P(v[2]), a.batch, H, W, st), 100)
+    nbytes = a.batch * H * W * (6 + 36)
+    value = a.batch * world * steps / dt
+    line = {'metric': 'images/sec device input pipeline: 3 views + targets (%dx%d)' % (H, W), 'value': round(value, 1),
+            'unit': 'images/sec', 'n_gpus': world, 'steps': steps, 'warmup': a.warmup,
+            'ms_per_step': round(dt / steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'u8->f32', 'data': 'synthetic uint8 crops resident in HBM, random joints',
+            'config': {'workload': 'inputs_%dx%d_3views_targets' % (H, W), 'batch_per_gpu': a.batch, 'joints': J},
+            'roofline': {'bound': 'hbm', 'kernel': 'make_views_kernel', 'achieved': round(nbytes / (ms * 1e-3) / 1e9, 1),
+                         'peak': 8000.0, 'unit': 'GB/s', 'frac': round(nbytes / (ms * 1e-3) / 1e9 / 8000.0, 4),
+                         'traffic': None, 'us_per_launch': round(ms * 1e3, 2),
+                         'algorithmic_bytes_per_launch': nbytes}}
+    if world == 1 and not a.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(a.workload, path='inputs')
+    return line
+
+
 def cpu_baseline(workload, budget_s=25.0, hard_timeout_s=150.0, path='train'):
     """The CPU oracle's AdvMix step on this host (bounded sample: B=4, 1 warm-up + a few timed
     steps), in a CPU-only child process with a hard timeout so the bench always finishes."""
@@ -277,8 +334,9 @@ def main():
     ap.add_argument('--workload', default='hrnet_w32', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=32, help='images per GPU (TRAIN.BATCH_SIZE_PER_GPU)')
     ap.add_argument('--exec', dest='exec_mode', default='graph', choices=['graph', 'eager'])
-    ap.add_argument('--path', default='train', choices=['train', 'validate'],
-                    help='train = the headline AdvMix step; validate = the validate() batch body (SURVEY 8 f1)')
+    ap.add_argument('--path', default='train', choices=['train', 'validate', 'inputs'],
+                    help='train = the headline AdvMix step; validate = the validate() batch body (SURVEY 8 f1); '
+                         'inputs = the device input pipeline (SURVEY 8 f2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     a = ap.parse_args()
@@ -299,8 +357,8 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29555')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
-    if a.path == 'validate':
-        line = bench_validate(a, device, rank, world)
+    if a.path in ('validate', 'inputs'):
+        line = (bench_validate if a.path == 'validate' else bench_inputs)(a, device, rank, world)
         if world > 1 or force_sync:
             dist.barrier()
             dist.destroy_process_group()

@@ -65,6 +65,33 @@ def validate_main(workload, budget, cores):
                                     workload, B, n, warm, cores, os.cpu_count() or 0)}), flush=True)
 
 
+def inputs_main(workload, budget, cores):
+    """The reference-style per-sample host pipeline: 3 x ToTensor+Normalize, GridMask, one target render."""
+    import numpy as np
+    from oracle import inputpipe as ip
+    H, W = (384, 288) if workload == 'hrnet_w48' else (256, 192)
+    B, J = 32, 17
+    base, aug, jt, vis = ip.synth_samples('bench.cpu.inp', B, J, H, W)
+    rng = np.random.RandomState(5)
+
+    def batch():
+        for b in range(B):
+            v0 = ip.to_tensor_normalize(base[b])
+            ip.to_tensor_normalize(aug[b])
+            ip.grid_aug(ip.to_tensor_normalize(base[b]), jt[b], vis[b], ip.grid_draws(H, W, 0.5, 0.7, 1, rng), J)
+            ip.generate_target(jt[b], vis[b], (W, H), (W // 4, H // 4), 2)
+        return v0
+    batch()
+    n, t0 = 0, time.time()
+    while n < 50 and (n == 0 or time.time() - t0 < budget):
+        batch()
+        n += 1
+    dt = time.time() - t0
+    print(json.dumps({'value': round(B * n / dt, 1), 'unit': 'images/sec', 'cores': 1, 'kind': 'port',
+                      'sample': 'per-sample host pipeline (3x ToTensor+Normalize, GridMask, generate_target), %dx%d, '
+                                '%d batches of %d in one process (a DataLoader worker)' % (H, W, n, B)}), flush=True)
+
+
 def main():
     workload, budget = sys.argv[1], float(sys.argv[2])
     cores = effective_cpus()
@@ -74,6 +101,9 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     if len(sys.argv) > 3 and sys.argv[3] == 'validate':
         return validate_main(workload, budget, cores)
+    if len(sys.argv) > 3 and sys.argv[3] == 'inputs':
+        torch.set_num_threads(1)
+        return inputs_main(workload, 10.0, 1)
     from oracle import detinit, configs
     from oracle.posenet import posenet_spec, trainable
     from oracle.unet import unet_spec, unet_transposed_names

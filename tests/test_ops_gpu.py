@@ -570,6 +570,16 @@ def test_make_views_bit_exact_vs_oracle_and_reference_mask():
     # no AutoAugment crop, no GridMask table: three copies of the clean view
     a, b_, c = make_views(torch.from_numpy(base).to(dev()))
     assert torch.equal(a, b_) and torch.equal(a, c)
+    # a width that is not a multiple of 4 (scalar path) against the restatement alone
+    B, H, W = 3, 30, 50
+    base, aug, jt, vis = oip.synth_samples('inp.odd', B, 5, H, W)
+    params = [(7, 4, 3, 5), None, (11, 6, 0, 10)]
+    v0, v1, v2 = make_views(torch.from_numpy(base).to(dev()), torch.from_numpy(aug).to(dev()), pack_grid(params, dev()))
+    for b in range(B):
+        want0 = oip.to_tensor_normalize(base[b])
+        assert torch.equal(v0[b].cpu(), want0) and torch.equal(v1[b].cpu(), oip.to_tensor_normalize(aug[b]))
+        out, _, _ = oip.grid_aug(want0, jt[b], vis[b], params[b], 5)
+        assert torch.equal(v2[b].cpu(), out)
 
 
 def test_render_targets_bit_exact_vs_reference():

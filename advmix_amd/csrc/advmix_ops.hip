@@ -170,7 +170,7 @@ AdvmixOpts& advmix_opts() {
     static AdvmixOpts o = [] {
         // conv3 (LDS-patch persistent 3x3) is opt-in: alone it wins on 128->128 @16x12 (28.7 vs 34.9 us)
         // but one 135-KB-LDS workgroup per CU blocks the concurrent lanes: 89.9 vs 86.3 ms per AdvMix step
-        AdvmixOpts d{1, 0, 512, 256, 1, 0};
+        AdvmixOpts d{1, 0, 512, 256, 1, 0, 1};
         const char* e;
         if ((e = getenv("ADVMIX_CONV")) && e[0] == 'i') d.direct = 0;
         if ((e = getenv("ADVMIX_CONV3"))) d.conv3 = e[0] != '0';
@@ -178,6 +178,7 @@ AdvmixOpts& advmix_opts() {
         if ((e = getenv("ADVMIX_CONV3_GRID"))) d.conv3_grid = atoi(e);
         if ((e = getenv("ADVMIX_WGRAD"))) d.wgrad_direct = e[0] != '0';
         if ((e = getenv("ADVMIX_MFMA16"))) d.mfma16 = e[0] != '0';
+        if ((e = getenv("ADVMIX_KSPLIT_WG"))) d.ksplit_wg = e[0] != '0';
         return d;
     }();
     return o;
@@ -194,6 +195,7 @@ extern "C" int advmix_set_option(const char* name, int value) {
     else if (!strcmp(name, "conv3_grid")) o.conv3_grid = value > 0 ? value : 256;
     else if (!strcmp(name, "wgrad_direct")) o.wgrad_direct = value;
     else if (!strcmp(name, "mfma16")) o.mfma16 = value;
+    else if (!strcmp(name, "ksplit_wg")) o.ksplit_wg = value;
     else return ADVMIX_EINVAL;
     return ADVMIX_OK;
 }

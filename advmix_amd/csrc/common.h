@@ -63,6 +63,7 @@ struct AdvmixOpts {
     int conv3_grid;        // persistent workgroups (256 = one per CU)
     int wgrad_direct;      // 1: register-fragment wgrad kernel allowed
     int mfma16;            // 1: conv_direct uses the 16x16x4 MFMA shape (16 pixel rows x 64 B per fragment load)
+    int ksplit_wg;         // 1: layers with too few tiles split K inside the workgroup (fused epilogue kept), 0: across the grid
 };
 AdvmixOpts& advmix_opts();
 

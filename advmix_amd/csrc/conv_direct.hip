@@ -78,7 +78,13 @@ template <> struct MfmaShape<16> {
 
 template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT, bool EPI, int MR>
 __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
-    static_assert(WM * WN == 4, "4 waves");
+    // WK waves of the workgroup split K BETWEEN THEM (WM x WN x WK = 4 waves): the low-resolution layers have too
+    // few output tiles to fill the chip; instead of slicing K across workgroups (SPLIT: zero-fill + fp32 atomics,
+    // no fused epilogue) a 32x32 tile is computed by four waves that each take every fourth K chunk and meet
+    // in LDS, so the fused BN / residual / activation / statistics epilogue still applies.
+    static_assert(WM * WN == 4 || WM * WN == 2 || WM * WN == 1, "WM x WN x WK = 4 waves");
+    constexpr int WK = 4 / (WM * WN);
+    static_assert(!(SPLIT && WK > 1), "one kind of K split at a time");
     typedef MfmaShape<MR> MS;
     constexpr int NSUB = 32 / MR;              // MFMA tiles per 32 rows / 32 columns
     constexpr int KL = 64 / MR;                // k-lanes: lanes that hold different k of the same row
@@ -86,15 +92,19 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int KQ = KC / (4 * KL);          // float4 k-groups per chunk (4 k per k-lane each)
     constexpr int LDB = KC + 4;
-    constexpr int BSL = (BN * KC / 4 + 255) / 256;
+    constexpr int BCH = BN * KC / 4;           // float4 staging slots per chunk
+    constexpr int BSL = (BCH * WK + 255) / 256;
+    constexpr int RED = WK > 1 ? WK * RM * RN * MS::NR * 64 : 0;          // floats of the cross-wave reduction
+    constexpr int BSZ = (WK * BN * LDB * 2 > RED) ? WK * BN * LDB : (RED + 1) / 2;
 
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDB];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BSZ];
     __shared__ int4 taptab[64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int l31 = lane % MR, lh = lane / MR;             // row within the MFMA tile, k-lane
-    const int wm = wid / WN, wn = wid % WN;
+    const int wk = wid / (WM * WN), wmn = wid % (WM * WN);
+    const int wm = wmn / WN, wn = wmn % WN;
 
     int Hp, Wp, Th, Tw, rh = 0, rw = 0, phh = 0, phw = 0, zsl = blockIdx.z;
     if (MODE == 0) {
@@ -158,20 +168,23 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
         }
     }
     // ---- per-thread B staging slots --------------------------------------------------------
-    int b_row[BSL], b_k4[BSL];
+    int b_row[BSL], b_k4[BSL], b_kk[BSL];
     unsigned b_off[BSL];
 #pragma unroll
     for (int i = 0; i < BSL; ++i) {
         int s = tid + 256 * i;
+        b_kk[i] = s / BCH;                                  // which of the WK chunks of a step this slot stages
+        s -= b_kk[i] * BCH;
+        const bool in = b_kk[i] < WK;
         if (!BT) {
             b_row[i] = s / (KC / 4);                        // n
             b_k4[i] = (s % (KC / 4)) * 4;                   // k (4 consecutive)
-            bool ok = s < BN * KC / 4 && (n0 + b_row[i]) < p.Co;
+            bool ok = in && (n0 + b_row[i]) < p.Co;
             b_off[i] = ok ? (unsigned)(((n0 + b_row[i]) * Kfull + b_k4[i]) * 4) : OOB;
         } else {
             b_k4[i] = s / (BN / 4);                         // k (one)
             b_row[i] = (s % (BN / 4)) * 4;                  // n (4 consecutive; Co % 4 == 0 is checked on the host)
-            bool ok = s < BN * KC / 4 && (n0 + b_row[i]) < p.Co;
+            bool ok = in && (n0 + b_row[i]) < p.Co;
             b_off[i] = ok ? (unsigned)((b_k4[i] * p.R * p.S * p.Co + n0 + b_row[i]) * 4) : OOB;
         }
     }
@@ -192,16 +205,20 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
 #pragma unroll
             for (int r = 0; r < MS::NR; ++r) acc[t][u][r] = 0.f;
 
-    // chunk cursor (of the chunk being ISSUED)
-    int tap = ch_lo / cpt;
-    int c0 = (ch_lo - tap * cpt) * KC;
+    // chunk cursor (of the STEP being issued: WK consecutive chunks, wave wk multiplies chunk cur + wk)
+    int cur = ch_lo;
 
-    auto issue = [&](f32x4 (&A)[RM][KQ]) {                 // loads of the chunk at (tap, c0)
+    auto issue = [&](f32x4 (&A)[RM][KQ]) {                 // loads of the step starting at chunk ``cur``
+        const int ck = cur + wk;                           // this wave's chunk; past the end -> zeros
+        int tap = ck / cpt;
+        const int c0 = (ck - tap * cpt) * KC;
+        const bool live = ck < ch_hi;
+        if (!live) tap = 0;
         const int4 tt = taptab[tap];
 #pragma unroll
         for (int t = 0; t < RM; ++t) {
             int hi = a_h[t] + tt.x, wi = a_w[t] + tt.y;
-            bool ok = a_ok[t] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
+            bool ok = live && a_ok[t] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
             unsigned off = ok ? (unsigned)(((a_nb[t] + hi * p.Wi + wi) * p.Ci + c0 + lh * 4) * 4) : OOB;
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
@@ -215,13 +232,23 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
         }
 #if !(defined(CD_DBG) && (CD_DBG & 2))
 #pragma unroll
-        for (int i = 0; i < BSL; ++i)
-            Br[i] = bload(wr, b_off[i] == OOB ? OOB
-                              : b_off[i] + (BT ? (unsigned)(((c0 * p.R * p.S + tt.w) * p.Co) * 4)
-                                             : (unsigned)((tt.z + c0) * 4)));
+        for (int i = 0; i < BSL; ++i) {
+            int cb, tb, c0b;
+            if (WK == 1) {
+                cb = ck; tb = tap; c0b = c0;
+            } else {
+                cb = cur + b_kk[i];
+                tb = cb / cpt;
+                c0b = (cb - tb * cpt) * KC;
+            }
+            const bool lb = cb < ch_hi && b_off[i] != OOB;
+            const int4 tq = taptab[lb ? tb : 0];
+            Br[i] = bload(wr, !lb ? OOB
+                              : b_off[i] + (BT ? (unsigned)(((c0b * p.R * p.S + tq.w) * p.Co) * 4)
+                                             : (unsigned)((tq.z + c0b) * 4)));
+        }
 #endif
-        c0 += KC;
-        if (c0 >= p.Ci) { c0 = 0; ++tap; }
+        cur += WK;
     };
     auto stage = [&](int buf) {
 #if defined(CD_DBG) && (CD_DBG & 2)                  /* no weight staging at all */
@@ -229,12 +256,13 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
 #endif
 #pragma unroll
         for (int i = 0; i < BSL; ++i)
-            if (tid + 256 * i < BN * KC / 4) {
+            if (tid + 256 * i < BCH * WK) {
+                float* dst = &Bs[buf][b_kk[i] * (BN * LDB)];
                 if (!BT) {
-                    *reinterpret_cast<f32x4*>(&Bs[buf][b_row[i] * LDB + b_k4[i]]) = Br[i];
+                    *reinterpret_cast<f32x4*>(&dst[b_row[i] * LDB + b_k4[i]]) = Br[i];
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) Bs[buf][(b_row[i] + e) * LDB + b_k4[i]] = Br[i][e];
+                    for (int e = 0; e < 4; ++e) dst[(b_row[i] + e) * LDB + b_k4[i]] = Br[i][e];
                 }
             }
     };
@@ -249,7 +277,7 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
                 b[u] = f32x4{fb, fb, fb, fb};
 #else
                 b[u] = *reinterpret_cast<const f32x4*>(
-                    &Bs[buf][(wn * TN * 32 + u * MR + l31) * LDB + q * (4 * KL) + lh * 4]);
+                    &Bs[buf][wk * (BN * LDB) + (wn * TN * 32 + u * MR + l31) * LDB + q * (4 * KL) + lh * 4]);
 #endif
             }
 #pragma unroll
@@ -261,7 +289,7 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
         }
     };
 
-    const int nch = ch_hi - ch_lo;
+    const int nch = (ch_hi - ch_lo + WK - 1) / WK;         // steps
     if (nch > 0) {
         issue(A0);
         stage(0);
@@ -291,8 +319,34 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     // ---- epilogue -----------------------------------------------------------------------------
     // BN column sums: the WM waves that share a column meet in LDS (the weight buffer is free now), so a
     // workgroup issues ONE pair of fp64 atomics per column instead of one per wave
-    float* sred = &Bs[0][0];                               // [2][WM][BN]
+    float* sred = &Bs[0][0];                               // [2][WK * WM][BN]
     const bool stats = EPI && p.stats != nullptr;          // uniform over the grid
+    constexpr int RSL = MS::NR / WK;                       // accumulator registers a wave finishes itself
+    static_assert(MS::NR % WK == 0, "epilogue slices");
+    const int r_lo = WK > 1 ? wk * RSL : 0;
+    if (WK > 1) {                                          // the WK partial tiles meet in LDS
+        float* red = &Bs[0][0];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < RM; ++t)
+#pragma unroll
+            for (int u = 0; u < RN; ++u)
+#pragma unroll
+                for (int r = 0; r < MS::NR; ++r)
+                    red[((wk * RM * RN + t * RN + u) * MS::NR + r) * 64 + lane] = acc[t][u][r];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < RM; ++t)
+#pragma unroll
+            for (int u = 0; u < RN; ++u)
+#pragma unroll
+                for (int r = 0; r < RSL; ++r) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int k = 0; k < WK; ++k) v += red[((k * RM * RN + t * RN + u) * MS::NR + r_lo + r) * 64 + lane];
+                    acc[t][u][r] = v;                          // slot r now holds accumulator register r_lo + r
+                }
+    }
     if (stats) __syncthreads();                            // every wave is done reading Bs
 #pragma unroll
     for (int u = 0; u < RN; ++u) {
@@ -309,8 +363,8 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
 #pragma unroll
         for (int t = 0; t < RM; ++t) {
 #pragma unroll
-            for (int r = 0; r < MS::NR; ++r) {
-                int m = m0 + wm * TM * 32 + t * MR + MS::row(r, lh);
+            for (int r = 0; r < RSL; ++r) {
+                int m = m0 + wm * TM * 32 + t * MR + MS::row(r_lo + r, lh);
                 if (m >= Mp || !cvalid) continue;
                 int64_t off;
                 if (MODE == 0) {
@@ -344,8 +398,8 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
             }
             if (lh == 0) {
                 const int cb = wn * TN * 32 + u * MR + l31;
-                sred[wm * BN + cb] = s1;
-                sred[(WM + wm) * BN + cb] = s2;
+                sred[(wk * WM + wm) * BN + cb] = s1;
+                sred[((WK + wk) * WM + wm) * BN + cb] = s2;
             }
         }
     }
@@ -354,9 +408,9 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
         if (tid < BN && n0 + tid < p.Co) {
             double d1 = 0.0, d2 = 0.0;
 #pragma unroll
-            for (int k = 0; k < WM; ++k) {
+            for (int k = 0; k < WK * WM; ++k) {
                 d1 += (double)sred[k * BN + tid];
-                d2 += (double)sred[(WM + k) * BN + tid];
+                d2 += (double)sred[(WK * WM + k) * BN + tid];
             }
             // the per-workgroup sums are folded onto stats_nbg slots per column (768 workgroups on the
             // dominant shape -> 12 atomics per address), which norm_finalize reduces and re-zeroes
@@ -394,6 +448,16 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
                 if (ns > nch / 4) ns = nch / 4;
                 if (ns > 8) ns = 8;
                 if (ns < 1) ns = 1;
+            }
+            // Enough 32 x 32 tiles to give every CU a workgroup: split K between the four waves of a workgroup
+            // (no zero-fill, no atomics, fused epilogue kept).  3x3 128->128 @16x12: 29.1 vs 35.8 us;
+            // 256->256 @8x6: 37.0 vs 34.8 us but the separate statistics / BN pass and the memset disappear;
+            // with fewer tiles (U-Net bottleneck, 4x4 512->512 @4x3: 84 vs 59 us) the grid-level split wins.
+            const int64_t b32 = (int64_t)cdiv(Mmax, 32) * cdiv(p.Co, 32) * phases;
+            if (ns > 1 && advmix_opts().ksplit_wg && b32 >= 256) {
+                LAUNCHD(1, 1, 1, 1, false);                                // 32 x 32, four waves share K in the workgroup
+                ADVMIX_CHECK_LAUNCH();
+                return ADVMIX_OK;
             }
             if (ns > 1 && (p.bn_gamma || p.res || p.act || p.stats)) return -2;   // fused epilogue needs whole-K tiles
             if (ns > 1) {

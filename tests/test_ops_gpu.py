@@ -60,19 +60,21 @@ CONV_CASES = [
 ]
 
 
-@pytest.fixture(params=['auto', 'lds3x3', 'direct', 'direct16', 'igemm'])
+@pytest.fixture(params=['auto', 'lds3x3', 'direct', 'direct16', 'direct_wg', 'igemm'])
 def conv_path(request):
     """Force each generation of the conv kernels in turn (advmix_set_option)."""
     from advmix_amd.ops import set_option
     cfg = {'auto': (1, 0, 512), 'lds3x3': (1, 1, 1), 'direct': (1, 0, 512), 'direct16': (1, 0, 512),
-           'igemm': (0, 0, 512)}[request.param]
+           'direct_wg': (1, 0, 512), 'igemm': (0, 0, 512)}[request.param]
     set_option('wgrad_direct', {'igemm': 0, 'auto': 1}.get(request.param, 2))   # 2 = force where eligible
     set_option('direct', cfg[0])
     set_option('conv3', cfg[1])
     set_option('conv3_min_items', cfg[2])
     set_option('mfma16', 1 if request.param == 'direct16' else 0)      # 16x16x4 MFMA shape in conv_direct
+    set_option('ksplit_wg', 1 if request.param in ('direct_wg', 'auto') else 0)  # K split inside the workgroup
     yield request.param
     set_option('mfma16', 0)
+    set_option('ksplit_wg', 1)
     set_option('direct', 1)
     set_option('wgrad_direct', 1)
     set_option('conv3', 0)
@@ -220,7 +222,16 @@ def test_norm_statistics_survive_large_mean(ratio):
     (2, 3, 32, 24, 64, 3, 2, 1, 1, False),      # Cin = 3: first-generation conv + separate norm
     (3, 48, 20, 12, 96, 3, 2, 1, 1, False),
 ])
-def test_conv_bn_fused_member(case):
+@pytest.mark.parametrize('ksplit_wg', [0, 1])
+def test_conv_bn_fused_member(case, ksplit_wg):
+    _ops().set_option('ksplit_wg', ksplit_wg)
+    try:
+        _conv_bn_fused_member(case)
+    finally:
+        _ops().set_option('ksplit_wg', 1)
+
+
+def _conv_bn_fused_member(case):
     ops = _ops()
     d = dev()
     B, Ci, H, W, Co, k, s_, p_, act, has_res = case

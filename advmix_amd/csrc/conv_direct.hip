@@ -421,12 +421,43 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     }
 }
 
+// Tile configuration for a problem (the only place that decides it; advmix_conv_direct_config reports it).
+enum Cfg { CFG_128x32 = 1, CFG_128x64 = 2, CFG_64x64 = 3, CFG_64x64_GRID_SPLIT = 4, CFG_32x32_WAVE_SPLIT = 5 };
+
+static Cfg pick_cfg(int64_t Mmax, int Co, int phases, int nch, int* nsplit) {
+    *nsplit = 1;
+    if (Co <= 32) return CFG_128x32;                       // (256 x 32 measured: 34.9 vs 27.5 us)
+    if ((int64_t)cdiv(Mmax, 128) * cdiv(Co, 64) * phases >= 512) return CFG_128x64;
+    const int64_t b64 = (int64_t)cdiv(Mmax, 64) * cdiv(Co, 64) * phases;
+    int ns = 1;
+    if (b64 < 256 && nch >= 8) {                           // too few workgroups: split K
+        ns = (int)((512 + b64 - 1) / b64);
+        if (ns > nch / 4) ns = nch / 4;
+        if (ns > 8) ns = 8;
+        if (ns < 1) ns = 1;
+    }
+    if (ns <= 1) return CFG_64x64;
+    // Enough 32 x 32 tiles to give every CU a workgroup: split K between the four waves of a workgroup (no
+    // zero-fill, no atomics, fused epilogue kept).  3x3 128->128 @16x12: 29.1 vs 35.8 us; 256->256 @8x6: 37.0 vs
+    // 34.8 us but the separate statistics / BN pass and the memset disappear; with fewer tiles (U-Net
+    // bottleneck, 4x4 512->512 @4x3: 84 vs 59 us) the grid-level split wins.
+    const int64_t b32 = (int64_t)cdiv(Mmax, 32) * cdiv(Co, 32) * phases;
+    if (advmix_opts().ksplit_wg && b32 >= 256) return CFG_32x32_WAVE_SPLIT;
+    *nsplit = ns;
+    return CFG_64x64_GRID_SPLIT;
+}
+
+static void problem_shape(int mode, int Ci, int R, int S, int stride, int KC, int* phases, int* nch) {
+    *phases = mode == 0 ? 1 : stride * stride;
+    const int maxtaps = mode == 0 ? R * S : ((R + stride - 1) / stride) * ((S + stride - 1) / stride);
+    *nch = maxtaps * (Ci / KC);
+}
+
 template <int MODE, int KC, bool BT, bool EPI, int MR>
 int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
     static_assert(!EPI || (MODE == 0 && !BT), "fused epilogue: forward gather only");
-    const int phases = MODE == 0 ? 1 : p.stride * p.stride;
-    const int maxtaps = MODE == 0 ? p.R * p.S : ((p.R + p.stride - 1) / p.stride) * ((p.S + p.stride - 1) / p.stride);
-    const int nch = maxtaps * (p.Ci / KC);
+    int phases, nch, ns;
+    problem_shape(MODE, p.Ci, p.R, p.S, p.stride, KC, &phases, &nch);
 #define LAUNCHD(TM_, TN_, WM_, WN_, SP_)                                                          \
     do {                                                                                          \
         dim3 g(cdiv(Mmax, 32 * TM_ * WM_), cdiv(p.Co, 32 * TN_ * WN_), phases * p.nsplit);        \
@@ -434,41 +465,18 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
     } while (0)
     p.nsplit = 1;
     p.stats_nbg = ADVMIX_STAT_SLOTS;
-    if (p.Co <= 32) {
-        LAUNCHD(1, 1, 4, 1, false);                                        // 128 x 32 (256 x 32 measured: 34.9 vs 27.5 us)
-    } else {
-        const int64_t b128 = (int64_t)cdiv(Mmax, 128) * cdiv(p.Co, 64) * phases;
-        if (b128 >= 512) {
-            LAUNCHD(1, 2, 4, 1, false);                                    // 128 x 64
-        } else {
-            const int64_t b64 = (int64_t)cdiv(Mmax, 64) * cdiv(p.Co, 64) * phases;
-            int ns = 1;
-            if (b64 < 256 && nch >= 8) {                                   // too few workgroups: split K
-                ns = (int)((512 + b64 - 1) / b64);
-                if (ns > nch / 4) ns = nch / 4;
-                if (ns > 8) ns = 8;
-                if (ns < 1) ns = 1;
-            }
-            // Enough 32 x 32 tiles to give every CU a workgroup: split K between the four waves of a workgroup
-            // (no zero-fill, no atomics, fused epilogue kept).  3x3 128->128 @16x12: 29.1 vs 35.8 us;
-            // 256->256 @8x6: 37.0 vs 34.8 us but the separate statistics / BN pass and the memset disappear;
-            // with fewer tiles (U-Net bottleneck, 4x4 512->512 @4x3: 84 vs 59 us) the grid-level split wins.
-            const int64_t b32 = (int64_t)cdiv(Mmax, 32) * cdiv(p.Co, 32) * phases;
-            if (ns > 1 && advmix_opts().ksplit_wg && b32 >= 256) {
-                LAUNCHD(1, 1, 1, 1, false);                                // 32 x 32, four waves share K in the workgroup
-                ADVMIX_CHECK_LAUNCH();
-                return ADVMIX_OK;
-            }
-            if (ns > 1 && (p.bn_gamma || p.res || p.act || p.stats)) return -2;   // fused epilogue needs whole-K tiles
-            if (ns > 1) {
-                p.nsplit = ns;
-                if (hipMemsetAsync(p.y, 0, (size_t)p.N * p.Ho * p.Wo * p.Co * sizeof(float), st) != hipSuccess)
-                    return ADVMIX_ELAUNCH;
-                LAUNCHD(1, 1, 2, 2, true);                                 // 64 x 64, K split + atomics
-            } else {
-                LAUNCHD(1, 1, 2, 2, false);                                // 64 x 64
-            }
-        }
+    switch (pick_cfg(Mmax, p.Co, phases, nch, &ns)) {
+        case CFG_128x32: LAUNCHD(1, 1, 4, 1, false); break;
+        case CFG_128x64: LAUNCHD(1, 2, 4, 1, false); break;
+        case CFG_64x64: LAUNCHD(1, 1, 2, 2, false); break;
+        case CFG_32x32_WAVE_SPLIT: LAUNCHD(1, 1, 1, 1, false); break;      // four waves share K in the workgroup
+        case CFG_64x64_GRID_SPLIT:                                         // K across gridDim.z + atomics
+            if (p.bn_gamma || p.res || p.act || p.stats) return -2;        // fused epilogue needs whole-K tiles
+            p.nsplit = ns;
+            if (hipMemsetAsync(p.y, 0, (size_t)p.N * p.Ho * p.Wo * p.Co * sizeof(float), st) != hipSuccess)
+                return ADVMIX_ELAUNCH;
+            LAUNCHD(1, 1, 2, 2, true);
+            break;
     }
 #undef LAUNCHD
     ADVMIX_CHECK_LAUNCH();
@@ -511,4 +519,17 @@ int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const 
 #undef LAUNCH_KC
     if (stats_nbg) *stats_nbg = p.stats_nbg;
     return rc;
+}
+
+// Which conv_direct tile configuration a problem gets (tests assert that the shapes meant to exercise a
+// kernel variant really reach it): 1 = 128x32, 2 = 128x64, 3 = 64x64, 4 = 64x64 + grid K split,
+// 5 = 32x32 + K split between the waves of a workgroup; -1 = not served by conv_direct.
+// mode 0: forward (Mmax = N*Ho*Wo output pixels); mode 1: transposed gather (per-phase rows of the LARGER side).
+extern "C" int advmix_conv_direct_config(int mode, int N, int Ho, int Wo, int Ci, int Co, int R, int S, int stride) {
+    if (Ci % 16 != 0 || R * S > 64 || N <= 0 || stride < 1) return -1;
+    const int KC = Ci % 32 == 0 ? 32 : 16;
+    int phases, nch, ns;
+    direct::problem_shape(mode, Ci, R, S, stride, KC, &phases, &nch);
+    const int64_t Mmax = mode == 0 ? (int64_t)N * Ho * Wo : (int64_t)N * cdiv(Ho, stride) * cdiv(Wo, stride);
+    return (int)direct::pick_cfg(Mmax, Co, phases, nch, &ns);
 }

@@ -79,6 +79,12 @@ int advmix_conv_tr_w(const float* x, const float* w, const float* bias, float* y
                      int N, int Hs, int Ws, int Ck, int Hb, int Wb, int Cn,
                      int R, int S, int stride, int pad, void* stream);
 
+/* Which tile configuration the second-generation conv kernel picks (introspection for tests / tuning):
+ * 1 = 128x32, 2 = 128x64, 3 = 64x64, 4 = 64x64 + K split across the grid (atomics), 5 = 32x32 + K split between
+ * the waves of a workgroup; -1 = not served.  mode 0: forward, (Ho, Wo) = output size, Ci = reduction channels;
+ * mode 1: input gradient / transposed conv, (Ho, Wo) = the LARGER (gradient) side, Ci = channels reduced over. */
+int advmix_conv_direct_config(int mode, int N, int Ho, int Wo, int Ci, int Co, int R, int S, int stride);
+
 /* dw[Ca][R][S][Cb] += sum_p a[p, Ca] * b[gather(p,r,s), Cb]   (fp32 atomics, split over pixels)
  * a: [N,Ha,Wa,Ca] at the conv's OUTPUT resolution, b: [N,Hb,Wb,Cb] at its INPUT resolution.
  * Conv2d: a = dY, b = X.   ConvTranspose2d: a = X, b = dY (gives [Cin][R][S][Cout]). */

@@ -57,6 +57,8 @@ CONV_CASES = [
     (2, 64, 20, 24, 48, 3, 1, 1, True),     # LDS-patch kernel: 2 channel chunks, ragged tiles, Co % 32 != 0
     (1, 32, 9, 17, 32, 3, 1, 1, False),
     (2, 96, 16, 16, 64, 3, 1, 1, False),
+    (32, 256, 8, 6, 256, 3, 1, 1, True),    # HRNet's lowest branch at the bench batch: 32x32 tiles, K split between waves
+    (16, 128, 32, 24, 128, 3, 2, 1, False), # stride-2 fuse conv: wave-split forward, phase-decomposed input gradient
 ]
 
 
@@ -79,6 +81,26 @@ def conv_path(request):
     set_option('wgrad_direct', 1)
     set_option('conv3', 0)
     set_option('conv3_min_items', 512)
+
+
+def test_conv_tile_configuration_table():
+    """The shapes the tests rely on to reach a kernel variant really get it (advmix_conv_direct_config)."""
+    from advmix_amd._lib import lib
+    ops = _ops()
+    ops.set_option('ksplit_wg', 1)
+    cfgq = lib.advmix_conv_direct_config
+    assert cfgq(0, 32, 64, 48, 32, 32, 3, 3, 1) == 1          # dominant conv: 128x32
+    assert cfgq(0, 32, 64, 48, 64, 64, 3, 3, 1) == 2          # stem-sized: 128x64
+    assert cfgq(0, 32, 32, 24, 64, 64, 3, 3, 1) == 3          # 64x64
+    assert cfgq(0, 32, 8, 6, 256, 256, 3, 3, 1) == 5          # wave split, forward
+    assert cfgq(1, 32, 8, 6, 256, 256, 3, 3, 1) == 5          # wave split, input gradient
+    assert cfgq(0, 16, 16, 12, 128, 128, 3, 3, 2) == 5        # the stride-2 case of CONV_CASES (output 16x12)
+    assert cfgq(0, 2, 8, 6, 256, 256, 3, 3, 1) == 4           # too few tiles: grid split + atomics
+    assert cfgq(0, 32, 4, 3, 512, 512, 4, 4, 2) == 4          # U-Net bottleneck
+    ops.set_option('ksplit_wg', 0)
+    assert cfgq(0, 32, 8, 6, 256, 256, 3, 3, 1) == 4
+    ops.set_option('ksplit_wg', 1)
+    assert cfgq(0, 2, 15, 11, 3, 64, 7, 7, 2) == -1           # Cin = 3: first-generation kernel
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
@@ -218,7 +240,8 @@ def test_norm_statistics_survive_large_mean(ratio):
     (8, 32, 64, 48, 32, 3, 1, 1, 1, True),      # fused epilogue, 128x32 tiles
     (8, 64, 32, 24, 64, 3, 1, 1, 1, False),     # 64x64 tiles
     (4, 256, 16, 12, 64, 1, 1, 0, 0, False),
-    (2, 256, 8, 6, 256, 3, 1, 1, 1, True),      # K-split shape: falls back to the separate kernels
+    (2, 256, 8, 6, 256, 3, 1, 1, 1, True),      # grid K-split shape: falls back to the separate kernels
+    (32, 256, 8, 6, 256, 3, 1, 1, 1, True),     # wave K-split: fused epilogue (ksplit_wg = 1) vs grid split (0)
     (2, 3, 32, 24, 64, 3, 2, 1, 1, False),      # Cin = 3: first-generation conv + separate norm
     (3, 48, 20, 12, 96, 3, 2, 1, 1, False),
 ])

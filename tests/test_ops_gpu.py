@@ -59,6 +59,7 @@ CONV_CASES = [
     (2, 96, 16, 16, 64, 3, 1, 1, False),
     (32, 256, 8, 6, 256, 3, 1, 1, True),    # HRNet's lowest branch at the bench batch: 32x32 tiles, K split between waves
     (16, 128, 32, 24, 128, 3, 2, 1, False), # stride-2 fuse conv: wave-split forward, phase-decomposed input gradient
+    (8, 128, 64, 64, 128, 1, 1, 0, True),   # enough rows for the 128x64 tile in both directions
 ]
 
 
@@ -92,6 +93,7 @@ def test_conv_tile_configuration_table():
     assert cfgq(0, 32, 64, 48, 32, 32, 3, 3, 1) == 1          # dominant conv: 128x32
     assert cfgq(0, 32, 64, 48, 64, 64, 3, 3, 1) == 2          # stem-sized: 128x64
     assert cfgq(0, 32, 32, 24, 64, 64, 3, 3, 1) == 3          # 64x64
+    assert cfgq(0, 8, 64, 64, 128, 128, 1, 1, 1) == 2 and cfgq(1, 8, 64, 64, 128, 128, 1, 1, 1) == 2   # CONV_CASES[-1]
     assert cfgq(0, 32, 8, 6, 256, 256, 3, 3, 1) == 5          # wave split, forward
     assert cfgq(1, 32, 8, 6, 256, 256, 3, 3, 1) == 5          # wave split, input gradient
     assert cfgq(0, 16, 16, 12, 128, 128, 3, 3, 2) == 5        # the stride-2 case of CONV_CASES (output 16x12)

@@ -29,6 +29,7 @@ SIGNATURES = {
     'advmix_conv_tr': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_tr_w': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_direct_config': [_i] * 9,
+    'advmix_conv_tr_w_add': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],
     'advmix_transpose_w': [_p, _p, _i, _i, _i, _p],
     'advmix_bias_grad': [_p, _p, _l, _i, _p],

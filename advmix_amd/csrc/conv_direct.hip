@@ -379,6 +379,9 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
 #if defined(CD_DBG) && (CD_DBG & 4)                  /* no output stores (kept alive by an impossible value) */
                 if (v != 123456.789f) continue;
 #endif
+                // transposed gather (input gradients): an addend, e.g. the other gradient of a tensor with two
+                // consumers, rides in the epilogue instead of a separate add kernel (slice 0 only under SPLIT)
+                if (MODE == 1 && p.res && (!SPLIT || zsl == 0)) v += p.res[off];
                 if (SPLIT) { atomicAdd(p.y + off, v); continue; }
                 if (EPI) {
                     s1 += v;
@@ -471,7 +474,7 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
         case CFG_64x64: LAUNCHD(1, 1, 2, 2, false); break;
         case CFG_32x32_WAVE_SPLIT: LAUNCHD(1, 1, 1, 1, false); break;      // four waves share K in the workgroup
         case CFG_64x64_GRID_SPLIT:                                         // K across gridDim.z + atomics
-            if (p.bn_gamma || p.res || p.act || p.stats) return -2;        // fused epilogue needs whole-K tiles
+            if (p.bn_gamma || (MODE == 0 && p.res) || p.act || p.stats) return -2;   // fused epilogue needs whole-K tiles
             p.nsplit = ns;
             if (hipMemsetAsync(p.y, 0, (size_t)p.N * p.Ho * p.Wo * p.Co * sizeof(float), st) != hipSuccess)
                 return ADVMIX_ELAUNCH;
@@ -494,7 +497,7 @@ int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const 
                                 int* stats_nbg) {
     if (Ci % 16 != 0 || R * S > 64) return -1;
     if (bt && (mode != 1 || Co % 4 != 0)) return -1;
-    if (epi && mode != 0) return -2;
+    if (epi && mode != 0 && (epi->gamma || epi->act || epi->stats)) return -2;   // mode 1 takes an addend only
     const int64_t xb = (int64_t)N * Hi * Wi * Ci * 4, wb = (int64_t)Co * R * S * Ci * 4;
     if (xb >= 0x7fffffffLL || wb >= 0x7fffffffLL) return -1;
     direct::ConvD p{x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, (int)xb, (int)wb, 1,

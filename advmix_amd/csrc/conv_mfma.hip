@@ -563,3 +563,18 @@ extern "C" int advmix_conv_fwd_ex(const float* x, const float* w, const float* b
                                          (int64_t)N * Ho * Wo, (hipStream_t)stream, 0, &e, stats_nbg);
     return rc < 0 ? ADVMIX_EINVAL : rc;
 }
+
+// y = conv_transpose(x, w) + addend (same layout as y, may be NULL): the input gradient of a conv whose input has
+// another consumer (residual, fuse layers) takes that consumer's gradient in the epilogue.  conv_direct only.
+extern "C" int advmix_conv_tr_w_add(const float* x, const float* w, const float* addend, float* y,
+                                    int N, int Hs, int Ws, int Ck, int Hb, int Wb, int Cn,
+                                    int R, int S, int stride, int pad, void* stream) {
+    if (!x || !w || !y || N <= 0 || Ck <= 0 || Cn <= 0 || stride < 1 || stride > 8) return ADVMIX_EINVAL;
+    if (Hs != (Hb + 2 * pad - R) / stride + 1 || Ws != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
+    if (!use_direct()) return ADVMIX_EINVAL;
+    ConvEpi epi{nullptr, nullptr, nullptr, nullptr, addend, 0.f, 0, nullptr};
+    int64_t Mmax = (int64_t)N * cdiv(Hb, stride) * cdiv(Wb, stride);
+    int rc = advmix_conv_direct_dispatch(1, x, w, nullptr, y, N, Hs, Ws, Ck, Hb, Wb, Cn, R, S, stride, pad, Mmax,
+                                         (hipStream_t)stream, 1, addend ? &epi : nullptr);
+    return rc < 0 ? ADVMIX_EINVAL : rc;
+}

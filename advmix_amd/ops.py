@@ -140,6 +140,21 @@ def _wt(st, w, A, T, B):
 # members: fwd(st, lane, tensors, meta, needs) -> (outputs, saved, extra)
 #          bwd(st, lane, saved, extra, meta, grads, needs) -> input grads (aligned with tensors)
 # =============================================================================================
+def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to=None):
+    """Input gradient of a conv (+ ``add_to``, another gradient of the same input: summed in the kernel's
+    epilogue on the conv_direct path, by advmix_add otherwise)."""
+    dx = empty_nhwc(B, Ci, Hi, Wi, x.device)
+    if Co % 16 == 0 and Ci % 4 == 0 and _direct_ok():          # weights consumed in their own layout
+        if add_to is not None and (add_to.shape != dx.shape or add_to.stride() != dx.stride()):
+            raise RuntimeError('advmix_amd: gradient fan-in of differently laid out tensors')
+        call('advmix_conv_tr_w_add', _p(dy), _p(w), _p(add_to), _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
+             stride, pad, st)
+        return dx
+    wt = _wt(st, w, Co, R * S, Ci)
+    call('advmix_conv_tr', _p(dy), _p(wt), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, st)
+    return dx if add_to is None else _add(st, keep(dx), add_to)
+
+
 class Conv:
     NHWC = (0,)      # inputs made dense NHWC BEFORE the lanes fork (None = all)
     """nn.Conv2d (square stride / padding, dilation 1, groups 1).  tensors = (x, w, bias|None)."""
@@ -159,8 +174,10 @@ class Conv:
              stride, pad, st)
         return (y,), (x, w, bias), None
 
+    ADD_TO = True    # bwd(..., add_to): another gradient of the input, summed in the dgrad epilogue
+
     @staticmethod
-    def bwd(st, lane, saved, extra, meta, grads, needs):
+    def bwd(st, lane, saved, extra, meta, grads, needs, add_to=None):
         x, w, bias = saved
         stride, pad = meta
         dy = nhwc(grads[0])
@@ -169,14 +186,7 @@ class Conv:
         Ho, Wo = dy.shape[2], dy.shape[3]
         dx = None
         if needs[0]:
-            dx = empty_nhwc(B, Ci, Hi, Wi, x.device)
-            if Co % 16 == 0 and Ci % 4 == 0 and _direct_ok():      # weights consumed in their own layout
-                call('advmix_conv_tr_w', _p(dy), _p(w), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
-                     stride, pad, st)
-            else:
-                wt = _wt(st, w, Co, R * S, Ci)
-                call('advmix_conv_tr', _p(dy), _p(wt), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
-                     stride, pad, st)
+            dx = _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to)
         if needs[1]:
             call('advmix_conv_wgrad', _p(dy), _p(x), _p(_grad_buf(w, st)), B, Ho, Wo, Co, Hi, Wi, Ci,
                  R, S, stride, pad, st)
@@ -337,8 +347,10 @@ class ConvBN:
              Co, 1, rows, Co, act, st)
         return (y,), (x, w, c, y, mean, invstd, gamma, beta), residual is not None
 
+    ADD_TO = True
+
     @staticmethod
-    def bwd(st, lane, saved, has_res, meta, grads, needs):
+    def bwd(st, lane, saved, has_res, meta, grads, needs, add_to=None):
         stride, pad, act, training = meta[0], meta[1], meta[2], meta[3]
         if not training:
             raise RuntimeError('advmix_amd: backward through eval-mode BatchNorm is not on the hot path')
@@ -361,14 +373,7 @@ class ConvBN:
              _p(ws), st)
         dx = None
         if needs[0]:
-            dx = empty_nhwc(B, Ci, Hi, Wi, x.device)
-            if Co % 16 == 0 and Ci % 4 == 0 and _direct_ok():
-                call('advmix_conv_tr_w', _p(dc), _p(w), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
-                     stride, pad, st)
-            else:
-                wt = _wt(st, w, Co, R * S, Ci)
-                call('advmix_conv_tr', _p(dc), _p(wt), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
-                     stride, pad, st)
+            dx = _conv_dgrad(st, dc, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to)
         if needs[1]:
             call('advmix_conv_wgrad', _p(dc), _p(x), _p(_grad_buf(w, st)), B, Ho, Wo, Co, Hi, Wi, Ci,
                  R, S, stride, pad, st)
@@ -589,6 +594,9 @@ class JointsLoss:
         return out, None, None
 
 
+FANIN_FUSED = __import__('os').environ.get('ADVMIX_FANIN', '1') != '0'
+
+
 def _add(st, a, b):
     """a + b for two dense tensors of identical layout, on the member's stream (gradient fan-in
     inside a Chain; a torch add would run on the caller's stream)."""
@@ -651,7 +659,12 @@ class Chain:
             go = grad.pop(dst, None)
             if go is None or not any(nin):
                 continue
-            r = op.bwd(st, lane, saved[sp:sp + sc], ex, smeta, [go], nin)
+            if FANIN_FUSED and getattr(op, 'ADD_TO', False) and refs[0] is not None and refs[0][0] == 's' \
+                    and nin[0] and refs[0][1] in grad:
+                # the input already has a gradient from another consumer: the conv's dgrad epilogue adds it
+                r = op.bwd(st, lane, saved[sp:sp + sc], ex, smeta, [go], nin, grad.pop(refs[0][1]))
+            else:
+                r = op.bwd(st, lane, saved[sp:sp + sc], ex, smeta, [go], nin)
             for ref, g in zip(refs, r):
                 if g is None or ref is None:
                     continue

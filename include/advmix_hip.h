@@ -79,6 +79,12 @@ int advmix_conv_tr_w(const float* x, const float* w, const float* bias, float* y
                      int N, int Hs, int Ws, int Ck, int Hb, int Wb, int Cn,
                      int R, int S, int stride, int pad, void* stream);
 
+/* advmix_conv_tr_w plus an addend in the epilogue: y = conv_transpose(x, w) + addend (addend laid out like y; NULL =
+ * none).  Used for the input gradient of a conv whose input has a second consumer. */
+int advmix_conv_tr_w_add(const float* x, const float* w, const float* addend, float* y,
+                         int N, int Hs, int Ws, int Ck, int Hb, int Wb, int Cn,
+                         int R, int S, int stride, int pad, void* stream);
+
 /* Which tile configuration the second-generation conv kernel picks (introspection for tests / tuning):
  * 1 = 128x32, 2 = 128x64, 3 = 64x64, 4 = 64x64 + K split across the grid (atomics), 5 = 32x32 + K split between
  * the waves of a workgroup; -1 = not served.  mode 0: forward, (Ho, Wo) = output size, Ci = reduction channels;

@@ -646,3 +646,31 @@ def test_render_targets_bit_exact_vs_reference():
     base, aug, jt, vis = oip.synth_samples('inp.coco', 3, 17, 256, 192)
     _, tw = TargetRenderer((192, 256), (48, 64), 2, joints_weight=jw, device=dev()).render(jt, vis)
     assert np.array_equal(tw[0].cpu().numpy(), g['coco.jw.tw0'])
+
+
+@pytest.mark.parametrize('case', [
+    (4, 32, 64, 48, 32, 3, 1, 1),       # 128x32 tile
+    (2, 256, 8, 6, 256, 3, 1, 1),       # grid K split: the addend joins slice 0
+    (32, 256, 8, 6, 256, 3, 1, 1),      # wave K split
+    (2, 64, 18, 14, 48, 3, 2, 1),       # stride 2: phase-decomposed gather, every phase adds its part
+    (2, 64, 16, 12, 128, 1, 2, 0),      # 1x1 stride 2: three of four phases have no tap and still take the addend
+])
+def test_dgrad_with_addend_in_epilogue(case):
+    """advmix_conv_tr_w_add: input gradient + another gradient of the same tensor (fan-in) in one launch."""
+    ops = _ops()
+    B, Ci, H, W, Co, k, s, p = case
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    w = rnd(Co, Ci, k, k, seed=61, scale=(Ci * k * k) ** -0.5)
+    dy = rnd(B, Co, Ho, Wo, seed=62)
+    other = rnd(B, Ci, H, W, seed=63)
+    xr = torch.zeros(B, Ci, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, w, None, s, p).backward(dy)
+    want = xr.grad + other
+    x = cl(torch.zeros(B, Ci, H, W))
+    st = torch.cuda.current_stream().cuda_stream
+    import ctypes
+    got = ops._conv_dgrad(ctypes.c_void_p(st), cl(dy), cl(w), x, B, Ho, Wo, Co, H, W, Ci, k, k, s, p, cl(other))
+    check('dgrad + addend', got, want)
+    got0 = ops._conv_dgrad(ctypes.c_void_p(st), cl(dy), cl(w), x, B, Ho, Wo, Co, H, W, Ci, k, k, s, p, None)
+    check('dgrad', got0, xr.grad)
+    del ops._KEEP[:]

@@ -368,3 +368,87 @@ def test_launch_chains_equal_the_level_schedule(monkeypatch):
     for k in a[3]:
         s = float(b[3][k].abs().max()) + 1e-12
         assert float((a[3][k] - b[3][k]).abs().max()) <= 1e-3 * s + 1e-9, k
+
+
+def _tiny_setup(salt=10, lr=1e-3):
+    from oracle import configs
+    from oracle.posenet import calibrate
+    from oracle.synth import synth_batch
+    from advmix_amd.core.loss import JointsMSELoss
+    from advmix_amd.utils.utils import get_optimizer
+    net, extra, J, B, H, W = 'pose_hrnet', configs.HRNET_TINY, 5, 2, 64, 64
+    D, T, G = build_states(net, extra, J, salt=salt)
+    calib = synth_batch('hrnet_tiny.calib', B, J, H, W)[0][0]
+    calibrate(net, T, calib, extra)
+    calibrate(net, D, calib, extra)
+    cfg, mD, mG, mT = product_models(net, extra, J, D, T, G, lr=lr)
+    optD, optG = get_optimizer(cfg, mD), get_optimizer(cfg, mG)
+    mD.train(); mG.train(); mT.eval()
+    return cfg, mD, mG, mT, JointsMSELoss(True), optD, optG, (B, J, H, W)
+
+
+def test_train_advmix_loop_first_iteration_matches_reference():
+    """The loop mirror itself (function.py:107-197): batches in the reference loader's format, meters, the
+    tensorboard counter; the first iteration's loss_D equals the number the REAL train_advmix recorded."""
+    from oracle.synth import synth_batch
+    from advmix_amd.core.function import train_advmix
+    cfg, mD, mG, mT, crit, optD, optG, (B, J, H, W) = _tiny_setup()
+    cfg['PRINT_FREQ'] = 2
+    g = gold_npz('advmix_steps.npz')
+    batches = []
+    for it in range(3):
+        v, t, w = synth_batch('hrnet_tiny.it%d' % it, B, J, H, W)
+        batches.append((v, [t, t, t], [w, w, w], [{}, {}, {}]))
+    seen = []
+    writer = types.SimpleNamespace(add_scalar=lambda k, v, s: seen.append((k, float(v), s)))
+    wd = {'writer': writer, 'train_global_steps': 0}
+    args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
+    train_advmix(cfg, args, batches, [mD, mG, mT], crit, [optD, optG], 0, '/tmp', '/tmp', wd)
+    assert wd['train_global_steps'] == 2                     # i = 0 and i = 2
+    want = g['hrnet_tiny.losses'][0]
+    first = [v for k, v, s in seen if k == 'train_loss'][0]
+    assert abs(first - (0.9 * want[0] + 0.1 * want[1])) <= 1e-3 * max(1.0, abs(want[0]))
+    assert all(not p.requires_grad for p in mD.parameters())          # left frozen, like the reference
+    assert int(mD.state_dict()['bn1.num_batches_tracked']) == 1 + 2 * 3   # calibration + two forwards per batch
+
+
+def test_graph_runner_matches_eager_step_from_the_same_state():
+    """AdvMixGraphRunner (three HIP graphs, static batch buffers, load_batch) against the eager advmix_step.
+    Two runs cannot be compared across several Adam updates - eager itself is not reproducible there: Adam's
+    first steps move every element by ~lr * sign(g), and the sign of a rounding-noise gradient follows the order
+    of the fp32 atomics (measured: two eager runs from one state differ by 3.6 % in loss after ONE update).  So
+    the graph is replayed and the eager step run from the SAME parameter / optimizer / BN state: loss_D (computed
+    before any update) must agree tightly, everything after the D update loosely."""
+    import copy
+    from oracle.synth import synth_batch
+    from advmix_amd.core.function import advmix_step
+    from advmix_amd.graph import AdvMixGraphRunner
+    args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
+    B, J, H, W = 2, 5, 64, 64
+    data = []
+    for it in range(2):
+        v, t, w = synth_batch('hrnet_tiny.it%d' % it, B, J, H, W)
+        data.append(([x.cuda().contiguous() for x in v], t.cuda(), w.cuda()))
+    cfg, gD, gG, gT, crit, goD, goG, _ = _tiny_setup(lr=1e-4)
+    runner = AdvMixGraphRunner(args, gD, gG, gT, crit, goD, goG, *data[0], warmup=2)
+    # clone the post-warm-up state into eager models
+    cfg, mD, mG, mT, crit2, optD, optG, _ = _tiny_setup(lr=1e-4)
+    mD.load_state_dict(copy.deepcopy(gD.state_dict()))
+    mG.load_state_dict(copy.deepcopy(gG.state_dict()))
+    optD.load_state_dict(copy.deepcopy(goD.state_dict()))
+    optG.load_state_dict(copy.deepcopy(goG.state_dict()))
+    runner.load_batch(*data[1])
+    loss_g, out_g = runner.step()
+    loss_g, out_g = float(loss_g), out_g.detach().float().cpu().clone()
+    loss_e, out_e = advmix_step(args, mD, mG, mT, crit2, optD, optG, *data[1])
+    assert abs(float(loss_e) - loss_g) <= 1e-4 * max(1.0, abs(loss_g)), (float(loss_e), loss_g)
+    scale = float(out_e.abs().max())
+    assert float((out_e.detach().float().cpu() - out_g).abs().max()) <= 0.05 * scale      # after one Adam update
+    tot = bad = 0
+    for (k, a_), (_, b_) in zip(list(mD.named_parameters()) + list(mG.named_parameters()),
+                                list(gD.named_parameters()) + list(gG.named_parameters())):
+        d = (a_.detach() - b_.detach()).abs()
+        tot += d.numel()
+        bad += int((d > 2e-5).sum())
+    assert 1.0 - bad / tot >= 0.9, 1.0 - bad / tot
+    assert int(gD.state_dict()['bn1.num_batches_tracked']) == int(mD.state_dict()['bn1.num_batches_tracked'])

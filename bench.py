@@ -308,6 +308,57 @@ def bench_inputs(a, device, rank, world):
     return line
 
 
+def bench_nms(a, device, rank, world):
+    """--path nms: the lib/nms row.  A step = the post-process of one image: box NMS over
+    N = 1000 scored boxes through the reproduced ``_nms`` ABI (H2D, 64-wide bitmask kernel, D2H, host greedy
+    pass - per-call malloc/free like the reference) plus OKS-NMS over 30 person candidates (fp64 OKS matrix on
+    the device, greedy pass on the host).  Latency-bound by design: the reference's interface is host to host."""
+    import numpy as np
+    from advmix_amd.nms.nms import gpu_nms, oks_nms
+    rng = np.random.RandomState(11 + rank)
+    N = 1000
+    xy = rng.rand(N, 2) * 400
+    wh = rng.rand(N, 2) * 120 + 10
+    dets = np.concatenate([xy, xy + wh, rng.rand(N, 1)], 1).astype(np.float32)
+    people = []
+    base = rng.rand(6, 17, 2) * 300 + 50
+    for n in range(30):
+        k = np.zeros((17, 3)); k[:, :2] = base[n % 6] + rng.randn(17, 2) * 4; k[:, 2] = rng.rand(17)
+        people.append({'keypoints': k.reshape(-1), 'area': float(rng.rand() * 20000 + 5000), 'score': float(rng.rand())})
+
+    def one():
+        return len(gpu_nms(dets, 0.5)), len(oks_nms(people, 0.9))
+    for _ in range(a.warmup):
+        one()
+    torch.cuda.synchronize()
+    steps = max(a.steps, 100)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        kept = one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        gpu_nms(dets, 0.5)
+    torch.cuda.synchronize()
+    dt_box = time.perf_counter() - t1
+    if rank != 0:
+        return None
+    line = {'metric': 'images/sec NMS post-process (box NMS N=1000 + OKS-NMS 30 persons)', 'value': round(world * steps / dt, 1),
+            'unit': 'images/sec', 'n_gpus': world, 'steps': steps, 'warmup': a.warmup, 'ms_per_step': round(dt / steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 IoU / f64 OKS -> int indices',
+            'data': 'synthetic boxes / keypoints (host arrays, as the reference interface takes them)',
+            'config': {'workload': 'nms_box1000_oks30', 'kept': list(kept)},
+            'box_nms_us_per_call': round(dt_box / steps * 1e6, 1),
+            'roofline': {'bound': 'latency', 'kernel': 'nms_mask (16 x 16 tiles of 64 x 64 IoUs, one ballot per row)',
+                         'achieved': None, 'peak': None, 'unit': None, 'frac': None, 'traffic': None,
+                         'note': '1 M IoUs = a few microseconds of device work; the call is bound by hipMalloc/free + '
+                                 'two PCIe copies + the host greedy pass, all of which the reference ABI prescribes'}}
+    if world == 1 and not a.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(a.workload, path='nms')
+    return line
+
+
 def cpu_baseline(workload, budget_s=25.0, hard_timeout_s=150.0, path='train'):
     """The CPU oracle's AdvMix step on this host (bounded sample: B=4, 1 warm-up + a few timed
     steps), in a CPU-only child process with a hard timeout so the bench always finishes."""
@@ -334,7 +385,7 @@ def main():
     ap.add_argument('--workload', default='hrnet_w32', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=32, help='images per GPU (TRAIN.BATCH_SIZE_PER_GPU)')
     ap.add_argument('--exec', dest='exec_mode', default='graph', choices=['graph', 'eager'])
-    ap.add_argument('--path', default='train', choices=['train', 'validate', 'inputs'],
+    ap.add_argument('--path', default='train', choices=['train', 'validate', 'inputs', 'nms'],
                     help='train = the headline AdvMix step; validate = the validate() batch body (SURVEY 8 f1); '
                          'inputs = the device input pipeline (SURVEY 8 f2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -357,8 +408,8 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29555')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
-    if a.path in ('validate', 'inputs'):
-        line = (bench_validate if a.path == 'validate' else bench_inputs)(a, device, rank, world)
+    if a.path in ('validate', 'inputs', 'nms'):
+        line = {'validate': bench_validate, 'inputs': bench_inputs, 'nms': bench_nms}[a.path](a, device, rank, world)
         if world > 1 or force_sync:
             dist.barrier()
             dist.destroy_process_group()

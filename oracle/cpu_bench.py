@@ -92,6 +92,32 @@ def inputs_main(workload, budget, cores):
                                 '%d batches of %d in one process (a DataLoader worker)' % (H, W, n, B)}), flush=True)
 
 
+def nms_main(budget):
+    """The oracle's restatements of the native box NMS (C, the .cu semantics) and of oks_nms (numpy) on one image."""
+    import numpy as np
+    from oracle import nms as onms
+    rng = np.random.RandomState(11)
+    N = 1000
+    xy = rng.rand(N, 2) * 400
+    wh = rng.rand(N, 2) * 120 + 10
+    dets = np.concatenate([xy, xy + wh, rng.rand(N, 1)], 1).astype(np.float32)
+    people = []
+    base = rng.rand(6, 17, 2) * 300 + 50
+    for n in range(30):
+        k = np.zeros((17, 3)); k[:, :2] = base[n % 6] + rng.randn(17, 2) * 4; k[:, 2] = rng.rand(17)
+        people.append({'keypoints': k.reshape(-1), 'area': float(rng.rand() * 20000 + 5000), 'score': float(rng.rand())})
+    onms.build()
+    onms.gpu_nms(dets, 0.5); onms.oks_nms(people, 0.9)
+    n, t0 = 0, time.time()
+    while n < 2000 and time.time() - t0 < budget:
+        onms.gpu_nms(dets, 0.5); onms.oks_nms(people, 0.9)
+        n += 1
+    dt = time.time() - t0
+    print(json.dumps({'value': round(n / dt, 1), 'unit': 'images/sec', 'cores': 1, 'kind': 'port',
+                      'sample': 'C restatement of the box NMS (N=1000) + numpy oks_nms (30 persons), %d images, 1 thread' % n}),
+          flush=True)
+
+
 def main():
     workload, budget = sys.argv[1], float(sys.argv[2])
     cores = effective_cpus()
@@ -101,6 +127,8 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     if len(sys.argv) > 3 and sys.argv[3] == 'validate':
         return validate_main(workload, budget, cores)
+    if len(sys.argv) > 3 and sys.argv[3] == 'nms':
+        return nms_main(10.0)
     if len(sys.argv) > 3 and sys.argv[3] == 'inputs':
         torch.set_num_threads(1)
         return inputs_main(workload, 10.0, 1)

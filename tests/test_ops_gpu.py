@@ -674,3 +674,41 @@ def test_dgrad_with_addend_in_epilogue(case):
     got0 = ops._conv_dgrad(ctypes.c_void_p(st), cl(dy), cl(w), x, B, Ho, Wo, Co, H, W, Ci, k, k, s, p, None)
     check('dgrad', got0, xr.grad)
     del ops._KEEP[:]
+
+
+def test_edge_cases_empty_single_boundary():
+    """Degenerate inputs the reference code paths accept: empty / single-person OKS-NMS, all joints weighted out,
+    constant heat-maps (ties -> first index), joints whose gaussian just touches / just misses the heat-map."""
+    from oracle import inputpipe as oip, validate as oval
+    from advmix_amd.nms.nms import oks_nms, soft_oks_nms
+    from advmix_amd.core.loss import JointsMSELoss
+    from advmix_amd.dataset.JointsDataset import TargetRenderer
+    ops = _ops()
+    assert oks_nms([], 0.9) == [] and soft_oks_nms([], 0.9) == []
+    one = [{'keypoints': np.arange(51, dtype=np.float64), 'area': 100.0, 'score': 0.5}]
+    assert list(oks_nms(one, 0.9)) == [0] and list(soft_oks_nms(one, 0.9)) == [0]
+    # every joint weighted out: loss 0, gradient 0
+    out = cl(rnd(2, 5, 8, 6, seed=71)).requires_grad_(True)
+    loss = JointsMSELoss(True).cuda()(out, cl(rnd(2, 5, 8, 6, seed=72)), torch.zeros(2, 5, 1, device=dev()))
+    loss.backward()
+    assert float(loss) == 0.0 and float(out.grad.abs().max()) == 0.0
+    # constant maps: numpy.argmax returns index 0; positive constant -> coords (0, 0) kept, transformed
+    hm = np.full((2, 3, 8, 6), 0.25, dtype=np.float32)
+    hm[1] = -1.0                                            # all negative: masked to (0, 0) too
+    c = np.array([[100., 120.], [50., 60.]], np.float32)
+    s = np.array([[1., 1.25], [0.5, 0.625]], np.float32)
+    coords, preds, mx = ops.final_preds(torch.from_numpy(hm).to(dev()), c, s, True)
+    p, mv, oc = oval.get_final_preds(hm.copy(), c, s, True)
+    assert np.array_equal(coords.cpu().numpy(), oc) and float(np.abs(oc).max()) == 0.0
+    assert np.array_equal(mx.cpu().numpy()[:, :, None], mv)
+    assert np.abs(preds.cpu().numpy().astype(np.float64) - p).max() <= 1e-4
+    # gaussian support just inside / just outside each border (JointsDataset.py:455-461)
+    W, H, Wh, Hh = 48, 64, 12, 16
+    xs = [-28.0, -26.0, -24.1, 0.0, 47.9, (Wh + 5) * 4.0, (Wh + 6) * 4.0 - 2.1, (Wh + 6) * 4.0, 400.0]
+    jt = np.zeros((1, len(xs), 3)); vis = np.ones((1, len(xs), 3))
+    jt[0, :, 0] = xs
+    jt[0, :, 1] = [10.0, -30.0, 5.0, 63.9, 90.0, 88.0, 20.0, 30.0, 10.0]
+    tgt, tw = TargetRenderer((W, H), (Wh, Hh), 2, device=dev()).render(jt, vis)
+    want_t, want_w = oip.generate_target(jt[0], vis[0], (W, H), (Wh, Hh), 2)
+    assert np.array_equal(tgt[0].cpu().numpy(), want_t) and np.array_equal(tw[0].cpu().numpy(), want_w)
+    assert 0 < int(want_w.sum()) < len(xs)

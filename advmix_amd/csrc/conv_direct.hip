@@ -291,29 +291,34 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
 
     const int nch = (ch_hi - ch_lo + WK - 1) / WK;         // steps
     if (nch > 0) {
+        // Steady-state loop with NO conditional load issue and one body: the conditional "issue the next chunk
+        // if there is one" of the first version merged two control-flow paths in front of the MFMAs, and the
+        // compiler's conservative s_waitcnt for the merge (vmcnt(4..1)) made every chunk's MFMAs wait for the
+        // loads of the NEXT chunk that had just been issued - load latency was added to, not hidden behind, the
+        // multiplies, and the two unrolled halves ping-ponged the accumulator between register ranges through
+        // v_accvgpr moves.  The last chunk is peeled; the in-flight set is copied into the multiply set with
+        // 16 register moves per chunk.
         issue(A0);
         stage(0);
+#if !(defined(CD_DBG) && (CD_DBG & 2))
         __syncthreads();
-        for (int ci = 0; ci < nch; ci += 2) {
-            // even chunk: multiply (A0, Bs[0]) while (A1, Br) of the next chunk are in flight
-            bool more = ci + 1 < nch;
-            if (more) issue(A1);
-            compute(A0, 0);
-            if (!more) break;
-            stage(1);
+#endif
+        int buf = 0;
+        for (int ci = 0; ci + 1 < nch; ++ci) {
+            issue(A1);                                     // chunk ci + 1 in flight ...
+            __builtin_amdgcn_sched_barrier(0);             // (the scheduler otherwise sinks the weight load below the MFMAs)
+            compute(A0, buf);                              // ... while chunk ci is multiplied
+            stage(buf ^ 1);
 #if !(defined(CD_DBG) && (CD_DBG & 2))
             __syncthreads();
 #endif
-            // odd chunk
-            more = ci + 2 < nch;
-            if (more) issue(A0);
-            compute(A1, 1);
-#if defined(CD_DBG) && (CD_DBG & 2)
-            if (more) stage(0);
-#else
-            if (more) { stage(0); __syncthreads(); }
-#endif
+#pragma unroll
+            for (int t = 0; t < RM; ++t)
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) A0[t][q] = A1[t][q];
+            buf ^= 1;
         }
+        compute(A0, buf);
     }
 
     // ---- epilogue -----------------------------------------------------------------------------

@@ -31,7 +31,7 @@ struct ConvD {
     int N, Hi, Wi, Ci;
     int Ho, Wo, Co;
     int R, S, stride, pad;
-    int xbytes, wbytes;     // buffer sizes for the hardware range check
+    int xbytes, wbytes, ybytes;   // buffer sizes for the hardware range check
     int nsplit;             // K-chunk slices (gridDim.z = phases * nsplit)
     // optional fused epilogue (MODE 0, no K split): eval-mode BatchNorm + residual + activation, and/or
     // per-wave column sums of the raw conv output for a following train-mode BatchNorm
@@ -353,6 +353,13 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
                 }
     }
     if (stats) __syncthreads();                            // every wave is done reading Bs
+    // Straight-line stores: out-of-tile lanes get an out-of-range offset and the hardware drops their write
+    // (reads return 0), so there is no per-element branch.  The first version branched around every store, and
+    // the compiler's s_waitcnt for the bias value at each re-convergence (vmcnt(0) - which on gfx9 also counts
+    // STORES) made every store wait for the previous one to be acknowledged.
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.y), 0, p.ybytes,
+                                                                        0x00020000);
 #pragma unroll
     for (int u = 0; u < RN; ++u) {
         const int col = n0 + wn * TN * 32 + u * MR + l31;
@@ -364,38 +371,43 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
             bn_is = 1.0f / sqrtf(p.bn_rv[col] + p.bn_eps);
             bn_g = p.bn_gamma[col]; bn_b = p.bn_beta[col]; bn_m = p.bn_rm[col];
         }
+        const bool addend = MODE == 1 && p.res && (!SPLIT || zsl == 0);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int t = 0; t < RM; ++t) {
 #pragma unroll
             for (int r = 0; r < RSL; ++r) {
                 int m = m0 + wm * TM * 32 + t * MR + MS::row(r_lo + r, lh);
-                if (m >= Mp || !cvalid) continue;
-                int64_t off;
+                const bool valid = m < Mp && cvalid;
+                if (!valid) m = 0;
+                int off;                                   // element offset (the host checks that y fits 2^31 bytes)
                 if (MODE == 0) {
-                    off = (int64_t)m * p.Co + col;
+                    off = m * p.Co + col;
                 } else {
                     int n = m / (Hp * Wp);
                     int rem = m - n * (Hp * Wp);
                     int hi_ = rem / Wp, wi_ = rem - hi_ * Wp;
-                    off = ((int64_t)(n * p.Ho + rh + hi_ * p.stride) * p.Wo + rw + wi_ * p.stride) * p.Co + col;
+                    off = ((n * p.Ho + rh + hi_ * p.stride) * p.Wo + rw + wi_ * p.stride) * p.Co + col;
                 }
+                const unsigned boff = valid ? (unsigned)off * 4u : OOB;
                 float v = acc[t][u][r] + bv;
 #if defined(CD_DBG) && (CD_DBG & 4)                  /* no output stores (kept alive by an impossible value) */
                 if (v != 123456.789f) continue;
 #endif
                 // transposed gather (input gradients): an addend, e.g. the other gradient of a tensor with two
                 // consumers, rides in the epilogue instead of a separate add kernel (slice 0 only under SPLIT)
-                if (MODE == 1 && p.res && (!SPLIT || zsl == 0)) v += p.res[off];
-                if (SPLIT) { atomicAdd(p.y + off, v); continue; }
+                if (addend) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, boff, 0, 0));
+                if (SPLIT) {
+                    if (valid) atomicAdd(p.y + off, v);
+                    continue;
+                }
                 if (EPI) {
-                    s1 += v;
-                    s2 += v * v;
+                    if (valid) { s1 += v; s2 += v * v; }
                     if (bn) v = (v - bn_m) * bn_is * bn_g + bn_b;
-                    if (p.res) v += p.res[off];
+                    if (p.res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, boff, 0, 0));
                     v = act_fwd(v, p.act);
                 }
-                p.y[off] = v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, boff, 0, 0);
             }
         }
         if (stats) {                                        // wave-uniform branch: every lane shuffles
@@ -504,8 +516,9 @@ int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const 
     if (bt && (mode != 1 || Co % 4 != 0)) return -1;
     if (epi && mode != 0 && (epi->gamma || epi->act || epi->stats)) return -2;   // mode 1 takes an addend only
     const int64_t xb = (int64_t)N * Hi * Wi * Ci * 4, wb = (int64_t)Co * R * S * Ci * 4;
-    if (xb >= 0x7fffffffLL || wb >= 0x7fffffffLL) return -1;
-    direct::ConvD p{x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, (int)xb, (int)wb, 1,
+    const int64_t yb = (int64_t)N * Ho * Wo * Co * 4;
+    if (xb >= 0x7fffffffLL || wb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return -1;
+    direct::ConvD p{x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, (int)xb, (int)wb, (int)yb, 1,
                     nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0};
     if (epi) {
         p.bn_gamma = epi->gamma; p.bn_beta = epi->beta; p.bn_rm = epi->rm; p.bn_rv = epi->rv; p.res = epi->res;

@@ -231,16 +231,17 @@ struct WgP {
     float* dw;
     int N, Ha, Wa, Ca, Hb, Wb, Cb;
     int R, S, stride, pad;
-    int chunk;               // pixels per z-slice (multiple of 16)
+    int chunk;               // pixels per z-slice (multiple of 32)
 };
 
 template <int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
     constexpr int BMw = 32 * WM, BNw = 32 * WN;
-    constexpr int ASL = (16 * BMw / 4 + 255) / 256;    // float4 slots per thread
-    constexpr int BSL = (16 * BNw / 4 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float As[16 * BMw];
-    __shared__ __attribute__((aligned(16))) float Bs[16 * BNw];
+    constexpr int KS = 32;                             // pixels per step (16 MFMAs per wave between barriers)
+    constexpr int ASL = (KS * BMw / 4 + 255) / 256;    // float4 slots per thread
+    constexpr int BSL = (KS * BNw / 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float As[2][KS * BMw];       // double-buffered: one barrier per step
+    __shared__ __attribute__((aligned(16))) float Bs[2][KS * BNw];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
 #pragma unroll
     for (int i = 0; i < ASL; ++i) {
         int s = tid + 256 * i;
-        a_in[i] = s < 16 * BMw / 4;
+        a_in[i] = s < KS * BMw / 4;
         a_k[i] = s / (BMw / 4);
         a_c[i] = (s % (BMw / 4)) * 4;
     }
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
 #pragma unroll
     for (int i = 0; i < BSL; ++i) {
         int s = tid + 256 * i;
-        b_in[i] = s < 16 * BNw / 4;
+        b_in[i] = s < KS * BNw / 4;
         b_k[i] = s / (BNw / 4);
         b_c[i] = (s % (BNw / 4)) * 4;
 #pragma unroll
@@ -324,33 +325,40 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
             }
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < ASL; ++i)
-            if (a_in[i]) *reinterpret_cast<f32x4*>(&As[a_k[i] * BMw + a_c[i]]) = ra[i];
+            if (a_in[i]) *reinterpret_cast<f32x4*>(&As[buf][a_k[i] * BMw + a_c[i]]) = ra[i];
 #pragma unroll
         for (int i = 0; i < BSL; ++i)
-            if (b_in[i]) *reinterpret_cast<f32x4*>(&Bs[b_k[i] * BNw + b_c[i]]) = rb[i];
+            if (b_in[i]) *reinterpret_cast<f32x4*>(&Bs[buf][b_k[i] * BNw + b_c[i]]) = rb[i];
     };
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+    // Branch-free steady state (a tile past the slice loads zeros, so the prefetch is unconditional): the first
+    // version's "if (more) load" made the compiler shuttle the accumulator AGPR -> VGPR -> AGPR around the branch
+    // on every 8-MFMA step, and it paid two barriers per 16 pixels.
     load_tile(p_lo);
-    store_tile();
+    store_tile(0);
     __syncthreads();
-    for (int pt = p_lo; pt < p_hi; pt += 16) {
-        const bool more = pt + 16 < p_hi;
-        if (more) load_tile(pt + 16);
+    int buf = 0;
+    for (int pt = p_lo; pt < p_hi; pt += KS) {
+        load_tile(pt + KS);
+        __builtin_amdgcn_sched_barrier(0);
+        float av[KS / 2], bv[KS / 2];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            float a = As[(kk * 2 + lh) * BMw + wm * 32 + l31];
-            float b = Bs[(kk * 2 + lh) * BNw + wn * 32 + l31];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int kk = 0; kk < KS / 2; ++kk) {
+            av[kk] = As[buf][(kk * 2 + lh) * BMw + wm * 32 + l31];
+            bv[kk] = Bs[buf][(kk * 2 + lh) * BNw + wn * 32 + l31];
         }
+#pragma unroll
+        for (int kk = 0; kk < KS / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
+        store_tile(buf ^ 1);
         __syncthreads();
-        if (more) { store_tile(); __syncthreads(); }
+        buf ^= 1;
     }
 
     const int j = j0 + wn * 32 + l31;
@@ -496,7 +504,7 @@ extern "C" int advmix_conv_wgrad(const float* a, const float* b, float* dw,
         if (ns < 1) ns = 1;                                                               \
         int64_t maxs = (P + 63) / 64;                                                     \
         if (ns > maxs) ns = maxs;                                                         \
-        int64_t chunk = ((P + ns - 1) / ns + 15) / 16 * 16;                               \
+        int64_t chunk = ((P + ns - 1) / ns + 31) / 32 * 32;                               \
         p.chunk = (int)chunk;                                                             \
         dim3 g(cdiv(Ca, 32 * WM_), cdiv(Ntot, 32 * WN_), cdiv(P, chunk));                 \
         hipLaunchKernelGGL((conv_wgrad<WM_, WN_, V_>), g, dim3(256), 0, st, p);           \

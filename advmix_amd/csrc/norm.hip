@@ -35,6 +35,52 @@ __device__ __forceinline__ void d4_add(d4& a, const d4& b) {
 // KIND 0: (x, x^2)     KIND 1: (g, g*xhat) with g = dy*act'(y).   Accumulated in fp64: the
 // variance is later formed as E[x^2]-E[x]^2, which needs ~2x the input precision when
 // |mean| >> std (fp32 partials lose it: relative variance error ~1e-7*(1+mean^2/var)).
+// slope of the activation through its OUTPUT y, with the activation known at compile time (a run-time ``act``
+// put a scalar branch and an s_waitcnt vmcnt(0) around every element of the hot loops)
+template <int ACT>
+__device__ __forceinline__ float act_slope(float y) {
+    if (ACT == ADVMIX_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (ACT == ADVMIX_ACT_LEAKY02) return y > 0.f ? 1.f : 0.2f;
+    return 1.f;
+}
+
+// Several rows per thread with ALL their loads issued before the first use (the row loop of the first version
+// waited for each row's loads before touching the next: 6 dependent memory round trips per thread).
+template <int KIND, int ACT, int U>
+__device__ __forceinline__ void accum_rows(d4& s0, d4& s1, const float* x, const float* dy, const float* y,
+                                           int64_t r, int64_t rstep, int64_t r1, int ldy, int C, int c,
+                                           const f32x4& mu, const f32x4& is) {
+    f32x4 xv[U], gv[U], yv[U];
+    float ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t row = r + u * rstep;
+        ok[u] = row < r1 ? 1.f : 0.f;
+        const int64_t rr = row < r1 ? row : r;               // a valid address; its contribution is masked
+        xv[u] = *reinterpret_cast<const f32x4*>(x + rr * C + c);
+        if (KIND == 1) {
+            gv[u] = *reinterpret_cast<const f32x4*>(dy + rr * ldy + c);
+            if (ACT != ADVMIX_ACT_NONE) yv[u] = *reinterpret_cast<const f32x4*>(y + rr * ldy + c);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (KIND == 0) {
+                const double d = (double)(xv[u][e] * ok[u]);
+                s0.v[e] += d;
+                s1.v[e] += d * d;
+            } else {
+                float g = gv[u][e] * ok[u];
+                if (ACT != ADVMIX_ACT_NONE) g *= act_slope<ACT>(yv[u][e]);
+                s0.v[e] += (double)g;
+                s1.v[e] += (double)g * (double)((xv[u][e] - mu[e]) * is[e]);
+            }
+        }
+    }
+}
+
 template <int KIND>
 __device__ __forceinline__ void accum4(d4& s0, d4& s1, const float* x, const float* dy, const float* y,
                                        int64_t row, int ldy, int C, int c, const f32x4& mu, const f32x4& is,
@@ -63,7 +109,7 @@ __device__ __forceinline__ void accum4(d4& s0, d4& s1, const float* x, const flo
 }
 
 // partial[g][blk][2][C] (double)
-template <int KIND>
+template <int KIND, int ACT>
 __global__ __launch_bounds__(256) void norm_partial(const float* __restrict__ x, const float* __restrict__ dy,
                                                     const float* __restrict__ y, int ldy,
                                                     const float* __restrict__ mean,
@@ -87,7 +133,8 @@ __global__ __launch_bounds__(256) void norm_partial(const float* __restrict__ x,
                 mu = *reinterpret_cast<const f32x4*>(mean + (int64_t)g * C + cv * 4);
                 is = *reinterpret_cast<const f32x4*>(invstd + (int64_t)g * C + cv * 4);
             }
-            for (int64_t r = r0; r < r1; ++r) accum4<KIND>(s0, s1, x, dy, y, r, ldy, C, cv * 4, mu, is, act);
+            for (int64_t r = r0; r < r1; r += 4)
+                accum_rows<KIND, ACT, 4>(s0, s1, x, dy, y, r, 1, r1, ldy, C, cv * 4, mu, is);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 out[(int64_t)(cv * 4 + e) * nbg] = s0.v[e];
@@ -106,7 +153,8 @@ __global__ __launch_bounds__(256) void norm_partial(const float* __restrict__ x,
             mu = *reinterpret_cast<const f32x4*>(mean + (int64_t)g * C + cv * 4);
             is = *reinterpret_cast<const f32x4*>(invstd + (int64_t)g * C + cv * 4);
         }
-        for (int64_t r = r0 + rr; r < r1; r += RP) accum4<KIND>(s0, s1, x, dy, y, r, ldy, C, cv * 4, mu, is, act);
+        for (int64_t r = r0 + rr; r < r1; r += 3 * (int64_t)RP)
+            accum_rows<KIND, ACT, 3>(s0, s1, x, dy, y, r, RP, r1, ldy, C, cv * 4, mu, is);
     }
     red[0][tid] = s0;
     red[1][tid] = s1;
@@ -353,8 +401,8 @@ extern "C" int advmix_norm_stats(const float* x, int groups, int64_t Mg, int C, 
     double* partial = (double*)ws;
     dim3 g(sp.nbg, groups);
     if (C % 4 == 0)
-        hipLaunchKernelGGL((norm_partial<0>), g, dim3(256), 0, st, x, nullptr, nullptr, 0, nullptr, nullptr, partial,
-                           Mg, C, sp.rows_per_block, 0);
+        hipLaunchKernelGGL((norm_partial<0, ADVMIX_ACT_NONE>), g, dim3(256), 0, st, x, nullptr, nullptr, 0, nullptr,
+                           nullptr, partial, Mg, C, sp.rows_per_block, 0);
     else
         hipLaunchKernelGGL((norm_partial_scalar<0>), g, dim3(256), 0, st, x, nullptr, nullptr, 0, nullptr, nullptr,
                            partial, Mg, C, sp.rows_per_block, 0);
@@ -418,9 +466,15 @@ extern "C" int advmix_norm_bwd(const float* dy, const float* y, int ldy, const f
     float* coef = (float*)(partial + (int64_t)MAX_PARTIAL_BLOCKS * 2 * C);
     dim3 g(sp.nbg, groups);
     const bool vec = (C % 4 == 0) && (ldy % 4 == 0);
-    if (vec)
-        hipLaunchKernelGGL((norm_partial<1>), g, dim3(256), 0, st, x, dy, y, ldy, mean, invstd, partial, Mg, C,
-                           sp.rows_per_block, act);
+    if (vec && act == ADVMIX_ACT_RELU)
+        hipLaunchKernelGGL((norm_partial<1, ADVMIX_ACT_RELU>), g, dim3(256), 0, st, x, dy, y, ldy, mean, invstd, partial,
+                           Mg, C, sp.rows_per_block, act);
+    else if (vec && act == ADVMIX_ACT_LEAKY02)
+        hipLaunchKernelGGL((norm_partial<1, ADVMIX_ACT_LEAKY02>), g, dim3(256), 0, st, x, dy, y, ldy, mean, invstd,
+                           partial, Mg, C, sp.rows_per_block, act);
+    else if (vec)
+        hipLaunchKernelGGL((norm_partial<1, ADVMIX_ACT_NONE>), g, dim3(256), 0, st, x, dy, y, ldy, mean, invstd, partial,
+                           Mg, C, sp.rows_per_block, act);
     else
         hipLaunchKernelGGL((norm_partial_scalar<1>), g, dim3(256), 0, st, x, dy, y, ldy, mean, invstd, partial, Mg, C,
                            sp.rows_per_block, act);

@@ -12,16 +12,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Activations as selects on a slope that is uniform over the launch (ReLU 0, LeakyReLU 0.2, none 1): a chain of
+// run-time ``if (act == ...)`` per element compiled to scalar branches with an s_waitcnt vmcnt(0) at every
+// re-convergence in the memory-bound kernels.
+__device__ __forceinline__ float act_neg_slope(int act) {
+    return act == ADVMIX_ACT_RELU ? 0.f : (act == ADVMIX_ACT_LEAKY02 ? 0.2f : 1.f);
+}
 __device__ __forceinline__ float act_fwd(float v, int act) {
-    if (act == ADVMIX_ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == ADVMIX_ACT_LEAKY02) return v > 0.f ? v : 0.2f * v;
-    return v;
+    const float s = act_neg_slope(act);
+    return v > 0.f ? v : (s == 0.f ? 0.f : v * s);
 }
 // derivative expressed through the activation OUTPUT y (both activations are sign-preserving)
 __device__ __forceinline__ float act_grad(float y, int act) {
-    if (act == ADVMIX_ACT_RELU) return y > 0.f ? 1.f : 0.f;
-    if (act == ADVMIX_ACT_LEAKY02) return y > 0.f ? 1.f : 0.2f;
-    return 1.f;
+    return y > 0.f ? 1.f : act_neg_slope(act);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

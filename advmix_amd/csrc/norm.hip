@@ -279,10 +279,11 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
     constexpr int V = VEC ? 4 : 1;
     const int CV = C / V;
     const int64_t total = rows * CV;
+    const bool small = total < 0x7fffffff;                 // (a 64-bit division is ~100 instructions of software)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r = i / CV;
+        int64_t r = small ? (int64_t)((unsigned)i / (unsigned)CV) : i / CV;   // 32-bit divide when it fits
         int c = (int)(i - r * CV) * V;
-        int64_t gc = (r / Mg) * C + c;
+        int64_t gc = (small ? (int64_t)((unsigned)r / (unsigned)Mg) : r / Mg) * C + c;
         if (VEC) {
             f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * C + c);
             f32x4 mu = *reinterpret_cast<const f32x4*>(mean + gc);
@@ -311,8 +312,9 @@ __global__ __launch_bounds__(256) void bn_eval_kernel(const float* __restrict__ 
     constexpr int V = VEC ? 4 : 1;
     const int CV = C / V;
     const int64_t total = rows * CV;
+    const bool small = total < 0x7fffffff;                 // (a 64-bit division is ~100 instructions of software)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r = i / CV;
+        int64_t r = small ? (int64_t)((unsigned)i / (unsigned)CV) : i / CV;   // 32-bit divide when it fits
         int c = (int)(i - r * CV) * V;
         if (VEC) {
             f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * C + c);
@@ -346,10 +348,11 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(const float* __restrict__ 
     constexpr int V = VEC ? 4 : 1;
     const int CV = C / V;
     const int64_t total = rows * CV;
+    const bool small = total < 0x7fffffff;                 // (a 64-bit division is ~100 instructions of software)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r = i / CV;
+        int64_t r = small ? (int64_t)((unsigned)i / (unsigned)CV) : i / CV;   // 32-bit divide when it fits
         int c = (int)(i - r * CV) * V;
-        int64_t g = r / Mg;
+        int64_t g = small ? (int64_t)((unsigned)r / (unsigned)Mg) : r / Mg;
         if (VEC) {
             f32x4 gg = *reinterpret_cast<const f32x4*>(dy + r * ldy + c);
             if (act != ADVMIX_ACT_NONE) {

@@ -381,8 +381,8 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
                 const bool valid = m < Mp && cvalid;
                 if (!valid) m = 0;
                 int off;                                   // element offset (the host checks that y fits 2^31 bytes)
-                if (MODE == 0) {
-                    off = m * p.Co + col;
+                if (MODE == 0 || p.stride == 1) {          // (stride 1: one phase, rows are already output pixels -
+                    off = m * p.Co + col;                  //  no two integer divisions per accumulator register)
                 } else {
                     int n = m / (Hp * Wp);
                     int rem = m - n * (Hp * Wp);

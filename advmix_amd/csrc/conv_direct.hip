@@ -208,10 +208,24 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     // chunk cursor (of the STEP being issued: WK consecutive chunks, wave wk multiplies chunk cur + wk)
     int cur = ch_lo;
 
+    // (tap, first channel) cursors of the chunk each wave multiplies / each staging slot loads next; advanced by WK
+    // chunks per step without divisions
+    int a_tap = (ch_lo + wk) / cpt, a_c0 = ((ch_lo + wk) - a_tap * cpt) * KC;
+    int s_tap[BSL], s_c0[BSL];
+#pragma unroll
+    for (int i = 0; i < BSL; ++i) {
+        const int c = ch_lo + (WK == 1 ? 0 : b_kk[i]);
+        s_tap[i] = c / cpt;
+        s_c0[i] = (c - s_tap[i] * cpt) * KC;
+    }
+    auto advance = [&](int& tap_, int& c0_) {
+        c0_ += WK * KC;
+        while (c0_ >= p.Ci) { c0_ -= p.Ci; ++tap_; }
+    };
     auto issue = [&](f32x4 (&A)[RM][KQ]) {                 // loads of the step starting at chunk ``cur``
         const int ck = cur + wk;                           // this wave's chunk; past the end -> zeros
-        int tap = ck / cpt;
-        const int c0 = (ck - tap * cpt) * KC;
+        int tap = a_tap;
+        const int c0 = a_c0;
         const bool live = ck < ch_hi;
         if (!live) tap = 0;
         const int4 tt = taptab[tap];
@@ -233,14 +247,9 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
 #if !(defined(CD_DBG) && (CD_DBG & 2))
 #pragma unroll
         for (int i = 0; i < BSL; ++i) {
-            int cb, tb, c0b;
-            if (WK == 1) {
-                cb = ck; tb = tap; c0b = c0;
-            } else {
-                cb = cur + b_kk[i];
-                tb = cb / cpt;
-                c0b = (cb - tb * cpt) * KC;
-            }
+            const int cb = WK == 1 ? ck : cur + b_kk[i];
+            const int tb = s_tap[i], c0b = s_c0[i];
+            advance(s_tap[i], s_c0[i]);
             const bool lb = cb < ch_hi && b_off[i] != OOB;
             const int4 tq = taptab[lb ? tb : 0];
             Br[i] = bload(wr, !lb ? OOB
@@ -249,6 +258,7 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
         }
 #endif
         cur += WK;
+        advance(a_tap, a_c0);
     };
     auto stage = [&](int buf) {
 #if defined(CD_DBG) && (CD_DBG & 2)                  /* no weight staging at all */

@@ -147,9 +147,12 @@ def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_
     if Co % 16 == 0 and Ci % 4 == 0 and _direct_ok():          # weights consumed in their own layout
         if add_to is not None and (add_to.shape != dx.shape or add_to.stride() != dx.stride()):
             raise RuntimeError('advmix_amd: gradient fan-in of differently laid out tensors')
-        call('advmix_conv_tr_w_add', _p(dy), _p(w), _p(add_to), _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
-             stride, pad, st)
-        return dx
+        rc = lib.advmix_conv_tr_w_add(_p(dy), _p(w), _p(add_to), _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
+                                      stride, pad, st)
+        if rc == 0:
+            return dx
+        if rc != 1:                                        # 1 = EINVAL: not served (a tensor of 2 GiB or more) -> first-generation kernel
+            raise RuntimeError('advmix_conv_tr_w_add failed: %d' % rc)
     wt = _wt(st, w, Co, R * S, Ci)
     call('advmix_conv_tr', _p(dy), _p(wt), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, st)
     return dx if add_to is None else _add(st, keep(dx), add_to)
@@ -211,12 +214,16 @@ class Deconv:
         Wo = (Wi - 1) * stride - 2 * pad + S
         y = empty_nhwc(B, Co, Ho, Wo, x.device)
         if Ci % 16 == 0 and Co % 4 == 0 and _direct_ok():
-            call('advmix_conv_tr_w', _p(x), _p(w), _p(bias), _p(y), B, Hi, Wi, Ci, Ho, Wo, Co, R, S,
-                 stride, pad, st)
+            rc = lib.advmix_conv_tr_w(_p(x), _p(w), _p(bias), _p(y), B, Hi, Wi, Ci, Ho, Wo, Co, R, S,
+                                      stride, pad, st)
         else:
+            rc = 1
+        if rc == 1:                                        # not served by the second-generation kernel
             wt = _wt(st, w, Ci, R * S, Co)                # [Co][R][S][Ci]
             call('advmix_conv_tr', _p(x), _p(wt), _p(bias), _p(y), B, Hi, Wi, Ci, Ho, Wo, Co, R, S,
                  stride, pad, st)
+        elif rc != 0:
+            raise RuntimeError('advmix_conv_tr_w failed: %d' % rc)
         return (y,), (x, w, bias), None
 
     @staticmethod

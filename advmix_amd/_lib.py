@@ -30,11 +30,14 @@ SIGNATURES = {
     'advmix_conv_tr_w': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_direct_config': [_i] * 9,
     'advmix_conv_tr_w_add': [_p, _p, _p, _p] + [_i] * 11 + [_p],
+    'advmix_conv_tr_w_bnb': [_p, _p, _p, _p] + [_i] * 11 + [_p, _p, _p, _p, _i, _p, _p, _p],
     'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],
     'advmix_transpose_w': [_p, _p, _i, _i, _i, _p],
     'advmix_bias_grad': [_p, _p, _l, _i, _p],
     'advmix_norm_stats': [_p, _i, _l, _i, _f, _p, _p, _p, _p, _p, _f, _p, _p],
     'advmix_norm_apply': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _i, _p],
+    'advmix_norm_apply_slots': [_p, _p, _i, _l, _i, _f, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _p],
+    'advmix_norm_bwd_apply_slots': [_p, _p, _p, _p, _p, _p, _i, _l, _i, _p, _p, _p, _p],
     'advmix_bn_eval': [_p, _p, _p, _p, _p, _f, _p, _p, _l, _i, _i, _p],
     'advmix_norm_bwd': [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _p],
     'advmix_act_copy': [_p, _i, _p, _i, _l, _i, _i, _p],

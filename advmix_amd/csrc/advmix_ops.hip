@@ -168,17 +168,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 AdvmixOpts& advmix_opts() {
     static AdvmixOpts o = [] {
-        // conv3 (LDS-patch persistent 3x3) is opt-in: alone it wins on 128->128 @16x12 (28.7 vs 34.9 us)
-        // but one 135-KB-LDS workgroup per CU blocks the concurrent lanes: 89.9 vs 86.3 ms per AdvMix step
-        AdvmixOpts d{1, 0, 512, 256, 1, 0, 1};
+        AdvmixOpts d{1, 1, 1, 16};
         const char* e;
         if ((e = getenv("ADVMIX_CONV")) && e[0] == 'i') d.direct = 0;
-        if ((e = getenv("ADVMIX_CONV3"))) d.conv3 = e[0] != '0';
-        if ((e = getenv("ADVMIX_CONV3_MIN_ITEMS"))) d.conv3_min_items = atoi(e);
-        if ((e = getenv("ADVMIX_CONV3_GRID"))) d.conv3_grid = atoi(e);
         if ((e = getenv("ADVMIX_WGRAD"))) d.wgrad_direct = e[0] != '0';
-        if ((e = getenv("ADVMIX_MFMA16"))) d.mfma16 = e[0] != '0';
         if ((e = getenv("ADVMIX_KSPLIT_WG"))) d.ksplit_wg = e[0] != '0';
+        if ((e = getenv("ADVMIX_STAT_SLOTS"))) d.stat_slots = atoi(e);
         return d;
     }();
     return o;
@@ -190,12 +185,9 @@ extern "C" int advmix_set_option(const char* name, int value) {
     if (!name) return ADVMIX_EINVAL;
     AdvmixOpts& o = advmix_opts();
     if (!strcmp(name, "direct")) o.direct = value;
-    else if (!strcmp(name, "conv3")) o.conv3 = value;
-    else if (!strcmp(name, "conv3_min_items")) o.conv3_min_items = value;
-    else if (!strcmp(name, "conv3_grid")) o.conv3_grid = value > 0 ? value : 256;
     else if (!strcmp(name, "wgrad_direct")) o.wgrad_direct = value;
-    else if (!strcmp(name, "mfma16")) o.mfma16 = value;
     else if (!strcmp(name, "ksplit_wg")) o.ksplit_wg = value;
+    else if (!strcmp(name, "stat_slots")) o.stat_slots = value;
     else return ADVMIX_EINVAL;
     return ADVMIX_OK;
 }

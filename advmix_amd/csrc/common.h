@@ -38,14 +38,19 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-#define ADVMIX_STAT_SLOTS 64
-// optional fused conv epilogue (forward gather only)
+#define ADVMIX_STAT_SLOTS_MAX 64
+// optional fused conv epilogue
 struct ConvEpi {
-    const float *gamma, *beta, *rm, *rv;   // eval-mode BatchNorm (all four or none)
-    const float* res;                      // residual added after BN
+    const float *gamma, *beta, *rm, *rv;   // forward gather: eval-mode BatchNorm (all four or none)
+    const float* res;                      // forward gather: residual added after BN; transposed gather: addend
     float eps;
     int act;
-    double* stats;                         // out: [2][Co][nbg] column (sum, sumsq) of the RAW conv output
+    double* stats;                         // out: [2][Co][ns] fp64 slots.  forward gather: column (sum, sumsq) of the
+                                           // RAW conv output; transposed gather: (sum g, sum g * xhat), see bnb_*
+    // transposed gather + stats: the output is dL/dy of y = act(BN(c) + residual); the epilogue writes
+    // g = that * act'(y) and the two BatchNorm-backward channel sums
+    const float *bnb_y, *bnb_c, *bnb_mean, *bnb_invstd;
+    int bnb_act;
 };
 // conv_direct.hip: second-generation conv; returns -1 when the shape is not eligible, -2 when only the
 // fused epilogue is unavailable
@@ -54,19 +59,12 @@ int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const 
                                 int stride, int pad, int64_t Mmax, hipStream_t st, int bt = 0,
                                 const ConvEpi* epi = nullptr, int* stats_nbg = nullptr);
 
-// conv3x3_lds.hip: LDS-resident-patch 3x3/s1/p1 conv (flip = 1: its input gradient); -1 = not eligible
-int advmix_conv3x3_lds_dispatch(int flip, const float* x, const float* w, const float* bias, float* y, int N, int H,
-                                int W, int Ci, int Co, hipStream_t st);
-
 // runtime-tunable dispatch options (advmix_set_option / ADVMIX_* environment at first use)
 struct AdvmixOpts {
-    int direct;            // 1: conv_direct / conv3x3_lds allowed, 0: first-generation conv_igemm only
-    int conv3;             // 1: LDS-patch 3x3 kernel allowed
-    int conv3_min_items;   // minimum (tile x chunk) items before the persistent 3x3 kernel is used
-    int conv3_grid;        // persistent workgroups (256 = one per CU)
+    int direct;            // 1: conv_direct allowed, 0: first-generation conv_igemm only
     int wgrad_direct;      // 1: register-fragment wgrad kernel allowed
-    int mfma16;            // 1: conv_direct uses the 16x16x4 MFMA shape (16 pixel rows x 64 B per fragment load)
     int ksplit_wg;         // 1: layers with too few tiles split K inside the workgroup (fused epilogue kept), 0: across the grid
+    int stat_slots;        // fp64 slots per channel the statistics epilogues fold their workgroup sums onto (power of 2 <= 64)
 };
 AdvmixOpts& advmix_opts();
 

@@ -39,7 +39,13 @@ struct ConvD {
     float bn_eps;
     int act;
     double* stats;          // [2][Co][stats_nbg]: (sum, sum of squares), wave slabs folded onto
-    int stats_nbg;          // stats_nbg (= STAT_SLOTS) slots with fp64 atomics; must be zero on entry
+    int stats_nbg;          // stats_nbg slots with fp64 atomics; must be zero on entry
+    // MODE 1 + EPI: this launch is the input gradient g0 = dL/dy of a tensor y = act(BN(c) + residual) (train mode).
+    // The epilogue multiplies by the activation's slope (through y), writes g = g0 * act'(y) and accumulates the two
+    // BatchNorm-backward channel sums (sum g, sum g * xhat) into ``stats``: the separate statistics pass over
+    // (dy, y, c) and its finalize launch disappear (norm.hip: norm_bwd_apply_slots consumes the slots).
+    const float *bnb_y, *bnb_c, *bnb_mean, *bnb_invstd;
+    int bnb_act;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -54,12 +60,11 @@ constexpr unsigned OOB = 0x80000000u;   // >= any buffer size we accept -> load 
 // BT: the weight operand is given k-major, w[Ck][R][S][Cn] (a Conv2d's own [Co][R][S][Ci] seen from its
 // input gradient, a ConvTranspose2d's own [Ci][R][S][Co] seen from its forward): a thread loads 4
 // consecutive n of one k and scatters them into the [n][k] LDS image, so no re-layout kernel is needed.
-// MR = rows of the MFMA shape: 32 -> v_mfma_f32_32x32x2 (lane: row l%32, k-lane l/32 of 2; a fragment load
-// touches 32 pixel rows x 32 B), 16 -> v_mfma_f32_16x16x4 (row l%16, k-lane l/16 of 4; 16 pixel rows x 64 B per
-// load, i.e. half as many cache lines per instruction at the same MFMA rate).  A 32x32 wave tile is NSUB x NSUB
-// MFMA tiles.
-template <int MR> struct MfmaShape;
-template <> struct MfmaShape<32> {
+// v_mfma_f32_32x32x2: lane l holds row l % 32 and k-lane l / 32 (of 2); a fragment load touches 32 pixel rows x 32 B.
+// (The 16x16x4 shape - 16 rows x 64 B per load - was built, measured 25.4 vs 25.9 us alone and 455 vs 468 images/s
+// in the step, and removed.)
+constexpr int MR = 32;
+struct MS {
     typedef f32x16 acc_t;
     static constexpr int NR = 16;
     static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
@@ -67,16 +72,8 @@ template <> struct MfmaShape<32> {
     }
     static __device__ __forceinline__ int row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
 };
-template <> struct MfmaShape<16> {
-    typedef f32x4 acc_t;
-    static constexpr int NR = 4;
-    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
-        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ int row(int r, int lk) { return 4 * lk + r; }
-};
 
-template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT, bool EPI, int MR>
+template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT, bool EPI>
 __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     // WK waves of the workgroup split K BETWEEN THEM (WM x WN x WK = 4 waves): the low-resolution layers have too
     // few output tiles to fill the chip; instead of slicing K across workgroups (SPLIT: zero-fill + fp32 atomics,
@@ -85,7 +82,6 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     static_assert(WM * WN == 4 || WM * WN == 2 || WM * WN == 1, "WM x WN x WK = 4 waves");
     constexpr int WK = 4 / (WM * WN);
     static_assert(!(SPLIT && WK > 1), "one kind of K split at a time");
-    typedef MfmaShape<MR> MS;
     constexpr int NSUB = 32 / MR;              // MFMA tiles per 32 rows / 32 columns
     constexpr int KL = 64 / MR;                // k-lanes: lanes that hold different k of the same row
     constexpr int RM = TM * NSUB, RN = TN * NSUB;
@@ -197,7 +193,7 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     // 3x3 32->32 conv and 47 % vs 60 % on the 128x64 tile (130 VGPRs -> 2 waves/SIMD), i.e. the
     // kernel is not bound by load latency per wave.
     f32x4 A0[RM][KQ], A1[RM][KQ], Br[BSL];
-    typename MS::acc_t acc[RM][RN];
+    MS::acc_t acc[RM][RN];
 #pragma unroll
     for (int t = 0; t < RM; ++t)
 #pragma unroll
@@ -370,6 +366,10 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.ybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.y), 0, p.ybytes,
                                                                         0x00020000);
+    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bnb_c ? p.bnb_c : p.y), 0, p.ybytes,
+                                                                        0x00020000);
+    const __amdgpu_buffer_rsrc_t yyr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bnb_y ? p.bnb_y : p.y), 0, p.ybytes,
+                                                                         0x00020000);
 #pragma unroll
     for (int u = 0; u < RN; ++u) {
         const int col = n0 + wn * TN * 32 + u * MR + l31;
@@ -382,6 +382,10 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
             bn_g = p.bn_gamma[col]; bn_b = p.bn_beta[col]; bn_m = p.bn_rm[col];
         }
         const bool addend = MODE == 1 && p.res && (!SPLIT || zsl == 0);
+        const bool bnb = EPI && MODE == 1;                  // BatchNorm-backward producer (see ConvD)
+        float bb_mu = 0.f, bb_is = 0.f;
+        if (bnb && cvalid) { bb_mu = p.bnb_mean[col]; bb_is = p.bnb_invstd[col]; }
+        const float bb_slope = act_neg_slope(p.bnb_act);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int t = 0; t < RM; ++t) {
@@ -411,11 +415,19 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
                     if (valid) atomicAdd(p.y + off, v);
                     continue;
                 }
-                if (EPI) {
+                if (EPI && MODE == 0) {
                     if (valid) { s1 += v; s2 += v * v; }
                     if (bn) v = (v - bn_m) * bn_is * bn_g + bn_b;
                     if (p.res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, boff, 0, 0));
                     v = act_fwd(v, p.act);
+                }
+                if (bnb) {                                  // out-of-tile lanes load 0 and contribute 0
+                    const float cv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cr, boff, 0, 0));
+                    if (p.bnb_act != ADVMIX_ACT_NONE) {
+                        const float yv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yyr, boff, 0, 0));
+                        v = yv > 0.f ? v : v * bb_slope;
+                    }
+                    if (valid) { s1 += v; s2 += v * ((cv - bb_mu) * bb_is); }
                 }
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, boff, 0, 0);
             }
@@ -483,25 +495,24 @@ static void problem_shape(int mode, int Ci, int R, int S, int stride, int KC, in
     *nch = maxtaps * (Ci / KC);
 }
 
-template <int MODE, int KC, bool BT, bool EPI, int MR>
+template <int MODE, int KC, bool BT, bool EPI>
 int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
-    static_assert(!EPI || (MODE == 0 && !BT), "fused epilogue: forward gather only");
+    static_assert(!EPI || (MODE == 0 && !BT) || (MODE == 1 && BT), "fused epilogues: forward gather, or BN-backward on the k-major transposed gather");
     int phases, nch, ns;
     problem_shape(MODE, p.Ci, p.R, p.S, p.stride, KC, &phases, &nch);
 #define LAUNCHD(TM_, TN_, WM_, WN_, SP_)                                                          \
     do {                                                                                          \
         dim3 g(cdiv(Mmax, 32 * TM_ * WM_), cdiv(p.Co, 32 * TN_ * WN_), phases * p.nsplit);        \
-        hipLaunchKernelGGL((conv_direct<TM_, TN_, WM_, WN_, KC, MODE, SP_, BT, (EPI && !SP_), MR>), g, dim3(256), 0, st, p); \
+        hipLaunchKernelGGL((conv_direct<TM_, TN_, WM_, WN_, KC, MODE, SP_, BT, (EPI && !SP_)>), g, dim3(256), 0, st, p); \
     } while (0)
     p.nsplit = 1;
-    p.stats_nbg = ADVMIX_STAT_SLOTS;
     switch (pick_cfg(Mmax, p.Co, phases, nch, &ns)) {
         case CFG_128x32: LAUNCHD(1, 1, 4, 1, false); break;
         case CFG_128x64: LAUNCHD(1, 2, 4, 1, false); break;
         case CFG_64x64: LAUNCHD(1, 1, 2, 2, false); break;
         case CFG_32x32_WAVE_SPLIT: LAUNCHD(1, 1, 1, 1, false); break;      // four waves share K in the workgroup
         case CFG_64x64_GRID_SPLIT:                                         // K across gridDim.z + atomics
-            if (p.bn_gamma || (MODE == 0 && p.res) || p.act || p.stats) return -2;   // fused epilogue needs whole-K tiles
+            if (p.bn_gamma || (MODE == 0 && p.res) || p.act || p.stats || p.bnb_c) return -2;   // fused epilogue needs whole-K tiles
             p.nsplit = ns;
             if (hipMemsetAsync(p.y, 0, (size_t)p.N * p.Ho * p.Wo * p.Co * sizeof(float), st) != hipSuccess)
                 return ADVMIX_ELAUNCH;
@@ -524,29 +535,41 @@ int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const 
                                 int* stats_nbg) {
     if (Ci % 16 != 0 || R * S > 64) return -1;
     if (bt && (mode != 1 || Co % 4 != 0)) return -1;
-    if (epi && mode != 0 && (epi->gamma || epi->act || epi->stats)) return -2;   // mode 1 takes an addend only
+    if (epi && mode != 0 && (epi->gamma || epi->act)) return -2;                 // mode 1: addend and/or BN-backward sums
+    if (epi && mode != 0 && epi->stats && !(bt && epi->bnb_c && epi->bnb_mean && epi->bnb_invstd &&
+                                            (epi->bnb_act == ADVMIX_ACT_NONE || epi->bnb_y))) return -2;
     const int64_t xb = (int64_t)N * Hi * Wi * Ci * 4, wb = (int64_t)Co * R * S * Ci * 4;
     const int64_t yb = (int64_t)N * Ho * Wo * Co * 4;
     if (xb >= 0x7fffffffLL || wb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return -1;
     direct::ConvD p{x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, (int)xb, (int)wb, (int)yb, 1,
-                    nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0};
+                    nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0,
+                    nullptr, nullptr, nullptr, nullptr, 0};
+    int ns = stats_nbg && *stats_nbg > 0 ? *stats_nbg : advmix_opts().stat_slots;
+    if (ns < 1 || ns > 64 || (ns & (ns - 1))) ns = 16;
+    p.stats_nbg = ns;
+    bool bnb = false;
     if (epi) {
         p.bn_gamma = epi->gamma; p.bn_beta = epi->beta; p.bn_rm = epi->rm; p.bn_rv = epi->rv; p.res = epi->res;
         p.bn_eps = epi->eps; p.act = epi->act; p.stats = epi->stats;
+        if (mode != 0 && epi->stats) {
+            bnb = true;
+            p.bnb_y = epi->bnb_y; p.bnb_c = epi->bnb_c; p.bnb_mean = epi->bnb_mean; p.bnb_invstd = epi->bnb_invstd;
+            p.bnb_act = epi->bnb_act;
+        }
     }
     int rc;
-#define LAUNCH_KC(MODE_, BT_, EPI_, MR_)                                                        \
-    (Ci % 32 == 0 ? direct::launch<MODE_, 32, BT_, EPI_, MR_>(p, Mmax, st) : direct::launch<MODE_, 16, BT_, EPI_, MR_>(p, Mmax, st))
-#define LAUNCH_MR(MODE_, BT_, EPI_) (advmix_opts().mfma16 ? LAUNCH_KC(MODE_, BT_, EPI_, 16) : LAUNCH_KC(MODE_, BT_, EPI_, 32))
-    if (bt)
-        rc = LAUNCH_MR(1, true, false);
+#define LAUNCH_KC(MODE_, BT_, EPI_)                                                             \
+    (Ci % 32 == 0 ? direct::launch<MODE_, 32, BT_, EPI_>(p, Mmax, st) : direct::launch<MODE_, 16, BT_, EPI_>(p, Mmax, st))
+    if (bt && bnb)
+        rc = LAUNCH_KC(1, true, true);
+    else if (bt)
+        rc = LAUNCH_KC(1, true, false);
     else if (mode == 1)
-        rc = LAUNCH_MR(1, false, false);
+        rc = LAUNCH_KC(1, false, false);
     else if (epi)
-        rc = LAUNCH_MR(0, false, true);
+        rc = LAUNCH_KC(0, false, true);
     else
-        rc = LAUNCH_MR(0, false, false);
-#undef LAUNCH_MR
+        rc = LAUNCH_KC(0, false, false);
 #undef LAUNCH_KC
     if (stats_nbg) *stats_nbg = p.stats_nbg;
     return rc;

@@ -441,10 +441,6 @@ extern "C" int advmix_conv_fwd(const float* x, const float* w, const float* bias
                                int R, int S, int stride, int pad, void* stream) {
     if (!x || !w || !y || N <= 0 || Ci <= 0 || Co <= 0 || R * S > 64 || stride < 1) return ADVMIX_EINVAL;
     if (Ho != (Hi + 2 * pad - R) / stride + 1 || Wo != (Wi + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
-    if (use_direct() && R == 3 && S == 3 && stride == 1 && pad == 1) {
-        int rc = advmix_conv3x3_lds_dispatch(0, x, w, bias, y, N, Hi, Wi, Ci, Co, (hipStream_t)stream);
-        if (rc >= 0) return rc;
-    }
     if (use_direct()) {
         int rc = advmix_conv_direct_dispatch(0, x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad,
                                              (int64_t)N * Ho * Wo, (hipStream_t)stream);
@@ -462,11 +458,6 @@ extern "C" int advmix_conv_tr(const float* x, const float* wt, const float* bias
     // (Hb, Wb) must be a valid input size for a conv producing (Hs, Ws)
     if (Hs != (Hb + 2 * pad - R) / stride + 1 || Ws != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
     int64_t Mmax = (int64_t)N * cdiv(Hb, stride) * cdiv(Wb, stride);
-    if (use_direct() && R == 3 && S == 3 && stride == 1 && pad == 1) {
-        // the adjoint of a 3x3/s1/p1 conv is the same conv on dY with mirrored taps
-        int rc = advmix_conv3x3_lds_dispatch(1, x, wt, bias, y, N, Hs, Ws, Ck, Cn, (hipStream_t)stream);
-        if (rc >= 0) return rc;
-    }
     if (use_direct()) {
         int rc = advmix_conv_direct_dispatch(1, x, wt, bias, y, N, Hs, Ws, Ck, Hb, Wb, Cn, R, S, stride, pad, Mmax,
                                              (hipStream_t)stream);
@@ -566,7 +557,7 @@ extern "C" int advmix_conv_fwd_ex(const float* x, const float* w, const float* b
     if ((bn_gamma != nullptr) != (bn_beta && bn_rm && bn_rv)) return ADVMIX_EINVAL;
     if (stats && !stats_nbg) return ADVMIX_EINVAL;
     if (!use_direct()) return ADVMIX_EINVAL;
-    ConvEpi e{bn_gamma, bn_beta, bn_rm, bn_rv, residual, bn_eps, act, stats};
+    ConvEpi e{bn_gamma, bn_beta, bn_rm, bn_rv, residual, bn_eps, act, stats, nullptr, nullptr, nullptr, nullptr, 0};
     int rc = advmix_conv_direct_dispatch(0, x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad,
                                          (int64_t)N * Ho * Wo, (hipStream_t)stream, 0, &e, stats_nbg);
     return rc < 0 ? ADVMIX_EINVAL : rc;
@@ -580,9 +571,33 @@ extern "C" int advmix_conv_tr_w_add(const float* x, const float* w, const float*
     if (!x || !w || !y || N <= 0 || Ck <= 0 || Cn <= 0 || stride < 1 || stride > 8) return ADVMIX_EINVAL;
     if (Hs != (Hb + 2 * pad - R) / stride + 1 || Ws != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
     if (!use_direct()) return ADVMIX_EINVAL;
-    ConvEpi epi{nullptr, nullptr, nullptr, nullptr, addend, 0.f, 0, nullptr};
+    ConvEpi epi{nullptr, nullptr, nullptr, nullptr, addend, 0.f, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     int64_t Mmax = (int64_t)N * cdiv(Hb, stride) * cdiv(Wb, stride);
     int rc = advmix_conv_direct_dispatch(1, x, w, nullptr, y, N, Hs, Ws, Ck, Hb, Wb, Cn, R, S, stride, pad, Mmax,
                                          (hipStream_t)stream, 1, addend ? &epi : nullptr);
+    return rc < 0 ? ADVMIX_EINVAL : rc;
+}
+
+// Input gradient of a conv whose INPUT is y = act(BN(c) + residual) of a train-mode BatchNorm:
+//   g = (conv_transpose(x, w) + addend) * act'(y)        written to ``g_out`` (same layout as y)
+//   stats[0][ch][slot] += sum g,  stats[1][ch][slot] += sum g * (c - mean) * invstd      (fp64 atomics, ns slots)
+// i.e. everything BatchNorm backward needs from a pass over (dy, y, c) is produced here; advmix_norm_bwd_apply_slots
+// finishes it.  ``bn_y`` may be NULL when act == ADVMIX_ACT_NONE.  ``*stats_ns``: in = slots per channel to use
+// (0 = the library default), out = the number used.  Returns 1 (ADVMIX_EINVAL) when the shape is not served (grid
+// K split, tensors >= 2 GiB, Ck % 16 != 0): nothing was launched and the caller runs the separate kernels.
+extern "C" int advmix_conv_tr_w_bnb(const float* x, const float* w, const float* addend, float* g_out,
+                                    int N, int Hs, int Ws, int Ck, int Hb, int Wb, int Cn,
+                                    int R, int S, int stride, int pad,
+                                    const float* bn_y, const float* bn_c, const float* bn_mean, const float* bn_invstd,
+                                    int act, double* stats, int* stats_ns, void* stream) {
+    if (!x || !w || !g_out || !bn_c || !bn_mean || !bn_invstd || !stats || !stats_ns) return ADVMIX_EINVAL;
+    if (N <= 0 || Ck <= 0 || Cn <= 0 || stride < 1 || stride > 8) return ADVMIX_EINVAL;
+    if (act != ADVMIX_ACT_NONE && !bn_y) return ADVMIX_EINVAL;
+    if (Hs != (Hb + 2 * pad - R) / stride + 1 || Ws != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
+    if (!use_direct()) return ADVMIX_EINVAL;
+    ConvEpi epi{nullptr, nullptr, nullptr, nullptr, addend, 0.f, 0, stats, bn_y, bn_c, bn_mean, bn_invstd, act};
+    int64_t Mmax = (int64_t)N * cdiv(Hb, stride) * cdiv(Wb, stride);
+    int rc = advmix_conv_direct_dispatch(1, x, w, nullptr, g_out, N, Hs, Ws, Ck, Hb, Wb, Cn, R, S, stride, pad, Mmax,
+                                         (hipStream_t)stream, 1, &epi, stats_ns);
     return rc < 0 ? ADVMIX_EINVAL : rc;
 }

@@ -52,19 +52,40 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(int n, float thresh, cons
     }
 }
 
+// OKS of person i against every person j (lib/nms/nms.py:75-94), fp64.  ``np.sum`` over the K per-joint terms is
+// numpy's pairwise summation: for 8 <= K <= 128 eight running sums over strides of 8, combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the K % 8 tail added one by one; for K < 8 a plain running sum.
+// The kernel adds in exactly that order, so the only difference left against the reference is the last-bit
+// rounding of exp() (device libm vs the host's).
 __global__ void oks_matrix_kernel(const double* __restrict__ kpts, const double* __restrict__ areas,
                                   const double* __restrict__ sigmas, int n, int K, double* __restrict__ ious) {
+#pragma clang fp contract(off)                            /* numpy rounds dx**2, dy**2 and their sum separately: no fma */
     int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const double* g = kpts + (int64_t)i * K * 3;
     const double* d = kpts + (int64_t)j * K * 3;
     const double eps = 2.220446049250313e-16;             // np.spacing(1)
-    double s = 0.0;
-    for (int k = 0; k < K; ++k) {
+    const double denom = (areas[i] + areas[j]) / 2 + eps;
+    auto term = [&](int k) {
         double var = (sigmas[k] * 2) * (sigmas[k] * 2);
         double dx = d[3 * k] - g[3 * k], dy = d[3 * k + 1] - g[3 * k + 1];
-        double e = (dx * dx + dy * dy) / var / ((areas[i] + areas[j]) / 2 + eps) / 2;
-        s += exp(-e);
+        double e = (dx * dx + dy * dy) / var / denom / 2;
+        return exp(-e);
+    };
+    double s = 0.0;
+    if (K < 8) {
+        for (int k = 0; k < K; ++k) s += term(k);
+    } else {
+        double r[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = term(q);
+        int k = 8;
+        for (; k < K - (K % 8); k += 8) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r[q] += term(k + q);
+        }
+        s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; k < K; ++k) s += term(k);
     }
     ious[(int64_t)i * n + j] = K ? s / K : 0.0;
 }
@@ -118,7 +139,7 @@ extern "C" int advmix_nms_host(int* keep_out, int* num_out, const float* boxes_h
 
 extern "C" int advmix_oks_matrix(const double* kpts, const double* areas, const double* sigmas, int n, int K,
                                  double* ious, void* stream) {
-    if (!kpts || !areas || !sigmas || !ious || n <= 0 || K <= 0) return ADVMIX_EINVAL;
+    if (!kpts || !areas || !sigmas || !ious || n <= 0 || K <= 0 || K > 128) return ADVMIX_EINVAL;   // (numpy recurses past 128)
     hipLaunchKernelGGL(oks_matrix_kernel, dim3(cdiv(n, 64), n), dim3(64), 0, (hipStream_t)stream, kpts, areas, sigmas,
                        n, K, ious);
     ADVMIX_CHECK_LAUNCH();

@@ -382,6 +382,171 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(const float* __restrict__ 
     }
 }
 
+
+// ---- statistics folded into their consumer ------------------------------------------------------------------------
+// The conv epilogues (conv_direct: forward column sums; transposed gather: BatchNorm-backward sums) add their
+// per-workgroup fp64 partial sums into ``ns`` slots per channel, slots[2][C][ns].  The kernels below reduce the slots
+// THEMSELVES (every workgroup, for the <= 64 channels it streams) instead of waiting for a one-wave-per-channel
+// finalize launch in between: 2 x 593 launches of ~4.9 us per AdvMix step were 6.9 % of the kernel time and sat on the
+// critical path of every conv -> BN -> conv chain.  The slots are per layer and zero-filled once per network pass
+// (ops.py), so nobody re-zeroes them in-kernel.
+constexpr int SLOT_CT = 64;                              // channels per workgroup (channel tile)
+
+// sums[k][ch] = sum over the ns slots of statistic k of channel ct0 + ch (ch < ctn <= 64); ns a power of two <= 64
+__device__ __forceinline__ void reduce_slots(const double* __restrict__ slots, int ns, int C, int ct0, int ctn,
+                                             double (*sums)[SLOT_CT]) {
+    const int tid = threadIdx.x;
+    const int sl = tid % ns, gpp = 256 / ns;
+    for (int gi = tid / ns; gi < 2 * ctn; gi += gpp) {
+        const int k = gi / ctn, ch = gi - k * ctn;
+        double v = slots[((int64_t)k * C + ct0 + ch) * ns + sl];
+        for (int o = ns >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (sl == 0) sums[k][ch] = v;
+    }
+}
+
+struct RowTile { int64_t r0, r1; int tpr, rpi, cv, rr; };
+__device__ __forceinline__ RowTile row_tile(int64_t rows, int ctn) {
+    RowTile t;
+    const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+    t.r0 = (int64_t)blockIdx.x * per;
+    t.r1 = t.r0 + per < rows ? t.r0 + per : rows;
+    t.tpr = ctn >> 2;                                    // threads per row slice (float4 each)
+    t.rpi = 256 / t.tpr;                                 // rows per iteration
+    t.cv = threadIdx.x % t.tpr;
+    t.rr = threadIdx.x / t.tpr;
+    return t;
+}
+
+// y = act((c - mean) * invstd * gamma + beta + res), train mode, statistics from the conv epilogue's slots.
+// Workgroup (0, ct) also publishes mean / invstd (saved for backward) and updates the running statistics.
+__global__ __launch_bounds__(256) void norm_apply_slots_kernel(
+        const float* __restrict__ c, const double* __restrict__ slots, int ns, int64_t rows, int C, float eps,
+        const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res,
+        float* __restrict__ y, int act, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+        float* running_mean, float* running_var, int64_t* nbt, float momentum) {
+    __shared__ double sums[2][SLOT_CT];
+    __shared__ float smu[SLOT_CT], sis[SLOT_CT];
+    const int tid = threadIdx.x;
+    const int ct0 = blockIdx.y * SLOT_CT;
+    const int ctn = C - ct0 < SLOT_CT ? C - ct0 : SLOT_CT;
+    reduce_slots(slots, ns, C, ct0, ctn, sums);
+    __syncthreads();
+    if (tid < ctn) {
+        const double m = sums[0][tid] / (double)rows;
+        double var = sums[1][tid] / (double)rows - m * m;
+        if (var < 0) var = 0;
+        const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
+        smu[tid] = mu;
+        sis[tid] = is;
+        if (blockIdx.x == 0) {
+            const int ch = ct0 + tid;
+            mean_out[ch] = mu;
+            invstd_out[ch] = is;
+            if (running_mean) {
+                const double unb = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+                running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + (double)momentum * m);
+                running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + (double)momentum * unb);
+            }
+            if (ch == 0 && nbt) *nbt += 1;
+        }
+    }
+    __syncthreads();
+    const RowTile t = row_tile(rows, ctn);
+    if (t.rr >= t.rpi) return;
+    const int cl = t.cv * 4, ch = ct0 + cl;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(&smu[cl]), is = *reinterpret_cast<const f32x4*>(&sis[cl]);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + ch), b = *reinterpret_cast<const f32x4*>(beta + ch);
+    constexpr int U = 4;
+    for (int64_t r = t.r0 + t.rr; r < t.r1; r += (int64_t)U * t.rpi) {
+        f32x4 xv[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = r + (int64_t)u * t.rpi;
+            const int64_t rr_ = row < t.r1 ? row : r;
+            xv[u] = *reinterpret_cast<const f32x4*>(c + rr_ * C + ch);
+            if (res) rv[u] = *reinterpret_cast<const f32x4*>(res + rr_ * C + ch);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = r + (int64_t)u * t.rpi;
+            if (row >= t.r1) break;
+            f32x4 o = (xv[u] - mu) * is;
+            o = o * g + b;
+            if (res) o += rv[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = act_fwd(o[e], act);
+            *reinterpret_cast<f32x4*>(y + row * C + ch) = o;
+        }
+    }
+}
+
+// dx = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)) with g ALREADY multiplied by the activation's slope
+// (the producing input-gradient conv did that in its epilogue and left sum(g), sum(g * xhat) in the slots).
+// Workgroup (0, ct) also accumulates dgamma / dbeta.
+__global__ __launch_bounds__(256) void norm_bwd_apply_slots_kernel(
+        const float* __restrict__ g, const float* __restrict__ c, const float* __restrict__ mean,
+        const float* __restrict__ invstd, const float* __restrict__ gamma, const double* __restrict__ slots, int ns,
+        int64_t rows, int C, float* __restrict__ dx, float* dgamma, float* dbeta) {
+    __shared__ double sums[2][SLOT_CT];
+    __shared__ float sc1[SLOT_CT], sc2[SLOT_CT];
+    const int tid = threadIdx.x;
+    const int ct0 = blockIdx.y * SLOT_CT;
+    const int ctn = C - ct0 < SLOT_CT ? C - ct0 : SLOT_CT;
+    reduce_slots(slots, ns, C, ct0, ctn, sums);
+    __syncthreads();
+    if (tid < ctn) {
+        sc1[tid] = (float)(sums[0][tid] / (double)rows);
+        sc2[tid] = (float)(sums[1][tid] / (double)rows);
+        if (blockIdx.x == 0) {
+            if (dbeta) dbeta[ct0 + tid] += (float)sums[0][tid];
+            if (dgamma) dgamma[ct0 + tid] += (float)sums[1][tid];
+        }
+    }
+    __syncthreads();
+    const RowTile t = row_tile(rows, ctn);
+    if (t.rr >= t.rpi) return;
+    const int cl = t.cv * 4, ch = ct0 + cl;
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>(&sc1[cl]), c2 = *reinterpret_cast<const f32x4*>(&sc2[cl]);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + ch), is = *reinterpret_cast<const f32x4*>(invstd + ch);
+    f32x4 k = is;
+    if (gamma) k = k * *reinterpret_cast<const f32x4*>(gamma + ch);
+    constexpr int U = 4;
+    for (int64_t r = t.r0 + t.rr; r < t.r1; r += (int64_t)U * t.rpi) {
+        f32x4 gv[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = r + (int64_t)u * t.rpi;
+            const int64_t rr_ = row < t.r1 ? row : r;
+            gv[u] = *reinterpret_cast<const f32x4*>(g + rr_ * C + ch);
+            xv[u] = *reinterpret_cast<const f32x4*>(c + rr_ * C + ch);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = r + (int64_t)u * t.rpi;
+            if (row >= t.r1) break;
+            const f32x4 xh = (xv[u] - mu) * is;
+            *reinterpret_cast<f32x4*>(dx + row * C + ch) = k * (gv[u] - c1 - xh * c2);
+        }
+    }
+}
+
+// grid for the slot kernels: (row blocks, channel tiles); ~2048 workgroups, at least 4 row-iterations each
+static dim3 slot_grid(int64_t rows, int C) {
+    const int nct = cdiv(C, SLOT_CT);
+    const int ctn = C < SLOT_CT ? C : SLOT_CT;
+    const int rpi = 256 / (ctn / 4);
+    int64_t nb = (rows + 4 * rpi - 1) / (4 * rpi);
+    const int64_t cap = 2048 / nct > 0 ? 2048 / nct : 1;
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    return dim3((unsigned)nb, (unsigned)nct);
+}
+
+static bool slots_ok(int ns, int C) {
+    return ns >= 1 && ns <= 64 && !(ns & (ns - 1)) && C % 4 == 0;   // (threads past the last whole row slice idle)
+}
+
 static int stream_blocks(int64_t total) {
     int64_t b = (total + 255) / 256;
     return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
@@ -490,6 +655,37 @@ extern "C" int advmix_norm_bwd(const float* dy, const float* y, int ldy, const f
     else
         hipLaunchKernelGGL((norm_bwd_apply<false>), dim3(stream_blocks(rows * C)), dim3(256), 0, st, dy, y, ldy, x,
                            mean, invstd, gamma, coef, dx, dres, Mg, rows, C, act);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+// Train-mode BatchNorm forward whose statistics were accumulated by the producing conv's epilogue into
+// slots[2][C][ns] (fp64, see conv_direct.hip): reduces them, writes mean / invstd, updates the running statistics and
+// applies y = act(BN(c) + residual) in ONE launch.  Returns ADVMIX_EINVAL (and launches nothing) for shapes it does
+// not serve (C % 4 != 0, a channel tile that does not divide the workgroup): the caller falls back to
+// advmix_norm_finalize + advmix_norm_apply.
+extern "C" int advmix_norm_apply_slots(const float* c, const double* slots, int ns, int64_t rows, int C, float eps,
+                                       const float* gamma, const float* beta, const float* residual, float* y,
+                                       int act, float* mean, float* invstd, float* running_mean, float* running_var,
+                                       int64_t* nbt, float momentum, void* stream) {
+    if (!c || !slots || !gamma || !beta || !y || !mean || !invstd || rows <= 0 || C <= 0) return ADVMIX_EINVAL;
+    if ((running_mean != nullptr) != (running_var != nullptr)) return ADVMIX_EINVAL;
+    if (!slots_ok(ns, C)) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(norm_apply_slots_kernel, slot_grid(rows, C), dim3(256), 0, (hipStream_t)stream, c, slots, ns, rows,
+                       C, eps, gamma, beta, residual, y, act, mean, invstd, running_mean, running_var, nbt, momentum);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+// BatchNorm backward (groups = 1) whose two channel sums were left in slots[2][C][ns] by the input-gradient conv
+// that produced ``g`` (= dy * act'(y), see advmix_conv_tr_w_bnb): dx, and dgamma += / dbeta += when given.
+extern "C" int advmix_norm_bwd_apply_slots(const float* g, const float* c, const float* mean, const float* invstd,
+                                           const float* gamma, const double* slots, int ns, int64_t rows, int C,
+                                           float* dx, float* dgamma, float* dbeta, void* stream) {
+    if (!g || !c || !mean || !invstd || !slots || !dx || rows <= 0 || C <= 0) return ADVMIX_EINVAL;
+    if (!slots_ok(ns, C)) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(norm_bwd_apply_slots_kernel, slot_grid(rows, C), dim3(256), 0, (hipStream_t)stream, g, c, mean,
+                       invstd, gamma, slots, ns, rows, C, dx, dgamma, dbeta);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }

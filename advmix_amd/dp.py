@@ -48,4 +48,54 @@ class GradSync:
                 chunk.div_(self.world)
 
     def sync(self, optimizer):
-        self.all_reduce_mean(optimizer.flat_grads)
+        """Average the optimizer's gradients over ranks: ONE flat buffer for FlatAdam; any other
+        torch.optim.Optimizer (host tests, the SGD branch) falls back to its per-parameter gradients."""
+        flat = getattr(optimizer, 'flat_grads', None)
+        if flat is not None:
+            self.all_reduce_mean(flat)
+            return
+        for g in optimizer.param_groups:
+            for p in g['params']:
+                if p.grad is not None:
+                    self.all_reduce_mean(p.grad.view(-1))
+
+    def broadcast_state(self, models, optimizers, src=0):
+        """Make every replica start from rank ``src``'s state.  The reference's single-process nn.DataParallel
+        re-broadcasts GPU 0's weights before every forward (tools/train.py:69,106,109) and never seeds torch, so
+        with one process per GPU each rank would otherwise start from its own random G / final_layer / D and the
+        averaged gradients would be applied to different weights.  Sent once, after ``get_optimizer``: the flat
+        parameter buffer, Adam moments and step counter of each optimizer, then every buffer (BatchNorm running
+        statistics, num_batches_tracked) and every parameter no optimizer owns (the teacher) of each model."""
+        if self.world == 1 and not self.force:
+            return
+        owned = set()
+        tensors = []
+        for opt in optimizers:
+            if opt is None:
+                continue
+            for g in opt.param_groups:
+                owned.update(id(p) for p in g['params'])
+            if hasattr(opt, 'flat_state'):
+                tensors += opt.flat_state()
+            else:
+                for g in opt.param_groups:
+                    for p in g['params']:
+                        tensors.append(p.data)
+                        st = opt.state.get(p, {})
+                        tensors += [st[k] for k in sorted(st) if torch.is_tensor(st[k])]
+        for m in models:
+            if m is None:
+                continue
+            tensors += [p.data for p in m.parameters() if id(p) not in owned]
+            tensors += list(m.buffers())
+        for t in tensors:
+            dist.broadcast(t, src, group=self.group)
+        if tensors and tensors[0].is_cuda:
+            torch.cuda.current_stream(tensors[0].device).synchronize()
+
+    def checkpoint_rank(self):
+        """The reference saves ``model.module.state_dict()`` = GPU 0's replica (tools/train.py:311-337), whose
+        BatchNorm running statistics come from GPU 0's shard only (nn.DataParallel updates replica 0's buffers in
+        place and discards the others).  Here rank 0's buffers ARE that shard's statistics: only rank 0 writes
+        checkpoints, and nothing is averaged."""
+        return (dist.get_rank(self.group) if self.world > 1 else 0) == 0

@@ -15,6 +15,29 @@ import torch
 from .core.function import advmix_phase_a, advmix_phase_b, advmix_step
 
 
+def _snapshot(models, optimizers):
+    """Clones of everything a training step mutates: each optimizer's flat parameters / Adam moments / step counter
+    / gradient buffer, and every module buffer (BatchNorm running_mean, running_var, num_batches_tracked)."""
+    pairs = []
+    for opt in optimizers:
+        if opt is not None:
+            pairs += [(t, t.clone()) for t in opt.flat_state() + [opt.flat_grads]]
+    for m in models:
+        if m is not None:
+            pairs += [(b, b.clone()) for b in m.buffers()]
+    flags = [(p, p.requires_grad) for m in models if m is not None for p in m.parameters()]
+    return pairs, flags
+
+
+def _restore(snap):
+    pairs, flags = snap
+    with torch.no_grad():
+        for t, c in pairs:
+            t.copy_(c)
+    for p, f in flags:
+        p.requires_grad = f
+
+
 class AdvMixGraphRunner:
     def __init__(self, args, model, model_G, model_teacher, criterion, optimizer, optimizer_G,
                  inputs, target, target_weight, grad_sync=None, warmup=2):
@@ -23,6 +46,11 @@ class AdvMixGraphRunner:
         # static input buffers: new batches are copied into these
         self.inputs = [v.clone() for v in inputs]
         self.target, self.tw = target.clone(), target_weight.clone()
+        # The eager warm-up (allocator pool, lazy workspaces, RCCL communicators) runs REAL steps on the live
+        # models: without a snapshot D and G would take ``warmup`` extra Adam updates on batch 0 and the BatchNorm
+        # running statistics 2 x warmup extra momentum updates before the first replayed batch - a different
+        # trajectory from the reference loop (function.py:129-171).  Everything a step mutates is restored.
+        snap = _snapshot([model, model_G, model_teacher], [optimizer, optimizer_G])
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                     # eager warm-up off the default stream
@@ -30,6 +58,7 @@ class AdvMixGraphRunner:
                 advmix_step(args, model, model_G, model_teacher, criterion, optimizer, optimizer_G,
                             self.inputs, self.target, self.tw, grad_sync)
         torch.cuda.current_stream(dev).wait_stream(side)
+        _restore(snap)
         torch.cuda.synchronize(dev)
         optimizer.sync_hyper()
         optimizer_G.sync_hyper()

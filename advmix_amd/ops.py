@@ -67,6 +67,10 @@ def _grad_buf(p, st):
     """param.grad, created on demand.  The zero-fill runs on the MEMBER's stream ``st``: a torch
     zeros_() would be enqueued on the caller's stream and race with a side lane's accumulation."""
     if p.grad is None:
+        flat = getattr(p, '_flat_grad_view', None)         # owned by FlatAdam: something set the grads to None
+        if flat is not None:                               # (nn.Module.zero_grad) - re-attach the flat view instead of
+            p.grad = flat                                  # a standalone tensor the optimizer would never read
+            return flat
         g = torch.empty_like(p, memory_format=torch.preserve_format)
         call('advmix_fill', _p(g), 0.0, g.numel(), st)
         p.grad = g
@@ -75,8 +79,46 @@ def _grad_buf(p, st):
 
 _ws_cache = {}
 WS_BYTES = 48 << 20      # fixed per-lane scratch: norm partials need <= 512*2*C*8 B (C = 2048: 16.8 MB)
-STAT_OFF = 40 << 20      # last 8 MB: zero-initialised fp64 slots the fused conv epilogue accumulates into
-STAT_SLOTS = 64          # (= ADVMIX_STAT_SLOTS); advmix_norm_finalize leaves them zero again
+STAT_SLOTS = int(__import__('os').environ.get('ADVMIX_STAT_SLOTS', '16'))   # fp64 slots per channel the statistics
+assert STAT_SLOTS in (1, 2, 4, 8, 16, 32, 64)                                # epilogues fold their workgroup sums onto
+
+
+class StatArena:
+    """The fp64 statistics slots of ONE network: for every conv -> train-mode BatchNorm pair a forward set
+    (column sum / sum of squares of the conv output, written by the conv's epilogue) and a backward set (sum g,
+    sum g * xhat, written by the epilogue of the input-gradient conv that produces g), each [2][C][STAT_SLOTS].
+    The consumers (norm_apply_slots / norm_bwd_apply_slots) reduce the slots themselves - no finalize launch - and
+    nobody re-zeroes them in a kernel: the whole arena is zero-filled ONCE at the start of every training forward
+    (``begin_pass``, on the caller's stream before any lane forks; ~10 MB for HRNet-W32).  ``pass_id`` / ``dirty``
+    guard the backward sets: a set may be accumulated into once per pass; any other pattern (two backwards through
+    one forward, a backward from an older forward) takes the unfused path, which needs no slots."""
+
+    def __init__(self):
+        self.t, self.size, self.pass_id, self.dirty = None, 0, 0, set()
+
+    def reserve(self, channels):
+        off = self.size
+        self.size += 2 * channels * STAT_SLOTS
+        return off
+
+    def begin_pass(self, device):
+        if self.size == 0:
+            return
+        if self.t is None or self.t.device != device:
+            self.t = torch.empty(self.size, device=device, dtype=torch.float64)
+        call('advmix_fill', ctypes.c_void_p(self.t.data_ptr()), 0.0, 2 * self.size, _st())
+        self.pass_id += 1
+        self.dirty.clear()
+
+    def ptr(self, off):
+        return ctypes.c_void_p(self.t.data_ptr() + 8 * off)
+
+    def claim_bwd(self, off, pass_id):
+        """True (once) if the backward set at ``off`` is still clean for the pass the forward belonged to."""
+        if self.t is None or pass_id != self.pass_id or off in self.dirty:
+            return False
+        self.dirty.add(off)
+        return True
 
 
 def _workspace(device, nbytes, lane):
@@ -140,13 +182,36 @@ def _wt(st, w, A, T, B):
 # members: fwd(st, lane, tensors, meta, needs) -> (outputs, saved, extra)
 #          bwd(st, lane, saved, extra, meta, grads, needs) -> input grads (aligned with tensors)
 # =============================================================================================
-def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to=None):
+BNB_FUSED = __import__('os').environ.get('ADVMIX_BNB', '1') != '0'
+COUNTERS = {'bnb': 0}       # launches whose epilogue carried a BatchNorm backward (tests assert the path is taken)
+
+
+def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to=None, bnb=None):
     """Input gradient of a conv (+ ``add_to``, another gradient of the same input: summed in the kernel's
-    epilogue on the conv_direct path, by advmix_add otherwise)."""
+    epilogue on the conv_direct path, by advmix_add otherwise).
+
+    ``bnb`` (dict): the conv's input is y = act(BN(c) + res) of a train-mode ConvBN earlier in the same chain and
+    this is the LAST contribution to dL/dy.  Where the kernel serves the shape, the epilogue also multiplies by
+    act'(y) and accumulates the two BatchNorm-backward channel sums into the producer's slots; ``bnb['done']`` is
+    then set to the slot count and the result is g = dL/dy * act'(y) instead of dL/dy."""
     dx = empty_nhwc(B, Ci, Hi, Wi, x.device)
     if Co % 16 == 0 and Ci % 4 == 0 and _direct_ok():          # weights consumed in their own layout
         if add_to is not None and (add_to.shape != dx.shape or add_to.stride() != dx.stride()):
             raise RuntimeError('advmix_amd: gradient fan-in of differently laid out tensors')
+        if bnb is not None and BNB_FUSED:
+            if tuple(bnb['c'].shape) != tuple(dx.shape) or bnb['c'].stride() != dx.stride():
+                raise RuntimeError('advmix_amd: BatchNorm-backward epilogue on a differently laid out tensor')
+            nsv = ctypes.c_int(STAT_SLOTS)
+            rc = lib.advmix_conv_tr_w_bnb(_p(dy), _p(w), _p(add_to), _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride,
+                                          pad, _p(bnb['y']) if bnb['act'] != ACT_NONE else None, _p(bnb['c']),
+                                          _p(bnb['mean']), _p(bnb['invstd']), bnb['act'], bnb['slots'],
+                                          ctypes.byref(nsv), st)
+            if rc == 0:
+                bnb['done'] = nsv.value
+                COUNTERS['bnb'] += 1
+                return dx
+            if rc != 1:
+                raise RuntimeError('advmix_conv_tr_w_bnb failed: %d' % rc)
         rc = lib.advmix_conv_tr_w_add(_p(dy), _p(w), _p(add_to), _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
                                       stride, pad, st)
         if rc == 0:
@@ -180,7 +245,7 @@ class Conv:
     ADD_TO = True    # bwd(..., add_to): another gradient of the input, summed in the dgrad epilogue
 
     @staticmethod
-    def bwd(st, lane, saved, extra, meta, grads, needs, add_to=None):
+    def bwd(st, lane, saved, extra, meta, grads, needs, add_to=None, pre=0, bnb=None):
         x, w, bias = saved
         stride, pad = meta
         dy = nhwc(grads[0])
@@ -189,7 +254,7 @@ class Conv:
         Ho, Wo = dy.shape[2], dy.shape[3]
         dx = None
         if needs[0]:
-            dx = _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to)
+            dx = _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to, bnb)
         if needs[1]:
             call('advmix_conv_wgrad', _p(dy), _p(x), _p(_grad_buf(w, st)), B, Ho, Wo, Co, Hi, Wi, Ci,
                  R, S, stride, pad, st)
@@ -299,16 +364,22 @@ class BatchNorm:
 
 class ConvBN:
     """conv (bias-free) -> BatchNorm -> (+residual) -> activation as ONE member (pose_hrnet.py:41-57).
-    tensors = (x, w, gamma, beta, rmean, rvar, nbt, residual|None); meta = (stride, pad, act, training,
-    momentum, eps).  eval: a single launch (BN folded into the conv epilogue).  training: the conv epilogue
-    also emits the per-slab column sums, so the statistics pass over the conv output disappears
-    (conv -> finalize -> apply).  Shapes the fused epilogue does not serve fall back to the separate kernels."""
+    tensors = (x, w, gamma, beta, rmean, rvar, nbt, residual|None); meta = (stride, pad, act, training, momentum,
+    eps[, arena, fwd_off, bwd_off]) - the network's StatArena and this layer's two slot sets.
+    eval: a single launch (BN folded into the conv epilogue).  training: TWO launches - the conv, whose epilogue
+    leaves the column sums in the layer's slots, and norm_apply_slots, which reduces the slots itself, publishes
+    mean / invstd, updates the running statistics and applies BN + residual + activation (the one-wave-per-channel
+    finalize launch in between is gone).  Shapes the fused epilogue does not serve fall back to the separate kernels.
+    backward: when the gradient arrives already multiplied by act'(y) with its two channel sums in the layer's
+    backward slots (``pre`` = slot count; produced by the epilogue of the input-gradient conv of the consumer, see
+    Chain.bwd), ONE launch (norm_bwd_apply_slots) replaces the statistics pass + finalize + apply."""
     NHWC = (0, 7)
 
     @staticmethod
     def fwd(st, lane, t, meta, needs):
         x, w, gamma, beta, rmean, rvar, nbt, residual = t
-        stride, pad, act, training, momentum, eps = meta
+        stride, pad, act, training, momentum, eps = meta[:6]
+        arena, fwd_off, bwd_off = meta[6:9] if len(meta) > 6 else (None, 0, 0)
         x = nhwc(x)
         _check_w(w)
         res = nhwc(residual) if residual is not None else None
@@ -334,33 +405,59 @@ class ConvBN:
         c = empty_nhwc(B, Co, Ho, Wo, x.device)
         mean = torch.empty(Co, device=x.device, dtype=torch.float32)
         invstd = torch.empty(Co, device=x.device, dtype=torch.float32)
-        ws = _workspace(x.device, lib.advmix_norm_ws_bytes(1, Co), lane)
         rc = 1
-        if fused_ok and 2 * Co * STAT_SLOTS * 8 <= WS_BYTES - STAT_OFF:
-            nbg = ctypes.c_int(0)
-            slots = ctypes.c_void_p(ws.data_ptr() + STAT_OFF)
+        if fused_ok:
+            if arena is not None and arena.t is not None:
+                slots = arena.ptr(fwd_off)
+            else:                                           # functional use outside a network: private slots,
+                tmp = keep(torch.empty(2 * Co * STAT_SLOTS, device=x.device, dtype=torch.float64))
+                call('advmix_fill', _p(tmp), 0.0, 2 * tmp.numel(), st)     # zeroed on THIS member's stream
+                slots = _p(tmp)
+            nbg = ctypes.c_int(STAT_SLOTS)
             rc = lib.advmix_conv_fwd_ex(_p(x), _p(w), None, _p(c), *geom, None, None, None, None, 0.0, None, 0,
                                         slots, ctypes.byref(nbg), st)
             if rc == 0:
-                call('advmix_norm_finalize', slots, nbg.value, rows, Co, eps, _p(mean), _p(invstd), _p(rmean),
-                     _p(rvar), _p(nbt), momentum, st)
+                rc2 = lib.advmix_norm_apply_slots(_p(c), slots, nbg.value, rows, Co, eps, _p(gamma), _p(beta), _p(res),
+                                                  _p(y), act, _p(mean), _p(invstd), _p(rmean), _p(rvar), _p(nbt),
+                                                  momentum, st)
+                if rc2 == 1:                                # e.g. Co % 4 != 0: separate finalize + apply
+                    call('advmix_norm_finalize', slots, nbg.value, rows, Co, eps, _p(mean), _p(invstd), _p(rmean),
+                         _p(rvar), _p(nbt), momentum, st)
+                    call('advmix_norm_apply', _p(c), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), _p(y),
+                         Co, 1, rows, Co, act, st)
+                elif rc2 != 0:
+                    raise RuntimeError('advmix_norm_apply_slots failed: %d' % rc2)
             elif rc != 1:
                 raise RuntimeError('advmix_conv_fwd_ex failed: %d' % rc)
         if rc == 1:
+            ws = _workspace(x.device, lib.advmix_norm_ws_bytes(1, Co), lane)
             call('advmix_conv_fwd', _p(x), _p(w), None, _p(c), *geom, st)
             call('advmix_norm_stats', _p(c), 1, rows, Co, eps, _p(mean), _p(invstd), _p(rmean), _p(rvar),
                  _p(nbt), momentum, _p(ws), st)
-        call('advmix_norm_apply', _p(c), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), _p(y),
-             Co, 1, rows, Co, act, st)
-        return (y,), (x, w, c, y, mean, invstd, gamma, beta), residual is not None
+            call('advmix_norm_apply', _p(c), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), _p(y),
+                 Co, 1, rows, Co, act, st)
+        extra = (residual is not None, arena, arena.pass_id if arena is not None else 0, bwd_off)
+        return (y,), (x, w, c, y, mean, invstd, gamma, beta), extra
 
     ADD_TO = True
 
     @staticmethod
-    def bwd(st, lane, saved, has_res, meta, grads, needs, add_to=None):
+    def bnb_target(saved, extra, meta):
+        """What the input-gradient conv of this layer's CONSUMER needs to fold this layer's BatchNorm-backward
+        statistics into its epilogue (None if the layer's backward slots cannot be used for this pass)."""
+        has_res, arena, pass_id, bwd_off = extra
+        act = meta[2]
+        if arena is None or act not in (ACT_NONE, ACT_RELU) or not arena.claim_bwd(bwd_off, pass_id):
+            return None
+        x, w, c, y, mean, invstd, gamma, beta = saved
+        return {'y': y, 'c': c, 'mean': mean, 'invstd': invstd, 'act': act, 'slots': arena.ptr(bwd_off)}
+
+    @staticmethod
+    def bwd(st, lane, saved, extra, meta, grads, needs, add_to=None, pre=0, bnb=None):
         stride, pad, act, training = meta[0], meta[1], meta[2], meta[3]
         if not training:
             raise RuntimeError('advmix_amd: backward through eval-mode BatchNorm is not on the hot path')
+        has_res, arena, _pass, bwd_off = extra
         x, w, c, y, mean, invstd, gamma, beta = saved
         dy = nhwc(grads[0])
         B, Ci, Hi, Wi = x.shape
@@ -370,17 +467,23 @@ class ConvBN:
         need_res = has_res and needs[7]
         dc = keep(empty_nhwc(B, Co, Ho, Wo, x.device))
         dres = None
-        if need_res:
-            dres = dy if act == ACT_NONE else empty_nhwc(B, Co, Ho, Wo, x.device)
-        ws = _workspace(x.device, lib.advmix_norm_ws_bytes(1, Co), lane)
         dg = _grad_buf(gamma, st) if needs[2] else None
         db = _grad_buf(beta, st) if needs[3] else None
-        call('advmix_norm_bwd', _p(dy), _p(y), Co, _p(c), _p(mean), _p(invstd), _p(gamma), _p(dc),
-             _p(dres) if (need_res and act != ACT_NONE) else None, _p(dg), _p(db), 1, rows, Co, act,
-             _p(ws), st)
+        if pre:                                             # dy is g = dL/dy * act'(y); its sums are in the slots
+            call('advmix_norm_bwd_apply_slots', _p(dy), _p(c), _p(mean), _p(invstd), _p(gamma), arena.ptr(bwd_off),
+                 pre, rows, Co, _p(dc), _p(dg), _p(db), st)
+            if need_res:
+                dres = dy
+        else:
+            if need_res:
+                dres = dy if act == ACT_NONE else empty_nhwc(B, Co, Ho, Wo, x.device)
+            ws = _workspace(x.device, lib.advmix_norm_ws_bytes(1, Co), lane)
+            call('advmix_norm_bwd', _p(dy), _p(y), Co, _p(c), _p(mean), _p(invstd), _p(gamma), _p(dc),
+                 _p(dres) if (need_res and act != ACT_NONE) else None, _p(dg), _p(db), 1, rows, Co, act,
+                 _p(ws), st)
         dx = None
         if needs[0]:
-            dx = _conv_dgrad(st, dc, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to)
+            dx = _conv_dgrad(st, dc, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to, bnb)
         if needs[1]:
             call('advmix_conv_wgrad', _p(dc), _p(x), _p(_grad_buf(w, st)), B, Ho, Wo, Co, Hi, Wi, Ci,
                  R, S, stride, pad, st)
@@ -646,7 +749,8 @@ class Chain:
             nin = tuple(False if r is None else (need[r[1]] if r[0] == 's' else bool(needs[r[1]])) for r in refs)
             o, sv, ex = op.fwd(st, lane, tin, smeta, nin)
             wants = any(nin)
-            if not wants:
+            if not wants:                                  # nothing to differentiate: drop the references, but only
+                _KEEP.extend(v for v in sv if torch.is_tensor(v))   # after the lanes have joined (see keep())
                 sv = ()
             keep(o[0])                                     # an intermediate nobody saved must outlive the lanes
             val[dst], need[dst] = o[0], wants
@@ -654,24 +758,72 @@ class Chain:
             saved += list(sv)
         return tuple(val[s_] for s_ in out_slots), tuple(saved), rec
 
+    _fusion_cache = {}
+
+    @staticmethod
+    def bnb_plan(subs):
+        """{consumer index k: producer index j}: sub k is a conv whose dgrad can carry the BatchNorm-backward
+        epilogue of sub j.  Holds when k reads slot s = output of ConvBN j through its conv input only and k is the
+        FIRST consumer of s in forward order - in the reversed backward sweep every other contribution to dL/ds has
+        then already been summed (and rides into k's dgrad epilogue as the addend), so k's epilogue sees the
+        complete gradient."""
+        key = id(subs)
+        plan = Chain._fusion_cache.get(key)
+        if plan is None:
+            prod = {dst: j for j, (_o, _r, _m, dst) in enumerate(subs)}
+            first_use = {}
+            for k, (_o, refs, _m, _d) in enumerate(subs):
+                for r in refs:
+                    if r is not None and r[0] == 's':
+                        first_use.setdefault(r[1], k)
+            plan = {}
+            for k, (op, refs, _m, _d) in enumerate(subs):
+                r0 = refs[0] if refs else None
+                if not getattr(op, 'ADD_TO', False) or r0 is None or r0[0] != 's':
+                    continue
+                j = prod.get(r0[1])
+                if j is None or first_use.get(r0[1]) != k or sum(1 for r in refs if r == r0) != 1:
+                    continue
+                if subs[j][0] is ConvBN and subs[j][2][3]:            # a train-mode conv + BatchNorm
+                    plan[k] = j
+            Chain._fusion_cache[key] = plan
+        return plan
+
     @staticmethod
     def bwd(st, lane, saved, rec, meta, grads, needs):
         subs, ext_slots, out_slots = meta
-        grad = {}
+        plan = Chain.bnb_plan(subs) if BNB_FUSED else {}
+        grad, pre = {}, {}
         for s_, g in zip(out_slots, grads):
             if g is not None:
                 grad[s_] = g if s_ not in grad else _add(st, grad[s_], g)
         flat = [None] * len(needs)
-        for (op, refs, smeta, dst), (sp, sc, ex, nin) in zip(reversed(subs), reversed(rec)):
+        for k in range(len(subs) - 1, -1, -1):
+            (op, refs, smeta, dst), (sp, sc, ex, nin) = subs[k], rec[k]
             go = grad.pop(dst, None)
             if go is None or not any(nin):
                 continue
+            kw = {}
+            if dst in pre:                                 # go is already g = dL/dy * act'(y), sums in the slots
+                kw['pre'] = pre.pop(dst)
+            bnb = None
+            if k in plan and nin[0] and any(rec[plan[k]][3]) and rec[plan[k]][1]:
+                jsp, jsc, jex, _jn = rec[plan[k]]
+                bnb = ConvBN.bnb_target(saved[jsp:jsp + jsc], jex, subs[plan[k]][2])
+                if bnb is not None:
+                    kw['bnb'] = bnb
             if FANIN_FUSED and getattr(op, 'ADD_TO', False) and refs[0] is not None and refs[0][0] == 's' \
                     and nin[0] and refs[0][1] in grad:
                 # the input already has a gradient from another consumer: the conv's dgrad epilogue adds it
-                r = op.bwd(st, lane, saved[sp:sp + sc], ex, smeta, [go], nin, grad.pop(refs[0][1]))
+                r = op.bwd(st, lane, saved[sp:sp + sc], ex, smeta, [go], nin, grad.pop(refs[0][1]), **kw)
             else:
-                r = op.bwd(st, lane, saved[sp:sp + sc], ex, smeta, [go], nin)
+                r = op.bwd(st, lane, saved[sp:sp + sc], ex, smeta, [go], nin, **kw)
+            if bnb is not None:
+                if 'done' in bnb:
+                    pre[refs[0][1]] = bnb['done']
+                else:                                      # shape not served: release the slot set again
+                    jex = rec[plan[k]][2]
+                    jex[1].dirty.discard(jex[3])
             for ref, g in zip(refs, r):
                 if g is None or ref is None:
                     continue
@@ -719,8 +871,9 @@ class GroupFn(torch.autograd.Function):
             t = flat[pos:pos + cnt]
             needs = needs_all[pos:pos + cnt]
             o, sv, ex = op.fwd(handles[i % nl], i % nl, t, meta, needs)
-            if not any(needs):                             # frozen member (e.g. the teacher riding along):
-                sv = ()                                    # nothing to differentiate, keep nothing alive
+            if not any(needs):                             # frozen member (e.g. the teacher riding along): nothing to
+                _KEEP.extend(v for v in sv if torch.is_tensor(v))   # differentiate; its temporaries (mean, invstd,
+                sv = ()                                    # the raw conv output) still outlive the lanes' join
                 nondiff += list(o)
             spans.append((pos, cnt, len(outs), len(o), len(saved), len(sv)))
             outs += list(o)

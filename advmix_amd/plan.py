@@ -315,6 +315,14 @@ class PlanNet(nn.Module):
                     self._last_use[s] = li
         self._cache = None
         self._chain_meta = {}
+        # fp64 statistics slots (ops.StatArena): a forward and a backward set per conv + BatchNorm pair
+        self._arena = ops.StatArena()
+        self._stat_off = {}
+        ch_of = {name: shape[0] for name, shape, kind in plan.params if kind == 'bn_w'}
+        for st in plan.steps:
+            if st[0] == 'bn':
+                c = ch_of[st[1] + '.weight']
+                self._stat_off[st[1]] = (self._arena.reserve(c), self._arena.reserve(c))
 
     @staticmethod
     def _default_init(shape, kind):
@@ -503,7 +511,7 @@ class PlanNet(nn.Module):
                     (slots[s], T[cname + '.weight'], T[bname + '.weight'], T[bname + '.bias'],
                      T[bname + '.running_mean'], T[bname + '.running_var'], T[bname + '.num_batches_tracked'],
                      slots[res] if res is not None else None),
-                    (stride, pad, act, train, BN_MOMENTUM, BN_EPS))
+                    (stride, pad, act, train, BN_MOMENTUM, BN_EPS, self._arena) + self._stat_off[bname])
         if k in ('conv', 'deconv'):
             _, name, s, d, stride, pad, hb = st
             return (ops.Conv if k == 'conv' else ops.Deconv,
@@ -546,6 +554,8 @@ class PlanRun:
         self.slots = [None] * len(net.plan.ch)
         self.slots[0] = x
         self.li = 0
+        if self.train and torch.is_tensor(x) and x.is_cuda:
+            net._arena.begin_pass(x.device)                # zero the statistics slots once, before any lane forks
 
     @property
     def done(self):

@@ -67,14 +67,22 @@ class FlatAdam(torch.optim.Optimizer):
                 if old_grad is not None:
                     g.copy_(old_grad)
                 p.grad = g
+                p._flat_grad_view = g                     # ops._grad_buf re-attaches it if the grad is set to None
                 self._offsets.append(off)
                 off += _ceil4(p.numel())
+        self._grad_views = [p.grad for p in ps]
         self._flat = (fp, fg, torch.zeros_like(fp), torch.zeros_like(fp))
         g0 = self.param_groups[0]
         self._hyper = torch.tensor([g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps']],
                                    device=dev, dtype=torch.float32)
         self._hyper_host = (g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'])
         self._step = torch.zeros((), device=dev, dtype=torch.int64)
+
+    def flat_state(self):
+        """Everything a replica needs to continue identically: parameters, Adam moments, step counter
+        (dp.GradSync.broadcast_state sends these from rank 0)."""
+        self._ensure_flat()
+        return [self._flat[0], self._flat[2], self._flat[3], self._step]
 
     @property
     def flat_params(self):
@@ -96,8 +104,24 @@ class FlatAdam(torch.optim.Optimizer):
             self._hyper_host = cur
 
     # ---- torch.optim API ------------------------------------------------------------------
+    def _attach_grads(self, strict):
+        """Every p.grad must alias its slot of the flat gradient buffer (the backward kernels accumulate into
+        p.grad, step() reads the flat buffer).  nn.Module.zero_grad() / ``p.grad = None`` detach them: zero_grad
+        re-attaches silently, step() (``strict``) refuses to apply gradients that went somewhere else."""
+        for p, gv in zip(self._params(), self._grad_views):
+            g = p.grad
+            if g is gv:
+                continue
+            if g is not None and g.data_ptr() == gv.data_ptr():
+                continue
+            if strict and g is not None:
+                raise RuntimeError('FlatAdam: a parameter\'s .grad no longer aliases the flat gradient buffer '
+                                   '(was it replaced after zero_grad(set_to_none=True)?); its gradient would be lost')
+            p.grad = gv
+
     def zero_grad(self, set_to_none=False):
         self._ensure_flat()
+        self._attach_grads(strict=False)
         fg = self._flat[1]
         call('advmix_fill', ctypes.c_void_p(fg.data_ptr()), 0.0, fg.numel(),
              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -107,6 +131,7 @@ class FlatAdam(torch.optim.Optimizer):
         self._ensure_flat()
         if sync_hyper and not torch.cuda.is_current_stream_capturing():
             self.sync_hyper()
+        self._attach_grads(strict=True)
         fp, fg, m, v = self._flat
         P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
         call('advmix_adam', P(fp), P(fg), P(m), P(v), fp.numel(), P(self._hyper), P(self._step),

@@ -35,8 +35,9 @@ extern "C" {
 #define ADVMIX_ACT_LEAKY02 2   /* LeakyReLU(0.2), lib/models/Unet_generator.py:42 */
 
 int advmix_version(void);
-/* dispatch knobs for A/B runs and tests: "direct" (0 = first-generation conv only), "conv3" (LDS-patch 3x3
- * kernel on/off), "conv3_min_items", "conv3_grid", "wgrad_direct".  Unknown name -> ADVMIX_EINVAL. */
+/* dispatch knobs for A/B runs and tests: "direct" (0 = first-generation conv only), "wgrad_direct", "ksplit_wg"
+ * (K split inside the workgroup vs across the grid), "stat_slots" (fp64 slots per channel of the statistics
+ * epilogues).  Unknown name -> ADVMIX_EINVAL. */
 int advmix_set_option(const char* name, int value);
 
 /* ---- convolution family: replaces nn.Conv2d / nn.ConvTranspose2d forward+backward
@@ -85,6 +86,20 @@ int advmix_conv_tr_w_add(const float* x, const float* w, const float* addend, fl
                          int N, int Hs, int Ws, int Ck, int Hb, int Wb, int Cn,
                          int R, int S, int stride, int pad, void* stream);
 
+/* Input gradient of a conv whose INPUT is y = act(BN(c) + residual) of a train-mode BatchNorm
+ * (pose_hrnet.py:41-57 backward): g = (conv_transpose(x, w) + addend) * act'(y) is written to g_out and the two
+ * BatchNorm-backward channel sums are accumulated with fp64 atomics into stats[2][Cn][ns] (zero on entry):
+ * stats[0] += sum g, stats[1] += sum g * (c - mean) * invstd.  bn_y may be NULL when act == ADVMIX_ACT_NONE.
+ * *stats_ns: in = slots per channel (0 = library default, a power of two <= 64), out = the number used.
+ * Returns ADVMIX_EINVAL without launching when the shape is not served (grid K split, Ck % 16 != 0, >= 2 GiB);
+ * the caller then runs advmix_conv_tr_w_add + advmix_norm_bwd.  Replaces torch autograd's cudnn_batch_norm_backward
+ * reduction pass. */
+int advmix_conv_tr_w_bnb(const float* x, const float* w, const float* addend, float* g_out,
+                         int N, int Hs, int Ws, int Ck, int Hb, int Wb, int Cn,
+                         int R, int S, int stride, int pad,
+                         const float* bn_y, const float* bn_c, const float* bn_mean, const float* bn_invstd,
+                         int act, double* stats, int* stats_ns, void* stream);
+
 /* Which tile configuration the second-generation conv kernel picks (introspection for tests / tuning):
  * 1 = 128x32, 2 = 128x64, 3 = 64x64, 4 = 64x64 + K split across the grid (atomics), 5 = 32x32 + K split between
  * the waves of a workgroup; -1 = not served.  mode 0: forward, (Ho, Wo) = output size, Ci = reduction channels;
@@ -120,6 +135,20 @@ int advmix_norm_stats(const float* x, int groups, int64_t rows_per_group, int C,
 int advmix_norm_finalize(double* partial, int nbg, int64_t rows, int C, float eps, float* mean,
                          float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                          float momentum, void* stream);
+/* Train-mode BatchNorm forward with the finalize folded in: reduces the slots[2][C][ns] sums left by
+ * advmix_conv_fwd_ex (every workgroup for the channels it streams), writes mean / invstd (saved for backward), updates
+ * the running statistics / num_batches_tracked (may be NULL) and applies y = act(BN(c) + residual) in ONE launch.
+ * The slots are NOT re-zeroed (the caller zero-fills its per-layer slots once per network pass).
+ * ADVMIX_EINVAL without launching when C % 4 != 0 or ns is not a power of two <= 64. */
+int advmix_norm_apply_slots(const float* c, const double* slots, int ns, int64_t rows, int C, float eps,
+                            const float* gamma, const float* beta, const float* residual, float* y, int act,
+                            float* mean, float* invstd, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked, float momentum, void* stream);
+/* BatchNorm backward from the slots advmix_conv_tr_w_bnb filled: dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)),
+ * dgamma += sum g*xhat, dbeta += sum g (either may be NULL).  g is already multiplied by the activation's slope. */
+int advmix_norm_bwd_apply_slots(const float* g, const float* c, const float* mean, const float* invstd,
+                                const float* gamma, const double* slots, int ns, int64_t rows, int C,
+                                float* dx, float* dgamma, float* dbeta, void* stream);
 /* y = act((x - mean)*invstd*gamma + beta + residual); gamma/beta/residual may be NULL.
  * y rows have stride ldy floats (>= C) so the result can land in a channel slice. */
 int advmix_norm_apply(const float* x, const float* mean, const float* invstd,

@@ -132,14 +132,20 @@ def gen_loss(M):
         json.dump({'kat': kat, 'random': rnd}, f)
 
 
-def gen_forward(M):
+FORWARD_CASES = (('hrnet_tiny', 'pose_hrnet', configs.HRNET_TINY, 5, 2, 64, 64),
+                 ('resnet18_tiny', 'pose_resnet', configs.RES18_TINY, 5, 2, 64, 64),
+                 ('hrnet_w32', 'pose_hrnet', configs.HRNET_W32, 17, 2, 256, 192),
+                 ('resnet50', 'pose_resnet', configs.RES50, 17, 2, 256, 192))
+# BASELINE.json configs[3] (C4): HRNet-W48 384x288 with UnetGenerator(9, 3, 5) (tools/_init_parse.py:132-134)
+C4_CASE = ('hrnet_w48', 'pose_hrnet', configs.HRNET_W48, 17, 2, 384, 288)
+# the benchmarked batch: the tile configurations conv_direct picks at B = 32 differ from those at B = 2
+B32_CASE = ('hrnet_w32_b32', 'pose_hrnet', configs.HRNET_W32, 17, 32, 256, 192)
+
+
+def gen_forward(M, cases=FORWARD_CASES, fname='forward.npz'):
     """Per-model forward/backward vectors (train + eval mode)."""
     res = {}
-    for tag, net, extra, J, B, H, W in (
-            ('hrnet_tiny', 'pose_hrnet', configs.HRNET_TINY, 5, 2, 64, 64),
-            ('resnet18_tiny', 'pose_resnet', configs.RES18_TINY, 5, 2, 64, 64),
-            ('hrnet_w32', 'pose_hrnet', configs.HRNET_W32, 17, 2, 256, 192),
-            ('resnet50', 'pose_resnet', configs.RES50, 17, 2, 256, 192)):
+    for tag, net, extra, J, B, H, W in cases:
         cfg, D, G, _ = build_ref_models(M, net, extra, J, 6 if H % 64 == 0 and W % 64 == 0 else 5)
         views, tgt, tw = synth_batch(tag, B, J, H, W)
         calibrate_ref(D, views[2])
@@ -176,7 +182,7 @@ def gen_forward(M):
             res['%s.ggrad.%s' % (tag, k)] = np.array([float(gp[k].grad.double().sum()),
                                                        float(gp[k].grad.double().abs().sum())])
         print('forward', tag, float(loss), flush=True)
-    np.savez_compressed(os.path.join(OUT, 'forward.npz'), **res)
+    np.savez_compressed(os.path.join(OUT, fname), **res)
 
 
 class Rec:
@@ -194,16 +200,18 @@ class Rec:
         return self
 
 
-def gen_advmix(M):
+ADVMIX_CASES = (('hrnet_tiny', 'pose_hrnet', configs.HRNET_TINY, 5, 2, 64, 64, 3),
+                ('resnet18_tiny', 'pose_resnet', configs.RES18_TINY, 5, 2, 64, 64, 3),
+                ('hrnet_w32', 'pose_hrnet', configs.HRNET_W32, 17, 2, 256, 192, 2),
+                ('resnet50', 'pose_resnet', configs.RES50, 17, 2, 256, 192, 2))
+
+
+def gen_advmix(M, cases=ADVMIX_CASES, fname='advmix_steps.npz', jname='advmix_checksums.json', downs=6, plain=True):
     """2-3 iterations of the REAL train_advmix / train loops on tiny + full models."""
     fn = M['core.function']
     res, meta = {}, {}
-    for tag, net, extra, J, B, H, W, iters in (
-            ('hrnet_tiny', 'pose_hrnet', configs.HRNET_TINY, 5, 2, 64, 64, 3),
-            ('resnet18_tiny', 'pose_resnet', configs.RES18_TINY, 5, 2, 64, 64, 3),
-            ('hrnet_w32', 'pose_hrnet', configs.HRNET_W32, 17, 2, 256, 192, 2),
-            ('resnet50', 'pose_resnet', configs.RES50, 17, 2, 256, 192, 2)):
-        cfg, D, G, Tm = build_ref_models(M, net, extra, J, 6, salt=10)
+    for tag, net, extra, J, B, H, W, iters in cases:
+        cfg, D, G, Tm = build_ref_models(M, net, extra, J, downs, salt=10)
         args = AD(alpha=0.1, adv_loss_weight=1.0)
         calib = synth_batch(tag + '.calib', B, J, H, W)[0][0]
         calibrate_ref(Tm, calib)
@@ -233,8 +241,10 @@ def gen_advmix(M):
                      'nbt': int(sdD['bn1.num_batches_tracked'])}
         print('advmix', tag, res[tag + '.losses'].tolist(), flush=True)
 
+        if not plain:
+            continue
         # plain (non-AdvMix) loop, function.py:30-95
-        cfg, D, _, _ = build_ref_models(M, net, extra, J, 6, salt=20)
+        cfg, D, _, _ = build_ref_models(M, net, extra, J, downs, salt=20)
         calibrate_ref(D, calib)
         optD = torch.optim.Adam(D.parameters(), lr=1e-3)
         crit = Rec(M['core.loss'].JointsMSELoss(True))
@@ -248,9 +258,22 @@ def gen_advmix(M):
         sdD = D.state_dict()
         meta[tag]['plain_D'] = checksum(sdD, [k for k in sdD if sdD[k].is_floating_point()])
         print('plain', tag, crit.vals, flush=True)
-    np.savez_compressed(os.path.join(OUT, 'advmix_steps.npz'), **res)
-    with open(os.path.join(OUT, 'advmix_checksums.json'), 'w') as f:
+    np.savez_compressed(os.path.join(OUT, fname), **res)
+    with open(os.path.join(OUT, jname), 'w') as f:
         json.dump(meta, f)
+
+
+def gen_c4(M):
+    """C4 (HRNet-W48 384x288 + UnetGenerator(9,3,5)): forward/backward vectors and the real train_advmix loop."""
+    gen_forward(M, (C4_CASE,), 'c4_forward.npz')
+    gen_advmix(M, (C4_CASE + (2,),), 'c4_advmix_steps.npz', 'c4_advmix_checksums.json', downs=5, plain=False)
+
+
+def gen_b32(M):
+    """HRNet-W32 256x192 at the benchmarked batch (B = 32): forward/backward vectors and ONE real train_advmix
+    iteration, so the tiles conv_direct dispatches at B = 32 are covered at network level."""
+    gen_forward(M, (B32_CASE,), 'b32_forward.npz')
+    gen_advmix(M, (B32_CASE + (1,),), 'b32_advmix_steps.npz', 'b32_advmix_checksums.json', plain=False)
 
 
 def gen_nms(M):
@@ -476,7 +499,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     M = import_reference()
-    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe']
+    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe', 'c4', 'b32']
     for w in which:
         globals()['gen_' + w](M)
         print('done', w, flush=True)

@@ -16,7 +16,15 @@ CASES = {
     'resnet18_tiny': ('pose_resnet', configs.RES18_TINY, 5, 2, 64, 64, 3),
     'hrnet_w32': ('pose_hrnet', configs.HRNET_W32, 17, 2, 256, 192, 2),
     'resnet50': ('pose_resnet', configs.RES50, 17, 2, 256, 192, 2),
+    # BASELINE.json configs[3] (C4): HRNet-W48 384x288 with UnetGenerator(9, 3, 5)
+    'hrnet_w48': ('pose_hrnet', configs.HRNET_W48, 17, 2, 384, 288, 2),
 }
+DOWNS = {'hrnet_w48': 5}                        # U-Net depth per case (default 6; tools/_init_parse.py:132-134)
+GOLD_FILES = {'hrnet_w48': ('c4_forward.npz', 'c4_advmix_steps.npz', 'c4_advmix_checksums.json')}
+
+
+def gold_files(tag):
+    return GOLD_FILES.get(tag, ('forward.npz', 'advmix_steps.npz', 'advmix_checksums.json'))
 
 
 def gold_json(name):

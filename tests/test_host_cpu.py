@@ -115,6 +115,58 @@ def test_grad_sync_two_ranks_gloo(tmp_path):
         assert p.wait(timeout=120) == 0
 
 
+_WORKER_BCAST = r'''
+import os, sys, torch, torch.nn as nn, torch.distributed as dist
+sys.path.insert(0, %r)
+from advmix_amd.dp import GradSync
+rank = int(os.environ['RANK'])
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ['MASTER_PORT'],
+                        rank=rank, world_size=2)
+torch.manual_seed(100 + rank)                   # the reference never seeds torch: every rank starts differently
+def net():
+    return nn.Sequential(nn.Conv2d(3, 4, 3, padding=1), nn.BatchNorm2d(4), nn.ReLU(), nn.Conv2d(4, 2, 1))
+D, G, T = net(), net(), net()
+for m in (D, G, T):
+    for b in m.buffers():
+        if b.is_floating_point(): b.add_(torch.rand_like(b))       # distinct BN statistics per rank
+optD, optG = torch.optim.Adam(D.parameters(), 1e-2), torch.optim.Adam(G.parameters(), 1e-2)
+gs = GradSync()
+def same(t):
+    got = [torch.zeros_like(t), torch.zeros_like(t)]
+    dist.all_gather(got, t.contiguous())
+    return torch.equal(got[0], got[1])
+ok = not same(next(D.parameters()).data)        # they really differ before the broadcast
+gs.broadcast_state([D, G, T], [optD, optG])
+ok = ok and all(same(t.data) for m in (D, G, T) for t in list(m.parameters()) + list(m.buffers()))
+x = torch.randn(4, 3, 8, 8)                     # a different shard per rank
+for m, opt in ((D, optD), (G, optG)):
+    opt.zero_grad()
+    m(x).square().mean().backward()
+    gs.sync(opt)
+    opt.step()
+ok = ok and all(same(p.data) for m in (D, G) for p in m.parameters())       # replicas stay identical after step 1
+ok = ok and all(same(opt.state[p]['exp_avg']) for opt in (optD, optG) for g in opt.param_groups for p in g['params'])
+ok = ok and not same(D[1].running_mean)         # BatchNorm statistics stay per replica (DataParallel semantics)
+ok = ok and gs.checkpoint_rank() == (rank == 0)
+dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+'''
+
+
+def test_broadcast_state_makes_replicas_identical_gloo(tmp_path):
+    """ADVICE r1 (high): without a rank-0 broadcast each process starts from its own random weights.  Two ranks
+    with different seeds -> broadcast_state -> one synced Adam step on different shards -> parameters and Adam
+    moments bit-identical on both ranks; BN running statistics stay per replica."""
+    script = tmp_path / 'wb.py'
+    script.write_text(_WORKER_BCAST % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29613')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env))
+    for p in procs:
+        assert p.wait(timeout=180) == 0
+
+
 def test_coco_rescore_is_the_reference_running_sum():
     """dataset.coco.rescore (vectorised over persons) == the per-person float32 running sum of
     coco.py:340-353 as restated by the oracle - bit for bit, including persons with no confident joint."""

@@ -9,7 +9,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import CASES, gold_json, gold_npz, build_states, checksum_close   # noqa: E402
+from helpers import CASES, DOWNS, gold_files, gold_json, gold_npz, build_states, checksum_close   # noqa: E402
+
+REPORT = {}      # worst err / bound ratio per checked quantity (printed by the tests)
+GRAD_MEDIAN_TOL = 0.15   # median per-tensor D-gradient error vs the fp32 oracle after a device-side update
 from smoke_step import (product_models, assert_close, run_smoke, assert_grads,      # noqa: E402
                         pull_params, match_fraction)
 
@@ -40,19 +43,19 @@ def test_forward_backward_vs_oracle_and_golden(tag):
     from advmix_amd import ops
     from advmix_amd.core.loss import JointsMSELoss
     net, extra, J, B, H, W, _ = CASES[tag]
-    g = gold_npz('forward.npz')
-    D, T, G = build_states(net, extra, J)
+    downs = DOWNS.get(tag, 6)
+    g = gold_npz(gold_files(tag)[0])
+    D, T, G = build_states(net, extra, J, unet_downs=downs)
     views, tgt, tw = synth_batch(tag, B, J, H, W)
     calibrate(net, D, views[2], extra)
-    cfg, mD, mG, _ = product_models(net, extra, J, D, T, G)
+    cfg, mD, mG, _ = product_models(net, extra, J, D, T, G, downs=downs)
 
     mD.eval()                                             # eval-mode (teacher-style) forward
     with torch.no_grad():
         ye = mD(views[0].cuda())
         ye_ref = posenet_forward(net, D, views[0], extra, False)
-    assert_close('eval out', ye, ye_ref)
-    gs = max(1.0, float(ye_ref.abs().max()))
-    assert float(np.abs(strided(ye.cpu().contiguous()) - g[tag + '.eval_out']).max()) <= 1e-3 * gs
+    assert_close('eval out', ye, ye_ref, report=REPORT)
+    assert_close('eval out vs golden', strided(ye.cpu().contiguous()), g[tag + '.eval_out'], report=REPORT)
 
     mD.train()                                            # train-mode forward + full backward
     x = views[1].cuda().requires_grad_(True)
@@ -67,15 +70,15 @@ def test_forward_backward_vs_oracle_and_golden(tag):
     yr = posenet_forward(net, D, xr, extra, True)
     lr = joints_loss(yr, tgt, tw, True)
     g32 = dict(zip(names + ['x'], torch.autograd.grad(lr, [D[k] for k in names] + [xr])))
-    assert_close('train out', yt, yr)
-    ts = max(1.0, float(yr.abs().max()))
-    assert float(np.abs(strided(yt.detach().cpu().contiguous()) - g[tag + '.train_out']).max()) <= 1e-3 * ts
+    assert_close('train out', yt, yr, report=REPORT)
+    assert_close('train out vs golden', strided(yt.detach().cpu().contiguous()), g[tag + '.train_out'], report=REPORT)
     assert_close('loss', loss.detach(), lr.detach(), 1e-4)
     assert_close('loss vs golden', [float(loss.detach())], g[tag + '.loss'], 1e-4)
     got = {k: p.grad.detach().cpu() for k, p in mD.named_parameters()}
     got['x'] = x.grad.cpu()
     stats = assert_grads('D grads', names + ['x'], got, g32, g64)
     print(tag, 'D-grad median rel err hip %.2e fp32-oracle %.2e outliers %d' % stats)
+    print(tag, 'worst err/bound ratios', {k: round(v, 3) for k, v in REPORT.items()})
     sd = mD.state_dict()
     for k in D:
         if k.endswith(('running_mean', 'running_var')):
@@ -87,15 +90,14 @@ def test_forward_backward_vs_oracle_and_golden(tag):
         G[k].requires_grad_(True)
     gi = ops.cat_views([v.cuda().contiguous() for v in views])
     lg = mG(gi)
-    lg_ref = unet_forward(G, torch.cat(views, 1))
-    assert_close('unet out', lg, lg_ref)
-    assert float(np.abs(strided(lg.detach().cpu().contiguous()) - g[tag + '.unet_out']).max()) <= \
-        1e-3 * max(1.0, float(lg_ref.abs().max()))
+    lg_ref = unet_forward(G, torch.cat(views, 1), num_downs=downs)
+    assert_close('unet out', lg, lg_ref, report=REPORT)
+    assert_close('unet out vs golden', strided(lg.detach().cpu().contiguous()), g[tag + '.unet_out'], report=REPORT)
     proj = detinit.normal(tag + '.gproj', lg_ref.shape)
     (lg * proj.cuda()).sum().backward()
     gg32 = dict(zip(G, torch.autograd.grad((lg_ref * proj).sum(), list(G.values()))))
     G64 = {k: v.detach().double().requires_grad_(True) for k, v in G.items()}
-    lg64 = unet_forward(G64, torch.cat(views, 1).double())
+    lg64 = unet_forward(G64, torch.cat(views, 1).double(), num_downs=downs)
     gg64 = dict(zip(G, torch.autograd.grad((lg64 * proj.double()).sum(), list(G64.values()))))
     gmax = max(float(v.abs().max()) for v in gg64.values())
     # conv biases that feed an InstanceNorm have an exactly-zero true gradient: compare those
@@ -120,13 +122,14 @@ def test_advmix_and_plain_steps_vs_oracle_and_golden(tag):
     from advmix_amd.core.loss import JointsMSELoss
     from advmix_amd.utils.utils import get_optimizer
     net, extra, J, B, H, W, iters = CASES[tag]
-    g = gold_npz('advmix_steps.npz')
-    meta = gold_json('advmix_checksums.json')[tag]
-    D, T, G = build_states(net, extra, J, salt=10)
+    downs = DOWNS.get(tag, 6)
+    g = gold_npz(gold_files(tag)[1])
+    meta = gold_json(gold_files(tag)[2])[tag]
+    D, T, G = build_states(net, extra, J, unet_downs=downs, salt=10)
     calib = synth_batch(tag + '.calib', B, J, H, W)[0][0]
     calibrate(net, T, calib, extra)
     calibrate(net, D, calib, extra)
-    cfg, mD, mG, mT = product_models(net, extra, J, D, T, G)
+    cfg, mD, mG, mT = product_models(net, extra, J, D, T, G, downs=downs)
     optD, optG = get_optimizer(cfg, mD), get_optimizer(cfg, mG)
     oD, oG = Adam(D, trainable(D)), Adam(G, list(G))
     crit = JointsMSELoss(True)
@@ -146,11 +149,12 @@ def test_advmix_and_plain_steps_vs_oracle_and_golden(tag):
         def force():
             fracs.append(match_fraction(mD, D, atol))     # oracle's own update vs the device's
             pull_params(mD, D)
-        ref = ostep(net, extra, D, G, T, oD, oG, v, t, w, alpha=0.1, after_D_step=force)
+        ref = ostep(net, extra, D, G, T, oD, oG, v, t, w, alpha=0.1, after_D_step=force,
+                    unet_kw={'num_downs': downs})
         fracs.append(match_fraction(mG, G, atol))
         pull_params(mG, G)
-        assert_close('loss_D', loss_D, ref['loss_D'])
-        assert_close('out2', out, ref['out2'])
+        assert_close('loss_D', loss_D, ref['loss_D'], report=REPORT)
+        assert_close('out2', out, ref['out2'], report=REPORT)
         if it == 0:                                       # golden: the reference's own numbers
             want = g[tag + '.losses'][0]
             assert_close('loss_D vs golden', [float(loss_D)], [0.9 * want[0] + 0.1 * want[1]])
@@ -160,7 +164,9 @@ def test_advmix_and_plain_steps_vs_oracle_and_golden(tag):
         gD = {k: p.grad.detach().cpu() for k, p in mD.named_parameters()}
         mh = np.median([float((gD[k] - ref['gD'][k]).abs().max()) / (float(ref['gD'][k].abs().max()) + 1e-30)
                         for k in ref['gD']])
-        assert mh <= 0.15, ('median D-grad error vs fp32 oracle', mh)
+        print(tag, 'it', it, 'median D-grad error vs fp32 oracle %.3e' % mh)
+        assert mh <= GRAD_MEDIAN_TOL, ('median D-grad error vs fp32 oracle', mh)
+    print(tag, 'worst err/bound ratios', {k: round(v, 3) for k, v in REPORT.items()})
     sd = mD.state_dict()
     assert int(sd['bn1.num_batches_tracked']) == meta['nbt']       # calib + 2 forwards / iteration
     for k in D:
@@ -170,9 +176,11 @@ def test_advmix_and_plain_steps_vs_oracle_and_golden(tag):
     assert all(not p.requires_grad for p in mD.parameters())       # function.py:158 leaves D frozen
     print(tag, 'element match fractions after each update', ['%.4f' % f for f in fracs])
 
-    D, _, _ = build_states(net, extra, J, salt=20)        # plain (non-AdvMix) loop, function.py:30-95
+    if tag + '.plain_losses' not in g.files:              # (C4 fixture: AdvMix loop only)
+        return
+    D, _, _ = build_states(net, extra, J, unet_downs=downs, salt=20)   # plain (non-AdvMix) loop, function.py:30-95
     calibrate(net, D, calib, extra)
-    cfg, mD, _, _ = product_models(net, extra, J, D, T, G)
+    cfg, mD, _, _ = product_models(net, extra, J, D, T, G, downs=downs)
     optD, oD = get_optimizer(cfg, mD), Adam(D, trainable(D))
     mD.train()
     for it in range(2):
@@ -185,6 +193,70 @@ def test_advmix_and_plain_steps_vs_oracle_and_golden(tag):
         assert_close('plain out', out, ref['out'])
         if it == 0:
             assert_close('plain loss vs golden', [float(loss)], [g[tag + '.plain_losses'][0]])
+
+
+def test_network_parity_at_the_benchmarked_batch():
+    """HRNet-W32 256x192 at B = 32, the batch bench.py times: conv_direct dispatches other tile configurations
+    there than at B = 2 (128x32 / 128x64 tiles, the in-workgroup K split instead of the grid split).  Eval forward,
+    train forward + loss against the CPU oracle (full tensors) and the vectors the REAL reference produced at B = 32;
+    then one whole AdvMix step against the real train_advmix's first iteration."""
+    from oracle import configs
+    from oracle.posenet import posenet_forward, calibrate
+    from oracle.loss import joints_loss
+    from oracle.synth import synth_batch, strided
+    from advmix_amd._lib import lib
+    from advmix_amd.core.function import advmix_step
+    from advmix_amd.core.loss import JointsMSELoss
+    from advmix_amd.utils.utils import get_optimizer
+    tag, net, extra, J, B, H, W = 'hrnet_w32_b32', 'pose_hrnet', configs.HRNET_W32, 17, 32, 256, 192
+    # the tiles this batch reaches (1 = 128x32, 2 = 128x64, 3 = 64x64, 5 = 32x32 + K split between the waves)
+    cfgs = {lib.advmix_conv_direct_config(0, B, 64 >> i, 48 >> i, 32 << i, 32 << i, 3, 3, 1) for i in range(4)}
+    cfgs.add(lib.advmix_conv_direct_config(0, B, 64, 48, 64, 256, 1, 1, 1))
+    assert {1, 2, 5} <= cfgs, cfgs
+    g = gold_npz('b32_forward.npz')
+    D, T, G = build_states(net, extra, J)
+    views, tgt, tw = synth_batch(tag, B, J, H, W)
+    calibrate(net, D, views[2], extra)
+    cfg, mD, mG, mT = product_models(net, extra, J, D, T, G)
+    rep = {}
+    mD.eval()
+    with torch.no_grad():
+        ye = mD(views[0].cuda())
+        ye_ref = posenet_forward(net, D, views[0], extra, False)
+    assert_close('eval out', ye, ye_ref, report=rep)
+    assert_close('eval out vs golden', strided(ye.cpu().contiguous()), g[tag + '.eval_out'], report=rep)
+    mD.train()
+    with torch.no_grad():
+        yt = mD(views[1].cuda())
+        loss = JointsMSELoss(True)(yt, tgt.cuda(), tw.cuda())
+        yr = posenet_forward(net, D, views[1], extra, True)
+        lr = joints_loss(yr, tgt, tw, True)
+    assert_close('train out', yt, yr, report=rep)
+    assert_close('train out vs golden', strided(yt.cpu().contiguous()), g[tag + '.train_out'], report=rep)
+    assert_close('loss', loss, lr, 1e-4, report=rep)
+    assert_close('loss vs golden', [float(loss)], g[tag + '.loss'], 1e-4, report=rep)
+    del mD, mG, mT, ye, yt
+
+    ga = gold_npz('b32_advmix_steps.npz')
+    D, T, G = build_states(net, extra, J, salt=10)
+    calib = synth_batch(tag + '.calib', B, J, H, W)[0][0]
+    calibrate(net, T, calib, extra)
+    calibrate(net, D, calib, extra)
+    cfg, mD, mG, mT = product_models(net, extra, J, D, T, G)
+    optD, optG = get_optimizer(cfg, mD), get_optimizer(cfg, mG)
+    mD.train(); mG.train(); mT.eval()
+    args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
+    v, t, w = synth_batch(tag + '.it0', B, J, H, W)
+    loss_D, out = advmix_step(args, mD, mG, mT, JointsMSELoss(True), optD, optG,
+                              [x.cuda().contiguous() for x in v], t.cuda(), w.cuda())
+    want = ga[tag + '.losses'][0]
+    assert_close('loss_D vs golden', [float(loss_D)], [0.9 * want[0] + 0.1 * want[1]], report=rep)
+    # out2 = D(tmp) AFTER the first Adam update (lr * sign(g) per element: implementation-dependent where g is
+    # rounding noise, see test_advmix_and_plain_steps_vs_oracle_and_golden) -> a loose bound on the heat-maps
+    o2 = strided(out.cpu().contiguous(), 2048)
+    dev = float(np.abs(o2 - ga[tag + '.out2.it0']).max()) / float(np.abs(ga[tag + '.out2.it0']).max())
+    print(tag, 'worst err/bound ratios', {k: round(x, 3) for k, x in rep.items()}, 'out2 after update: rel dev %.3e' % dev)
+    assert dev <= 0.05, dev
 
 
 def test_smoke_entry():

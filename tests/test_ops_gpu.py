@@ -54,7 +54,7 @@ CONV_CASES = [
     (2, 256, 8, 6, 256, 3, 1, 1, False),
     (2, 512, 6, 4, 512, 4, 2, 1, True),
     (2, 40, 7, 5, 72, 3, 1, 1, True),
-    (2, 64, 20, 24, 48, 3, 1, 1, True),     # LDS-patch kernel: 2 channel chunks, ragged tiles, Co % 32 != 0
+    (2, 64, 20, 24, 48, 3, 1, 1, True),     # 2 channel chunks, ragged tiles, Co % 32 != 0
     (1, 32, 9, 17, 32, 3, 1, 1, False),
     (2, 96, 16, 16, 64, 3, 1, 1, False),
     (32, 256, 8, 6, 256, 3, 1, 1, True),    # HRNet's lowest branch at the bench batch: 32x32 tiles, K split between waves
@@ -63,25 +63,17 @@ CONV_CASES = [
 ]
 
 
-@pytest.fixture(params=['auto', 'lds3x3', 'direct', 'direct16', 'direct_wg', 'igemm'])
+@pytest.fixture(params=['auto', 'direct', 'direct_wg', 'igemm'])
 def conv_path(request):
     """Force each generation of the conv kernels in turn (advmix_set_option)."""
     from advmix_amd.ops import set_option
-    cfg = {'auto': (1, 0, 512), 'lds3x3': (1, 1, 1), 'direct': (1, 0, 512), 'direct16': (1, 0, 512),
-           'direct_wg': (1, 0, 512), 'igemm': (0, 0, 512)}[request.param]
     set_option('wgrad_direct', {'igemm': 0, 'auto': 1}.get(request.param, 2))   # 2 = force where eligible
-    set_option('direct', cfg[0])
-    set_option('conv3', cfg[1])
-    set_option('conv3_min_items', cfg[2])
-    set_option('mfma16', 1 if request.param == 'direct16' else 0)      # 16x16x4 MFMA shape in conv_direct
+    set_option('direct', 0 if request.param == 'igemm' else 1)
     set_option('ksplit_wg', 1 if request.param in ('direct_wg', 'auto') else 0)  # K split inside the workgroup
     yield request.param
-    set_option('mfma16', 0)
     set_option('ksplit_wg', 1)
     set_option('direct', 1)
     set_option('wgrad_direct', 1)
-    set_option('conv3', 0)
-    set_option('conv3_min_items', 512)
 
 
 def test_conv_tile_configuration_table():
@@ -301,6 +293,90 @@ def _conv_bn_fused_member(case):
                 check('dres', rg.grad, rr.grad)
 
 
+def _plan_reference(plan, sd, x):
+    """float64 torch interpretation of a Plan's conv / bn steps (train-mode BatchNorm), independent of ops.py."""
+    slots = {0: x}
+    for st in plan.steps:
+        if st[0] == 'conv':
+            _, name, s_, d_, stride, pad, hb = st
+            slots[d_] = F.conv2d(slots[s_], sd[name + '.weight'], sd[name + '.bias'] if hb else None, stride, pad)
+        elif st[0] == 'bn':
+            _, name, s_, d_, res, act = st
+            o = F.batch_norm(slots[s_], None, None, sd[name + '.weight'], sd[name + '.bias'], True, 0.1, 1e-5)
+            if res is not None:
+                o = o + slots[res]
+            slots[d_] = F.relu(o) if act == 1 else o
+        else:
+            raise ValueError(st[0])
+    return slots[plan.out]
+
+
+@pytest.mark.parametrize('frozen', [False, True])
+def test_chain_bn_backward_fused_into_dgrad_epilogue(frozen):
+    """Residual blocks as ONE launch chain: the input-gradient conv of each consumer carries the BatchNorm-backward
+    epilogue of its producer (advmix_conv_tr_w_bnb -> advmix_norm_bwd_apply_slots) wherever the chain allows it.
+    Fused vs unfused device paths agree to rounding (same masks: both read the stored y); both agree with a
+    float64 torch interpretation of the plan.  ``frozen``: the G-step mode (input gradient only)."""
+    import advmix_amd.ops as ops
+    from advmix_amd.plan import Plan, PlanNet
+    P = Plan(16)
+    P.tag = 'all'
+    x = P.conv_bn(0, 'stem', 'stem_bn', 32, 3, 1, 1, 1)
+    x = P.block('BASIC', x, 'b0', 32)
+    x = P.block('BASIC', x, 'b1', 32)
+    x = P.block('BOTTLENECK', x, 'b2', 16)                   # 32 -> 64, 1x1 convs and a downsample path
+    x = P.block('BASIC', x, 'b3', 64, 2)                     # stride-2 block: phase-decomposed input gradient
+    P.out = P.conv(x, 'final', 8, 1, 1, 0, bias=True)
+    torch.manual_seed(5)
+    net = PlanNet(P)
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if p.dim() == 1 and k.endswith('.weight'):        # BatchNorm gamma
+                p.uniform_(0.6, 1.4)
+            elif p.dim() == 1:                                 # BatchNorm beta, conv bias
+                p.normal_(0, 0.2)
+    net = net.to(dev()).train()
+    sd = {k: v.detach().double().cpu().requires_grad_(v.is_floating_point()) for k, v in net.state_dict().items()}
+    B, H, W = 8, 24, 16
+    xin = rnd(B, 16, H, W, seed=77)
+    dy = rnd(B, 8, H // 2, W // 2, seed=78)
+    xr = xin.clone().requires_grad_(True)
+    yr = _plan_reference(P, sd, xr)
+    yr.backward(dy)
+    if frozen:
+        for p in net.parameters():
+            p.requires_grad = False
+    names = [k for k, _ in net.named_parameters()]
+    got = {}
+    for fused in (True, False):
+        ops.BNB_FUSED = fused
+        ops.COUNTERS['bnb'] = 0
+        try:
+            for p in net.parameters():
+                p.grad = None
+            xg = cl(xin).requires_grad_(True)
+            y = net(xg)
+            y.backward(cl(dy))
+            torch.cuda.synchronize()
+        finally:
+            ops.BNB_FUSED = True
+        got[fused] = {'x': xg.grad.detach().cpu().double(), 'y': y.detach().cpu().double()}
+        if not frozen:
+            got[fused].update({k: p.grad.detach().cpu().double() for k, p in net.named_parameters()})
+        n_fused = ops.COUNTERS['bnb']
+        assert (n_fused >= 7) if fused else (n_fused == 0), n_fused        # 11 conv+BN pairs, the chain fuses most
+    check('y', got[True]['y'], yr, 2e-4)
+    for k in got[True]:
+        if k == 'y':
+            continue
+        ref = xr.grad if k == 'x' else sd[k].grad
+        a, b = got[True][k], got[False][k]
+        scale = max(float(ref.abs().max()), 1e-9)
+        assert float((a - b).abs().max()) <= 5e-5 * scale, (k, float((a - b).abs().max()), scale)
+        frac = float(((a - ref).abs() <= 1e-3 * scale).double().mean())
+        assert frac >= 0.999, (k, frac)                       # (a flipped ReLU mask moves isolated elements)
+
+
 def test_batch_norm_frozen_params_input_grad_only():
     """G-step mode: D frozen (set_require_grad False) but BN still in train mode."""
     ops = _ops()
@@ -503,6 +579,55 @@ def test_nms_bit_exact_vs_oracle():
     call('advmix_nms_host', keep.ctypes.data_as(ctypes.c_void_p), ctypes.byref(num),
          d2.ctypes.data_as(ctypes.c_void_p), 0, 5, ctypes.c_float(th), 0)
     assert num.value == 0
+
+
+def test_oks_pairs_engineered_onto_the_threshold():
+    """``oks_nms`` keeps a pair when ``oks <= thresh`` (nms.py:121).  Persons built so that the OKS is an exactly
+    representable k/17 in ANY correct implementation (k joints coincide -> exp(-0) = 1, the other 17 - k are so far
+    away that exp underflows to 0): thresh = that value keeps the pair, one ulp below suppresses it.  Random pairs:
+    the device matrix (numpy's pairwise summation order, no fma contraction) within 2 ulp of the numpy restatement."""
+    from advmix_amd.nms import nms as pn
+    from oracle import nms as onms
+    rng = np.random.Generator(np.random.Philox(key=11))
+    J = 17
+    base = rng.random((J, 3)) * 100
+    people = [base.copy()]
+    ks = [17, 9, 1, 0]
+    for k in ks:                                         # person 1 + idx: k coinciding joints
+        q = base.copy()
+        q[k:, 0:2] += 1e6
+        people.append(q)
+    for _ in range(3):
+        people.append(rng.random((J, 3)) * 100)
+    areas = [3000.0] * len(people)
+    scores = [1.0 - 0.01 * i for i in range(len(people))]            # person 0 first
+    db = [{'score': s, 'keypoints': kk, 'area': a} for s, kk, a in zip(scores, people, areas)]
+    kp = np.array([kk.flatten() for kk in people])
+    M = pn._oks_matrix(kp, np.array(areas), None)
+    ref = np.stack([onms.oks_iou(kp[i], kp, areas[i], np.array(areas)) for i in range(len(people))])
+    for idx, k in enumerate(ks):
+        assert M[0, 1 + idx] == k / 17 == ref[0, 1 + idx], (k, M[0, 1 + idx], ref[0, 1 + idx])
+    ulp = np.abs(M - ref) / np.spacing(np.maximum(np.abs(ref), 1e-300))
+    assert ulp.max() <= 2, ulp.max()
+    for k in (17, 9, 1):
+        t = k / 17
+        for th in (t, float(np.nextafter(t, 0.0)), float(np.nextafter(t, 2.0))):
+            want = [int(i) for i in onms.oks_nms(db, th)]
+            assert [int(i) for i in pn.oks_nms(db, th)] == want, (k, th)
+            assert [int(i) for i in pn.soft_oks_nms(db, th)] == [int(i) for i in onms.soft_oks_nms(db, th)], (k, th)
+        idx = 1 + ks.index(k)
+        assert idx in [int(i) for i in pn.oks_nms(db, t)]                             # oks == thresh: kept
+        assert idx not in [int(i) for i in pn.oks_nms(db, float(np.nextafter(t, 0.0)))]   # one ulp below: suppressed
+    rnd_db = []
+    kk = rng.random((40, J, 3)) * 100
+    kk[:20] = kk[0] + rng.normal(0, 2.0, (20, J, 3))
+    ar = rng.random(40) * 4000 + 500
+    kp = kk.reshape(40, -1)
+    M = pn._oks_matrix(kp, ar, None)
+    ref = np.stack([onms.oks_iou(kp[i], kp, ar[i], ar) for i in range(40)])
+    ulp = np.abs(M - ref) / np.spacing(np.maximum(np.abs(ref), 1e-300))
+    print('oks matrix: max ulp distance to numpy %.1f, bit-identical %.1f %%' % (ulp.max(), 100 * (M == ref).mean()))
+    assert ulp.max() <= 2
 
 
 # ---- validation path kernels (SURVEY.md 8 f1) -----------------------------------------------------------------

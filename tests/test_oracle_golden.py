@@ -11,7 +11,7 @@ from oracle.posenet import posenet_spec, posenet_forward, calibrate, trainable
 from oracle.unet import unet_spec, unet_forward
 from oracle.step import Adam, advmix_step, plain_step
 from oracle.synth import synth_batch, strided, checksum
-from helpers import CASES, gold_json, gold_npz, build_states, close, checksum_close, GOLD
+from helpers import CASES, DOWNS, gold_files, gold_json, gold_npz, build_states, close, checksum_close, GOLD
 from oracle import configs
 
 torch.set_num_threads(8)
@@ -96,8 +96,9 @@ def test_oks_nms_matches_reference():
 @pytest.mark.parametrize('tag', list(CASES))
 def test_forward_backward_matches_reference(tag):
     net, extra, J, B, H, W, _ = CASES[tag]
-    g = gold_npz('forward.npz')
-    D, _, G = build_states(net, extra, J)
+    downs = DOWNS.get(tag, 6)
+    g = gold_npz(gold_files(tag)[0])
+    D, _, G = build_states(net, extra, J, unet_downs=downs)
     views, tgt, tw = synth_batch(tag, B, J, H, W)
     calibrate(net, D, views[2], extra)
     with torch.no_grad():
@@ -123,7 +124,7 @@ def test_forward_backward_matches_reference(tag):
             close(D[key[len(tag) + 4:]].detach().numpy(), g[key], 1e-4, 1e-3)
     for k in G:
         G[k].requires_grad_(True)
-    lg = unet_forward(G, torch.cat(views, 1))
+    lg = unet_forward(G, torch.cat(views, 1), num_downs=downs)
     close(strided(lg), g[tag + '.unet_out'])
     gg = dict(zip(G, torch.autograd.grad((lg * detinit.normal(tag + '.gproj', lg.shape)).sum(), list(G.values()))))
     for key in g.files:
@@ -137,9 +138,10 @@ def test_forward_backward_matches_reference(tag):
 @pytest.mark.parametrize('tag', list(CASES))
 def test_advmix_and_plain_steps_match_reference(tag):
     net, extra, J, B, H, W, iters = CASES[tag]
-    g = gold_npz('advmix_steps.npz')
-    meta = gold_json('advmix_checksums.json')[tag]
-    D, T, G = build_states(net, extra, J, salt=10)
+    downs = DOWNS.get(tag, 6)
+    g = gold_npz(gold_files(tag)[1])
+    meta = gold_json(gold_files(tag)[2])[tag]
+    D, T, G = build_states(net, extra, J, unet_downs=downs, salt=10)
     calib = synth_batch(tag + '.calib', B, J, H, W)[0][0]
     calibrate(net, T, calib, extra)
     calibrate(net, D, calib, extra)
@@ -147,7 +149,7 @@ def test_advmix_and_plain_steps_match_reference(tag):
     optG = Adam(G, list(G))
     for it in range(iters):
         v, t, w = synth_batch('%s.it%d' % (tag, it), B, J, H, W)
-        r = advmix_step(net, extra, D, G, T, optD, optG, v, t, w, alpha=0.1)
+        r = advmix_step(net, extra, D, G, T, optD, optG, v, t, w, alpha=0.1, unet_kw={'num_downs': downs})
         want = g[tag + '.losses'][it]
         close([float(r['l_hm']), float(r['l_kd']), -float(r['loss_G'])], want, 1e-4, 1e-3)
         close(strided(r['out1'], 2048), g['%s.out1.it%d' % (tag, it)])
@@ -155,6 +157,8 @@ def test_advmix_and_plain_steps_match_reference(tag):
     assert int(D['bn1.num_batches_tracked']) == meta['nbt']       # calib + 2 per iteration
     checksum_close(checksum(D, meta['D'].keys()), meta['D'])
     checksum_close(checksum(G, meta['G'].keys()), meta['G'])
+    if 'plain_D' not in meta:                              # (C4 fixture: AdvMix loop only)
+        return
 
     D, _, _ = build_states(net, extra, J, salt=20)
     calibrate(net, D, calib, extra)
@@ -164,6 +168,23 @@ def test_advmix_and_plain_steps_match_reference(tag):
         r = plain_step(net, extra, D, optD, v[0], t, w)
         close([float(r['loss'])], [g[tag + '.plain_losses'][it]], 1e-4, 1e-3)
     checksum_close(checksum(D, meta['plain_D'].keys()), meta['plain_D'])
+
+
+def test_forward_at_the_benchmarked_batch_matches_reference():
+    """HRNet-W32 256x192 at B = 32 (the batch bench.py runs): eval forward, train forward and loss against the
+    vectors the REAL reference produced at that batch (tests/golden/b32_forward.npz)."""
+    tag, net, extra, J, B, H, W = 'hrnet_w32_b32', 'pose_hrnet', configs.HRNET_W32, 17, 32, 256, 192
+    g = gold_npz('b32_forward.npz')
+    D, _, _ = build_states(net, extra, J)
+    views, tgt, tw = synth_batch(tag, B, J, H, W)
+    calibrate(net, D, views[2], extra)
+    with torch.no_grad():
+        ye = posenet_forward(net, D, views[0], extra, False)
+        yt = posenet_forward(net, D, views[1], extra, True)
+        loss = joints_loss(yt, tgt, tw, True)
+    close(strided(ye), g[tag + '.eval_out'])
+    close(strided(yt), g[tag + '.train_out'])
+    close([float(loss)], g[tag + '.loss'], 1e-5, 1e-4)
 
 
 # ---- validation path (SURVEY.md 8 f1): oracle/validate.py against the real reference's outputs ----------------

@@ -94,6 +94,72 @@ def advmix_step(args, model, model_G, model_teacher, criterion, optimizer, optim
     return loss_D, output
 
 
+# ---- the loops' fast path: HIP-graph replay + one-batch-ahead device prefetch ---------------------------------------
+# The step has static shapes, so train_advmix / train capture it ONCE per (models, optimizers, batch shape) into HIP
+# graphs (graph.AdvMixGraphRunner / PlainGraphRunner) and replay it per batch; a batch of another shape (the ragged
+# last batch of an epoch) runs eagerly.  ADVMIX_EXEC=eager disables the capture.
+GRAPH_EXEC = os.environ.get('ADVMIX_EXEC', 'graph') != 'eager'
+_RUNNERS = {}
+
+
+def _runner_for(kind, key_objs, sig, build):
+    """One cached runner per set of live objects; ``sig`` = shapes and loss weights it was captured with.
+    Returns None when a runner exists for other shapes (no second capture: that batch runs eagerly)."""
+    key = (kind,) + tuple(id(o) for o in key_objs)
+    hit = _RUNNERS.get(key)
+    if hit is not None and all(a is b for a, b in zip(hit[2], key_objs)):
+        return hit[1] if hit[0] == sig else None
+    runner = build()
+    _RUNNERS[key] = (sig, runner, tuple(key_objs))         # (the objects are kept alive with their runner)
+    return runner
+
+
+def release_graphs():
+    """Drop every captured step (and the models / optimizers it keeps alive)."""
+    _RUNNERS.clear()
+
+
+class _Prefetch:
+    """Iterate a loader one batch ahead.  While the step of batch i runs, the tensors of batch i+1 are copied to the
+    device on a side HIP stream (asynchronously when the loader pins its memory, PIN_MEMORY in the experiment YAMLs);
+    the consumer waits for the copy's event before it touches them.  ``pick(batch)`` names the tensors that go to the
+    device; everything else (metas) passes through untouched."""
+
+    def __init__(self, loader, pick):
+        self.it, self.pick = iter(loader), pick
+        self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self.nxt = self._fetch()
+
+    def _fetch(self):
+        try:
+            batch = next(self.it)
+        except StopIteration:
+            return None
+        host = self.pick(batch)
+        if self.stream is None or all(t.is_cuda for t in host):
+            return batch, [t.float() if t.is_floating_point() else t for t in host], None
+        with torch.cuda.stream(self.stream):
+            dev = [t.cuda(non_blocking=True).float() for t in host]
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return batch, dev, ev
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        cur = self.nxt
+        if cur is None:
+            raise StopIteration
+        self.nxt = self._fetch()                           # batch i+1 goes in flight before batch i is consumed
+        batch, dev, ev = cur
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            for t in dev:
+                t.record_stream(torch.cuda.current_stream())
+        return batch, dev
+
+
 def _log(config, epoch, i, n, batch_time, data_time, losses, acc, bs, writer_dict):
     msg = 'Epoch: [{0}][{1}/{2}]\t' \
           'Time {batch_time.val:.3f}s ({batch_time.avg:.3f}s)\t' \
@@ -120,11 +186,21 @@ def train(config, args, train_loader, model, criterion, optimizer, epoch,
     model.train()
     end = time.time()
     n = len(train_loader) if hasattr(train_loader, '__len__') else -1
-    for i, (input, target, target_weight, meta) in enumerate(train_loader):
+    pick = lambda b: [b[0], b[1][0] if isinstance(b[1], (list, tuple)) else b[1], b[2]]     # noqa: E731  (:48-51)
+    for i, ((input, _t, _w, meta), (x, target, target_weight)) in enumerate(_Prefetch(train_loader, pick)):
         data_time.update(time.time() - end)
-        target = _cuda(target[0] if isinstance(target, (list, tuple)) else target)      # :50
-        target_weight = _cuda(target_weight)
-        loss, outputs = plain_step(model, criterion, optimizer, input, target, target_weight, grad_sync)
+        x = x.contiguous()
+        runner = None
+        if GRAPH_EXEC:
+            from ..graph import PlainGraphRunner
+            sig = (tuple(x.shape), tuple(target.shape), tuple(target_weight.shape), id(grad_sync))
+            runner = _runner_for('plain', (model, criterion, optimizer), sig, lambda: PlainGraphRunner(
+                model, criterion, optimizer, x, target, target_weight, grad_sync))
+        if runner is not None:
+            runner.load_batch(x, target, target_weight)
+            loss, outputs = runner.step()
+        else:
+            loss, outputs = plain_step(model, criterion, optimizer, x, target, target_weight, grad_sync)
         losses.update(loss.item(), input.size(0))                                        # :62
         _, avg_acc, cnt, pred = accuracy(outputs, target)
         acc.update(avg_acc, cnt)
@@ -143,13 +219,25 @@ def train_advmix(config, args, train_loader, models, criterion, optimizers, epoc
     optimizer, optimizer_G = optimizers[0], optimizers[1]
     end = time.time()
     n = len(train_loader) if hasattr(train_loader, '__len__') else -1
-    for i, (inputs, targets, target_weights, metas) in enumerate(train_loader):
+    pick = lambda b: [b[0][0], b[0][1], b[0][2], b[1][0], b[2][0]]                        # noqa: E731  (:129-133)
+    for i, (_batch, dev) in enumerate(_Prefetch(train_loader, pick)):
         data_time.update(time.time() - end)
-        inputs = [_cuda(v).float().contiguous() for v in inputs]                         # :129-133
-        target = _cuda(targets[0])
-        target_weight = _cuda(target_weights[0])
-        loss_D, output = advmix_step(args, model, model_G, model_teacher, criterion, optimizer,
-                                     optimizer_G, inputs, target, target_weight, grad_sync)
+        inputs = [v.contiguous() for v in dev[:3]]
+        target, target_weight = dev[3], dev[4]
+        runner = None
+        if GRAPH_EXEC:
+            from ..graph import AdvMixGraphRunner
+            sig = (tuple(inputs[0].shape), tuple(target.shape), tuple(target_weight.shape), float(args.alpha),
+                   float(args.adv_loss_weight), id(grad_sync))
+            runner = _runner_for('advmix', (model, model_G, model_teacher, criterion, optimizer, optimizer_G), sig,
+                                 lambda: AdvMixGraphRunner(args, model, model_G, model_teacher, criterion, optimizer,
+                                                           optimizer_G, inputs, target, target_weight, grad_sync))
+        if runner is not None:                             # replay the captured step on this batch
+            runner.load_batch(inputs, target, target_weight)
+            loss_D, output = runner.step()
+        else:                                              # another batch shape: eager
+            loss_D, output = advmix_step(args, model, model_G, model_teacher, criterion, optimizer,
+                                         optimizer_G, inputs, target, target_weight, grad_sync)
         losses.update(loss_D.item(), inputs[0].size(0))                                  # :167
         _, avg_acc, cnt, pred = accuracy(output, target)                                 # :168
         acc.update(avg_acc, cnt)

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 AdvmixOpts& advmix_opts() {
     static AdvmixOpts o = [] {
-        AdvmixOpts d{1, 1, 1, 16};
+        AdvmixOpts d{1, 1, 1, 0};
         const char* e;
         if ((e = getenv("ADVMIX_CONV")) && e[0] == 'i') d.direct = 0;
         if ((e = getenv("ADVMIX_WGRAD"))) d.wgrad_direct = e[0] != '0';

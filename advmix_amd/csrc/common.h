@@ -64,7 +64,7 @@ struct AdvmixOpts {
     int direct;            // 1: conv_direct allowed, 0: first-generation conv_igemm only
     int wgrad_direct;      // 1: register-fragment wgrad kernel allowed
     int ksplit_wg;         // 1: layers with too few tiles split K inside the workgroup (fused epilogue kept), 0: across the grid
-    int stat_slots;        // fp64 slots per channel the statistics epilogues fold their workgroup sums onto (power of 2 <= 64)
+    int stat_slots;        // fp64 slots per channel the statistics epilogues fold their workgroup sums onto (power of 2 <= 64; 0 = by grid size)
 };
 AdvmixOpts& advmix_opts();
 

@@ -392,16 +392,42 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(const float* __restrict__ 
 // (ops.py), so nobody re-zeroes them in-kernel.
 constexpr int SLOT_CT = 64;                              // channels per workgroup (channel tile)
 
-// sums[k][ch] = sum over the ns slots of statistic k of channel ct0 + ch (ch < ctn <= 64); ns a power of two <= 64
+// sums[k][ch] = sum over the ns slots of statistic k of channel ct0 + ch (ch < ctn <= 64); ns a power of two <= 64.
+// Every (statistic, channel) pair is summed by 256 / pairs threads ("parts"), each loading ITS contiguous run of
+// slots with independent 16-byte loads before the first add (a load -> shuffle loop waited one L2 round trip per
+// iteration: 18.7 instead of 6.3 us for the whole apply launch at 64 slots), then the parts meet in LDS.
 __device__ __forceinline__ void reduce_slots(const double* __restrict__ slots, int ns, int C, int ct0, int ctn,
-                                             double (*sums)[SLOT_CT]) {
+                                             double (*sums)[SLOT_CT], double* red /* [4][2 * SLOT_CT] */) {
     const int tid = threadIdx.x;
-    const int sl = tid % ns, gpp = 256 / ns;
-    for (int gi = tid / ns; gi < 2 * ctn; gi += gpp) {
-        const int k = gi / ctn, ch = gi - k * ctn;
-        double v = slots[((int64_t)k * C + ct0 + ch) * ns + sl];
-        for (int o = ns >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (sl == 0) sums[k][ch] = v;
+    const int pairs = 2 * ctn;                           // <= 128
+    int parts = 256 / pairs;                             // >= 2
+    if (parts > 4) parts = 4;
+    if (parts > ns) parts = ns;
+    const int per = ns / parts;                          // slots per part (ns and parts are powers of two)
+    const int pr = tid % pairs, part = tid / pairs;
+    if (part < parts) {
+        const int k = pr / ctn, ch = pr - k * ctn;
+        const double* src = slots + ((int64_t)k * C + ct0 + ch) * ns + part * per;
+        double acc = 0.0;
+        if (per >= 2) {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (2 * i < per) v[i] = *reinterpret_cast<const d2*>(src + 2 * i);
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (2 * i < per) acc += v[i][0] + v[i][1];
+        } else {
+            acc = src[0];
+        }
+        red[part * (2 * SLOT_CT) + pr] = acc;
+    }
+    __syncthreads();
+    if (tid < pairs) {
+        double a = red[tid];
+        for (int q = 1; q < parts; ++q) a += red[q * (2 * SLOT_CT) + tid];
+        sums[tid / ctn][tid % ctn] = a;
     }
 }
 
@@ -426,11 +452,12 @@ __global__ __launch_bounds__(256) void norm_apply_slots_kernel(
         float* __restrict__ y, int act, float* __restrict__ mean_out, float* __restrict__ invstd_out,
         float* running_mean, float* running_var, int64_t* nbt, float momentum) {
     __shared__ double sums[2][SLOT_CT];
+    __shared__ double red[4 * 2 * SLOT_CT];
     __shared__ float smu[SLOT_CT], sis[SLOT_CT];
     const int tid = threadIdx.x;
     const int ct0 = blockIdx.y * SLOT_CT;
     const int ctn = C - ct0 < SLOT_CT ? C - ct0 : SLOT_CT;
-    reduce_slots(slots, ns, C, ct0, ctn, sums);
+    reduce_slots(slots, ns, C, ct0, ctn, sums, red);
     __syncthreads();
     if (tid < ctn) {
         const double m = sums[0][tid] / (double)rows;
@@ -489,11 +516,12 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_slots_kernel(
         const float* __restrict__ invstd, const float* __restrict__ gamma, const double* __restrict__ slots, int ns,
         int64_t rows, int C, float* __restrict__ dx, float* dgamma, float* dbeta) {
     __shared__ double sums[2][SLOT_CT];
+    __shared__ double red[4 * 2 * SLOT_CT];
     __shared__ float sc1[SLOT_CT], sc2[SLOT_CT];
     const int tid = threadIdx.x;
     const int ct0 = blockIdx.y * SLOT_CT;
     const int ctn = C - ct0 < SLOT_CT ? C - ct0 : SLOT_CT;
-    reduce_slots(slots, ns, C, ct0, ctn, sums);
+    reduce_slots(slots, ns, C, ct0, ctn, sums, red);
     __syncthreads();
     if (tid < ctn) {
         sc1[tid] = (float)(sums[0][tid] / (double)rows);

@@ -12,7 +12,7 @@ The RCCL calls stay outside the graphs.  The autograd tape recorded while captur
 is consumed while capturing graph 2; all three share one memory pool."""
 import torch
 
-from .core.function import advmix_phase_a, advmix_phase_b, advmix_step
+from .core.function import advmix_phase_a, advmix_phase_b, advmix_step, plain_step
 
 
 def _snapshot(models, optimizers):
@@ -96,3 +96,47 @@ class AdvMixGraphRunner:
             self.sync.sync(self.optG)
         self.g3.replay()
         return self.loss_D, self.output
+
+
+class PlainGraphRunner:
+    """The plain (non-AdvMix) step of ``train`` (lib/core/function.py:48-59) as HIP graphs: [forward, loss, zero_grad,
+    backward] -> all-reduce (outside the graphs) -> [Adam]."""
+
+    def __init__(self, model, criterion, optimizer, input, target, target_weight, grad_sync=None, warmup=2):
+        self.opt, self.sync = optimizer, grad_sync
+        dev = input.device
+        self.input, self.target, self.tw = input.clone(), target.clone(), target_weight.clone()
+        snap = _snapshot([model], [optimizer])
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                plain_step(model, criterion, optimizer, self.input, self.target, self.tw, grad_sync)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        _restore(snap)
+        torch.cuda.synchronize(dev)
+        optimizer.sync_hyper()
+        self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        mode = dict(capture_error_mode='thread_local')
+        with torch.cuda.graph(self.g1, **mode):
+            outputs = model(self.input)
+            loss = criterion(outputs, self.target, self.tw)
+            optimizer.zero_grad()
+            loss.backward()
+            self.loss, self.output = loss.detach(), outputs.detach()
+        with torch.cuda.graph(self.g2, pool=self.g1.pool(), **mode):
+            optimizer.step(sync_hyper=False)
+        torch.cuda.synchronize(dev)
+
+    def load_batch(self, input, target, target_weight):
+        self.input.copy_(input, non_blocking=True)
+        self.target.copy_(target, non_blocking=True)
+        self.tw.copy_(target_weight, non_blocking=True)
+
+    def step(self):
+        self.opt.sync_hyper()
+        self.g1.replay()
+        if self.sync is not None:
+            self.sync.sync(self.opt)
+        self.g2.replay()
+        return self.loss, self.output

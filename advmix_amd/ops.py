@@ -79,8 +79,8 @@ def _grad_buf(p, st):
 
 _ws_cache = {}
 WS_BYTES = 48 << 20      # fixed per-lane scratch: norm partials need <= 512*2*C*8 B (C = 2048: 16.8 MB)
-STAT_SLOTS = int(__import__('os').environ.get('ADVMIX_STAT_SLOTS', '16'))   # fp64 slots per channel the statistics
-assert STAT_SLOTS in (1, 2, 4, 8, 16, 32, 64)                                # epilogues fold their workgroup sums onto
+STAT_SLOTS = 64          # capacity reserved per channel and statistic; a launch uses 16 or 64 of them (conv_direct.hip)
+STAT_SLOTS_ASK = int(__import__('os').environ.get('ADVMIX_STAT_SLOTS', '0'))   # 0 = the kernel's choice
 
 
 class StatArena:
@@ -125,7 +125,7 @@ def _workspace(device, nbytes, lane):
     """Per-(device, lane) scratch of fixed size, allocated once (never re-allocated while another
     lane might still be using the old one).  Lanes never share scratch; within a lane kernels
     are stream-ordered."""
-    if nbytes > STAT_OFF:
+    if nbytes > WS_BYTES:
         raise ValueError('norm workspace of %d bytes exceeds the per-lane scratch (%d)' % (nbytes, WS_BYTES))
     key = (device.index, lane)
     w = _ws_cache.get(key)
@@ -201,7 +201,7 @@ def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_
         if bnb is not None and BNB_FUSED:
             if tuple(bnb['c'].shape) != tuple(dx.shape) or bnb['c'].stride() != dx.stride():
                 raise RuntimeError('advmix_amd: BatchNorm-backward epilogue on a differently laid out tensor')
-            nsv = ctypes.c_int(STAT_SLOTS)
+            nsv = ctypes.c_int(STAT_SLOTS_ASK)
             rc = lib.advmix_conv_tr_w_bnb(_p(dy), _p(w), _p(add_to), _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride,
                                           pad, _p(bnb['y']) if bnb['act'] != ACT_NONE else None, _p(bnb['c']),
                                           _p(bnb['mean']), _p(bnb['invstd']), bnb['act'], bnb['slots'],
@@ -413,7 +413,7 @@ class ConvBN:
                 tmp = keep(torch.empty(2 * Co * STAT_SLOTS, device=x.device, dtype=torch.float64))
                 call('advmix_fill', _p(tmp), 0.0, 2 * tmp.numel(), st)     # zeroed on THIS member's stream
                 slots = _p(tmp)
-            nbg = ctypes.c_int(STAT_SLOTS)
+            nbg = ctypes.c_int(STAT_SLOTS_ASK)
             rc = lib.advmix_conv_fwd_ex(_p(x), _p(w), None, _p(c), *geom, None, None, None, None, 0.0, None, 0,
                                         slots, ctypes.byref(nbg), st)
             if rc == 0:
@@ -725,7 +725,7 @@ class Chain:
     lanes after every conv+BN instead.
 
     tensors = (external slot tensors..., then every other tensor of every sub-member)
-    meta    = (subs, ext_slots, out_slots); subs[i] = (op, refs, sub_meta, dst_slot) with refs[j] =
+    meta    = (subs, ext_slots, out_slots[, bnb_plan]); subs[i] = (op, refs, sub_meta, dst_slot) with refs[j] =
               ('s', slot) | ('i', flat index into tensors) | None for the sub-member's j-th tensor.
     The sub-members are the ordinary member classes; their gradients w.r.t. a slot that has several
     consumers are summed here (``advmix_add``), which is what autograd's fan-in adds did before."""
@@ -740,7 +740,7 @@ class Chain:
 
     @staticmethod
     def fwd(st, lane, t, meta, needs):
-        subs, ext_slots, out_slots = meta
+        subs, ext_slots, out_slots = meta[:3]
         val = {s_: t[i] for i, s_ in enumerate(ext_slots)}
         need = {s_: bool(needs[i]) for i, s_ in enumerate(ext_slots)}
         saved, rec = [], []
@@ -758,8 +758,6 @@ class Chain:
             saved += list(sv)
         return tuple(val[s_] for s_ in out_slots), tuple(saved), rec
 
-    _fusion_cache = {}
-
     @staticmethod
     def bnb_plan(subs):
         """{consumer index k: producer index j}: sub k is a conv whose dgrad can carry the BatchNorm-backward
@@ -767,32 +765,28 @@ class Chain:
         FIRST consumer of s in forward order - in the reversed backward sweep every other contribution to dL/ds has
         then already been summed (and rides into k's dgrad epilogue as the addend), so k's epilogue sees the
         complete gradient."""
-        key = id(subs)
-        plan = Chain._fusion_cache.get(key)
-        if plan is None:
-            prod = {dst: j for j, (_o, _r, _m, dst) in enumerate(subs)}
-            first_use = {}
-            for k, (_o, refs, _m, _d) in enumerate(subs):
-                for r in refs:
-                    if r is not None and r[0] == 's':
-                        first_use.setdefault(r[1], k)
-            plan = {}
-            for k, (op, refs, _m, _d) in enumerate(subs):
-                r0 = refs[0] if refs else None
-                if not getattr(op, 'ADD_TO', False) or r0 is None or r0[0] != 's':
-                    continue
-                j = prod.get(r0[1])
-                if j is None or first_use.get(r0[1]) != k or sum(1 for r in refs if r == r0) != 1:
-                    continue
-                if subs[j][0] is ConvBN and subs[j][2][3]:            # a train-mode conv + BatchNorm
-                    plan[k] = j
-            Chain._fusion_cache[key] = plan
+        prod = {dst: j for j, (_o, _r, _m, dst) in enumerate(subs)}
+        first_use = {}
+        for k, (_o, refs, _m, _d) in enumerate(subs):
+            for r in refs:
+                if r is not None and r[0] == 's':
+                    first_use.setdefault(r[1], k)
+        plan = {}
+        for k, (op, refs, _m, _d) in enumerate(subs):
+            r0 = refs[0] if refs else None
+            if not getattr(op, 'ADD_TO', False) or r0 is None or r0[0] != 's':
+                continue
+            j = prod.get(r0[1])
+            if j is None or first_use.get(r0[1]) != k or sum(1 for r in refs if r == r0) != 1:
+                continue
+            if subs[j][0] is ConvBN and subs[j][2][3]:                # a train-mode conv + BatchNorm
+                plan[k] = j
         return plan
 
     @staticmethod
     def bwd(st, lane, saved, rec, meta, grads, needs):
-        subs, ext_slots, out_slots = meta
-        plan = Chain.bnb_plan(subs) if BNB_FUSED else {}
+        subs, ext_slots, out_slots = meta[:3]
+        plan = (meta[3] if len(meta) > 3 else Chain.bnb_plan(subs)) if BNB_FUSED else {}
         grad, pre = {}, {}
         for s_, g in zip(out_slots, grads):
             if g is not None:

@@ -496,7 +496,8 @@ class PlanNet(nn.Module):
                         refs.append(('i', len(ext) + len(names)))
                         names.append(t.name)
                 subs.append((op, tuple(refs), meta, self._dst(sub)))
-            cached = ((tuple(subs), tuple(ext), tuple(outs)), tuple(names))
+            subs = tuple(subs)
+            cached = ((subs, tuple(ext), tuple(outs), ops.Chain.bnb_plan(subs)), tuple(names))
             self._chain_meta[key] = cached
         meta, names = cached
         return (ops.Chain, tuple(slots[s] for s in meta[1]) + tuple(T[n] for n in names), meta)

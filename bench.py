@@ -111,38 +111,107 @@ def _event_time(run, iters, reps=5):
     return vals[len(vals) // 2], vals
 
 
-def time_dominant_kernel(B, device, iters=100):
-    """HIP-event timing of the dominant kernel: the 3x3 s1 32->32 conv on the 64x48 branch
-    (64 launches per HRNet-W32 forward), launched back to back through the C ABI (ctypes adds
-    ~3 us of host time per call, below the kernel time, so the event average is the launch
-    duration).  Events are recorded on the stream the kernel is launched on."""
+CONV_FAMILY = ((32, 64, 48), (64, 32, 24), (128, 16, 12), (256, 8, 6))     # HRNet-W32's 3x3 s1 C->C convs: 1.81 GF each at B = 32
+# launches per AdvMix step of each kind of a given conv: two train-mode student forwards + the eval-mode teacher, two
+# input gradients (D step, G step), one weight gradient (D step)
+KIND_WEIGHT = {'fwd+BN-sums': 2, 'fwd+BN-eval+ReLU': 1, 'dgrad+BN-bwd-sums': 2, 'wgrad': 1}
+
+
+def _latest_pmc():
+    """HBM bytes per launch of the dominant kernel from this round's rocprofv3 PMC passes (tools/pmc_conv.sh +
+    tools/summarize_pmc.py: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate --pmc runs); newest profiles/r*_pmc file."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_conv32_epi.json')))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        return round(json.load(f)['hbm_bytes_per_launch']), os.path.relpath(files[-1], ROOT)
+
+
+def time_conv_family(B, device, iters=100):
+    """The roofline object.  The step's time is the MFMA convs' (SURVEY 8 d3), and no single launch dominates: the four
+    branch resolutions of HRNet-W32 each run the same 1.81 GFLOP 3x3 conv, as forward (+ BatchNorm column sums, or +
+    eval BatchNorm + ReLU for the teacher), input gradient (+ the BatchNorm-backward sums of its producer) and weight
+    gradient.  Every member is timed live, back to back through the C ABI with HIP events on the launching stream;
+    ``frac`` is the launch-count-weighted FLOP/s of the whole family against the fp32 matrix peak, ``members`` lets
+    each number be recomputed, ``dominant`` is the most frequent single kernel (3x3 32->32 @64x48 + sums, 128 launches
+    per step) with its measured HBM traffic.  ``hbm_kernels``: the two BatchNorm kernels left on the path against the
+    8 TB/s HBM peak."""
     import ctypes
     from advmix_amd._lib import call
-    x = torch.randn(B, 64, 48, 32, device=device)
-    w = torch.randn(32, 3, 3, 32, device=device) * 0.05
-    y = torch.empty(B, 64, 48, 32, device=device)
-    slots = torch.zeros(2 * 32 * 64, device=device, dtype=torch.float64)   # BN column sums (fp64 atomics)
-    nbg = ctypes.c_int(0)
-    P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())       # noqa: E731
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    # the variant the training step launches: conv + per-channel sums for the following BatchNorm
-    run = lambda: call('advmix_conv_fwd_ex', P(x), P(w), None, P(y), B, 64, 48, 32, 64, 48, 32, 3, 3, 1, 1,  # noqa: E731
-                       None, None, None, None, 0.0, None, 0, P(slots), ctypes.byref(nbg), st)
-    ms, runs = _event_time(run, iters)
-    flops = 2.0 * B * 64 * 48 * 32 * 32 * 9
-    # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2
-    # on gfx950 + WRITE_SIZE, tools/pmc_conv.sh + tools/summarize_pmc.py); measured at B = 32
-    traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_conv32_epi.json')      # the same kernel variant (conv + BN sums)
-    if B == 32 and os.path.exists(pmc):
-        with open(pmc) as f:
-            traffic = round(json.load(f)['hbm_bytes_per_launch'])
-    return {'bound': 'mfma', 'kernel': 'conv_direct<1,1,4,1,32,fwd,epilogue=BN-sums> 3x3 s1 32->32 @64x48 (128x32 tile)',
-            'achieved': round(flops / (ms * 1e-3) / 1e12, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
-            'traffic_unit': 'HBM bytes per launch (PMC, corrected); algorithmic = 25.2e6',
-            'us_per_launch': round(ms * 1e3, 2), 'us_per_launch_runs': [round(v * 1e3, 2) for v in runs],
-            'algorithmic_gflop_per_launch': round(flops / 1e9, 3)}
+    members, hbm = [], []
+    tot_f = tot_t = 0.0
+    dominant = None
+    for C, H, W in CONV_FAMILY:
+        rows = B * H * W
+        x = torch.randn(B, H, W, C, device=device)
+        w = torch.randn(C, 3, 3, C, device=device) * (9 * C) ** -0.5
+        y, c2, dx = torch.empty_like(x), torch.randn_like(x), torch.empty_like(x)
+        dy = torch.randn_like(x)
+        dw = torch.zeros_like(w)
+        g, b, rm = (torch.randn(C, device=device) for _ in range(3))
+        rv = torch.rand(C, device=device) + 0.5
+        mean, invstd = torch.zeros(C, device=device), torch.ones(C, device=device)
+        slots = torch.zeros(2 * C * 64, device=device, dtype=torch.float64)
+        nbg = ctypes.c_int(0)
+        geom = (B, H, W, C, H, W, C, 3, 3, 1, 1)
+        flops = 2.0 * rows * C * C * 9
+
+        def reset():
+            nbg.value = 0
+        runs = {
+            'fwd+BN-sums': lambda: (reset(), call('advmix_conv_fwd_ex', P(x), P(w), None, P(y), *geom, None, None, None,
+                                                  None, 0.0, None, 0, P(slots), ctypes.byref(nbg), st)),
+            'fwd+BN-eval+ReLU': lambda: call('advmix_conv_fwd_ex', P(x), P(w), None, P(y), *geom, P(g), P(b), P(rm), P(rv),
+                                             1e-5, None, 1, None, None, st),
+            'dgrad+BN-bwd-sums': lambda: (reset(), call('advmix_conv_tr_w_bnb', P(dy), P(w), P(c2), P(dx), *geom, P(y),
+                                                        P(c2), P(mean), P(invstd), 1, P(slots), ctypes.byref(nbg), st)),
+            'wgrad': lambda: call('advmix_conv_wgrad', P(dy), P(x), P(dw), B, H, W, C, H, W, C, 3, 3, 1, 1, st),
+        }
+        for kind, run in runs.items():
+            ms, rr = _event_time(run, iters)
+            wgt = KIND_WEIGHT[kind]
+            tot_f += wgt * flops
+            tot_t += wgt * ms * 1e-3
+            m = {'kernel': '3x3 s1 %d->%d @%dx%d %s' % (C, C, H, W, kind), 'us_per_launch': round(ms * 1e3, 2),
+                 'tflops': round(flops / (ms * 1e-3) / 1e12, 2), 'frac': round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                 'launches_per_step_weight': wgt}
+            members.append(m)
+            if C == 32 and kind == 'fwd+BN-sums':
+                dominant = dict(m, us_per_launch_runs=[round(v * 1e3, 2) for v in rr],
+                                algorithmic_gflop_per_launch=round(flops / 1e9, 3))
+        if C in (32, 128):                                  # the two BatchNorm kernels left on the train path
+            res = torch.randn_like(x)
+            nbt = torch.zeros((), dtype=torch.int64, device=device)
+            call('advmix_conv_fwd_ex', P(x), P(w), None, P(c2), *geom, None, None, None, None, 0.0, None, 0, P(slots),
+                 ctypes.byref(nbg), st)
+            ns = nbg.value
+            for name, run, passes in (
+                    ('norm_apply_slots (BN + residual + ReLU, statistics from %d slots)' % ns,
+                     lambda: call('advmix_norm_apply_slots', P(c2), P(slots), ns, rows, C, 1e-5, P(g), P(b), P(res), P(y), 1,
+                                  P(mean), P(invstd), P(rm), P(rv), P(nbt), 0.1, st), 3),
+                    ('norm_bwd_apply_slots (BN backward from the slot sums)',
+                     lambda: call('advmix_norm_bwd_apply_slots', P(dy), P(c2), P(mean), P(invstd), P(g), P(slots), ns, rows,
+                                  C, P(dx), None, None, st), 3)):
+                ms, _ = _event_time(run, iters)
+                nbytes = passes * rows * C * 4
+                hbm.append({'kernel': '%s rows %d x C %d' % (name, rows, C), 'us_per_launch': round(ms * 1e3, 2),
+                            'algorithmic_bytes_per_launch': nbytes, 'achieved_GBps': round(nbytes / (ms * 1e-3) / 1e9, 1),
+                            'frac_of_8TBps': round(nbytes / (ms * 1e-3) / 1e9 / 8000.0, 4)})
+    traffic, src = _latest_pmc() if B == 32 else (None, None)
+    agg = tot_f / tot_t / 1e12
+    algo_bytes = 2 * B * 64 * 48 * 32 * 4 + 9 * 32 * 32 * 4
+    return {'bound': 'mfma',
+            'kernel': 'conv_direct / conv_wgrad family: 3x3 s1 C->C at the four HRNet-W32 branch resolutions x '
+                      '{fwd+BN sums, fwd+BN eval, dgrad+BN-bwd sums, wgrad}, launch-count weighted',
+            'achieved': round(agg, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(agg / FP32_MFMA_PEAK_TFLOPS, 4),
+            'traffic': traffic, 'traffic_unit': 'HBM bytes per launch of the dominant member (rocprofv3 PMC, corrected)',
+            'traffic_source': src, 'traffic_algorithmic_bytes': algo_bytes,
+            'traffic_ratio': round(traffic / algo_bytes, 3) if traffic else None,
+            'dominant': dominant, 'members': members, 'hbm_kernels': hbm}
 
 
 def time_eval_conv(B, device, iters=100):
@@ -359,7 +428,7 @@ def bench_nms(a, device, rank, world):
     return line
 
 
-def cpu_baseline(workload, budget_s=25.0, hard_timeout_s=150.0, path='train'):
+def cpu_baseline(workload, budget_s=25.0, hard_timeout_s=240.0, path="train"):
     """The CPU oracle's AdvMix step on this host (bounded sample: B=4, 1 warm-up + a few timed
     steps), in a CPU-only child process with a hard timeout so the bench always finishes."""
     import subprocess
@@ -380,14 +449,17 @@ def cpu_baseline(workload, budget_s=25.0, hard_timeout_s=150.0, path='train'):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)          # discard >= 10 warm-up steps, average >= 50
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='hrnet_w32', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=32, help='images per GPU (TRAIN.BATCH_SIZE_PER_GPU)')
     ap.add_argument('--exec', dest='exec_mode', default='graph', choices=['graph', 'eager'])
     ap.add_argument('--path', default='train', choices=['train', 'validate', 'inputs', 'nms'],
                     help='train = the headline AdvMix step; validate = the validate() batch body (SURVEY 8 f1); '
                          'inputs = the device input pipeline (SURVEY 8 f2)')
+    ap.add_argument('--through-loop', action='store_true',
+                    help='time core.function.train_advmix itself (the drop-in entry point): pinned host batches, H2D copies, '
+                         'graph replay, loss.item(), accuracy - the reference loop body lib/core/function.py:107-197')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     a = ap.parse_args()
@@ -428,34 +500,78 @@ def main():
     args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
     views, tgt, tw = synth(a.batch, J, H, W, device, 1234 + rank)
     sync = GradSync(force=force_sync) if (world > 1 or force_sync) else None
+    if sync is not None:
+        sync.broadcast_state([D, G, T], [optD, optG])          # every replica starts from rank 0's weights / Adam state
 
-    if a.exec_mode == 'graph':
-        runner = AdvMixGraphRunner(args, D, G, T, crit, optD, optG, views, tgt, tw, sync)
+    loop_note = None
+    if a.through_loop:
+        # The drop-in entry point itself: train_advmix over a loader of pinned HOST batches (DataLoader(pin_memory=True)
+        # in tools/train.py:295-301), i.e. H2D copies, capture on the first batch, replay, loss.item(), accuracy, meters.
+        import logging
+        from advmix_amd.core import function as F_
+        logging.getLogger(F_.__name__).setLevel(logging.WARNING)
+        cfg['PRINT_FREQ'] = 10 ** 9
+        host = []
+        for k in range(4):                                  # four distinct pinned batches, cycled
+            v, t, w = synth(a.batch, J, H, W, torch.device('cpu'), 1234 + rank + 100 * k)
+            host.append(([x.pin_memory() for x in v], [t.pin_memory()] * 3, [w.pin_memory()] * 3, [{}, {}, {}]))
 
-        def one_step():
-            loss_D, out = runner.step()
-            lv = loss_D.item()                                         # function.py:167
-            _, avg_acc, cnt, _ = accuracy(out, runner.target)          # function.py:168
-            return lv, avg_acc
+        class Loader:
+            def __init__(self, n):
+                self.n = n
+
+            def __len__(self):
+                return self.n
+
+            def __iter__(self):
+                return (host[i % len(host)] for i in range(self.n))
+
+        seen = {}
+
+        def run_loop(n):
+            wd = {'writer': types.SimpleNamespace(add_scalar=lambda k, v, s: seen.__setitem__(k, float(v))),
+                  'train_global_steps': 0}
+            F_.train_advmix(cfg, args, Loader(n), [D, G, T], crit, [optD, optG], 0, '', '', wd, sync)
+        run_loop(max(a.warmup, 3))                          # capture + warm-up
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_loop(a.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        lv, acc = seen.get('train_loss', float('nan')), seen.get('train_acc', 0.0)
+        loop_note = 'core.function.train_advmix over pinned host batches (H2D inside the timed region)'
     else:
-        def one_step():
-            loss_D, out = advmix_step(args, D, G, T, crit, optD, optG, views, tgt, tw, sync)
-            lv = loss_D.item()
-            _, avg_acc, cnt, _ = accuracy(out, tgt)
-            return lv, avg_acc
+        if a.exec_mode == 'graph':
+            runner = AdvMixGraphRunner(args, D, G, T, crit, optD, optG, views, tgt, tw, sync)
 
-    for _ in range(a.warmup):
-        one_step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        lv, acc = one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+            def one_step():
+                loss_D, out = runner.step()
+                lv = loss_D.item()                                         # function.py:167
+                _, avg_acc, cnt, _ = accuracy(out, runner.target)          # function.py:168
+                return lv, avg_acc
+        else:
+            def one_step():
+                loss_D, out = advmix_step(args, D, G, T, crit, optD, optG, views, tgt, tw, sync)
+                lv = loss_D.item()
+                _, avg_acc, cnt, _ = accuracy(out, tgt)
+                return lv, avg_acc
+
+        for _ in range(a.warmup):
+            one_step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            lv, acc = one_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -476,13 +592,14 @@ def main():
             'config': {'workload': '%s_%dx%d_advmix' % (a.workload, H, W), 'batch_per_gpu': a.batch,
                        'global_batch': a.batch * world, 'generator': 'UnetGenerator(9,3,%d)' % downs,
                        'parallelism': 'dp%d' % world, 'exec': 'hipgraph' if a.exec_mode == 'graph' else 'eager',
+                       'entry': loop_note or 'graph.AdvMixGraphRunner.step (inputs resident in HBM)',
                        'step_gflop_per_image': gflop_img},
             'step_tflops_per_gpu': round(value / world * gflop_img / 1e3, 2),
             'step_frac_of_fp32_mfma_peak': round(value / world * gflop_img / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
             'last_loss_D': round(lv, 6),
         }
         if not a.no_roofline:
-            line['roofline'] = time_dominant_kernel(a.batch, device)
+            line['roofline'] = time_conv_family(a.batch, device)
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(a.workload)
 

@@ -484,6 +484,63 @@ def test_train_advmix_loop_first_iteration_matches_reference():
     assert int(mD.state_dict()['bn1.num_batches_tracked']) == 1 + 2 * 3   # calibration + two forwards per batch
 
 
+@pytest.mark.parametrize('graph', [True, False])
+def test_loops_graph_path_and_eager_path_match_reference(graph):
+    """train_advmix / train capture the step on the first batch and replay it (core.function.GRAPH_EXEC); a batch of
+    another shape (the ragged last batch) runs eagerly.  Both modes: first-iteration losses equal the numbers the REAL
+    loops recorded, BatchNorm counters advance exactly twice (once) per batch - no trace of the capture warm-up."""
+    from oracle.synth import synth_batch
+    from advmix_amd.core import function as F_
+    g = gold_npz('advmix_steps.npz')
+    old = F_.GRAPH_EXEC
+    F_.GRAPH_EXEC = graph
+    F_.release_graphs()
+    try:
+        cfg, mD, mG, mT, crit, optD, optG, (B, J, H, W) = _tiny_setup()
+        cfg['PRINT_FREQ'] = 1
+        batches = []
+        for it in range(3):
+            v, t, w = synth_batch('hrnet_tiny.it%d' % it, B, J, H, W)
+            batches.append((v, [t, t, t], [w, w, w], [{}, {}, {}]))
+        v, t, w = synth_batch('hrnet_tiny.it0', B, J, H, W)                 # ragged last batch: B - 1 samples
+        batches.append(([x[:1].clone() for x in v], [t[:1]] * 3, [w[:1]] * 3, [{}, {}, {}]))
+        seen = []
+        wd = {'writer': types.SimpleNamespace(add_scalar=lambda k, v_, s: seen.append((k, float(v_)))),
+              'train_global_steps': 0}
+        args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
+        F_.train_advmix(cfg, args, batches, [mD, mG, mT], crit, [optD, optG], 0, '/tmp', '/tmp', wd)
+        assert len(F_._RUNNERS) == (1 if graph else 0)
+        want = g['hrnet_tiny.losses'][0]
+        losses = [v_ for k, v_ in seen if k == 'train_loss']
+        assert len(losses) == 4 and all(np.isfinite(losses))
+        assert_close('first loss_D', [losses[0]], [0.9 * want[0] + 0.1 * want[1]])
+        assert int(mD.state_dict()['bn1.num_batches_tracked']) == 1 + 2 * 4
+        assert all(not p.requires_grad for p in mD.parameters())
+
+        # the plain loop (function.py:30-95)
+        from helpers import build_states
+        from oracle.posenet import calibrate
+        from oracle import configs
+        D, T, G = build_states('pose_hrnet', configs.HRNET_TINY, J, salt=20)
+        calibrate('pose_hrnet', D, synth_batch('hrnet_tiny.calib', B, J, H, W)[0][0], configs.HRNET_TINY)
+        cfg2, pD, _, _ = product_models('pose_hrnet', configs.HRNET_TINY, J, D, T, G)
+        cfg2['PRINT_FREQ'] = 1
+        from advmix_amd.utils.utils import get_optimizer
+        opt = get_optimizer(cfg2, pD)
+        pb = []
+        for it in range(2):
+            v, t, w = synth_batch('hrnet_tiny.plain%d' % it, B, J, H, W)
+            pb.append((v[0], [t, t], w, {}))
+        seen.clear()
+        F_.train(cfg2, None, pb, pD, crit, opt, 0, '/tmp', '/tmp', wd)
+        pl = [v_ for k, v_ in seen if k == 'train_loss']
+        assert_close('plain first loss', [pl[0]], [g['hrnet_tiny.plain_losses'][0]])
+        assert int(pD.state_dict()['bn1.num_batches_tracked']) == 1 + 2
+    finally:
+        F_.GRAPH_EXEC = old
+        F_.release_graphs()
+
+
 def test_graph_runner_matches_eager_step_from_the_same_state():
     """AdvMixGraphRunner (three HIP graphs, static batch buffers, load_batch) against the eager advmix_step.
     Two runs cannot be compared across several Adam updates - eager itself is not reproducible there: Adam's

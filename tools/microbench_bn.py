@@ -12,7 +12,7 @@ import torch
 from advmix_amd._lib import call, lib
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-SLOTS = [int(v) for v in sys.argv[2:]] or [16, 32, 64]
+SLOTS = [int(v) for v in sys.argv[2:]] or [0, 16, 64]     # 0 = the kernel's own choice
 dev = torch.device('cuda:0')
 P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -82,14 +82,17 @@ for (C, H, W) in ((32, 64, 48), (64, 32, 24), (128, 16, 12), (256, 8, 6)):
                  P(ws), st)
             call('advmix_conv_tr_w_add', P(dc), P(w), P(res), P(dx), *geom, st)
 
+        conv_stats()
+        nsu = nbg.value                                       # slots actually used
+
         def bwd_new():
             nbg.value = ns
-            call('advmix_norm_bwd_apply_slots', P(dy), P(c), P(mean), P(invstd), P(g), P(slots), ns, rows, C, P(dc), P(dg),
+            call('advmix_norm_bwd_apply_slots', P(dy), P(c), P(mean), P(invstd), P(g), P(slots), nsu, rows, C, P(dc), P(dg),
                  P(db), st)
             call('advmix_conv_tr_w_bnb', P(dc), P(w), P(res), P(dx), *geom, P(y), P(c), P(mean), P(invstd), 1, P(slots),
                  ctypes.byref(nbg), st)
-        out.append('ns %2d: conv+sums %.1f | fwd old %.1f new %.1f | bwd old %.1f new %.1f' % (
-            ns, timeit(conv_stats), timeit(fwd_old), timeit(fwd_new), timeit(bwd_old), timeit(bwd_new)))
+        out.append('ns %2d(%2d): conv+sums %.1f | fwd old %.1f new %.1f | bwd old %.1f new %.1f' % (
+            ns, nsu, timeit(conv_stats), timeit(fwd_old), timeit(fwd_new), timeit(bwd_old), timeit(bwd_new)))
     print('\n   '.join(out), flush=True)
     apply_bytes = rows * C * 4 * 3
     t = timeit(lambda: call('advmix_norm_apply', P(c), P(mean), P(invstd), P(g), P(b), P(res), P(y), C, 1, rows, C, 1, st))

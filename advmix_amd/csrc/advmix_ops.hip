@@ -3,6 +3,7 @@
 // Reference sites: lib/core/function.py:137-144; lib/core/loss.py:25-65;
 // lib/core/inference.py:22-49; lib/utils/utils.py:89-92 (torch.optim.Adam defaults).
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 AdvmixOpts& advmix_opts() {
     static AdvmixOpts o = [] {
-        AdvmixOpts d{1, 1, 1, 0};
+        AdvmixOpts d{1, 1, 1, 0, 0};
         const char* e;
         if ((e = getenv("ADVMIX_CONV")) && e[0] == 'i') d.direct = 0;
         if ((e = getenv("ADVMIX_WGRAD"))) d.wgrad_direct = e[0] != '0';
@@ -177,6 +178,21 @@ AdvmixOpts& advmix_opts() {
         return d;
     }();
     return o;
+}
+
+void advmix_trace_launch(const char* kernel, dim3 grid, const char* kind, int N, int Hi, int Wi, int Ci, int Ho, int Wo,
+                         int Co, int R, int S, int stride, double flops) {
+    if (!advmix_opts().trace_shapes) return;
+    static FILE* f = [] {
+        const char* path = getenv("ADVMIX_TRACE_SHAPES");
+        FILE* h = path ? fopen(path, "w") : nullptr;
+        if (h) fprintf(h, "kernel,grid_x,grid_y,grid_z,kind,N,Hi,Wi,Ci,Ho,Wo,Co,R,S,stride,flops\n");
+        return h;
+    }();
+    if (!f) return;
+    fprintf(f, "\"%s\",%u,%u,%u,%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.0f\n", kernel, grid.x, grid.y, grid.z, kind, N, Hi, Wi,
+            Ci, Ho, Wo, Co, R, S, stride, flops);
+    fflush(f);
 }
 
 extern "C" int advmix_version(void) { return 1; }
@@ -188,6 +204,7 @@ extern "C" int advmix_set_option(const char* name, int value) {
     else if (!strcmp(name, "wgrad_direct")) o.wgrad_direct = value;
     else if (!strcmp(name, "ksplit_wg")) o.ksplit_wg = value;
     else if (!strcmp(name, "stat_slots")) o.stat_slots = value;
+    else if (!strcmp(name, "trace_shapes")) o.trace_shapes = value;
     else return ADVMIX_EINVAL;
     return ADVMIX_OK;
 }

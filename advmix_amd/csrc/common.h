@@ -64,9 +64,16 @@ struct AdvmixOpts {
     int direct;            // 1: conv_direct allowed, 0: first-generation conv_igemm only
     int wgrad_direct;      // 1: register-fragment wgrad kernel allowed
     int ksplit_wg;         // 1: layers with too few tiles split K inside the workgroup (fused epilogue kept), 0: across the grid
+    int trace_shapes;      // 1: log every MFMA launch's shape (advmix_trace_launch)
     int stat_slots;        // fp64 slots per channel the statistics epilogues fold their workgroup sums onto (power of 2 <= 64; 0 = by grid size)
 };
 AdvmixOpts& advmix_opts();
+
+// Measurement aid (off unless advmix_set_option("trace_shapes", 1) with ADVMIX_TRACE_SHAPES=<file> in the environment):
+// one CSV line per MFMA launch - kernel template, grid, problem shape, algorithmic FLOPs - so that a rocprofv3 kernel
+// trace, which groups by template only, can be split per SHAPE (tools/kernel_shapes.py joins on kernel + grid).
+void advmix_trace_launch(const char* kernel, dim3 grid, const char* kind, int N, int Hi, int Wi, int Ci, int Ho, int Wo,
+                         int Co, int R, int S, int stride, double flops);
 
 // wgrad_direct.hip: both operands loaded in fragment layout; -1 = not eligible
 int advmix_wgrad_direct_dispatch(const float* a, const float* b, float* dw, int N, int Ha, int Wa, int Ca, int Hb,

@@ -20,6 +20,7 @@
 // transposed gather (Conv2d dgrad / ConvTranspose2d fwd), exactly as conv_mfma.hip.
 #include "common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace direct {
 
@@ -55,6 +56,9 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
     return __builtin_bit_cast(f32x4, v);
 }
 
+#ifndef CD_STORE_AUX
+#define CD_STORE_AUX 0        /* cache policy of the epilogue stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1); see tools/build_variant.sh */
+#endif
 constexpr unsigned OOB = 0x80000000u;   // >= any buffer size we accept -> load returns 0
 
 // BT: the weight operand is given k-major, w[Ck][R][S][Cn] (a Conv2d's own [Co][R][S][Ci] seen from its
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
                     }
                     if (valid) { s1 += v; s2 += v * ((cv - bb_mu) * bb_is); }
                 }
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, boff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, boff, 0, CD_STORE_AUX);
             }
         }
         if (stats) {                                        // wave-uniform branch: every lane shuffles
@@ -504,6 +508,15 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
     do {                                                                                          \
         dim3 g(cdiv(Mmax, 32 * TM_ * WM_), cdiv(p.Co, 32 * TN_ * WN_), phases * p.nsplit);        \
         hipLaunchKernelGGL((conv_direct<TM_, TN_, WM_, WN_, KC, MODE, SP_, BT, (EPI && !SP_)>), g, dim3(256), 0, st, p); \
+        if (advmix_opts().trace_shapes) {                                                         \
+            char nm[96];                                                                          \
+            snprintf(nm, sizeof nm, "conv_direct<%d, %d, %d, %d, %d, %d, %s, %s, %s>", TM_, TN_, WM_, WN_, KC, MODE, \
+                     SP_ ? "true" : "false", BT ? "true" : "false", (EPI && !SP_) ? "true" : "false"); \
+            advmix_trace_launch(nm, g, MODE == 0 ? (p.stats ? "fwd+sums" : (p.bn_gamma ? "fwd+bn_eval" : "fwd")) \
+                                                 : (p.bnb_c ? "dgrad+bnb" : "dgrad"),              \
+                                p.N, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co, p.R, p.S, p.stride,      \
+                                2.0 * p.N * (MODE == 0 ? (double)p.Ho * p.Wo : (double)p.Hi * p.Wi) * p.Co * p.Ci * p.R * p.S); \
+        }                                                                                         \
     } while (0)
     p.nsplit = 1;
     switch (pick_cfg(Mmax, p.Co, phases, nch, &ns)) {

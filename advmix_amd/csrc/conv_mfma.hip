@@ -15,6 +15,7 @@
 // Replaces (reference): nn.Conv2d / nn.ConvTranspose2d in lib/models/pose_hrnet.py,
 // lib/models/pose_resnet.py, lib/models/Unet_generator.py (see include/advmix_hip.h).
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -499,6 +500,12 @@ extern "C" int advmix_conv_wgrad(const float* a, const float* b, float* dw,
         p.chunk = (int)chunk;                                                             \
         dim3 g(cdiv(Ca, 32 * WM_), cdiv(Ntot, 32 * WN_), cdiv(P, chunk));                 \
         hipLaunchKernelGGL((conv_wgrad<WM_, WN_, V_>), g, dim3(256), 0, st, p);           \
+        if (advmix_opts().trace_shapes) {                                                 \
+            char nm[64];                                                                  \
+            snprintf(nm, sizeof nm, "conv_wgrad<%d, %d, %s>", WM_, WN_, V_ ? "true" : "false"); \
+            advmix_trace_launch(nm, g, "wgrad", N, Hb, Wb, Cb, Ha, Wa, Ca, R, S, stride,  \
+                                2.0 * N * (double)Ha * Wa * Ca * Cb * R * S);             \
+        }                                                                                 \
     } while (0)
     if (Ca <= 32) {
         if (vec) LAUNCHW(1, 4, true); else LAUNCHW(1, 4, false);

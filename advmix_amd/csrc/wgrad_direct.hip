@@ -12,6 +12,7 @@
 // pixel slice; the four partial tiles are reduced through LDS and added to dW with ONE set of fp32
 // atomics (the atomic pipe runs at ~1.3 TB/s chip-wide, so partial sums must be merged on chip).
 #include "common.h"
+#include <stdio.h>
 
 namespace wgd {
 
@@ -160,6 +161,12 @@ int launch(WP& p, hipStream_t st) {
     p.chunk = (int)chunk;
     dim3 g(tiles, cdiv(P, chunk));
     hipLaunchKernelGGL((wgrad_direct<TM, TN>), g, dim3(256), lds, st, p);
+    if (advmix_opts().trace_shapes) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "wgrad_direct<%d, %d>", TM, TN);
+        advmix_trace_launch(nm, g, "wgrad", p.N, p.Hb, p.Wb, p.Cb, p.Ha, p.Wa, p.Ca, p.R, p.S, p.stride,
+                            2.0 * p.N * (double)p.Ha * p.Wa * p.Ca * p.Cb * p.R * p.S);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ADVMIX_OK : ADVMIX_ELAUNCH;
 }

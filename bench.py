@@ -460,9 +460,14 @@ def main():
     ap.add_argument('--through-loop', action='store_true',
                     help='time core.function.train_advmix itself (the drop-in entry point): pinned host batches, H2D copies, '
                          'graph replay, loss.item(), accuracy - the reference loop body lib/core/function.py:107-197')
+    ap.add_argument('--dump-shapes', default=None, metavar='CSV',
+                    help='log kernel template, grid, shape and FLOPs of every MFMA launch of ONE eager step (for '
+                         'tools/kernel_shapes.py) and exit')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     a = ap.parse_args()
+    if a.dump_shapes:
+        os.environ['ADVMIX_TRACE_SHAPES'] = os.path.abspath(a.dump_shapes)
 
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
@@ -503,6 +508,16 @@ def main():
     if sync is not None:
         sync.broadcast_state([D, G, T], [optD, optG])          # every replica starts from rank 0's weights / Adam state
 
+    if a.dump_shapes:
+        from advmix_amd import ops as _ops
+        advmix_step(args, D, G, T, crit, optD, optG, views, tgt, tw, sync)          # lazy buffers first
+        torch.cuda.synchronize()
+        _ops.set_option('trace_shapes', 1)
+        advmix_step(args, D, G, T, crit, optD, optG, views, tgt, tw, sync)
+        torch.cuda.synchronize()
+        _ops.set_option('trace_shapes', 0)
+        print('wrote', a.dump_shapes)
+        return
     loop_note = None
     if a.through_loop:
         # The drop-in entry point itself: train_advmix over a loader of pinned HOST batches (DataLoader(pin_memory=True)

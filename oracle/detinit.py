@@ -30,6 +30,8 @@ def fill_state_dict(spec, salt=0, gain=1.0):
     non-degenerate init: conv/deconv weights fan-out Kaiming-like, BN affine
     near (1, 0), running stats near (0, 1), biases small."""
     out = {}
+    spec = list(spec)
+    hrnet = any(n.startswith('stage2.') for n, _ in spec)      # (its head sees un-normalised fuse sums: larger inputs)
     for name, shape in spec:
         shape = tuple(shape)
         leaf = name.rsplit('.', 1)[-1]
@@ -43,7 +45,14 @@ def fill_state_dict(spec, salt=0, gain=1.0):
             fan = shape[0] * shape[2] * shape[3]
             if 'deconv' in name or _is_transposed(name):
                 fan = shape[1] * shape[2] * shape[3] / 4.0
-            out[name] = normal(name, shape, gain * (2.0 / fan) ** 0.5, salt=salt)
+            std = gain * (2.0 / fan) ** 0.5
+            if name.startswith('final_layer'):
+                # the head: fan-IN scaling, so that the heat-maps of the seeded networks are O(1) like real ones and
+                # the north-star bound (1e-3 abs + 1e-3 rel per element) is meaningful.  (Fan-out scaling over the 17
+                # joint channels gave heat-maps of magnitude 20-90, where an ABSOLUTE 1e-3 is 1e-5 of the scale:
+                # below what any fp32 evaluation of a 100-layer network reproduces.)
+                std = (0.045 if hrnet else 0.25) * (1.0 / (shape[1] * shape[2] * shape[3])) ** 0.5
+            out[name] = normal(name, shape, std, salt=salt)
         elif leaf == 'weight':          # BN gamma
             out[name] = normal(name, shape, 0.1, 1.0, salt=salt)
         else:                           # biases / BN beta

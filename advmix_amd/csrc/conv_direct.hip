@@ -56,8 +56,14 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
     return __builtin_bit_cast(f32x4, v);
 }
 
+// Cache policy of the epilogue stores (gfx940+ aux bits: 1 = sc0, 2 = nt, 16 = sc1).  sc1 = write-through: the output
+// leaves the XCD's L2 while the kernel still runs instead of being flushed at the kernel boundary (the 8 per-XCD L2s
+// are not coherent, so every boundary writes back what the predecessor left dirty: ~B / 6 TB/s for B dirty bytes).
+// Measured on the dominant conv (12.6 MB output; tools/build_variant.sh, gpurun_out/r2e/store_policy.log):
+// launch to launch 25.3 -> 23.7 us (+BN sums), 23.7 -> 22.4 us (plain); nt 24.5 / 22.8; the 4-stream aggregate
+// (95.5 TFLOP/s) and the step (536 -> 540 images/s) barely move - concurrent lanes already hide the boundary.
 #ifndef CD_STORE_AUX
-#define CD_STORE_AUX 0        /* cache policy of the epilogue stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1); see tools/build_variant.sh */
+#define CD_STORE_AUX 16
 #endif
 constexpr unsigned OOB = 0x80000000u;   // >= any buffer size we accept -> load returns 0
 

@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 from helpers import CASES, DOWNS, gold_files, gold_json, gold_npz, build_states, checksum_close   # noqa: E402
 
 REPORT = {}      # worst err / bound ratio per checked quantity (printed by the tests)
-GRAD_MEDIAN_TOL = 0.15   # median per-tensor D-gradient error vs the fp32 oracle after a device-side update
+GRAD_MEDIAN_TOL = 0.12   # median per-tensor D-gradient error vs the fp32 oracle after a device-side update: 3 x the largest
+                         # value observed over all cases (3.9e-2, resnet50 it 0; B = 2 nets are ill-conditioned)
 from smoke_step import (product_models, assert_close, run_smoke, assert_grads,      # noqa: E402
                         pull_params, match_fraction)
 
@@ -142,9 +143,11 @@ def test_advmix_and_plain_steps_vs_oracle_and_golden(tag):
         loss_D, out = advmix_step(args, mD, mG, mT, crit, optD, optG,
                                   [x.cuda().contiguous() for x in v], t.cuda(), w.cuda())
 
-        # Adam step 1 is lr*sign(g): identical to 1e-6 except where g is rounding noise; later
-        # steps are lr*m/sqrt(v): continuous in g, so they agree to (grad rel. error) * lr
-        atol = 1e-6 if it == 0 else 1e-4
+        # Adam step 1 is lr*g/(|g| + 1e-8): identical to ~1e-6 where |g| >> eps, and sensitive to the gradient's own
+        # rounding error where |g| ~ eps (the O(1)-heat-map fixtures have many such elements: d(update) =
+        # lr * eps/(|g|+eps) * (dg/g) ~ 1e-5 at |g| = 1e-8, dg/g = 1e-2); later steps are lr*m/sqrt(v): continuous in
+        # g, so they agree to (grad rel. error) * lr
+        atol = 1e-5 if it == 0 else 1e-4
 
         def force():
             fracs.append(match_fraction(mD, D, atol))     # oracle's own update vs the device's
@@ -238,12 +241,15 @@ def test_network_parity_at_the_benchmarked_batch():
     del mD, mG, mT, ye, yt
 
     ga = gold_npz('b32_advmix_steps.npz')
+    from oracle.posenet import trainable
+    from oracle.step import Adam, advmix_step as ostep
     D, T, G = build_states(net, extra, J, salt=10)
     calib = synth_batch(tag + '.calib', B, J, H, W)[0][0]
     calibrate(net, T, calib, extra)
     calibrate(net, D, calib, extra)
     cfg, mD, mG, mT = product_models(net, extra, J, D, T, G)
     optD, optG = get_optimizer(cfg, mD), get_optimizer(cfg, mG)
+    oD, oG = Adam(D, trainable(D)), Adam(G, list(G))
     mD.train(); mG.train(); mT.eval()
     args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
     v, t, w = synth_batch(tag + '.it0', B, J, H, W)
@@ -251,12 +257,12 @@ def test_network_parity_at_the_benchmarked_batch():
                               [x.cuda().contiguous() for x in v], t.cuda(), w.cuda())
     want = ga[tag + '.losses'][0]
     assert_close('loss_D vs golden', [float(loss_D)], [0.9 * want[0] + 0.1 * want[1]], report=rep)
-    # out2 = D(tmp) AFTER the first Adam update (lr * sign(g) per element: implementation-dependent where g is
-    # rounding noise, see test_advmix_and_plain_steps_vs_oracle_and_golden) -> a loose bound on the heat-maps
-    o2 = strided(out.cpu().contiguous(), 2048)
-    dev = float(np.abs(o2 - ga[tag + '.out2.it0']).max()) / float(np.abs(ga[tag + '.out2.it0']).max())
-    print(tag, 'worst err/bound ratios', {k: round(x, 3) for k, x in rep.items()}, 'out2 after update: rel dev %.3e' % dev)
-    assert dev <= 0.05, dev
+    # out2 = D(tmp) AFTER the first Adam update: teacher-forced against the oracle (it adopts the device's updated D,
+    # see test_advmix_and_plain_steps_vs_oracle_and_golden), then the strict element-wise bound applies
+    ref = ostep(net, extra, D, G, T, oD, oG, v, t, w, alpha=0.1, after_D_step=lambda: pull_params(mD, D))
+    assert_close('loss_D', loss_D, ref['loss_D'], report=rep)
+    assert_close('out2', out, ref['out2'], report=rep)
+    print(tag, 'worst err/bound ratios', {k: round(x, 3) for k, x in rep.items()})
 
 
 def test_smoke_entry():
@@ -433,13 +439,13 @@ def test_launch_chains_equal_the_level_schedule(monkeypatch):
     assert a[5] < b[5] / 3                                  # far fewer joins
     for i in (0, 2):
         assert float((a[i] - b[i]).abs().max()) <= 1e-5 * max(1.0, float(b[i].abs().max()))
-    for k in a[4]:                                          # BN running statistics
-        assert float((a[4][k].double() - b[4][k].double()).abs().max()) <= 1e-5 * max(1.0, float(b[4][k].double().abs().max())), k
+    for k in a[4]:                                          # BN running statistics (the deepest ones are variances over 8 rows)
+        assert float((a[4][k].double() - b[4][k].double()).abs().max()) <= 1e-4 * max(1.0, float(b[4][k].double().abs().max())), k
     scale = float(b[1].abs().max())
     assert float((a[1] - b[1]).abs().max()) <= 1e-3 * scale    # rounding differences amplified through train-mode BN
     for k in a[3]:
         s = float(b[3][k].abs().max()) + 1e-12
-        assert float((a[3][k] - b[3][k]).abs().max()) <= 1e-3 * s + 1e-9, k
+        assert float((a[3][k] - b[3][k]).abs().max()) <= 3e-3 * s + 1e-9, k
 
 
 def _tiny_setup(salt=10, lr=1e-3):

@@ -84,7 +84,9 @@ struct MS {
 };
 
 template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT, bool EPI>
-__global__ __launch_bounds__(256) void conv_direct(ConvD p) {
+// (min 3 waves / SIMD for the BatchNorm-backward variants: left free, the register allocator spreads their three
+// prefetched epilogue operands over 254 VGPRs = one wave per SIMD; the other variants keep their 52-108)
+__global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(ConvD p) {
     // WK waves of the workgroup split K BETWEEN THEM (WM x WN x WK = 4 waves): the low-resolution layers have too
     // few output tiles to fill the chip; instead of slicing K across workgroups (SPLIT: zero-fill + fp32 atomics,
     // no fused epilogue) a 32x32 tile is computed by four waves that each take every fourth K chunk and meet
@@ -197,6 +199,54 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
     __syncthreads();                                       // taptab visible
+
+    // ---- epilogue geometry, and its operands fetched NOW ------------------------------------------------------------
+    constexpr int RSL = MS::NR / WK;                       // accumulator registers a wave finishes itself
+    static_assert(MS::NR % WK == 0, "epilogue slices");
+    const int r_lo = WK > 1 ? wk * RSL : 0;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.y), 0, p.ybytes,
+                                                                        0x00020000);
+    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bnb_c ? p.bnb_c : p.y), 0, p.ybytes,
+                                                                        0x00020000);
+    const __amdgpu_buffer_rsrc_t yyr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bnb_y ? p.bnb_y : p.y), 0, p.ybytes,
+                                                                         0x00020000);
+    // element offset of accumulator register r of tile (t, u) in the output (the host checks that y fits 2^31 bytes)
+    int e_l31 = l31, e_lh = lh;                            // (made opaque again before the epilogue, see there)
+    auto elem_off = [&](int t, int u, int r, bool& valid) -> int {
+        const int col = n0 + wn * TN * 32 + u * MR + e_l31;
+        int m = m0 + wm * TM * 32 + t * MR + MS::row(r, e_lh);
+        valid = m < Mp && col < p.Co;
+        if (!valid) m = 0;
+        if (MODE == 0 || p.stride == 1)                    // (stride 1: one phase, rows are already output pixels -
+            return m * p.Co + col;                         //  no two integer divisions per accumulator register)
+        const int n = m / (Hp * Wp);
+        const int rem = m - n * (Hp * Wp);
+        const int hi_ = rem / Wp, wi_ = rem - hi_ * Wp;
+        return ((n * p.Ho + rh + hi_ * p.stride) * p.Wo + rw + wi_ * p.stride) * p.Co + col;
+    };
+    // The epilogue's READ operands - the residual (forward) / the addend (input gradient), and for the BatchNorm-
+    // backward epilogue the producer's c and y - are requested before the main loop and sit in registers until it ends.
+    // Loaded in the epilogue they were a pure memory phase with the matrix pipe idle, every wave of the launch at once:
+    // 3x3 32->32 @64x48 input gradient 23.5 us, + addend 28.0, + BatchNorm-backward sums 36.1.  Single-tile waves only
+    // (16 registers per operand).
+    constexpr bool PRE = RM * RN == 1 && !SPLIT;
+    const bool pre_a_on = PRE && p.res != nullptr && (MODE == 1 || EPI);
+    const bool pre_c_on = PRE && EPI && MODE == 1;
+    const bool pre_y_on = pre_c_on && p.bnb_act != ADVMIX_ACT_NONE;
+    float pre_a[RSL], pre_c[RSL], pre_y[RSL];
+#pragma unroll
+    for (int r = 0; r < RSL; ++r) {
+        pre_a[r] = 0.f; pre_c[r] = 0.f; pre_y[r] = 0.f;
+        if (PRE) {
+            bool valid;
+            const int off = elem_off(0, 0, r_lo + r, valid);
+            const unsigned boff = valid ? (unsigned)off * 4u : OOB;
+            if (pre_a_on) pre_a[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, boff, 0, 0));
+            if (pre_c_on) pre_c[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cr, boff, 0, 0));
+            if (pre_y_on) pre_y[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yyr, boff, 0, 0));
+        }
+    }
 
     // Two named register sets (statically indexed): one being multiplied, one in flight.  A third
     // set (two chunks of look-ahead) was measured and is NOT faster: 43.4 % vs 43.8 % on the
@@ -342,9 +392,6 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
     // workgroup issues ONE pair of fp64 atomics per column instead of one per wave
     float* sred = &Bs[0][0];                               // [2][WK * WM][BN]
     const bool stats = EPI && p.stats != nullptr;          // uniform over the grid
-    constexpr int RSL = MS::NR / WK;                       // accumulator registers a wave finishes itself
-    static_assert(MS::NR % WK == 0, "epilogue slices");
-    const int r_lo = WK > 1 ? wk * RSL : 0;
     if (WK > 1) {                                          // the WK partial tiles meet in LDS
         float* red = &Bs[0][0];
         __syncthreads();
@@ -368,18 +415,14 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
                     acc[t][u][r] = v;                          // slot r now holds accumulator register r_lo + r
                 }
     }
+    // The offsets of the prefetched operands are NOT kept across the main loop (16 more live registers per lane): the
+    // epilogue recomputes them from lane ids the compiler cannot connect to the earlier ones.
+    asm volatile("" : "+v"(e_l31), "+v"(e_lh));
     if (stats) __syncthreads();                            // every wave is done reading Bs
     // Straight-line stores: out-of-tile lanes get an out-of-range offset and the hardware drops their write
     // (reads return 0), so there is no per-element branch.  The first version branched around every store, and
     // the compiler's s_waitcnt for the bias value at each re-convergence (vmcnt(0) - which on gfx9 also counts
     // STORES) made every store wait for the previous one to be acknowledged.
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.ybytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.y), 0, p.ybytes,
-                                                                        0x00020000);
-    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bnb_c ? p.bnb_c : p.y), 0, p.ybytes,
-                                                                        0x00020000);
-    const __amdgpu_buffer_rsrc_t yyr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bnb_y ? p.bnb_y : p.y), 0, p.ybytes,
-                                                                         0x00020000);
 #pragma unroll
     for (int u = 0; u < RN; ++u) {
         const int col = n0 + wn * TN * 32 + u * MR + l31;
@@ -401,18 +444,8 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
         for (int t = 0; t < RM; ++t) {
 #pragma unroll
             for (int r = 0; r < RSL; ++r) {
-                int m = m0 + wm * TM * 32 + t * MR + MS::row(r_lo + r, lh);
-                const bool valid = m < Mp && cvalid;
-                if (!valid) m = 0;
-                int off;                                   // element offset (the host checks that y fits 2^31 bytes)
-                if (MODE == 0 || p.stride == 1) {          // (stride 1: one phase, rows are already output pixels -
-                    off = m * p.Co + col;                  //  no two integer divisions per accumulator register)
-                } else {
-                    int n = m / (Hp * Wp);
-                    int rem = m - n * (Hp * Wp);
-                    int hi_ = rem / Wp, wi_ = rem - hi_ * Wp;
-                    off = ((n * p.Ho + rh + hi_ * p.stride) * p.Wo + rw + wi_ * p.stride) * p.Co + col;
-                }
+                bool valid;
+                const int off = elem_off(t, u, r_lo + r, valid);
                 const unsigned boff = valid ? (unsigned)off * 4u : OOB;
                 float v = acc[t][u][r] + bv;
 #if defined(CD_DBG) && (CD_DBG & 4)                  /* no output stores (kept alive by an impossible value) */
@@ -420,7 +453,7 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
 #endif
                 // transposed gather (input gradients): an addend, e.g. the other gradient of a tensor with two
                 // consumers, rides in the epilogue instead of a separate add kernel (slice 0 only under SPLIT)
-                if (addend) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, boff, 0, 0));
+                if (addend) v += PRE ? pre_a[r] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, boff, 0, 0));
                 if (SPLIT) {
                     if (valid) atomicAdd(p.y + off, v);
                     continue;
@@ -428,13 +461,13 @@ __global__ __launch_bounds__(256) void conv_direct(ConvD p) {
                 if (EPI && MODE == 0) {
                     if (valid) { s1 += v; s2 += v * v; }
                     if (bn) v = (v - bn_m) * bn_is * bn_g + bn_b;
-                    if (p.res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, boff, 0, 0));
+                    if (p.res) v += PRE ? pre_a[r] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, boff, 0, 0));
                     v = act_fwd(v, p.act);
                 }
                 if (bnb) {                                  // out-of-tile lanes load 0 and contribute 0
-                    const float cv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cr, boff, 0, 0));
+                    const float cv = PRE ? pre_c[r] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cr, boff, 0, 0));
                     if (p.bnb_act != ADVMIX_ACT_NONE) {
-                        const float yv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yyr, boff, 0, 0));
+                        const float yv = PRE ? pre_y[r] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yyr, boff, 0, 0));
                         v = yv > 0.f ? v : v * bb_slope;
                     }
                     if (valid) { s1 += v; s2 += v * ((cv - bb_mu) * bb_is); }

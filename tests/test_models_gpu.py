@@ -136,7 +136,7 @@ def test_advmix_and_plain_steps_vs_oracle_and_golden(tag):
     crit = JointsMSELoss(True)
     args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
     mD.train(); mG.train(); mT.eval()
-    fracs = []
+    fracs, loose = [], []
     for it in range(iters):
         v, t, w = synth_batch('%s.it%d' % (tag, it), B, J, H, W)
         before = {k: p.detach().clone() for k, p in mD.named_parameters()}
@@ -151,6 +151,7 @@ def test_advmix_and_plain_steps_vs_oracle_and_golden(tag):
 
         def force():
             fracs.append(match_fraction(mD, D, atol))     # oracle's own update vs the device's
+            loose.append(match_fraction(mD, D, 10 * atol))
             pull_params(mD, D)
         ref = ostep(net, extra, D, G, T, oD, oG, v, t, w, alpha=0.1, after_D_step=force,
                     unet_kw={'num_downs': downs})
@@ -175,9 +176,11 @@ def test_advmix_and_plain_steps_vs_oracle_and_golden(tag):
     for k in D:
         if k.endswith(('running_mean', 'running_var')):
             assert_close(k, sd[k], D[k].detach())
-    assert min(fracs[:2]) >= 0.95 and min(fracs) >= 0.9, fracs
+    # >= 90 % of all elements within 1 % of lr of the oracle's own update (10 % of lr from the second update on),
+    # >= 97 % within ten times that; no element moves by more than lr (asserted above)
+    assert min(fracs) >= 0.9 and min(loose) >= 0.97, (fracs, loose)
     assert all(not p.requires_grad for p in mD.parameters())       # function.py:158 leaves D frozen
-    print(tag, 'element match fractions after each update', ['%.4f' % f for f in fracs])
+    print(tag, 'element match fractions after each update', ['%.4f' % f for f in fracs], ['%.4f' % f for f in loose])
 
     if tag + '.plain_losses' not in g.files:              # (C4 fixture: AdvMix loop only)
         return

@@ -26,8 +26,22 @@ if mode == 'fwd_stats':      # the variant the training step launches: conv + BN
                        None, None, None, None, 0.0, None, 0, P(slots), ctypes.byref(nbg), st)
 elif mode == 'fwd':
     run = lambda: call('advmix_conv_fwd', P(x), P(w), None, P(y), B, H, W, Ci, Ho, Wo, Co, k, k, s, p, st)
-elif mode == 'dgrad':
+elif mode == 'dgrad':        # weights pre-transposed to [Ci][R][S][Co] (one re-layout launch per use, or a mirror per step)
     run = lambda: call('advmix_conv_tr', P(y), P(wt), None, P(x), B, Ho, Wo, Co, H, W, Ci, k, k, s, p, st)
+elif mode == 'dgrad_bt':     # weights in their own layout, scattered into the LDS image (what the step launches)
+    run = lambda: call('advmix_conv_tr_w_add', P(y), P(w), None, P(x), B, Ho, Wo, Co, H, W, Ci, k, k, s, p, st)
+elif mode == 'dgrad_bt_add':
+    x2 = torch.randn_like(x)
+    run = lambda: call('advmix_conv_tr_w_add', P(y), P(w), P(x2), P(x), B, Ho, Wo, Co, H, W, Ci, k, k, s, p, st)
+elif mode == 'dgrad_bnb':    # + addend + BatchNorm-backward epilogue of the producer
+    x2, yy, cc = torch.randn_like(x), torch.randn_like(x), torch.randn_like(x)
+    mean, invstd = torch.zeros(Ci, device=dev), torch.ones(Ci, device=dev)
+    slots = torch.zeros(2 * Ci * 64, device=dev, dtype=torch.float64)
+    nbg = ctypes.c_int(0)
+    def run():
+        nbg.value = 0
+        call('advmix_conv_tr_w_bnb', P(y), P(w), P(x2), P(x), B, Ho, Wo, Co, H, W, Ci, k, k, s, p, P(yy), P(cc), P(mean),
+             P(invstd), 1, P(slots), ctypes.byref(nbg), st)
 else:
     run = lambda: call('advmix_conv_wgrad', P(y), P(x), P(dw), B, Ho, Wo, Co, H, W, Ci, k, k, s, p, st)
 for _ in range(5):

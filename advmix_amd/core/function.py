@@ -46,15 +46,51 @@ def plain_step(model, criterion, optimizer, input, target, target_weight, grad_s
     return loss.detach(), outputs.detach()
 
 
-def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, inputs, target, target_weight):
+def _backward_pieces(loss, net, cuts):
+    """The backward pass from ``loss`` as a list of closures, one per piece of ``net`` (``cuts`` = net.plan_cuts(),
+    ``net.last_cuts`` = the activations its forward recorded across those level boundaries).  Piece 0 runs from the
+    loss down to the highest cut, piece k from cut to cut, the last one to the leaves; each returns the range
+    [lo, hi) of the flat gradient buffer that is COMPLETE once it has run (parameters are laid out in execution order,
+    utils.FlatAdam), so the data-parallel all-reduce of that range can start while the next piece computes.
+    Weight gradients are side effects of the autograd nodes (ops.GroupFn), so asking autograd for the gradients of the
+    cut activations only still produces them."""
+    acts = list(net.last_cuts)
+    assert len(acts) == len(cuts), (len(acts), len(cuts))
+    total = net._level_elems[-1]
+    state = {'outs': [loss], 'gouts': [None]}
+    pieces = []
+    bounds = [c[1] for c in cuts] + [total]
+
+    def make(k):                                            # k counts DOWN from the top piece
+        def run():
+            if k > 0:
+                cut = acts[k - 1]
+                g = torch.autograd.grad(state['outs'], cut, grad_outputs=state['gouts'], allow_unused=True)
+                keep = [(t, gt) for t, gt in zip(cut, g) if gt is not None]
+                state['outs'], state['gouts'] = [t for t, _ in keep], [gt for _, gt in keep]
+            else:
+                torch.autograd.backward(state['outs'], state['gouts'])
+                state['outs'], state['gouts'] = [], []
+            return (bounds[k - 1] if k > 0 else 0), bounds[k]
+        return run
+    for k in range(len(cuts), -1, -1):
+        pieces.append(make(k))
+    return pieces
+
+
+def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, inputs, target, target_weight,
+                   cuts=None):
     """function.py:137-154: G forward, softmax-mix, D forward on the detached mix, teacher forward,
-    heat-map + KD loss, D backward.  Leaves D's gradients in ``optimizer.flat_grads``."""
+    heat-map + KD loss, D backward.  Leaves D's gradients in ``optimizer.flat_grads``.
+    ``cuts`` (data parallel, model.plan_cuts()): the backward pass is NOT run here; returned as closures instead
+    (see _backward_pieces) so that the caller can all-reduce each finished gradient range beside the next piece."""
     G_input = ops.cat_views(inputs)                                       # :137
     logits = model_G(G_input)                                             # :138 (softmax fused below)
     set_require_grad(model, True)                                         # :140
     optimizer.zero_grad()
     tmp = ops.softmax_mix(logits, inputs)                                 # :138,142-144
     D_output_detach = model(tmp.detach())                                 # :146
+    d_cut_acts = list(getattr(model, 'last_cuts', []))
     # (Measured and rejected: letting the teacher's levels ride along in the generator's and the
     # student's launch groups - 86.3 ms vs 85.8 ms per step; two lanes already saturate the chip.)
     with torch.no_grad():
@@ -62,17 +98,27 @@ def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, in
     loss_D_hm = criterion(D_output_detach, target, target_weight)
     loss_D_kd = criterion(D_output_detach, teacher_output, target_weight)
     loss_D = loss_D_hm * (1 - args.alpha) + loss_D_kd * args.alpha        # :151-153
+    if cuts:
+        model.last_cuts = d_cut_acts
+        return loss_D.detach(), tmp, _backward_pieces(loss_D, model, cuts)
     loss_D.backward()
     return loss_D.detach(), tmp
 
 
-def advmix_phase_b(args, model, criterion, optimizer, optimizer_G, tmp, target, target_weight):
-    """function.py:155-163: D update, then the adversarial pass through the frozen, updated D."""
+def advmix_phase_b(args, model, criterion, optimizer, optimizer_G, tmp, target, target_weight, cuts_G=None,
+                   model_G=None):
+    """function.py:155-163: D update, then the adversarial pass through the frozen, updated D.
+    ``cuts_G`` (data parallel): G's backward is returned in pieces like D's in advmix_phase_a; the first piece
+    contains the whole input-gradient pass through D."""
+    g_cut_acts = list(getattr(model_G, 'last_cuts', [])) if cuts_G else None    # recorded by G's forward in phase a
     optimizer.step()                                                      # :155
     set_require_grad(model, False)                                        # :158
     optimizer_G.zero_grad()
     output = model(tmp)                                                   # :160
     loss_G = -criterion(output, target, target_weight) * args.adv_loss_weight
+    if cuts_G:
+        model_G.last_cuts = g_cut_acts
+        return output.detach(), _backward_pieces(loss_G, model_G, cuts_G)
     loss_G.backward()
     return output.detach()
 
@@ -81,15 +127,29 @@ def advmix_step(args, model, model_G, model_teacher, criterion, optimizer, optim
                 inputs, target, target_weight, grad_sync=None):
     """function.py:137-164, one batch.  ``inputs``: 3 contiguous NCHW fp32 CUDA views.
     Returns (loss_D, output) with output = D(tmp) after the D update (the tensor the reference
-    feeds to ``accuracy``).  The two all-reduces of the data-parallel design sit exactly where
-    the reference's optimizers consume the gradients."""
-    loss_D, tmp = advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer,
-                                 inputs, target, target_weight)
-    if grad_sync is not None:
-        grad_sync.sync(optimizer)
-    output = advmix_phase_b(args, model, criterion, optimizer, optimizer_G, tmp, target, target_weight)
-    if grad_sync is not None:
-        grad_sync.sync(optimizer_G)
+    feeds to ``accuracy``).  Data parallel (``grad_sync``): the two gradient exchanges sit exactly where the
+    reference's optimizers consume the gradients, and each is OVERLAPPED with the backward pass that produces it - the
+    backward runs in pieces, and the finished range of the flat gradient buffer is all-reduced on a side HIP stream
+    while the next piece computes (dp.GradSync.reduce_async)."""
+    if grad_sync is None or not grad_sync.active:
+        loss_D, tmp = advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer,
+                                     inputs, target, target_weight)
+        output = advmix_phase_b(args, model, criterion, optimizer, optimizer_G, tmp, target, target_weight)
+        optimizer_G.step()                                                # :164
+        return loss_D, output
+    cuts_D, cuts_G = grad_sync.cuts_for(model), grad_sync.cuts_for(model_G)
+    loss_D, tmp, pieces = advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer,
+                                         inputs, target, target_weight, cuts_D)
+    for piece in pieces:
+        lo, hi = piece()
+        grad_sync.reduce_async(optimizer.flat_grads, lo, hi)
+    grad_sync.finish()
+    output, pieces = advmix_phase_b(args, model, criterion, optimizer, optimizer_G, tmp, target, target_weight,
+                                    cuts_G, model_G)
+    for piece in pieces:
+        lo, hi = piece()
+        grad_sync.reduce_async(optimizer_G.flat_grads, lo, hi)
+    grad_sync.finish()
     optimizer_G.step()                                                    # :164
     return loss_D, output
 

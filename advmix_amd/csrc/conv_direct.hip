@@ -230,7 +230,11 @@ __global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(C
     // Loaded in the epilogue they were a pure memory phase with the matrix pipe idle, every wave of the launch at once:
     // 3x3 32->32 @64x48 input gradient 23.5 us, + addend 28.0, + BatchNorm-backward sums 36.1.  Single-tile waves only
     // (16 registers per operand).
+#ifdef CD_NO_PRE
+    constexpr bool PRE = false;
+#else
     constexpr bool PRE = RM * RN == 1 && !SPLIT;
+#endif
     const bool pre_a_on = PRE && p.res != nullptr && (MODE == 1 || EPI);
     const bool pre_c_on = PRE && EPI && MODE == 1;
     const bool pre_y_on = pre_c_on && p.bnb_act != ADVMIX_ACT_NONE;

@@ -19,6 +19,42 @@ class GradSync:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.force = force          # run the collectives even with one rank (single-GPU test of the path)
         self._side = None
+        self.pieces = 3             # the backward pass is cut into this many pieces per network (see reduce_async)
+        self._cuts = {}
+
+    @property
+    def active(self):
+        return self.world > 1 or self.force
+
+    def cuts_for(self, net):
+        """Level boundaries at which ``net``'s backward pass is cut (PlanNet.plan_cuts), chosen once per network."""
+        key = id(net)
+        if key not in self._cuts:
+            self._cuts[key] = (net, net.plan_cuts(self.pieces) if hasattr(net, 'plan_cuts') else [])
+        return self._cuts[key][1]
+
+    def reduce_async(self, flat, lo, hi):
+        """Average flat[lo:hi] over the ranks on the side stream, ordered after everything enqueued so far on the
+        current stream - and WITHOUT making the current stream wait: the caller goes on with the next piece of the
+        backward pass (whose kernels write other ranges of ``flat``) and calls ``finish()`` before the optimizer."""
+        if not self.active or hi <= lo:
+            return
+        chunk = flat[lo:hi]
+        if flat.is_cuda:
+            cur = torch.cuda.current_stream(flat.device)
+            side = self._side_stream(flat.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for b in range(0, hi - lo, self.bucket_elems):
+                    dist.all_reduce(chunk[b:b + self.bucket_elems], op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+            chunk.div_(self.world)
+
+    def finish(self):
+        """The current stream waits for every reduce_async issued so far."""
+        if self._side is not None:
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
 
     def _side_stream(self, device):
         if self._side is None and device.type == 'cuda':

@@ -5,11 +5,13 @@ backward passes); driven eagerly from Python it is launch-bound.  The step has s
 so it is captured ONCE into HIP graphs (hipStreamBeginCapture via torch.cuda.CUDAGraph - every
 kernel in libadvmix_hip.so is capture-safe: no allocation, no sync) and replayed per batch.
 
-With data parallelism the step is cut into three graphs at the two points where gradients are
-exchanged (see dp.GradSync): [G fwd, mix, D fwd, T fwd, losses, D bwd] -> all-reduce(D grads)
--> [Adam(D), D fwd, loss, bwd through D into G] -> all-reduce(G grads) -> [Adam(G)].
-The RCCL calls stay outside the graphs.  The autograd tape recorded while capturing graph 1
-is consumed while capturing graph 2; all three share one memory pool."""
+Single GPU: two graphs (phase a: G fwd ... D bwd; phase b: Adam(D) ... G bwd, Adam(G)).
+With data parallelism the step is cut into seven graphs, one per piece of a backward pass (core.function.
+_backward_pieces): [G fwd, mix, D fwd, T fwd, losses, top third of D's bwd] | [middle third] | [bottom third] |
+[Adam(D), D fwd, loss, bwd through D, top third of G's bwd] | [middle] | [bottom] | [Adam(G)].  After each piece the
+range of the flat gradient buffer it completed is all-reduced on a side HIP stream (dp.GradSync.reduce_async) while
+the next graph runs; the RCCL calls stay outside the graphs.  The autograd tape recorded while capturing one graph is
+consumed while capturing the next; all share one memory pool."""
 import torch
 
 from .core.function import advmix_phase_a, advmix_phase_b, advmix_step, plain_step
@@ -62,19 +64,64 @@ class AdvMixGraphRunner:
         torch.cuda.synchronize(dev)
         optimizer.sync_hyper()
         optimizer_G.sync_hyper()
-        self.g1, self.g2, self.g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: only this thread launches work; RCCL's watchdog thread may query events meanwhile
         mode = dict(capture_error_mode='thread_local')
-        with torch.cuda.graph(self.g1, **mode):
-            self.loss_D, tmp = advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer,
-                                              self.inputs, self.target, self.tw)
-        pool = self.g1.pool()
-        with torch.cuda.graph(self.g2, pool=pool, **mode):
-            self.output = advmix_phase_b(args, model, criterion, optimizer, optimizer_G, tmp,
-                                         self.target, self.tw)
-        del tmp
-        with torch.cuda.graph(self.g3, pool=pool, **mode):
-            optimizer_G.step(sync_hyper=False)
+        self.segments = []          # [(graph, None | (optimizer, lo, hi) to all-reduce after it, finish-before flag)]
+        pool = [None]
+
+        def capture(fn):
+            g = torch.cuda.CUDAGraph()
+            kw = dict(mode) if pool[0] is None else dict(mode, pool=pool[0])
+            with torch.cuda.graph(g, **kw):
+                r = fn()
+            if pool[0] is None:
+                pool[0] = g.pool()
+            return g, r
+
+        sync = grad_sync if (grad_sync is not None and grad_sync.active) else None
+        if sync is None:
+            def seg_a():
+                self.loss_D, self._tmp = advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer,
+                                                        self.inputs, self.target, self.tw)
+            g, _ = capture(seg_a)
+            self.segments.append((g, None))
+
+            def seg_b():
+                self.output = advmix_phase_b(args, model, criterion, optimizer, optimizer_G, self._tmp,
+                                             self.target, self.tw)
+                optimizer_G.step(sync_hyper=False)
+            g, _ = capture(seg_b)
+            self.segments.append((g, None))
+        else:
+            # Data parallel: the step is cut where a range of a flat gradient buffer is complete (backward pieces of D,
+            # then of G).  After each segment's replay the range is all-reduced on the side stream (RCCL stays outside
+            # the graphs) while the NEXT segment - the next piece of the backward pass - already runs; the segment that
+            # holds the optimizer step is replayed after ``finish()``.
+            cuts_D, cuts_G = sync.cuts_for(model), sync.cuts_for(model_G)
+            box = {}
+
+            def seg_a0():
+                self.loss_D, self._tmp, box['pieces'] = advmix_phase_a(
+                    args, model, model_G, model_teacher, criterion, optimizer, self.inputs, self.target, self.tw, cuts_D)
+                return box['pieces'][0]()
+            g, rng = capture(seg_a0)
+            self.segments.append((g, (optimizer,) + tuple(rng)))
+            for piece in box['pieces'][1:]:
+                g, rng = capture(piece)
+                self.segments.append((g, (optimizer,) + tuple(rng)))
+
+            def seg_b0():
+                self.output, box['pieces'] = advmix_phase_b(args, model, criterion, optimizer, optimizer_G, self._tmp,
+                                                            self.target, self.tw, cuts_G, model_G)
+                return box['pieces'][0]()
+            g, rng = capture(seg_b0)                       # starts with Adam(D): replayed after finish()
+            self.segments.append((g, (optimizer_G,) + tuple(rng), True))
+            for piece in box['pieces'][1:]:
+                g, rng = capture(piece)
+                self.segments.append((g, (optimizer_G,) + tuple(rng)))
+            g, _ = capture(lambda: optimizer_G.step(sync_hyper=False))
+            self.segments.append((g, None, True))
+        self._tmp = None
         torch.cuda.synchronize(dev)
 
     def load_batch(self, inputs, target, target_weight):
@@ -88,13 +135,13 @@ class AdvMixGraphRunner:
         of graph-owned tensors (valid until the next replay)."""
         self.opt.sync_hyper()
         self.optG.sync_hyper()
-        self.g1.replay()
-        if self.sync is not None:
-            self.sync.sync(self.opt)
-        self.g2.replay()
-        if self.sync is not None:
-            self.sync.sync(self.optG)
-        self.g3.replay()
+        for seg in self.segments:
+            g, red = seg[0], seg[1]
+            if len(seg) > 2 and seg[2] and self.sync is not None:
+                self.sync.finish()                         # this segment's optimizer step consumes reduced gradients
+            g.replay()
+            if red is not None and self.sync is not None:
+                self.sync.reduce_async(red[0].flat_grads, red[1], red[2])
         return self.loss_D, self.output
 
 

@@ -231,20 +231,31 @@ def unet_plan(input_nc, output_nc, num_downs, ngf=64):
             return pre[i] + '.model.1', pre[i] + '.model.3'
         return pre[i] + '.model.1', pre[i] + '.model.5'
 
+    def seg(i, up):
+        """Launch chain of block i's down (up) half: outer / middle / inner thirds of the U.  One network pass runs
+        them one after the other either way; three chains instead of one give the data-parallel backward two points
+        where a finished range of the flat gradient buffer can be all-reduced while the rest still runs."""
+        third = 0 if i < num_downs // 3 else (1 if i < 2 * num_downs // 3 else 2)
+        return 'u%d' % (4 - third if up else third)           # d0 d1 | d2 d3 | d4 d5 u5 u4 | u3 u2 | u1 u0
+
     def level(i, a):
         """a = LeakyReLU'd input of block i (i >= 1); returns ReLU(cat([a, up-branch]))."""
         dn, un = names(i)
+        P.tag = seg(i, False)
         d = P.conv(a, dn, inner[i], 4, 2, 1, bias=True)
         if i == num_downs - 1:
             r = P.act(d, ACT_RELU)
         else:
             r = level(i + 1, P.inorm(d, ACT_LEAKY))
+        P.tag = seg(i, True)
         u = P.inorm(P.deconv(r, un, P.ch[a], 4, 2, 1, bias=True), ACT_NONE)
         return P.catact(a, u, ACT_RELU)
 
     dn, un = names(0)
+    P.tag = seg(0, False)
     d = P.conv(0, dn, inner[0], 4, 2, 1, bias=True)
     r = level(1, P.act(d, ACT_LEAKY))
+    P.tag = seg(0, True)
     P.out = P.deconv(r, un, output_nc, 4, 2, 1, bias=True)
     return P
 
@@ -315,6 +326,21 @@ class PlanNet(nn.Module):
                     self._last_use[s] = li
         self._cache = None
         self._chain_meta = {}
+        # execution order of the parameters (FlatAdam lays its flat buffers out in it) and, per level, how many
+        # parameter elements the levels up to it own: dp.GradSync cuts the backward pass there
+        rank, self._level_elems = 0, []
+        plist = dict(self.named_parameters())
+        acc = 0
+        for sts in self._levels:
+            for st in sts:
+                for sub in (st[1] if st[0] == 'chain' else (st,)):
+                    for nm in self._param_names(sub):
+                        plist[nm]._flat_rank = rank
+                        rank += 1
+                        acc += (plist[nm].numel() + 3) // 4 * 4
+            self._level_elems.append(acc)
+        self.cut_levels = ()        # levels after which forward() records the live activations (``last_cuts``)
+        self.last_cuts = []
         # fp64 statistics slots (ops.StatArena): a forward and a backward set per conv + BatchNorm pair
         self._arena = ops.StatArena()
         self._stat_off = {}
@@ -422,6 +448,33 @@ class PlanNet(nn.Module):
                 raise RuntimeError('plan has a dependency cycle')
             pending = rest
         return out
+
+    @staticmethod
+    def _param_names(st):
+        k = st[0]
+        if k == 'convbn':
+            return [st[1] + '.weight', st[2] + '.weight', st[2] + '.bias']
+        if k in ('conv', 'deconv'):
+            return [st[1] + '.weight'] + ([st[1] + '.bias'] if st[6] else [])
+        if k == 'bn':
+            return [st[1] + '.weight', st[1] + '.bias']
+        return []
+
+    def plan_cuts(self, pieces=3):
+        """Choose ``pieces - 1`` level boundaries that split the flat parameter buffer into roughly equal ranges and
+        arm forward() to record the activations alive across them.  Returns [(level, first flat element owned by the
+        levels above it)], ascending; the backward pass run piecewise over these cuts (core.function) finishes the
+        gradient range [elem, end) when the piece above the cut is done."""
+        total = self._level_elems[-1]
+        cuts = []
+        for k in range(1, pieces):
+            want = total * k / pieces
+            li = min(range(len(self._levels) - 1), key=lambda i: abs(self._level_elems[i] - want), default=None)
+            if li is not None and (li, self._level_elems[li]) not in cuts and 0 < self._level_elems[li] < total:
+                cuts.append((li, self._level_elems[li]))
+        cuts.sort()
+        self.cut_levels = tuple(c[0] for c in cuts)
+        return cuts
 
     @staticmethod
     def _dst(st):
@@ -555,6 +608,7 @@ class PlanRun:
         self.slots = [None] * len(net.plan.ch)
         self.slots[0] = x
         self.li = 0
+        net.last_cuts = []
         if self.train and torch.is_tensor(x) and x.is_cuda:
             net._arena.begin_pass(x.device)                # zero the statistics slots once, before any lane forks
 
@@ -577,6 +631,10 @@ class PlanRun:
             for s in net._srcs(st):
                 if net._last_use[s] == self.li and s != net.plan.out:
                     self.slots[s] = None
+        if self.li in net.cut_levels:                      # activations alive across this level boundary
+            net.last_cuts.append([t for s_, t in enumerate(self.slots)
+                                  if t is not None and s_ != 0 and net._last_use.get(s_, -1) > self.li
+                                  and t.requires_grad])
         self.li += 1
 
     @property

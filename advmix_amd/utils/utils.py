@@ -51,10 +51,18 @@ class FlatAdam(torch.optim.Optimizer):
         total = sum(_ceil4(p.numel()) for p in ps)
         fp = torch.zeros(total, device=dev, dtype=torch.float32)
         fg = torch.zeros(total, device=dev, dtype=torch.float32)
-        off = 0
+        # Layout: parameters in EXECUTION order (PlanNet stamps ``_flat_rank``), whatever order model.parameters()
+        # lists them in - the backward pass then completes the flat gradient buffer from its END towards its start, so
+        # dp.GradSync can all-reduce finished suffixes while earlier layers still run.  param_groups keep the
+        # reference order (torch.optim state_dict indices stay those of model.parameters()).
+        layout = sorted(range(len(ps)), key=lambda i: (getattr(ps[i], '_flat_rank', i), i))
+        offs, off = [0] * len(ps), 0
+        for i in layout:
+            offs[i] = off
+            off += _ceil4(ps[i].numel())
         self._offsets = []
         with torch.no_grad():
-            for p in ps:
+            for p, off in zip(ps, offs):
                 if p.dtype != torch.float32:
                     raise TypeError('FlatAdam handles fp32 parameters only')
                 if p.dim() == 4 and not p.is_contiguous(memory_format=torch.channels_last):
@@ -68,8 +76,8 @@ class FlatAdam(torch.optim.Optimizer):
                     g.copy_(old_grad)
                 p.grad = g
                 p._flat_grad_view = g                     # ops._grad_buf re-attaches it if the grad is set to None
+                p._flat_off = off                         # element offset of this parameter in the flat buffers
                 self._offsets.append(off)
-                off += _ceil4(p.numel())
         self._grad_views = [p.grad for p in ps]
         self._flat = (fp, fg, torch.zeros_like(fp), torch.zeros_like(fp))
         g0 = self.param_groups[0]
@@ -180,8 +188,12 @@ def get_optimizer(cfg, model):
     return None
 
 
-def save_checkpoint(states, is_best, output_dir, filename='checkpoint.pth', suffix=''):
-    """lib/utils/utils.py:97-108."""
+def save_checkpoint(states, is_best, output_dir, filename='checkpoint.pth', suffix='', grad_sync=None):
+    """lib/utils/utils.py:97-108.  Data parallel (``grad_sync``): only rank 0 writes.  Its replica IS what the
+    reference saves - nn.DataParallel keeps GPU 0's module, whose BatchNorm running statistics come from GPU 0's shard
+    alone (tools/train.py:311-337); parameters and Adam state are identical on every rank (dp.GradSync)."""
+    if grad_sync is not None and not grad_sync.checkpoint_rank():
+        return
     if suffix != '':
         torch.save(states, os.path.join(output_dir, filename[:-4] + '_' + suffix + '.pth'))
         if is_best and 'state_dict' in states:

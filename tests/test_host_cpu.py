@@ -99,6 +99,11 @@ ok = torch.allclose(flat, torch.arange(1000, dtype=torch.float32) * 1.5)
 class Opt: flat_grads = torch.full((77,), float(rank))
 o = Opt(); gs.sync(o)
 ok = ok and torch.allclose(o.flat_grads, torch.full((77,), 0.5))
+f2 = torch.full((1000,), float(rank + 1))            # ranges reduced piece by piece, suffix first (backward order)
+for lo, hi in ((700, 1000), (300, 700), (0, 300)):
+    gs.reduce_async(f2, lo, hi)
+gs.finish()
+ok = ok and gs.active and torch.allclose(f2, torch.full((1000,), 1.5))
 dist.destroy_process_group()
 sys.exit(0 if ok else 3)
 '''

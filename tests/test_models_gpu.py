@@ -550,6 +550,70 @@ def test_loops_graph_path_and_eager_path_match_reference(graph):
         F_.release_graphs()
 
 
+def test_data_parallel_path_on_one_rank_real_rccl():
+    """The data-parallel step with ONE rank and real RCCL (GradSync(force=True), as ADVMIX_FORCE_SYNC=1 does in
+    bench.py): the backward pass runs in pieces, every finished range of the flat gradient buffers is all-reduced on
+    the side stream beside the next piece, the optimizers wait for them.  With one rank an all-reduce(mean) is the
+    identity, so the result must equal the plain single-GPU step: gradients after phase a to rounding (fp32 atomics
+    order), the whole step as closely as two eager runs agree.  Eager and HIP-graph execution (seven graphs)."""
+    import copy
+    import torch.distributed as dist
+    from oracle.synth import synth_batch
+    from advmix_amd.core.function import advmix_step, advmix_phase_a
+    from advmix_amd.dp import GradSync
+    from advmix_amd.graph import AdvMixGraphRunner
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29631', rank=0, world_size=1,
+                                device_id=torch.device('cuda:0'))
+    try:
+        args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
+        B, J, H, W = 2, 5, 64, 64
+        v, t, w = synth_batch('hrnet_tiny.it0', B, J, H, W)
+        data = ([x.cuda().contiguous() for x in v], t.cuda(), w.cuda())
+        sync = GradSync(force=True, bucket_mb=0.25)
+        assert sync.active
+        # (1) gradients of phase a: plain backward vs pieces + all-reduces
+        cfg, D1, G1, T1, crit, oD1, oG1, _ = _tiny_setup(lr=1e-4)
+        cfg, D2, G2, T2, crit2, oD2, oG2, _ = _tiny_setup(lr=1e-4)
+        sync.broadcast_state([D2, G2, T2], [oD2, oG2])
+        l1, _ = advmix_phase_a(args, D1, G1, T1, crit, oD1, *data)
+        cuts = sync.cuts_for(D2)
+        assert len(cuts) == 2 and 0 < cuts[0][1] < cuts[1][1] < oD2.flat_grads.numel()
+        l2, _, pieces = advmix_phase_a(args, D2, G2, T2, crit2, oD2, *data, cuts)
+        done = []
+        for piece in pieces:
+            lo, hi = piece()
+            sync.reduce_async(oD2.flat_grads, lo, hi)
+            done.append((lo, hi))
+        sync.finish()
+        torch.cuda.synchronize()
+        assert [d[1] for d in done] == [oD2.flat_grads.numel(), cuts[1][1], cuts[0][1]] and done[-1][0] == 0
+        assert abs(float(l1) - float(l2)) <= 1e-6 * max(1.0, abs(float(l1)))
+        g1, g2 = oD1.flat_grads, oD2.flat_grads
+        assert float((g1 - g2).abs().max()) <= 1e-4 * float(g1.abs().max())
+        assert float(g2.abs().max()) > 0
+        # (2) the whole step, eager: synced pieces vs plain
+        cfg, D1, G1, T1, crit, oD1, oG1, _ = _tiny_setup(lr=1e-4)
+        cfg, D2, G2, T2, crit2, oD2, oG2, _ = _tiny_setup(lr=1e-4)
+        la, oa = advmix_step(args, D1, G1, T1, crit, oD1, oG1, *data)
+        lb, ob = advmix_step(args, D2, G2, T2, crit2, oD2, oG2, *data, sync)
+        assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(la)))
+        assert float((oa - ob).abs().max()) <= 0.05 * float(oa.abs().max())
+        fa, fb = oG1.flat_params, oG2.flat_params
+        assert float(((fa - fb).abs() > 2e-5).float().mean()) <= 0.1           # G really was updated identically
+        assert float((oG2.flat_grads).abs().max()) > 0
+        # (3) HIP graphs: seven segments, all-reduces between the replays
+        cfg, D3, G3, T3, crit3, oD3, oG3, _ = _tiny_setup(lr=1e-4)
+        runner = AdvMixGraphRunner(args, D3, G3, T3, crit3, oD3, oG3, *data, grad_sync=sync, warmup=1)
+        assert len(runner.segments) == 7
+        lg, og = runner.step()
+        assert abs(float(lg) - float(la)) <= 1e-6 * max(1.0, abs(float(la)))
+        assert float((og - oa).abs().max()) <= 0.05 * float(oa.abs().max())
+        assert int(D3.state_dict()['bn1.num_batches_tracked']) == int(D1.state_dict()['bn1.num_batches_tracked'])
+    finally:
+        dist.destroy_process_group()
+
+
 def test_graph_runner_matches_eager_step_from_the_same_state():
     """AdvMixGraphRunner (three HIP graphs, static batch buffers, load_batch) against the eager advmix_step.
     Two runs cannot be compared across several Adam updates - eager itself is not reproducible there: Adam's

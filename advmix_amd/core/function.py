@@ -65,8 +65,17 @@ def _backward_pieces(loss, net, cuts):
         def run():
             if k > 0:
                 cut = acts[k - 1]
-                g = torch.autograd.grad(state['outs'], cut, grad_outputs=state['gouts'], allow_unused=True)
-                keep = [(t, gt) for t, gt in zip(cut, g) if gt is not None]
+                # tensors alive across BOTH cuts already carry their complete gradient from above (nothing inside this
+                # piece consumes them, PlanNet.plan_cuts checks): they are handed on as they are.  Asking autograd for
+                # them again would make it run their producers - nodes of a LOWER piece - now and once more later.
+                have = {id(t): gt for t, gt in zip(state['outs'], state['gouts'])}
+                carried = [(t, have[id(t)]) for t in cut if id(t) in have]
+                cid = {id(t) for t, _ in carried}
+                ask = [t for t in cut if id(t) not in cid]
+                seeds = [(t, gt) for t, gt in zip(state['outs'], state['gouts']) if id(t) not in cid]
+                g = torch.autograd.grad([t for t, _ in seeds], ask, grad_outputs=[gt for _, gt in seeds],
+                                        allow_unused=True) if (ask and seeds) else [None] * len(ask)
+                keep = [(t, gt) for t, gt in zip(ask, g) if gt is not None] + carried
                 state['outs'], state['gouts'] = [t for t, _ in keep], [gt for _, gt in keep]
             else:
                 torch.autograd.backward(state['outs'], state['gouts'])

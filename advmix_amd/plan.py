@@ -319,11 +319,12 @@ class PlanNet(nn.Module):
                 level[d] = lvl
             groups.setdefault(lvl, []).append(st)
         self._levels = [groups[k] for k in sorted(groups)]
-        self._last_use = {}
+        self._last_use, self._use_levels = {}, {}
         for li, sts in enumerate(self._levels):
             for st in sts:
                 for s in self._srcs(st):
                     self._last_use[s] = li
+                    self._use_levels.setdefault(s, set()).add(li)
         self._cache = None
         self._chain_meta = {}
         # execution order of the parameters (FlatAdam lays its flat buffers out in it) and, per level, how many
@@ -473,8 +474,29 @@ class PlanNet(nn.Module):
             if li is not None and (li, self._level_elems[li]) not in cuts and 0 < self._level_elems[li] < total:
                 cuts.append((li, self._level_elems[li]))
         cuts.sort()
+        # A tensor alive across two cuts is carried through the piece between them with the gradient it already has
+        # (core.function._backward_pieces): legal only if nothing inside that piece consumes it (U-Net skip
+        # connections: consumed by their own block and by the up path far above).  Otherwise drop the upper cut.
+        ok = False
+        while not ok and len(cuts) > 1:
+            ok = True
+            for (la, _), (lb, _) in zip(cuts, cuts[1:]):
+                for s_, uses in self._use_levels.items():
+                    if s_ != 0 and max(uses) > lb and any(la < u <= lb for u in uses) and self._made_at(s_) <= la:
+                        cuts = [c for c in cuts if c[0] != lb]
+                        ok = False
+                        break
+                if not ok:
+                    break
         self.cut_levels = tuple(c[0] for c in cuts)
         return cuts
+
+    def _made_at(self, slot):
+        for li, sts in enumerate(self._levels):
+            for st in sts:
+                if slot in self._dsts(st):
+                    return li
+        return -1
 
     @staticmethod
     def _dst(st):
@@ -634,7 +656,7 @@ class PlanRun:
         if self.li in net.cut_levels:                      # activations alive across this level boundary
             net.last_cuts.append([t for s_, t in enumerate(self.slots)
                                   if t is not None and s_ != 0 and net._last_use.get(s_, -1) > self.li
-                                  and t.requires_grad])
+                                  and torch.is_tensor(t) and t.requires_grad])
         self.li += 1
 
     @property

@@ -193,7 +193,7 @@ def test_advmix_and_plain_steps_vs_oracle_and_golden(tag):
         v, t, w = synth_batch('%s.plain%d' % (tag, it), B, J, H, W)
         loss, out = plain_step(mD, crit, optD, v[0].cuda(), t.cuda(), w.cuda())
         ref = oplain(net, extra, D, oD, v[0], t, w)
-        assert match_fraction(mD, D, 1e-6 if it == 0 else 1e-4) >= 0.9
+        assert match_fraction(mD, D, 1e-5 if it == 0 else 1e-4) >= 0.9          # (atol: see the AdvMix loop above)
         pull_params(mD, D)
         assert_close('plain loss', loss, ref['loss'])
         assert_close('plain out', out, ref['out'])

@@ -46,60 +46,55 @@ def plain_step(model, criterion, optimizer, input, target, target_weight, grad_s
     return loss.detach(), outputs.detach()
 
 
-def _backward_pieces(loss, net, cuts):
-    """The backward pass from ``loss`` as a list of closures, one per piece of ``net`` (``cuts`` = net.plan_cuts(),
-    ``net.last_cuts`` = the activations its forward recorded across those level boundaries).  Piece 0 runs from the
-    loss down to the highest cut, piece k from cut to cut, the last one to the leaves; each returns the range
-    [lo, hi) of the flat gradient buffer that is COMPLETE once it has run (parameters are laid out in execution order,
-    utils.FlatAdam), so the data-parallel all-reduce of that range can start while the next piece computes.
-    Weight gradients are side effects of the autograd nodes (ops.GroupFn), so asking autograd for the gradients of the
-    cut activations only still produces them."""
-    acts = list(net.last_cuts)
-    assert len(acts) == len(cuts), (len(acts), len(cuts))
+def _backward_pieces(loss, net, cuts, pairs):
+    """The backward pass from ``loss`` as a list of closures, one per piece of ``net``.  ``cuts`` = net.plan_cuts();
+    ``pairs`` = net.last_cuts of the forward that ran with ``net.cut_levels`` armed: per cut the (original, detached
+    twin) activations alive across it.  Piece 0 runs from the loss down to the twins of the highest cut (autograd
+    stops there: they are leaves), piece k restarts from that cut's originals with the gradients the twins collected,
+    the last one reaches the network's leaves.  Each closure returns the range [lo, hi) of the flat gradient buffer
+    that is COMPLETE once it has run (parameters are laid out in execution order, utils.FlatAdam; weight gradients
+    are side effects of the autograd nodes, ops.GroupFn), so the data-parallel all-reduce of that range can start
+    while the next piece computes."""
+    assert len(pairs) == len(cuts), (len(pairs), len(cuts))
     total = net._level_elems[-1]
-    state = {'outs': [loss], 'gouts': [None]}
-    pieces = []
     bounds = [c[1] for c in cuts] + [total]
 
-    def make(k):                                            # k counts DOWN from the top piece
+    def make(k):                                            # k counts DOWN from the top piece (k = len(cuts))
         def run():
-            if k > 0:
-                cut = acts[k - 1]
-                # tensors alive across BOTH cuts already carry their complete gradient from above (nothing inside this
-                # piece consumes them, PlanNet.plan_cuts checks): they are handed on as they are.  Asking autograd for
-                # them again would make it run their producers - nodes of a LOWER piece - now and once more later.
-                have = {id(t): gt for t, gt in zip(state['outs'], state['gouts'])}
-                carried = [(t, have[id(t)]) for t in cut if id(t) in have]
-                cid = {id(t) for t, _ in carried}
-                ask = [t for t in cut if id(t) not in cid]
-                seeds = [(t, gt) for t, gt in zip(state['outs'], state['gouts']) if id(t) not in cid]
-                g = torch.autograd.grad([t for t, _ in seeds], ask, grad_outputs=[gt for _, gt in seeds],
-                                        allow_unused=True) if (ask and seeds) else [None] * len(ask)
-                keep = [(t, gt) for t, gt in zip(ask, g) if gt is not None] + carried
-                state['outs'], state['gouts'] = [t for t, _ in keep], [gt for _, gt in keep]
+            if k == len(cuts):
+                loss.backward()
             else:
-                torch.autograd.backward(state['outs'], state['gouts'])
-                state['outs'], state['gouts'] = [], []
+                live = [(o, t.grad) for o, t in pairs[k] if t.grad is not None]
+                torch.autograd.backward([o for o, _ in live], [g for _, g in live])
+                for _, t in pairs[k]:
+                    t.grad = None
             return (bounds[k - 1] if k > 0 else 0), bounds[k]
         return run
-    for k in range(len(cuts), -1, -1):
-        pieces.append(make(k))
-    return pieces
+    return [make(k) for k in range(len(cuts), -1, -1)]
 
 
 def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, inputs, target, target_weight,
                    cuts=None):
     """function.py:137-154: G forward, softmax-mix, D forward on the detached mix, teacher forward,
     heat-map + KD loss, D backward.  Leaves D's gradients in ``optimizer.flat_grads``.
-    ``cuts`` (data parallel, model.plan_cuts()): the backward pass is NOT run here; returned as closures instead
-    (see _backward_pieces) so that the caller can all-reduce each finished gradient range beside the next piece."""
+    ``cuts`` (data parallel) = (model.plan_cuts(), model_G.plan_cuts()): both forwards run with their autograd graph
+    cut at those levels and the backward pass is NOT run here; it is returned as closures (see _backward_pieces) so
+    that the caller can all-reduce each finished gradient range beside the next piece, together with G's cut record
+    for advmix_phase_b."""
     G_input = ops.cat_views(inputs)                                       # :137
+    if cuts:
+        model_G.cut_levels = tuple(c[0] for c in cuts[1])
     logits = model_G(G_input)                                             # :138 (softmax fused below)
+    pairs_G = model_G.last_cuts if cuts else None
+    model_G.cut_levels = ()
     set_require_grad(model, True)                                         # :140
     optimizer.zero_grad()
     tmp = ops.softmax_mix(logits, inputs)                                 # :138,142-144
+    if cuts:
+        model.cut_levels = tuple(c[0] for c in cuts[0])
     D_output_detach = model(tmp.detach())                                 # :146
-    d_cut_acts = list(getattr(model, 'last_cuts', []))
+    pairs_D = model.last_cuts if cuts else None
+    model.cut_levels = ()
     # (Measured and rejected: letting the teacher's levels ride along in the generator's and the
     # student's launch groups - 86.3 ms vs 85.8 ms per step; two lanes already saturate the chip.)
     with torch.no_grad():
@@ -108,26 +103,23 @@ def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, in
     loss_D_kd = criterion(D_output_detach, teacher_output, target_weight)
     loss_D = loss_D_hm * (1 - args.alpha) + loss_D_kd * args.alpha        # :151-153
     if cuts:
-        model.last_cuts = d_cut_acts
-        return loss_D.detach(), tmp, _backward_pieces(loss_D, model, cuts)
+        return loss_D.detach(), tmp, _backward_pieces(loss_D, model, cuts[0], pairs_D), pairs_G
     loss_D.backward()
     return loss_D.detach(), tmp
 
 
 def advmix_phase_b(args, model, criterion, optimizer, optimizer_G, tmp, target, target_weight, cuts_G=None,
-                   model_G=None):
+                   model_G=None, pairs_G=None):
     """function.py:155-163: D update, then the adversarial pass through the frozen, updated D.
-    ``cuts_G`` (data parallel): G's backward is returned in pieces like D's in advmix_phase_a; the first piece
-    contains the whole input-gradient pass through D."""
-    g_cut_acts = list(getattr(model_G, 'last_cuts', [])) if cuts_G else None    # recorded by G's forward in phase a
+    ``cuts_G`` / ``pairs_G`` (data parallel): G's backward is returned in pieces like D's in advmix_phase_a; the first
+    piece contains the whole input-gradient pass through D (whose graph is not cut in this phase)."""
     optimizer.step()                                                      # :155
     set_require_grad(model, False)                                        # :158
     optimizer_G.zero_grad()
     output = model(tmp)                                                   # :160
     loss_G = -criterion(output, target, target_weight) * args.adv_loss_weight
-    if cuts_G:
-        model_G.last_cuts = g_cut_acts
-        return output.detach(), _backward_pieces(loss_G, model_G, cuts_G)
+    if cuts_G is not None:
+        return output.detach(), _backward_pieces(loss_G, model_G, cuts_G, pairs_G)
     loss_G.backward()
     return output.detach()
 
@@ -147,14 +139,14 @@ def advmix_step(args, model, model_G, model_teacher, criterion, optimizer, optim
         optimizer_G.step()                                                # :164
         return loss_D, output
     cuts_D, cuts_G = grad_sync.cuts_for(model), grad_sync.cuts_for(model_G)
-    loss_D, tmp, pieces = advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer,
-                                         inputs, target, target_weight, cuts_D)
+    loss_D, tmp, pieces, pairs_G = advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer,
+                                                  inputs, target, target_weight, (cuts_D, cuts_G))
     for piece in pieces:
         lo, hi = piece()
         grad_sync.reduce_async(optimizer.flat_grads, lo, hi)
     grad_sync.finish()
     output, pieces = advmix_phase_b(args, model, criterion, optimizer, optimizer_G, tmp, target, target_weight,
-                                    cuts_G, model_G)
+                                    cuts_G, model_G, pairs_G)
     for piece in pieces:
         lo, hi = piece()
         grad_sync.reduce_async(optimizer_G.flat_grads, lo, hi)

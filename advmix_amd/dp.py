@@ -29,7 +29,7 @@ class GradSync:
     def cuts_for(self, net):
         """Level boundaries at which ``net``'s backward pass is cut (PlanNet.plan_cuts), chosen once per network."""
         key = id(net)
-        if key not in self._cuts:
+        if key not in self._cuts or self._cuts[key][0] is not net:
             self._cuts[key] = (net, net.plan_cuts(self.pieces) if hasattr(net, 'plan_cuts') else [])
         return self._cuts[key][1]
 

@@ -101,8 +101,9 @@ class AdvMixGraphRunner:
             box = {}
 
             def seg_a0():
-                self.loss_D, self._tmp, box['pieces'] = advmix_phase_a(
-                    args, model, model_G, model_teacher, criterion, optimizer, self.inputs, self.target, self.tw, cuts_D)
+                self.loss_D, self._tmp, box['pieces'], box['pairs_G'] = advmix_phase_a(
+                    args, model, model_G, model_teacher, criterion, optimizer, self.inputs, self.target, self.tw,
+                    (cuts_D, cuts_G))
                 return box['pieces'][0]()
             g, rng = capture(seg_a0)
             self.segments.append((g, (optimizer,) + tuple(rng)))
@@ -112,7 +113,7 @@ class AdvMixGraphRunner:
 
             def seg_b0():
                 self.output, box['pieces'] = advmix_phase_b(args, model, criterion, optimizer, optimizer_G, self._tmp,
-                                                            self.target, self.tw, cuts_G, model_G)
+                                                            self.target, self.tw, cuts_G, model_G, box['pairs_G'])
                 return box['pieces'][0]()
             g, rng = capture(seg_b0)                       # starts with Adam(D): replayed after finish()
             self.segments.append((g, (optimizer_G,) + tuple(rng), True))

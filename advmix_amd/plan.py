@@ -340,7 +340,11 @@ class PlanNet(nn.Module):
                         rank += 1
                         acc += (plist[nm].numel() + 3) // 4 * 4
             self._level_elems.append(acc)
-        self.cut_levels = ()        # levels after which forward() records the live activations (``last_cuts``)
+        # Levels after which the NEXT forward() cuts the autograd graph: every activation alive across the boundary is
+        # replaced by a detached twin (same memory) for the levels above, and (original, twin) is recorded in
+        # ``last_cuts``.  The backward pass then runs piece by piece (core.function._backward_pieces): the part above a
+        # cut leaves its gradients in the twins' .grad, the next piece starts from the originals with those gradients.
+        self.cut_levels = ()
         self.last_cuts = []
         # fp64 statistics slots (ops.StatArena): a forward and a backward set per conv + BatchNorm pair
         self._arena = ops.StatArena()
@@ -463,9 +467,9 @@ class PlanNet(nn.Module):
 
     def plan_cuts(self, pieces=3):
         """Choose ``pieces - 1`` level boundaries that split the flat parameter buffer into roughly equal ranges and
-        arm forward() to record the activations alive across them.  Returns [(level, first flat element owned by the
-        levels above it)], ascending; the backward pass run piecewise over these cuts (core.function) finishes the
-        gradient range [elem, end) when the piece above the cut is done."""
+        returns [(level, first flat element owned by the levels above it)], ascending.  With ``cut_levels`` set to those
+        levels for a forward pass, the backward run piecewise (core.function._backward_pieces) finishes the gradient
+        range [elem, end) when the piece above the cut is done."""
         total = self._level_elems[-1]
         cuts = []
         for k in range(1, pieces):
@@ -474,29 +478,7 @@ class PlanNet(nn.Module):
             if li is not None and (li, self._level_elems[li]) not in cuts and 0 < self._level_elems[li] < total:
                 cuts.append((li, self._level_elems[li]))
         cuts.sort()
-        # A tensor alive across two cuts is carried through the piece between them with the gradient it already has
-        # (core.function._backward_pieces): legal only if nothing inside that piece consumes it (U-Net skip
-        # connections: consumed by their own block and by the up path far above).  Otherwise drop the upper cut.
-        ok = False
-        while not ok and len(cuts) > 1:
-            ok = True
-            for (la, _), (lb, _) in zip(cuts, cuts[1:]):
-                for s_, uses in self._use_levels.items():
-                    if s_ != 0 and max(uses) > lb and any(la < u <= lb for u in uses) and self._made_at(s_) <= la:
-                        cuts = [c for c in cuts if c[0] != lb]
-                        ok = False
-                        break
-                if not ok:
-                    break
-        self.cut_levels = tuple(c[0] for c in cuts)
         return cuts
-
-    def _made_at(self, slot):
-        for li, sts in enumerate(self._levels):
-            for st in sts:
-                if slot in self._dsts(st):
-                    return li
-        return -1
 
     @staticmethod
     def _dst(st):
@@ -653,10 +635,15 @@ class PlanRun:
             for s in net._srcs(st):
                 if net._last_use[s] == self.li and s != net.plan.out:
                     self.slots[s] = None
-        if self.li in net.cut_levels:                      # activations alive across this level boundary
-            net.last_cuts.append([t for s_, t in enumerate(self.slots)
-                                  if t is not None and s_ != 0 and net._last_use.get(s_, -1) > self.li
-                                  and torch.is_tensor(t) and t.requires_grad])
+        if self.li in net.cut_levels:                      # cut the autograd graph at this level boundary
+            pairs = []
+            for s_, t in enumerate(self.slots):
+                if t is not None and s_ != 0 and net._last_use.get(s_, -1) > self.li and torch.is_tensor(t) \
+                        and t.requires_grad:
+                    twin = t.detach().requires_grad_(True)
+                    self.slots[s_] = twin
+                    pairs.append((t, twin))
+            net.last_cuts.append(pairs)
         self.li += 1
 
     @property

@@ -579,7 +579,7 @@ def test_data_parallel_path_on_one_rank_real_rccl():
         l1, _ = advmix_phase_a(args, D1, G1, T1, crit, oD1, *data)
         cuts = sync.cuts_for(D2)
         assert len(cuts) == 2 and 0 < cuts[0][1] < cuts[1][1] < oD2.flat_grads.numel()
-        l2, _, pieces = advmix_phase_a(args, D2, G2, T2, crit2, oD2, *data, cuts)
+        l2, _, pieces, _pg = advmix_phase_a(args, D2, G2, T2, crit2, oD2, *data, (cuts, sync.cuts_for(G2)))
         done = []
         for piece in pieces:
             lo, hi = piece()

@@ -550,7 +550,7 @@ def test_loops_graph_path_and_eager_path_match_reference(graph):
         F_.release_graphs()
 
 
-def test_data_parallel_path_on_one_rank_real_rccl():
+def _dp_one_rank_worker():
     """The data-parallel step with ONE rank and real RCCL (GradSync(force=True), as ADVMIX_FORCE_SYNC=1 does in
     bench.py): the backward pass runs in pieces, every finished range of the flat gradient buffers is all-reduced on
     the side stream beside the next piece, the optimizers wait for them.  With one rank an all-reduce(mean) is the
@@ -612,6 +612,19 @@ def test_data_parallel_path_on_one_rank_real_rccl():
         assert int(D3.state_dict()['bn1.num_batches_tracked']) == int(D1.state_dict()['bn1.num_batches_tracked'])
     finally:
         dist.destroy_process_group()
+
+
+def test_data_parallel_path_on_one_rank_real_rccl():
+    """Runs ``_dp_one_rank_worker`` in a CHILD process: RCCL's communicator setup / teardown and the seven-graph runner
+    stay out of the pytest process (a HIP-graph replay after destroy_process_group() in the same process crashed the
+    HIP runtime)."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ('import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_models_gpu as t; '
+            't._dp_one_rank_worker(); print("DP_ONE_RANK_OK")' % (os.path.dirname(here), here))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and 'DP_ONE_RANK_OK' in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
 
 
 def test_graph_runner_matches_eager_step_from_the_same_state():

@@ -511,7 +511,11 @@ __global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(C
 }
 
 // Tile configuration for a problem (the only place that decides it; advmix_conv_direct_config reports it).
-enum Cfg { CFG_128x32 = 1, CFG_128x64 = 2, CFG_64x64 = 3, CFG_64x64_GRID_SPLIT = 4, CFG_32x32_WAVE_SPLIT = 5 };
+enum Cfg { CFG_128x32 = 1, CFG_128x64 = 2, CFG_64x64 = 3, CFG_64x64_GRID_SPLIT = 4, CFG_32x32_WAVE_SPLIT = 5,
+           CFG_64x32_WAVE_SPLIT2 = 6 };
+
+// share of the chip's workgroup slots n workgroups fill when every CU takes ceil(n / 256) of them
+static double fill(int64_t n) { return n <= 0 ? 0.0 : (double)n / (256.0 * (double)((n + 255) / 256)); }
 
 static Cfg pick_cfg(int64_t Mmax, int Co, int phases, int nch, int* nsplit) {
     *nsplit = 1;
@@ -525,7 +529,14 @@ static Cfg pick_cfg(int64_t Mmax, int Co, int phases, int nch, int* nsplit) {
         if (ns > 8) ns = 8;
         if (ns < 1) ns = 1;
     }
-    if (ns <= 1) return CFG_64x64;
+    if (ns <= 1) {
+        // Between one and two 64 x 64 workgroups per CU the busiest CUs carry twice the work of the others (3x3 64->64
+        // @32x24, B = 32: 384 workgroups on 256 CUs, 31.3 us = 0.37 of peak where B = 64 reaches 0.51).  64 x 32 tiles
+        // whose two wave pairs split K double the workgroup count (768 = 3 per CU) and keep the fused epilogue.
+        const int64_t b6432 = (int64_t)cdiv(Mmax, 64) * cdiv(Co, 32) * phases;
+        if (advmix_opts().ksplit_wg && nch >= 4 && fill(b6432) > 1.15 * fill(b64)) return CFG_64x32_WAVE_SPLIT2;
+        return CFG_64x64;
+    }
     // Enough 32 x 32 tiles to give every CU a workgroup: split K between the four waves of a workgroup (no
     // zero-fill, no atomics, fused epilogue kept).  3x3 128->128 @16x12: 29.1 vs 35.8 us; 256->256 @8x6: 37.0 vs
     // 34.8 us but the separate statistics / BN pass and the memset disappear; with fewer tiles (U-Net
@@ -567,6 +578,7 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
         case CFG_128x64: LAUNCHD(1, 2, 4, 1, false); break;
         case CFG_64x64: LAUNCHD(1, 1, 2, 2, false); break;
         case CFG_32x32_WAVE_SPLIT: LAUNCHD(1, 1, 1, 1, false); break;      // four waves share K in the workgroup
+        case CFG_64x32_WAVE_SPLIT2: LAUNCHD(1, 1, 2, 1, false); break;     // two wave pairs share K
         case CFG_64x64_GRID_SPLIT:                                         // K across gridDim.z + atomics
             if (p.bn_gamma || (MODE == 0 && p.res) || p.act || p.stats || p.bnb_c) return -2;   // fused epilogue needs whole-K tiles
             p.nsplit = ns;
@@ -637,7 +649,8 @@ int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const 
 
 // Which conv_direct tile configuration a problem gets (tests assert that the shapes meant to exercise a
 // kernel variant really reach it): 1 = 128x32, 2 = 128x64, 3 = 64x64, 4 = 64x64 + grid K split,
-// 5 = 32x32 + K split between the waves of a workgroup; -1 = not served by conv_direct.
+// 5 = 32x32 + K split between the four waves of a workgroup, 6 = 64x32 + K split between two wave pairs;
+// -1 = not served by conv_direct.
 // mode 0: forward (Mmax = N*Ho*Wo output pixels); mode 1: transposed gather (per-phase rows of the LARGER side).
 extern "C" int advmix_conv_direct_config(int mode, int N, int Ho, int Wo, int Ci, int Co, int R, int S, int stride) {
     if (Ci % 16 != 0 || R * S > 64 || N <= 0 || stride < 1) return -1;

@@ -102,7 +102,7 @@ int advmix_conv_tr_w_bnb(const float* x, const float* w, const float* addend, fl
 
 /* Which tile configuration the second-generation conv kernel picks (introspection for tests / tuning):
  * 1 = 128x32, 2 = 128x64, 3 = 64x64, 4 = 64x64 + K split across the grid (atomics), 5 = 32x32 + K split between
- * the waves of a workgroup; -1 = not served.  mode 0: forward, (Ho, Wo) = output size, Ci = reduction channels;
+ * the four waves of a workgroup, 6 = 64x32 + K split between two wave pairs; -1 = not served.  mode 0: forward, (Ho, Wo) = output size, Ci = reduction channels;
  * mode 1: input gradient / transposed conv, (Ho, Wo) = the LARGER (gradient) side, Ci = channels reduced over. */
 int advmix_conv_direct_config(int mode, int N, int Ho, int Wo, int Ci, int Co, int R, int S, int stride);
 

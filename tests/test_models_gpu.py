@@ -215,10 +215,10 @@ def test_network_parity_at_the_benchmarked_batch():
     from advmix_amd.core.loss import JointsMSELoss
     from advmix_amd.utils.utils import get_optimizer
     tag, net, extra, J, B, H, W = 'hrnet_w32_b32', 'pose_hrnet', configs.HRNET_W32, 17, 32, 256, 192
-    # the tiles this batch reaches (1 = 128x32, 2 = 128x64, 3 = 64x64, 5 = 32x32 + K split between the waves)
+    # the tiles this batch reaches (1 = 128x32, 2 = 128x64, 5 = 32x32 + K split over four waves, 6 = 64x32 + K split over two pairs)
     cfgs = {lib.advmix_conv_direct_config(0, B, 64 >> i, 48 >> i, 32 << i, 32 << i, 3, 3, 1) for i in range(4)}
     cfgs.add(lib.advmix_conv_direct_config(0, B, 64, 48, 64, 256, 1, 1, 1))
-    assert {1, 2, 5} <= cfgs, cfgs
+    assert {1, 2, 5, 6} <= cfgs, cfgs
     g = gold_npz('b32_forward.npz')
     D, T, G = build_states(net, extra, J)
     views, tgt, tw = synth_batch(tag, B, J, H, W)

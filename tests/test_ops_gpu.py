@@ -60,6 +60,7 @@ CONV_CASES = [
     (32, 256, 8, 6, 256, 3, 1, 1, True),    # HRNet's lowest branch at the bench batch: 32x32 tiles, K split between waves
     (16, 128, 32, 24, 128, 3, 2, 1, False), # stride-2 fuse conv: wave-split forward, phase-decomposed input gradient
     (8, 128, 64, 64, 128, 1, 1, 0, True),   # enough rows for the 128x64 tile in both directions
+    (32, 64, 32, 24, 64, 3, 1, 1, False),   # HRNet's second branch at the bench batch: 64x32 tiles, K split between wave pairs
 ]
 
 
@@ -84,7 +85,9 @@ def test_conv_tile_configuration_table():
     cfgq = lib.advmix_conv_direct_config
     assert cfgq(0, 32, 64, 48, 32, 32, 3, 3, 1) == 1          # dominant conv: 128x32
     assert cfgq(0, 32, 64, 48, 64, 64, 3, 3, 1) == 2          # stem-sized: 128x64
-    assert cfgq(0, 32, 32, 24, 64, 64, 3, 3, 1) == 3          # 64x64
+    assert cfgq(0, 32, 32, 24, 64, 64, 3, 3, 1) == 6          # 64x32, K split between two wave pairs (384 64x64 tiles)
+    assert cfgq(1, 32, 32, 24, 64, 64, 3, 3, 1) == 6
+    assert cfgq(0, 64, 32, 24, 64, 64, 3, 3, 1) == 3          # 64x64 (768 of them)
     assert cfgq(0, 8, 64, 64, 128, 128, 1, 1, 1) == 2 and cfgq(1, 8, 64, 64, 128, 128, 1, 1, 1) == 2   # CONV_CASES[-1]
     assert cfgq(0, 32, 8, 6, 256, 256, 3, 3, 1) == 5          # wave split, forward
     assert cfgq(1, 32, 8, 6, 256, 256, 3, 3, 1) == 5          # wave split, input gradient

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(C
     constexpr int LDB = KC + 4;
     constexpr int BCH = BN * KC / 4;           // float4 staging slots per chunk
     constexpr int BSL = (BCH * WK + 255) / 256;
-    constexpr int RED = WK > 1 ? WK * RM * RN * MS::NR * 64 : 0;          // floats of the cross-wave reduction
+    constexpr int RED = WK > 1 ? 4 * RM * RN * MS::NR * 64 : 0;           // floats of the cross-wave reduction (4 waves)
     constexpr int BSZ = (WK * BN * LDB * 2 > RED) ? WK * BN * LDB : (RED + 1) / 2;
 
     __shared__ __attribute__((aligned(16))) float Bs[2][BSZ];
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(C
             for (int u = 0; u < RN; ++u)
 #pragma unroll
                 for (int r = 0; r < MS::NR; ++r)
-                    red[((wk * RM * RN + t * RN + u) * MS::NR + r) * 64 + lane] = acc[t][u][r];
+                    red[(((wk * WM * WN + wmn) * RM * RN + t * RN + u) * MS::NR + r) * 64 + lane] = acc[t][u][r];
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < RM; ++t)
@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(C
                 for (int r = 0; r < RSL; ++r) {
                     float v = 0.f;
 #pragma unroll
-                    for (int k = 0; k < WK; ++k) v += red[((k * RM * RN + t * RN + u) * MS::NR + r_lo + r) * 64 + lane];
+                    for (int k = 0; k < WK; ++k)                  // the WK waves that own the same (wm, wn) tile
+                        v += red[(((k * WM * WN + wmn) * RM * RN + t * RN + u) * MS::NR + r_lo + r) * 64 + lane];
                     acc[t][u][r] = v;                          // slot r now holds accumulator register r_lo + r
                 }
     }

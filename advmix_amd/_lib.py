@@ -32,6 +32,8 @@ SIGNATURES = {
     'advmix_conv_tr_w_add': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_tr_w_bnb': [_p, _p, _p, _p] + [_i] * 11 + [_p, _p, _p, _p, _i, _p, _p, _p],
     'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],
+    'advmix_conv_wgrad_det': [_p, _p, _p] + [_i] * 11 + [_p, _l, _p],
+    'advmix_bias_grad_det': [_p, _p, _l, _i, _p, _l, _p],
     'advmix_transpose_w': [_p, _p, _i, _i, _i, _p],
     'advmix_bias_grad': [_p, _p, _l, _i, _p],
     'advmix_norm_stats': [_p, _i, _l, _i, _f, _p, _p, _p, _p, _p, _f, _p, _p],
@@ -53,6 +55,7 @@ SIGNATURES = {
     'advmix_mix_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _p],
     'advmix_mix_bwd': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     'advmix_joints_loss': [_p, _p, _i, _p, _p, _p, _f, _i, _i, _i, _i, _p],
+    'advmix_joints_loss_det': [_p, _p, _i, _p, _p, _p, _f, _i, _i, _i, _i, _p, _p],
     'advmix_heatmap_argmax': [_p, _i, _p, _p, _i, _i, _i, _p],
     'advmix_adam': [_p, _p, _p, _p, _l, _p, _p, _p],
     'advmix_fill': [_p, _f, _l, _p],
@@ -71,6 +74,8 @@ for _name, _args in SIGNATURES.items():
     _fn.restype = ctypes.c_int
 lib.advmix_norm_ws_bytes.argtypes = [_i, _i]
 lib.advmix_norm_ws_bytes.restype = ctypes.c_int64
+lib.advmix_wgrad_det_ws_bytes.argtypes = [_i, _i, _i, _i]
+lib.advmix_wgrad_det_ws_bytes.restype = ctypes.c_int64
 
 
 class AdvmixHipError(RuntimeError):

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void joints_loss_kernel(const float* __restric
                                                           const float* __restrict__ target, int target_nhwc,
                                                           const float* __restrict__ tw, float* __restrict__ loss_out,
                                                           float* __restrict__ grad, float grad_scale, int B, int J,
-                                                          int HW, int mse) {
+                                                          int HW, int mse, double* part) {
     __shared__ double red[4];
     const int64_t total = (int64_t)B * HW * J;
     const float norm = 0.5f / ((float)J * (float)B * (float)HW);
@@ -117,7 +117,16 @@ __global__ __launch_bounds__(256) void joints_loss_kernel(const float* __restric
     __syncthreads();
     if (threadIdx.x == 0) {
         double s = red[0] + red[1] + red[2] + red[3];
-        atomicAdd(loss_out, (float)(s * (double)norm));
+        if (part) part[blockIdx.x] = s * (double)norm;     // deterministic mode: summed in block order by loss_sum_kernel
+        else atomicAdd(loss_out, (float)(s * (double)norm));
+    }
+}
+
+__global__ void loss_sum_kernel(const double* __restrict__ part, int n, float* __restrict__ loss_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += part[i];
+        *loss_out += (float)s;
     }
 }
 
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 AdvmixOpts& advmix_opts() {
     static AdvmixOpts o = [] {
-        AdvmixOpts d{1, 1, 1, 0, 0};
+        AdvmixOpts d{1, 1, 1, 0, 0, 0};
         const char* e;
         if ((e = getenv("ADVMIX_CONV")) && e[0] == 'i') d.direct = 0;
         if ((e = getenv("ADVMIX_WGRAD"))) d.wgrad_direct = e[0] != '0';
@@ -205,6 +214,7 @@ extern "C" int advmix_set_option(const char* name, int value) {
     else if (!strcmp(name, "ksplit_wg")) o.ksplit_wg = value;
     else if (!strcmp(name, "stat_slots")) o.stat_slots = value;
     else if (!strcmp(name, "trace_shapes")) o.trace_shapes = value;
+    else if (!strcmp(name, "deterministic")) o.deterministic = value;
     else return ADVMIX_EINVAL;
     return ADVMIX_OK;
 }
@@ -236,17 +246,32 @@ extern "C" int advmix_mix_bwd(const float* v0, const float* v1, const float* v2,
     return ADVMIX_OK;
 }
 
-extern "C" int advmix_joints_loss(const float* pred, const float* target, int target_nhwc, const float* tw,
-                                  float* loss_out, float* grad, float grad_scale, int B, int J, int HW, int mse,
-                                  void* stream) {
+static int joints_loss_impl(const float* pred, const float* target, int target_nhwc, const float* tw,
+                            float* loss_out, float* grad, float grad_scale, int B, int J, int HW, int mse,
+                            double* part, void* stream) {
     if (!pred || !target || !loss_out || B <= 0 || J <= 0 || HW <= 0) return ADVMIX_EINVAL;
     int64_t total = (int64_t)B * J * HW;
     int blocks = stream_blocks(total);
     if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(joints_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, target, target_nhwc,
-                       tw, loss_out, grad, grad_scale, B, J, HW, mse);
+                       tw, loss_out, grad, grad_scale, B, J, HW, mse, part);
+    if (part) hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, blocks, loss_out);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
+}
+
+extern "C" int advmix_joints_loss(const float* pred, const float* target, int target_nhwc, const float* tw,
+                                  float* loss_out, float* grad, float grad_scale, int B, int J, int HW, int mse,
+                                  void* stream) {
+    return joints_loss_impl(pred, target, target_nhwc, tw, loss_out, grad, grad_scale, B, J, HW, mse, nullptr, stream);
+}
+
+// deterministic variant: the <= 512 block sums go to ws (>= 4 KiB) and are added in block order
+extern "C" int advmix_joints_loss_det(const float* pred, const float* target, int target_nhwc, const float* tw,
+                                      float* loss_out, float* grad, float grad_scale, int B, int J, int HW, int mse,
+                                      void* ws, void* stream) {
+    if (!ws) return ADVMIX_EINVAL;
+    return joints_loss_impl(pred, target, target_nhwc, tw, loss_out, grad, grad_scale, B, J, HW, mse, (double*)ws, stream);
 }
 
 extern "C" int advmix_heatmap_argmax(const float* hm, int nhwc, int32_t* idx_out, float* max_out, int B, int J,

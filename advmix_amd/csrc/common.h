@@ -65,6 +65,7 @@ struct AdvmixOpts {
     int wgrad_direct;      // 1: register-fragment wgrad kernel allowed
     int ksplit_wg;         // 1: layers with too few tiles split K inside the workgroup (fused epilogue kept), 0: across the grid
     int trace_shapes;      // 1: log every MFMA launch's shape (advmix_trace_launch)
+    int deterministic;     // 1: conv_direct never splits K across the grid (fp32 atomics); see ops.py set_deterministic
     int stat_slots;        // fp64 slots per channel the statistics epilogues fold their workgroup sums onto (power of 2 <= 64; 0 = by grid size)
 };
 AdvmixOpts& advmix_opts();

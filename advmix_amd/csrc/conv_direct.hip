@@ -22,6 +22,13 @@
 #include <stdlib.h>
 #include <stdio.h>
 
+#ifdef CD_CLK                       /* diagnostic build (tools/build_variant.sh clk conv_direct -DCD_CLK): in-kernel shader clock */
+__device__ unsigned long long g_cd_clk[2 * 8192];
+extern "C" int advmix_dbg_clk(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cd_clk), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : 2;
+}
+#endif
+
 namespace direct {
 
 struct ConvD {
@@ -199,6 +206,10 @@ __global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(C
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
     __syncthreads();                                       // taptab visible
+#ifdef CD_CLK
+    unsigned long long clk_t0 = 0, clk_r0 = 0;
+    if (tid == 0) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
 
     // ---- epilogue geometry, and its operands fetched NOW ------------------------------------------------------------
     constexpr int RSL = MS::NR / WK;                       // accumulator registers a wave finishes itself
@@ -391,6 +402,12 @@ __global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(C
         compute(A0, buf);
     }
 
+#ifdef CD_CLK
+    if (tid == 0 && blockIdx.x < 8192 && blockIdx.y == 0 && blockIdx.z == 0) {   // shader cycles / 100 MHz ticks of the main loop
+        g_cd_clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_t0;
+        g_cd_clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
+#endif
     // ---- epilogue -----------------------------------------------------------------------------
     // BN column sums: the WM waves that share a column meet in LDS (the weight buffer is free now), so a
     // workgroup issues ONE pair of fp64 atomics per column instead of one per wave
@@ -544,6 +561,8 @@ static Cfg pick_cfg(int64_t Mmax, int Co, int phases, int nch, int* nsplit) {
     // bottleneck, 4x4 512->512 @4x3: 84 vs 59 us) the grid-level split wins.
     const int64_t b32 = (int64_t)cdiv(Mmax, 32) * cdiv(Co, 32) * phases;
     if (advmix_opts().ksplit_wg && b32 >= 256) return CFG_32x32_WAVE_SPLIT;
+    if (advmix_opts().deterministic)                       // the grid split adds with fp32 atomics: order varies run to run
+        return advmix_opts().ksplit_wg ? CFG_32x32_WAVE_SPLIT : CFG_64x64;
     *nsplit = ns;
     return CFG_64x64_GRID_SPLIT;
 }

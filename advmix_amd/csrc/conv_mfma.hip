@@ -233,7 +233,18 @@ struct WgP {
     int N, Ha, Wa, Ca, Hb, Wb, Cb;
     int R, S, stride, pad;
     int chunk;               // pixels per z-slice (multiple of 32)
-};
+    float* part;             // deterministic mode: slice z STORES its partial tile at part[z * Ca * Ntot + ...] instead of
+};                           // adding it to dw with fp32 atomics; reduce_slices_kernel sums the slices in order
+
+// dw[i] += part[0][i] + part[1][i] + ... in slice order: the deterministic tail of the weight / bias gradients
+__global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ part, int nslices, int64_t total,
+                                                            float* __restrict__ dw) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nslices; ++k) s += part[(int64_t)k * total + i];
+        dw[i] += s;
+    }
+}
 
 template <int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
@@ -367,7 +378,9 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (co < p.Ca) atomicAdd(p.dw + (int64_t)co * Ntot + j, acc[r]);
+        if (co >= p.Ca) continue;
+        if (p.part) p.part[((int64_t)blockIdx.z * p.Ca + co) * Ntot + j] = acc[r];
+        else atomicAdd(p.dw + (int64_t)co * Ntot + j, acc[r]);
     }
 }
 
@@ -386,7 +399,7 @@ __global__ void transpose_w_kernel(const float* __restrict__ in, float* __restri
 // db[c] += sum over rows of dy[rows, C]: 256 threads = RP row-lanes x Cp columns, LDS tree over the
 // row-lanes, one atomic per column per block (coalesced 4-byte lanes along c).
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db,
-                                                        int64_t rows, int C, int64_t rows_per_block) {
+                                                        int64_t rows, int C, int64_t rows_per_block, float* part) {
     __shared__ float red[256];
     const int Cp = C < 256 ? C : 256;
     const int RP = 256 / Cp;
@@ -404,7 +417,10 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
             if (rr < RP && (rr % (2 * step)) == 0 && rr + step < RP) red[tid] += red[tid + step * Cp];
             __syncthreads();
         }
-        if (rr == 0 && c < C) atomicAdd(db + c, red[tid]);
+        if (rr == 0 && c < C) {
+            if (part) part[(int64_t)blockIdx.x * C + c] = red[tid];
+            else atomicAdd(db + c, red[tid]);
+        }
         __syncthreads();
     }
 }
@@ -475,20 +491,20 @@ static int wgrad_target_blocks() {
     return v;
 }
 
-extern "C" int advmix_conv_wgrad(const float* a, const float* b, float* dw,
-                                 int N, int Ha, int Wa, int Ca, int Hb, int Wb, int Cb,
-                                 int R, int S, int stride, int pad, void* stream) {
+static int wgrad_impl(const float* a, const float* b, float* dw, int N, int Ha, int Wa, int Ca, int Hb, int Wb, int Cb,
+                      int R, int S, int stride, int pad, float* part, int64_t part_floats, void* stream) {
     if (!a || !b || !dw || N <= 0 || Ca <= 0 || Cb <= 0 || stride < 1) return ADVMIX_EINVAL;
     if (Ha != (Hb + 2 * pad - R) / stride + 1 || Wa != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
-    {
+    if (!part) {
         int rc = advmix_wgrad_direct_dispatch(a, b, dw, N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad, (hipStream_t)stream);
         if (rc >= 0) return rc;
     }
-    WgP p{a, b, dw, N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad, 0};
+    WgP p{a, b, dw, N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad, 0, part};
     const int64_t P = (int64_t)N * Ha * Wa;
     const int Ntot = R * S * Cb;
     const bool vec = (Ca % 4 == 0) && (Cb % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
+    int nslices = 1;
 #define LAUNCHW(WM_, WN_, V_)                                                             \
     do {                                                                                  \
         int tiles = cdiv(Ca, 32 * WM_) * cdiv(Ntot, 32 * WN_);                            \
@@ -499,6 +515,11 @@ extern "C" int advmix_conv_wgrad(const float* a, const float* b, float* dw,
         int64_t chunk = ((P + ns - 1) / ns + 31) / 32 * 32;                               \
         p.chunk = (int)chunk;                                                             \
         dim3 g(cdiv(Ca, 32 * WM_), cdiv(Ntot, 32 * WN_), cdiv(P, chunk));                 \
+        nslices = (int)g.z;                                                               \
+        if (part) {                                                                       \
+            if ((int64_t)nslices * Ca * Ntot > part_floats) return ADVMIX_EINVAL;         \
+            if (hipMemsetAsync(part, 0, sizeof(float) * (size_t)nslices * Ca * Ntot, st) != hipSuccess) return ADVMIX_ELAUNCH; \
+        }                                                                                 \
         hipLaunchKernelGGL((conv_wgrad<WM_, WN_, V_>), g, dim3(256), 0, st, p);           \
         if (advmix_opts().trace_shapes) {                                                 \
             char nm[64];                                                                  \
@@ -515,8 +536,37 @@ extern "C" int advmix_conv_wgrad(const float* a, const float* b, float* dw,
         if (vec) LAUNCHW(2, 2, true); else LAUNCHW(2, 2, false);
     }
 #undef LAUNCHW
+    if (part) {
+        const int64_t total = (int64_t)Ca * Ntot;
+        int blocks = (int)((total + 255) / 256);
+        hipLaunchKernelGGL(reduce_slices_kernel, dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, st, part, nslices, total, dw);
+    }
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
+}
+
+extern "C" int advmix_conv_wgrad(const float* a, const float* b, float* dw,
+                                 int N, int Ha, int Wa, int Ca, int Hb, int Wb, int Cb,
+                                 int R, int S, int stride, int pad, void* stream) {
+    return wgrad_impl(a, b, dw, N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad, nullptr, 0, stream);
+}
+
+// Deterministic weight gradient: every pixel slice STORES its partial tile into ``ws`` (ws_bytes; the call needs
+// 4 * slices * Ca * R * S * Cb bytes, at most advmix_wgrad_det_ws_bytes) and a second launch adds the slices to dw in
+// slice order - no fp32 atomics, bit-reproducible run to run.  ADVMIX_EINVAL when ws is too small.
+extern "C" int advmix_conv_wgrad_det(const float* a, const float* b, float* dw,
+                                     int N, int Ha, int Wa, int Ca, int Hb, int Wb, int Cb,
+                                     int R, int S, int stride, int pad, void* ws, int64_t ws_bytes, void* stream) {
+    if (!ws) return ADVMIX_EINVAL;
+    return wgrad_impl(a, b, dw, N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad, (float*)ws, ws_bytes / 4, stream);
+}
+
+extern "C" int64_t advmix_wgrad_det_ws_bytes(int Ca, int Cb, int R, int S) {
+    // slices * tiles <= max(wgrad_target_blocks, tiles) and a tile holds at most 64 x 128 outputs of which Ca x Ntot are
+    // real: slices * Ca * Ntot <= target_blocks * 64 * 128 floats, or one slice of the whole gradient
+    const int64_t whole = (int64_t)Ca * R * S * Cb;
+    const int64_t capped = (int64_t)wgrad_target_blocks() * 64 * 128;
+    return 4 * (whole > capped ? whole : capped);
 }
 
 extern "C" int advmix_transpose_w(const float* in, float* out, int A, int T, int B, void* stream) {
@@ -529,14 +579,29 @@ extern "C" int advmix_transpose_w(const float* in, float* out, int A, int T, int
     return ADVMIX_OK;
 }
 
-extern "C" int advmix_bias_grad(const float* dy, float* db, int64_t rows, int C, void* stream) {
+static int bias_grad_impl(const float* dy, float* db, int64_t rows, int C, float* part, int64_t part_floats, void* stream) {
     if (!dy || !db || rows <= 0 || C <= 0) return ADVMIX_EINVAL;
     int64_t rpb = (rows + 1023) / 1024;
     if (rpb < 32) rpb = 32;
     int blocks = (int)((rows + rpb - 1) / rpb);
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, db, rows, C, rpb);
+    if (part && (int64_t)blocks * C > part_floats) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, db, rows, C, rpb, part);
+    if (part)
+        hipLaunchKernelGGL(reduce_slices_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, part, blocks,
+                           (int64_t)C, db);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
+}
+
+extern "C" int advmix_bias_grad(const float* dy, float* db, int64_t rows, int C, void* stream) {
+    return bias_grad_impl(dy, db, rows, C, nullptr, 0, stream);
+}
+
+// deterministic variant: block partials in ws (<= 1024 * C floats), summed in block order
+extern "C" int advmix_bias_grad_det(const float* dy, float* db, int64_t rows, int C, void* ws, int64_t ws_bytes,
+                                    void* stream) {
+    if (!ws) return ADVMIX_EINVAL;
+    return bias_grad_impl(dy, db, rows, C, (float*)ws, ws_bytes / 4, stream);
 }
 
 extern "C" int advmix_conv_tr_w(const float* x, const float* w, const float* bias, float* y,

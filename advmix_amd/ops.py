@@ -183,6 +183,41 @@ def _wt(st, w, A, T, B):
 #          bwd(st, lane, saved, extra, meta, grads, needs) -> input grads (aligned with tensors)
 # =============================================================================================
 BNB_FUSED = __import__('os').environ.get('ADVMIX_BNB', '1') != '0'
+DETERMINISTIC = False
+
+
+def set_deterministic(on=True):
+    """Bit-reproducible mode: every accumulation whose ORDER varies run to run takes its ordered
+    form - weight / bias gradients and the loss sum store per-slice partials and add them in slice order
+    (advmix_conv_wgrad_det, advmix_bias_grad_det, advmix_joints_loss_det) instead of fp32 atomics; convolutions never
+    split K across the grid; BatchNorm statistics use the block-partial kernels (norm_stats / norm_bwd) instead of the
+    fp64 atomics of the conv epilogues.  Slower (more launches, no epilogue fusion); same results to rounding."""
+    global DETERMINISTIC
+    DETERMINISTIC = bool(on)
+    call('advmix_set_option', b'deterministic', 1 if on else 0)
+
+
+if __import__('os').environ.get('ADVMIX_DETERMINISTIC', '0') == '1':
+    set_deterministic(True)
+
+
+def _wgrad(st, lane, a, b, w, geom):
+    """Weight gradient accumulated into w.grad (atomics, or ordered partials in deterministic mode)."""
+    g = _grad_buf(w, st)
+    if DETERMINISTIC:
+        ws = _workspace(a.device, 0, lane)
+        call('advmix_conv_wgrad_det', _p(a), _p(b), _p(g), *geom, _p(ws), WS_BYTES, st)
+    else:
+        call('advmix_conv_wgrad', _p(a), _p(b), _p(g), *geom, st)
+
+
+def _bias_grad(st, lane, dy, bias, rows, C):
+    g = _grad_buf(bias, st)
+    if DETERMINISTIC:
+        ws = _workspace(dy.device, 0, lane)
+        call('advmix_bias_grad_det', _p(dy), _p(g), rows, C, _p(ws), WS_BYTES, st)
+    else:
+        call('advmix_bias_grad', _p(dy), _p(g), rows, C, st)
 COUNTERS = {'bnb': 0}       # launches whose epilogue carried a BatchNorm backward (tests assert the path is taken)
 
 
@@ -256,10 +291,9 @@ class Conv:
         if needs[0]:
             dx = _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to, bnb)
         if needs[1]:
-            call('advmix_conv_wgrad', _p(dy), _p(x), _p(_grad_buf(w, st)), B, Ho, Wo, Co, Hi, Wi, Ci,
-                 R, S, stride, pad, st)
+            _wgrad(st, lane, dy, x, w, (B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad))
         if bias is not None and needs[2]:
-            call('advmix_bias_grad', _p(dy), _p(_grad_buf(bias, st)), B * Ho * Wo, Co, st)
+            _bias_grad(st, lane, dy, bias, B * Ho * Wo, Co)
         return dx, None, None
 
 
@@ -305,10 +339,9 @@ class Deconv:
             call('advmix_conv_fwd', _p(dy), _p(w), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
                  stride, pad, st)
         if needs[1]:
-            call('advmix_conv_wgrad', _p(x), _p(dy), _p(_grad_buf(w, st)), B, Hi, Wi, Ci, Ho, Wo, Co,
-                 R, S, stride, pad, st)
+            _wgrad(st, lane, x, dy, w, (B, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad))
         if bias is not None and needs[2]:
-            call('advmix_bias_grad', _p(dy), _p(_grad_buf(bias, st)), B * Ho * Wo, Co, st)
+            _bias_grad(st, lane, dy, bias, B * Ho * Wo, Co)
         return dx, None, None
 
 
@@ -406,7 +439,7 @@ class ConvBN:
         mean = torch.empty(Co, device=x.device, dtype=torch.float32)
         invstd = torch.empty(Co, device=x.device, dtype=torch.float32)
         rc = 1
-        if fused_ok:
+        if fused_ok and not DETERMINISTIC:                  # (deterministic mode: block-partial statistics, no fp64 atomics)
             if arena is not None and arena.t is not None:
                 slots = arena.ptr(fwd_off)
             else:                                           # functional use outside a network: private slots,
@@ -485,8 +518,7 @@ class ConvBN:
         if needs[0]:
             dx = _conv_dgrad(st, dc, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to, bnb)
         if needs[1]:
-            call('advmix_conv_wgrad', _p(dc), _p(x), _p(_grad_buf(w, st)), B, Ho, Wo, Co, Hi, Wi, Ci,
-                 R, S, stride, pad, st)
+            _wgrad(st, lane, dc, x, w, (B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad))
         return dx, None, None, None, None, None, None, dres
 
 
@@ -691,8 +723,12 @@ class JointsLoss:
         loss = torch.empty((), device=pred.device, dtype=torch.float32)
         call('advmix_fill', _p(loss), 0.0, 1, st)
         grad = empty_nhwc(B, J, H, W, pred.device) if needs[0] else None
-        call('advmix_joints_loss', _p(pred), _p(target), t_nhwc, _p(w), _p(loss), _p(grad), 1.0,
-             B, J, H * W, 1 if mse else 0, st)
+        if DETERMINISTIC:
+            call('advmix_joints_loss_det', _p(pred), _p(target), t_nhwc, _p(w), _p(loss), _p(grad), 1.0,
+                 B, J, H * W, 1 if mse else 0, _p(_workspace(pred.device, 0, lane)), st)
+        else:
+            call('advmix_joints_loss', _p(pred), _p(target), t_nhwc, _p(w), _p(loss), _p(grad), 1.0,
+                 B, J, H * W, 1 if mse else 0, st)
         return (loss,), ((grad,) if needs[0] else ()), None
 
     @staticmethod
@@ -786,7 +822,7 @@ class Chain:
     @staticmethod
     def bwd(st, lane, saved, rec, meta, grads, needs):
         subs, ext_slots, out_slots = meta[:3]
-        plan = (meta[3] if len(meta) > 3 else Chain.bnb_plan(subs)) if BNB_FUSED else {}
+        plan = (meta[3] if len(meta) > 3 else Chain.bnb_plan(subs)) if (BNB_FUSED and not DETERMINISTIC) else {}
         grad, pre = {}, {}
         for s_, g in zip(out_slots, grads):
             if g is not None:

@@ -37,7 +37,8 @@ extern "C" {
 int advmix_version(void);
 /* dispatch knobs for A/B runs and tests: "direct" (0 = first-generation conv only), "wgrad_direct", "ksplit_wg"
  * (K split inside the workgroup vs across the grid), "stat_slots" (fp64 slots per channel of the statistics
- * epilogues).  Unknown name -> ADVMIX_EINVAL. */
+ * epilogues), "deterministic" (1: no K split across the grid), "trace_shapes" (measurement aid, see common.h).
+ * Unknown name -> ADVMIX_EINVAL. */
 int advmix_set_option(const char* name, int value);
 
 /* ---- convolution family: replaces nn.Conv2d / nn.ConvTranspose2d forward+backward
@@ -112,6 +113,16 @@ int advmix_conv_direct_config(int mode, int N, int Ho, int Wo, int Ci, int Co, i
 int advmix_conv_wgrad(const float* a, const float* b, float* dw,
                       int N, int Ha, int Wa, int Ca, int Hb, int Wb, int Cb,
                       int R, int S, int stride, int pad, void* stream);
+
+/* Deterministic variants (bit-reproducible run to run; ops.set_deterministic): the pixel slices / row blocks STORE
+ * their partial results into ws and a second launch adds them in slice order - no fp32 atomics.
+ * advmix_conv_wgrad_det needs 4 * slices * Ca * R * S * Cb bytes, never more than advmix_wgrad_det_ws_bytes();
+ * advmix_bias_grad_det 4 * 1024 * C bytes.  ADVMIX_EINVAL when ws is too small. */
+int advmix_conv_wgrad_det(const float* a, const float* b, float* dw,
+                          int N, int Ha, int Wa, int Ca, int Hb, int Wb, int Cb,
+                          int R, int S, int stride, int pad, void* ws, int64_t ws_bytes, void* stream);
+int64_t advmix_wgrad_det_ws_bytes(int Ca, int Cb, int R, int S);
+int advmix_bias_grad_det(const float* dy, float* db, int64_t rows, int C, void* ws, int64_t ws_bytes, void* stream);
 
 /* out[B][T][A] = in[A][T][B]  (weight re-layout for advmix_conv_tr) */
 int advmix_transpose_w(const float* in, float* out, int A, int T, int B, void* stream);
@@ -212,6 +223,10 @@ int advmix_mix_bwd(const float* v0, const float* v1, const float* v2, const floa
 int advmix_joints_loss(const float* pred, const float* target, int target_nhwc, const float* tw,
                        float* loss_out, float* grad, float grad_scale, int B, int J, int HW,
                        int mse, void* stream);
+/* deterministic variant: the <= 512 block sums are stored in ws (>= 4 KiB) and added in block order */
+int advmix_joints_loss_det(const float* pred, const float* target, int target_nhwc, const float* tw,
+                           float* loss_out, float* grad, float grad_scale, int B, int J, int HW,
+                           int mse, void* ws, void* stream);
 /* first-occurrence argmax over HW per (b, j) of an NHWC (nhwc=1) or NCHW heat-map;
  * idx_out[B*J] int32, max_out[B*J] */
 int advmix_heatmap_argmax(const float* hm, int nhwc, int32_t* idx_out, float* max_out,

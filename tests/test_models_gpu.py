@@ -627,6 +627,42 @@ def test_data_parallel_path_on_one_rank_real_rccl():
     assert out.returncode == 0 and 'DP_ONE_RANK_OK' in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
 
 
+def test_deterministic_mode_is_bit_reproducible():
+    """ops.set_deterministic(True): ordered partial sums instead of fp32 / fp64 atomics everywhere (weight and bias
+    gradients, the loss sum, BatchNorm statistics, no K split across the grid).  Two AdvMix steps run twice from the
+    same state: every parameter, Adam moment and BatchNorm buffer BIT-identical; and the deterministic step agrees with
+    the default (atomic) one to rounding."""
+    from oracle.synth import synth_batch
+    from advmix_amd import ops
+    from advmix_amd.core.function import advmix_step
+    args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
+    B, J, H, W = 2, 5, 64, 64
+    batches = []
+    for it in range(2):
+        v, t, w = synth_batch('hrnet_tiny.it%d' % it, B, J, H, W)
+        batches.append(([x.cuda().contiguous() for x in v], t.cuda(), w.cuda()))
+
+    def run():
+        cfg, D, G, T, crit, oD, oG, _ = _tiny_setup(lr=1e-3)
+        outs = []
+        for b in batches:
+            l, o = advmix_step(args, D, G, T, crit, oD, oG, *b)
+            outs += [l.clone(), o.clone()]
+        torch.cuda.synchronize()
+        state = [t.clone() for opt in (oD, oG) for t in opt.flat_state()] + [b.clone() for b in D.buffers()]
+        return outs + state
+    try:
+        ops.set_deterministic(True)
+        a, b = run(), run()
+    finally:
+        ops.set_deterministic(False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)                               # bit for bit
+    c = run()                                                  # default mode (atomics)
+    assert abs(float(a[0]) - float(c[0])) <= 1e-6 * max(1.0, abs(float(c[0])))
+    assert float((a[1] - c[1]).abs().max()) <= 0.05 * float(c[1].abs().max())
+
+
 def test_graph_runner_matches_eager_step_from_the_same_state():
     """AdvMixGraphRunner (three HIP graphs, static batch buffers, load_batch) against the eager advmix_step.
     Two runs cannot be compared across several Adam updates - eager itself is not reproducible there: Adam's

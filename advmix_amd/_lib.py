@@ -29,6 +29,7 @@ SIGNATURES = {
     'advmix_conv_tr': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_tr_w': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_direct_config': [_i] * 9,
+    'advmix_deconv4x4s2_narrow': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'advmix_conv_tr_w_add': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_tr_w_bnb': [_p, _p, _p, _p] + [_i] * 11 + [_p, _p, _p, _p, _i, _p, _p, _p],
     'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],
@@ -58,6 +59,7 @@ SIGNATURES = {
     'advmix_joints_loss_det': [_p, _p, _i, _p, _p, _p, _f, _i, _i, _i, _i, _p, _p],
     'advmix_heatmap_argmax': [_p, _i, _p, _p, _i, _i, _i, _p],
     'advmix_adam': [_p, _p, _p, _p, _l, _p, _p, _p],
+    'advmix_sgd': [_p, _p, _p, _l, _p, _p],
     'advmix_fill': [_p, _f, _l, _p],
     'advmix_make_views': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     'advmix_render_targets': [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

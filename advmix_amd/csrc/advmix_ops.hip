@@ -154,6 +154,24 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ h
 
 __global__ void adam_tick_kernel(int64_t* step) { *step += 1; }
 
+// torch.optim.SGD single-tensor math (dampening 0): g += wd * p; buf = momentum * buf + g; g = nesterov ? g + momentum *
+// buf : buf; p -= lr * g.  hyper = {lr, momentum, weight_decay, nesterov (0 / 1)} in device memory (graph-replay safe).
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ buf, int64_t n, const float* __restrict__ hyper) {
+    const float lr = hyper[0], mom = hyper[1], wd = hyper[2];
+    const bool nesterov = hyper[3] != 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        if (wd != 0.f) gi = gi + wd * p[i];
+        if (mom != 0.f) {
+            const float b = buf[i] * mom + gi;
+            buf[i] = b;
+            gi = nesterov ? gi + mom * b : b;
+        }
+        p[i] -= lr * gi;
+    }
+}
+
 // torch.optim.Adam single-tensor math (no wd, no amsgrad)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
@@ -171,6 +189,88 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         v[i] = vi;
         float denom = sqrtf(vi) / bc2s + eps;
         p[i] -= step_size * (mi / denom);
+    }
+}
+
+
+
+
+// ---- ConvTranspose2d 4x4 / stride 2 / pad 1 with a NARROW output (Cout <= 4): the U-Net's last layer, 128 -> 3 at
+// 256x192 (Unet_generator.py:51-57).  On the MFMA path it computes 32 output columns to keep 3 (507 us per step,
+// 0.06 of peak); here it is a VALU dot product bound by reading the input once.  Output pixels of one PARITY class
+// (oh % 2, ow % 2) use the same 2 x 2 taps, so a workgroup takes one class: thread (pixel lane 0..15, channel lane
+// 0..15) keeps the weights of its 8 input channels x 4 taps x Cout in registers and walks over its pixels; the 16
+// channel lanes of a pixel read 512 contiguous bytes per tap and meet in a 4-step shuffle.
+template <int CO>
+__global__ __launch_bounds__(256) void deconv4x4s2_narrow_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, float* __restrict__ y,
+                                                                 int N, int Hi, int Wi, int Ci, int pix_per_block) {
+    const int tid = threadIdx.x, cl = tid & 15, pl = tid >> 4;
+    const int phase = blockIdx.y, ph = phase >> 1, pw = phase & 1;
+    // taps of this class: kh in {kh0, kh0 + 2} reads input row a + dh, with a = oh / 2
+    const int kh0 = (ph + 1) & 1, kw0 = (pw + 1) & 1;
+    const int dh[2] = {ph == 0 ? 0 : 1, ph == 0 ? -1 : 0};   // kh0 -> dh[0], kh0 + 2 -> dh[1]
+    const int dw[2] = {pw == 0 ? 0 : 1, pw == 0 ? -1 : 0};
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    const int64_t P = (int64_t)N * Hi * Wi;                  // output pixels of one class
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = p0 + pix_per_block < P ? p0 + pix_per_block : P;
+    float acc_b[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc_b[o] = bias ? bias[o] : 0.f;
+    for (int c0 = 0; c0 < Ci; c0 += 128) {
+        const int ci = c0 + cl * 8;
+        const bool cok = ci < Ci;                            // (Ci % 8 == 0 is checked on the host)
+        float wr[2][2][8][CO];                               // this thread's weights: [tap h][tap w][channel][co]
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+#pragma unroll
+                    for (int o = 0; o < CO; ++o)
+                        wr[a][b][c][o] = cok ? w[(((int64_t)(ci + c) * 4 + kh0 + 2 * a) * 4 + kw0 + 2 * b) * CO + o] : 0.f;
+        for (int64_t p = p0 + pl; p < p1; p += 16) {
+            const int n = (int)(p / ((int64_t)Hi * Wi));
+            const int rem = (int)(p - (int64_t)n * Hi * Wi);
+            const int a_ = rem / Wi, b_ = rem - a_ * Wi;
+            float s[CO];
+#pragma unroll
+            for (int o = 0; o < CO; ++o) s[o] = 0.f;
+            f32x4 v[2][2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int ih = a_ + dh[a], iw = b_ + dw[b];
+                    const bool ok = cok && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
+                    const float* src = x + (((int64_t)n * Hi + (ok ? ih : 0)) * Wi + (ok ? iw : 0)) * Ci + (cok ? ci : 0);
+                    v[a][b][0] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    v[a][b][1] = ok ? *reinterpret_cast<const f32x4*>(src + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+#pragma unroll
+                        for (int o = 0; o < CO; ++o) s[o] = fmaf(v[a][b][c >> 2][c & 3], wr[a][b][c][o], s[o]);
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) s[o] += __shfl_xor(s[o], off, 64);   // the 16 channel lanes
+            }
+            if (cl == 0) {
+                float* dst = y + (((int64_t)n * Ho + 2 * a_ + ph) * Wo + 2 * b_ + pw) * CO;
+#pragma unroll
+                for (int o = 0; o < CO; ++o) {
+                    if (c0 == 0) dst[o] = s[o] + acc_b[o];
+                    else dst[o] += s[o];                    // further 128-channel passes (same thread, same pixel)
+                }
+            }
+        }
     }
 }
 
@@ -289,6 +389,35 @@ extern "C" int advmix_adam(float* p, const float* g, float* m, float* v, int64_t
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step);
     hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n)), dim3(256), 0, st, p, g, m, v, n, hyper, step);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+// ConvTranspose2d(Cin, Cout <= 4, kernel 4, stride 2, padding 1) forward, weights in their own layout
+// w[Cin][4][4][Cout]; x [N,Hi,Wi,Cin] -> y [N,2Hi,2Wi,Cout].  ADVMIX_EINVAL (nothing launched) for other shapes.
+extern "C" int advmix_deconv4x4s2_narrow(const float* x, const float* w, const float* bias, float* y, int N, int Hi,
+                                         int Wi, int Ci, int Co, void* stream) {
+    if (!x || !w || !y || N <= 0 || Hi <= 0 || Wi <= 0) return ADVMIX_EINVAL;
+    if (Co < 1 || Co > 4 || Ci % 8 != 0) return ADVMIX_EINVAL;
+    const int64_t P = (int64_t)N * Hi * Wi;
+    int ppb = 256;                                           // 16 pixels per pass x 16 passes per workgroup
+    while ((P + ppb - 1) / ppb > 4096) ppb *= 2;
+    dim3 g((unsigned)((P + ppb - 1) / ppb), 4);
+    hipStream_t st = (hipStream_t)stream;
+    switch (Co) {
+        case 1: hipLaunchKernelGGL((deconv4x4s2_narrow_kernel<1>), g, dim3(256), 0, st, x, w, bias, y, N, Hi, Wi, Ci, ppb); break;
+        case 2: hipLaunchKernelGGL((deconv4x4s2_narrow_kernel<2>), g, dim3(256), 0, st, x, w, bias, y, N, Hi, Wi, Ci, ppb); break;
+        case 3: hipLaunchKernelGGL((deconv4x4s2_narrow_kernel<3>), g, dim3(256), 0, st, x, w, bias, y, N, Hi, Wi, Ci, ppb); break;
+        default: hipLaunchKernelGGL((deconv4x4s2_narrow_kernel<4>), g, dim3(256), 0, st, x, w, bias, y, N, Hi, Wi, Ci, ppb); break;
+    }
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+// One SGD step over a flat parameter buffer (lib/utils/utils.py:80-88: optim.SGD(lr, momentum, weight_decay, nesterov)).
+extern "C" int advmix_sgd(float* p, const float* g, float* buf, int64_t n, const float* hyper, void* stream) {
+    if (!p || !g || !buf || !hyper || n <= 0) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(sgd_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, hyper);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }

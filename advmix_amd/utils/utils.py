@@ -80,11 +80,13 @@ class FlatAdam(torch.optim.Optimizer):
                 self._offsets.append(off)
         self._grad_views = [p.grad for p in ps]
         self._flat = (fp, fg, torch.zeros_like(fp), torch.zeros_like(fp))
-        g0 = self.param_groups[0]
-        self._hyper = torch.tensor([g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps']],
-                                   device=dev, dtype=torch.float32)
-        self._hyper_host = (g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'])
+        self._hyper_host = self._hyper_tuple()
+        self._hyper = torch.tensor(self._hyper_host, device=dev, dtype=torch.float32)
         self._step = torch.zeros((), device=dev, dtype=torch.int64)
+
+    def _hyper_tuple(self):
+        g0 = self.param_groups[0]
+        return (g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'])
 
     def flat_state(self):
         """Everything a replica needs to continue identically: parameters, Adam moments, step counter
@@ -105,8 +107,7 @@ class FlatAdam(torch.optim.Optimizer):
     def sync_hyper(self):
         """Push lr/betas/eps to the device if a scheduler changed them (host-side, not captured)."""
         self._ensure_flat()
-        g0 = self.param_groups[0]
-        cur = (g0['lr'], g0['betas'][0], g0['betas'][1], g0['eps'])
+        cur = self._hyper_tuple()
         if cur != self._hyper_host:
             self._hyper.copy_(torch.tensor(cur, dtype=torch.float32))
             self._hyper_host = cur
@@ -178,13 +179,73 @@ class FlatAdam(torch.optim.Optimizer):
         self.sync_hyper()
 
 
+class FlatSGD(FlatAdam):
+    """torch.optim.SGD(params, lr, momentum, weight_decay, nesterov) semantics (dampening 0) on the same flat buffers as
+    FlatAdam: one kernel per step, hyper-parameters in device memory, gradients accumulated in place by the backward
+    kernels (lib/utils/utils.py:80-88)."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0, nesterov=False):
+        if nesterov and momentum <= 0:
+            raise ValueError('Nesterov momentum requires a momentum')
+        torch.optim.Optimizer.__init__(self, list(params), dict(lr=lr, momentum=momentum, dampening=0,
+                                                                  weight_decay=weight_decay, nesterov=nesterov))
+        self._flat = None
+        if all(p.is_cuda for p in self._params()):
+            self._ensure_flat()
+
+    def _hyper_tuple(self):
+        g0 = self.param_groups[0]
+        return (g0['lr'], g0['momentum'], g0['weight_decay'], 1.0 if g0['nesterov'] else 0.0)
+
+    @torch.no_grad()
+    def step(self, closure=None, sync_hyper=True):
+        self._ensure_flat()
+        if sync_hyper and not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper()
+        self._attach_grads(strict=True)
+        fp, fg, buf, _ = self._flat
+        P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+        call('advmix_sgd', P(fp), P(fg), P(buf), fp.numel(), P(self._hyper),
+             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    def flat_state(self):
+        self._ensure_flat()
+        return [self._flat[0], self._flat[2]]
+
+    def state_dict(self):
+        self._ensure_flat()
+        ps = self._params()
+        state = {}
+        if self.param_groups[0]['momentum'] != 0:
+            for i, (p, off) in enumerate(zip(ps, self._offsets)):
+                state[i] = {'momentum_buffer': self._view(self._flat[2], off, p).detach().clone()}
+        groups = [dict((k, v) for k, v in g.items() if k != 'params') for g in self.param_groups]
+        for g in groups:
+            g['params'] = list(range(len(ps)))
+        return {'state': state, 'param_groups': groups}
+
+    def load_state_dict(self, sd):
+        self._ensure_flat()
+        ps = self._params()
+        for k, v in sd['param_groups'][0].items():
+            if k != 'params':
+                self.param_groups[0][k] = v
+        with torch.no_grad():
+            for i, (p, off) in enumerate(zip(ps, self._offsets)):
+                st = sd['state'].get(i) or sd['state'].get(str(i))
+                if st is not None and st.get('momentum_buffer') is not None:
+                    self._view(self._flat[2], off, p).copy_(st['momentum_buffer'])
+        self.sync_hyper()
+
+
 def get_optimizer(cfg, model):
-    """lib/utils/utils.py:78-94.  Only the Adam branch is on the hot path (every shipped
-    experiment uses it); the SGD branch is handed to torch.optim unchanged."""
+    """lib/utils/utils.py:78-94: Adam(lr) or SGD(lr, momentum, weight_decay, nesterov), both as ONE flat-buffer HIP
+    kernel per step."""
     if cfg.TRAIN.OPTIMIZER == 'adam':
         return FlatAdam(model.parameters(), lr=cfg.TRAIN.LR)
     if cfg.TRAIN.OPTIMIZER == 'sgd':
-        raise NotImplementedError('TRAIN.OPTIMIZER sgd is not on the MI355X hot path; use adam')
+        return FlatSGD(model.parameters(), lr=cfg.TRAIN.LR, momentum=cfg.TRAIN.MOMENTUM,
+                       weight_decay=cfg.TRAIN.WD, nesterov=cfg.TRAIN.NESTEROV)
     return None
 
 

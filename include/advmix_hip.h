@@ -101,6 +101,12 @@ int advmix_conv_tr_w_bnb(const float* x, const float* w, const float* addend, fl
                          const float* bn_y, const float* bn_c, const float* bn_mean, const float* bn_invstd,
                          int act, double* stats, int* stats_ns, void* stream);
 
+/* ConvTranspose2d(Cin, Cout <= 4, kernel 4, stride 2, padding 1) forward for NARROW outputs - the U-Net's last layer
+ * (Unet_generator.py:51-57, 128 -> 3): a VALU kernel bound by reading x once instead of an MFMA tile 32 columns wide.
+ * w in its own layout [Cin][4][4][Cout]; x [N,Hi,Wi,Cin] -> y [N,2Hi,2Wi,Cout].  ADVMIX_EINVAL for other shapes. */
+int advmix_deconv4x4s2_narrow(const float* x, const float* w, const float* bias, float* y, int N, int Hi, int Wi,
+                              int Ci, int Co, void* stream);
+
 /* Which tile configuration the second-generation conv kernel picks (introspection for tests / tuning):
  * 1 = 128x32, 2 = 128x64, 3 = 64x64, 4 = 64x64 + K split across the grid (atomics), 5 = 32x32 + K split between
  * the four waves of a workgroup, 6 = 64x32 + K split between two wave pairs; -1 = not served.  mode 0: forward, (Ho, Wo) = output size, Ci = reduction channels;
@@ -235,6 +241,9 @@ int advmix_heatmap_argmax(const float* hm, int nhwc, int32_t* idx_out, float* ma
  * incremented by the kernel launch itself (graph-replay safe). */
 int advmix_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
                 int64_t* step, void* stream);
+/* One torch.optim.SGD step (dampening 0) over a flat buffer (lib/utils/utils.py:80-88): hyper = {lr, momentum,
+ * weight_decay, nesterov as 0 / 1} in device memory; buf = the momentum buffer (zero before the first step). */
+int advmix_sgd(float* p, const float* g, float* buf, int64_t n, const float* hyper, void* stream);
 int advmix_fill(float* p, float value, int64_t n, void* stream);
 
 /* ---- three-view input pipeline on the device -------------------------------------------------

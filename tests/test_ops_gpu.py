@@ -546,6 +546,40 @@ def test_flat_adam_matches_torch():
     assert int(step) == 5
 
 
+@pytest.mark.parametrize('cfg', [(0.9, 1e-4, False), (0.9, 0.0, True), (0.0, 1e-4, False)])
+def test_flat_sgd_matches_torch(cfg):
+    """utils.FlatSGD (the SGD branch of get_optimizer, lib/utils/utils.py:80-88) against torch.optim.SGD: five steps on
+    a small conv + BN module, parameters and momentum buffers; state_dict round trip."""
+    from advmix_amd.utils.utils import FlatSGD
+    mom, wd, nest = cfg
+    torch.manual_seed(3)
+    ref = torch.nn.Sequential(torch.nn.Conv2d(4, 6, 3), torch.nn.BatchNorm2d(6))
+    mine = torch.nn.Sequential(torch.nn.Conv2d(4, 6, 3), torch.nn.BatchNorm2d(6))
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev())
+    o_ref = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=mom, weight_decay=wd, nesterov=nest)
+    o_mine = FlatSGD(mine.parameters(), lr=0.05, momentum=mom, weight_decay=wd, nesterov=nest)
+    for it in range(5):
+        o_mine.zero_grad()
+        for pr, pm in zip(ref.parameters(), mine.parameters()):
+            g = rnd(*pr.shape, seed=70 + it).float()
+            pr.grad = g.clone()
+            pm.grad.copy_(g.to(dev()).reshape(pm.grad.shape) if pm.dim() != 4 else g.to(dev()))
+        o_ref.step()
+        o_mine.step()
+        if it == 2:                                            # scheduler-style change of the learning rate
+            o_ref.param_groups[0]['lr'] = o_mine.param_groups[0]['lr'] = 0.01
+    for pr, pm in zip(ref.parameters(), mine.parameters()):
+        check('param', pm, pr.detach().double(), 1e-6)
+    sd = o_mine.state_dict()
+    if mom:
+        for i, pr in enumerate(ref.parameters()):
+            check('momentum', sd['state'][i]['momentum_buffer'], o_ref.state[pr]['momentum_buffer'].double(), 1e-6)
+    o2 = FlatSGD(mine.parameters(), lr=0.05, momentum=mom, weight_decay=wd, nesterov=nest)
+    o2.load_state_dict(sd)
+    assert o2.param_groups[0]['lr'] == 0.01
+
+
 def test_nms_bit_exact_vs_oracle():
     import ctypes
     from advmix_amd._lib import call

@@ -366,7 +366,13 @@ __global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(C
 #pragma unroll
                 for (int t = 0; t < RM; ++t)
 #pragma unroll
-                    for (int u = 0; u < RN; ++u) acc[t][u] = MS::mma(A[t][q][j], b[u][j], acc[t][u]);
+                    for (int u = 0; u < RN; ++u) {
+#if defined(CD_DBG) && (CD_DBG & 8)                  /* no MFMAs: how much of the STEP is matrix-pipe time? */
+                        acc[t][u][0] += A[t][q][j] * b[u][j];
+#else
+                        acc[t][u] = MS::mma(A[t][q][j], b[u][j], acc[t][u]);
+#endif
+                    }
         }
     };
 
@@ -537,7 +543,12 @@ static double fill(int64_t n) { return n <= 0 ? 0.0 : (double)n / (256.0 * (doub
 
 static Cfg pick_cfg(int64_t Mmax, int Co, int phases, int nch, int* nsplit) {
     *nsplit = 1;
-    if (Co <= 32) return CFG_128x32;                       // (256 x 32 measured: 34.9 vs 27.5 us)
+    if (Co <= 32) {                                        // (256 x 32 measured: 34.9 vs 27.5 us)
+        static const int force = [] { const char* e = getenv("ADVMIX_CFG32"); return e ? atoi(e) : 0; }();
+        if (force == 6 && nch >= 4) return CFG_64x32_WAVE_SPLIT2;
+        if (force == 5 && nch >= 8) return CFG_32x32_WAVE_SPLIT;
+        return CFG_128x32;
+    }
     if ((int64_t)cdiv(Mmax, 128) * cdiv(Co, 64) * phases >= 512) return CFG_128x64;
     const int64_t b64 = (int64_t)cdiv(Mmax, 64) * cdiv(Co, 64) * phases;
     int ns = 1;

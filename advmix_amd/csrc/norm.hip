@@ -6,6 +6,7 @@
 // groups = 1  : BatchNorm over all rows      (lib/models/pose_hrnet.py:34 and every nn.BatchNorm2d)
 // groups = N  : InstanceNorm per image       (lib/models/Unet_generator.py:19,43,45)
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -565,7 +566,8 @@ static dim3 slot_grid(int64_t rows, int C) {
     const int ctn = C < SLOT_CT ? C : SLOT_CT;
     const int rpi = 256 / (ctn / 4);
     int64_t nb = (rows + 4 * rpi - 1) / (4 * rpi);
-    const int64_t cap = 2048 / nct > 0 ? 2048 / nct : 1;
+    static const int wgs = [] { const char* e = getenv("ADVMIX_SLOT_WGS"); int v = e ? atoi(e) : 2048; return v > 0 ? v : 2048; }();
+    const int64_t cap = wgs / nct > 0 ? wgs / nct : 1;
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     return dim3((unsigned)nb, (unsigned)nct);

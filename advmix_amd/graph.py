@@ -5,7 +5,10 @@ backward passes); driven eagerly from Python it is launch-bound.  The step has s
 so it is captured ONCE into HIP graphs (hipStreamBeginCapture via torch.cuda.CUDAGraph - every
 kernel in libadvmix_hip.so is capture-safe: no allocation, no sync) and replayed per batch.
 
-Single GPU: two graphs (phase a: G fwd ... D bwd; phase b: Adam(D) ... G bwd, Adam(G)).
+Captured as LANE TAPES (ops.Tape): not one HIP graph with parallel branches - the ROCm runtime issues the nodes of such
+a graph one after the other at ~3 us each, which bounded the step - but a sequence of single-chain graphs, one per launch
+lane and level, replayed on the lanes' streams with host-side wait_stream() between them (0.6-0.9 us per kernel).
+Single GPU: two segments (phase a: G fwd ... D bwd; phase b: Adam(D) ... G bwd, Adam(G)).
 With data parallelism the step is cut into seven graphs, one per piece of a backward pass (core.function.
 _backward_pieces): [G fwd, mix, D fwd, T fwd, losses, top third of D's bwd] | [middle third] | [bottom third] |
 [Adam(D), D fwd, loss, bwd through D, top third of G's bwd] | [middle] | [bottom] | [Adam(G)].  After each piece the
@@ -14,6 +17,7 @@ the next graph runs; the RCCL calls stay outside the graphs.  The autograd tape 
 consumed while capturing the next; all share one memory pool."""
 import torch
 
+from . import ops
 from .core.function import advmix_phase_a, advmix_phase_b, advmix_step, plain_step
 
 
@@ -64,19 +68,11 @@ class AdvMixGraphRunner:
         torch.cuda.synchronize(dev)
         optimizer.sync_hyper()
         optimizer_G.sync_hyper()
-        # thread_local: only this thread launches work; RCCL's watchdog thread may query events meanwhile
-        mode = dict(capture_error_mode='thread_local')
-        self.segments = []          # [(graph, None | (optimizer, lo, hi) to all-reduce after it, finish-before flag)]
-        pool = [None]
+        self.segments = []          # [(segment id, None | (optimizer, lo, hi) to all-reduce after it, finish-before flag)]
+        self.seq = ops.GraphSeq(dev)
 
         def capture(fn):
-            g = torch.cuda.CUDAGraph()
-            kw = dict(mode) if pool[0] is None else dict(mode, pool=pool[0])
-            with torch.cuda.graph(g, **kw):
-                r = fn()
-            if pool[0] is None:
-                pool[0] = g.pool()
-            return g, r
+            return self.seq.capture(fn)
 
         sync = grad_sync if (grad_sync is not None and grad_sync.active) else None
         if sync is None:
@@ -140,7 +136,7 @@ class AdvMixGraphRunner:
             g, red = seg[0], seg[1]
             if len(seg) > 2 and seg[2] and self.sync is not None:
                 self.sync.finish()                         # this segment's optimizer step consumes reduced gradients
-            g.replay()
+            self.seq.replay(g)
             if red is not None and self.sync is not None:
                 self.sync.reduce_async(red[0].flat_grads, red[1], red[2])
         return self.loss_D, self.output
@@ -164,16 +160,16 @@ class PlainGraphRunner:
         _restore(snap)
         torch.cuda.synchronize(dev)
         optimizer.sync_hyper()
-        self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        mode = dict(capture_error_mode='thread_local')
-        with torch.cuda.graph(self.g1, **mode):
+        self.seq = ops.GraphSeq(dev)
+
+        def seg_a():
             outputs = model(self.input)
             loss = criterion(outputs, self.target, self.tw)
             optimizer.zero_grad()
             loss.backward()
             self.loss, self.output = loss.detach(), outputs.detach()
-        with torch.cuda.graph(self.g2, pool=self.g1.pool(), **mode):
-            optimizer.step(sync_hyper=False)
+        self.s1, _ = self.seq.capture(seg_a)
+        self.s2, _ = self.seq.capture(lambda: optimizer.step(sync_hyper=False))
         torch.cuda.synchronize(dev)
 
     def load_batch(self, input, target, target_weight):
@@ -183,8 +179,8 @@ class PlainGraphRunner:
 
     def step(self):
         self.opt.sync_hyper()
-        self.g1.replay()
+        self.seq.replay(self.s1)
         if self.sync is not None:
             self.sync.sync(self.opt)
-        self.g2.replay()
+        self.seq.replay(self.s2)
         return self.loss, self.output

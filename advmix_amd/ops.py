@@ -871,6 +871,177 @@ class Chain:
         return flat
 
 
+
+# =============================================================================================
+# Lane tapes: HIP-graph capture as a SEQUENCE of single-stream graphs
+# =============================================================================================
+class Tape:
+    """Captures a function as a sequence of single-stream HIP graphs plus host-side stream dependencies, instead of one
+    graph with parallel branches.
+
+    Why (tools/graph_launch_floor.py, tools/graph_per_lane.py on MI355X / ROCm 7.2): a replayed graph that is ONE chain
+    of kernels dispatches a node every 1.55 us (pre-built AQL packets); a graph with parallel branches falls off that
+    path - every node costs 2.6-3.2 us and the branches' nodes are issued one after the other, whatever queue they run
+    on (4 chains of 300 tiny kernels: 3.8 ms, against 0.46 ms for one chain), while four single-chain graphs replayed
+    on four streams dispatch a kernel every 0.6-0.9 us.  The AdvMix step launches ~3,500 kernels from four lanes:
+    in one multi-branch graph its lanes could start a kernel every ~12 us each, which is what bounded the step (with
+    every MFMA compiled out of conv_direct it still took 51 of 60 ms).
+
+    While ``ops.TAPE`` is set, GroupFn closes the open capture at every fork, captures each lane's members into a graph
+    of their own on the lane's stream, and reopens a capture on the main stream after the join; the fork / join
+    become ``wait`` items replayed with stream.wait_stream().  Everything runs on the calling thread
+    (torch.autograd.set_multithreading_enabled(False)), so captures begin and end on one thread.  All graphs share one
+    memory pool and are replayed in capture order."""
+
+    def __init__(self, device=None):
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+        self.main = torch.cuda.Stream(device=self.device)
+        self.items = []              # ('graph', CUDAGraph, stream) | ('wait', waiter stream, waited stream)
+        self.pool = None
+        self._open = None
+        self.mode = dict(capture_error_mode='thread_local')
+
+    # ---- capture ---------------------------------------------------------------------------
+    def open(self, stream):
+        assert self._open is None
+        g = torch.cuda.CUDAGraph()
+        ctx = torch.cuda.stream(stream)
+        ctx.__enter__()
+        if self.pool is None:
+            g.capture_begin(**self.mode)
+        else:
+            g.capture_begin(pool=self.pool, **self.mode)
+        self._open = (g, stream, ctx)
+
+    def close(self):
+        g, stream, ctx = self._open
+        g.capture_end()
+        ctx.__exit__(None, None, None)
+        if self.pool is None:
+            self.pool = g.pool()
+        self.items.append(('graph', g, stream))
+        self._open = None
+
+    def wait(self, waiter, waited):
+        self.items.append(('wait', waiter, waited))
+
+    def capture(self, fn):
+        """Run ``fn`` once under capture; returns its result.  The tape can be replayed afterwards."""
+        global TAPE
+        import gc
+        torch.cuda.synchronize(self.device)
+        gc.collect()
+        prev = TAPE
+        TAPE = self
+        try:
+            with torch.autograd.set_multithreading_enabled(False):
+                self.open(self.main)
+                try:
+                    r = fn()
+                finally:
+                    if self._open is not None:
+                        self.close()
+        finally:
+            TAPE = prev
+        torch.cuda.synchronize(self.device)
+        return r
+
+    # ---- replay ----------------------------------------------------------------------------
+    def replay(self, lo=0, hi=None):
+        """Replay items [lo, hi) (default: all).  The tape's main stream first waits for the caller's current stream and
+        the caller's stream waits for it afterwards, so a tape slice behaves like one stream-ordered operation."""
+        cur = torch.cuda.current_stream(self.device)
+        self.main.wait_stream(cur)
+        for it in self.items[lo:hi]:
+            if it[0] == 'graph':
+                with torch.cuda.stream(it[2]):
+                    it[1].replay()
+            else:
+                it[1].wait_stream(it[2])
+        cur.wait_stream(self.main)
+
+    @property
+    def n_graphs(self):
+        return sum(1 for it in self.items if it[0] == 'graph')
+
+
+TAPE = None
+USE_TAPE = __import__('os').environ.get('ADVMIX_TAPE', '1') != '0'    # runners: lane tapes (1) or one multi-branch graph (0)
+
+
+class GraphSeq:
+    """What the runners capture into: a Tape (default) or, with ADVMIX_TAPE=0, plain torch.cuda.graph captures (one
+    multi-branch HIP graph per ``capture`` call) sharing one pool.  ``capture(fn)`` returns (segment id, fn's result);
+    ``replay(segment id)`` replays that segment."""
+
+    def __init__(self, device):
+        self.tape = Tape(device) if USE_TAPE else None
+        self.graphs, self.segs, self.pool = [], [], None
+
+    def capture(self, fn):
+        if self.tape is not None:
+            lo = len(self.tape.items)
+            r = self.tape.capture(fn)
+            self.segs.append((lo, len(self.tape.items)))
+            return len(self.segs) - 1, r
+        g = torch.cuda.CUDAGraph()
+        kw = dict(capture_error_mode='thread_local')
+        if self.pool is not None:
+            kw['pool'] = self.pool
+        with torch.cuda.graph(g, **kw):
+            r = fn()
+        if self.pool is None:
+            self.pool = g.pool()
+        self.graphs.append(g)
+        return len(self.graphs) - 1, r
+
+    def replay(self, seg):
+        if self.tape is not None:
+            self.tape.replay(*self.segs[seg])
+        else:
+            self.graphs[seg].replay()
+
+    @property
+    def n_graphs(self):
+        return self.tape.n_graphs if self.tape is not None else len(self.graphs)
+
+
+def _lane_order(n, nl):
+    """Members in execution order: lane by lane (member i runs on lane i % nl)."""
+    return [i for l in range(nl) for i in range(l, n, nl)]
+
+
+def _run_lanes(dev, n, nl, run_member):
+    """Fork, run member i on lane i % nl via ``run_member(i, stream handle, lane)``, join.  Eager or inside an
+    ordinary capture: real stream fork / join.  On a Tape: one graph per lane."""
+    cur = torch.cuda.current_stream(dev)
+    side = _lanes(dev, nl - 1)
+    tape = TAPE
+    if tape is None or nl == 1:
+        for s_ in side:
+            s_.wait_stream(cur)
+        handles = [ctypes.c_void_p(cur.cuda_stream)] + [ctypes.c_void_p(s_.cuda_stream) for s_ in side]
+        for i in _lane_order(n, nl):
+            run_member(i, handles[i % nl], i % nl)
+        for s_ in side:
+            cur.wait_stream(s_)
+        return
+    assert cur == tape.main, 'Tape: GroupFn must run on the tape\'s main stream'
+    tape.close()                                           # everything before the fork: one graph on the main stream
+    streams = [tape.main] + side
+    for s_ in side:
+        tape.wait(s_, tape.main)
+    for l in range(nl):
+        tape.open(streams[l])
+        h = ctypes.c_void_p(streams[l].cuda_stream)
+        for i in range(l, n, nl):
+            run_member(i, h, l)
+        tape.close()
+    for s_ in side:
+        tape.wait(tape.main, s_)
+    tape.open(tape.main)
+
+
 # =============================================================================================
 class GroupFn(torch.autograd.Function):
     """Runs a list of independent members; member i on lane i % MAX_LANES (lane 0 = the
@@ -893,28 +1064,29 @@ class GroupFn(torch.autograd.Function):
                     flat[pos + k] = nhwc(flat[pos + k])
             pos += cnt
         _ensure_workspaces(dev, nl)
-        side = _lanes(dev, nl - 1)
-        for s in side:
-            s.wait_stream(cur)
-        handles = [ctypes.c_void_p(cur.cuda_stream)] + [ctypes.c_void_p(s.cuda_stream) for s in side]
-        outs, saved, spans, extras, nondiff = [], [], [], [], []
-        pos = 0
         needs_all = ctx.needs_input_grad[1:]
+        starts, pos = [], 0
+        for op, cnt, meta in members:
+            starts.append(pos)
+            pos += cnt
+        results = [None] * n
+
+        def run_member(i, handle, lane):
+            op, cnt, meta = members[i]
+            p0 = starts[i]
+            results[i] = op.fwd(handle, lane, flat[p0:p0 + cnt], meta, needs_all[p0:p0 + cnt])
+        _run_lanes(dev, n, nl, run_member)
+        outs, saved, spans, extras, nondiff = [], [], [], [], []
         for i, (op, cnt, meta) in enumerate(members):
-            t = flat[pos:pos + cnt]
-            needs = needs_all[pos:pos + cnt]
-            o, sv, ex = op.fwd(handles[i % nl], i % nl, t, meta, needs)
-            if not any(needs):                             # frozen member (e.g. the teacher riding along): nothing to
-                _KEEP.extend(v for v in sv if torch.is_tensor(v))   # differentiate; its temporaries (mean, invstd,
-                sv = ()                                    # the raw conv output) still outlive the lanes' join
+            o, sv, ex = results[i]
+            if not any(needs_all[starts[i]:starts[i] + cnt]):   # frozen member (e.g. the teacher riding along): nothing
+                _KEEP.extend(v for v in sv if torch.is_tensor(v))   # to differentiate; its temporaries were alive until
+                sv = ()                                    # the join (``results``), which is all they need
                 nondiff += list(o)
-            spans.append((pos, cnt, len(outs), len(o), len(saved), len(sv)))
+            spans.append((starts[i], cnt, len(outs), len(o), len(saved), len(sv)))
             outs += list(o)
             saved += list(sv)
             extras.append(ex)
-            pos += cnt
-        for s in side:
-            cur.wait_stream(s)
         del _KEEP[:]
         ctx.members, ctx.spans, ctx.extras = members, spans, extras
         ctx.n_in = len(flat)
@@ -933,21 +1105,20 @@ class GroupFn(torch.autograd.Function):
         cur = torch.cuda.current_stream(dev)
         gouts = [nhwc(g) if (g is not None and g.dim() == 4) else g for g in gouts]   # before the fork
         _ensure_workspaces(dev, nl)
-        side = _lanes(dev, nl - 1)
-        for s in side:
-            s.wait_stream(cur)
-        handles = [ctypes.c_void_p(cur.cuda_stream)] + [ctypes.c_void_p(s.cuda_stream) for s in side]
         grads = [None] * ctx.n_in
         needs_all = ctx.needs_input_grad[1:]
-        for i, ((op, cnt, meta), (ipos, icnt, opos, ocnt, spos, scnt)) in enumerate(zip(members, ctx.spans)):
+        spans, extras = ctx.spans, ctx.extras
+
+        def run_member(i, handle, lane):
+            op, cnt, meta = members[i]
+            ipos, icnt, opos, ocnt, spos, scnt = spans[i]
             g = gouts[opos:opos + ocnt]
             needs = needs_all[ipos:ipos + icnt]
             if all(x is None for x in g) or not any(needs):
-                continue
-            r = op.bwd(handles[i % nl], i % nl, saved[spos:spos + scnt], ctx.extras[i], meta, g, needs)
+                return
+            r = op.bwd(handle, lane, saved[spos:spos + scnt], extras[i], meta, g, needs)
             grads[ipos:ipos + icnt] = list(r) + [None] * (icnt - len(r))
-        for s in side:
-            cur.wait_stream(s)
+        _run_lanes(dev, len(members), nl, run_member)
         del _KEEP[:]
         return (None,) + tuple(grads)
 

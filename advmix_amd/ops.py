@@ -876,33 +876,47 @@ class Chain:
 # Lane tapes: HIP-graph capture as a SEQUENCE of single-stream graphs
 # =============================================================================================
 class Tape:
-    """Captures a function as a sequence of single-stream HIP graphs plus host-side stream dependencies, instead of one
-    graph with parallel branches.
+    """Captures a function as per-lane SEQUENCES of single-stream HIP graphs with device-side hand-offs between the
+    lanes, instead of one graph with parallel branches.
 
-    Why (tools/graph_launch_floor.py, tools/graph_per_lane.py on MI355X / ROCm 7.2): a replayed graph that is ONE chain
-    of kernels dispatches a node every 1.55 us (pre-built AQL packets); a graph with parallel branches falls off that
-    path - every node costs 2.6-3.2 us and the branches' nodes are issued one after the other, whatever queue they run
-    on (4 chains of 300 tiny kernels: 3.8 ms, against 0.46 ms for one chain), while four single-chain graphs replayed
-    on four streams dispatch a kernel every 0.6-0.9 us.  The AdvMix step launches ~3,500 kernels from four lanes:
-    in one multi-branch graph its lanes could start a kernel every ~12 us each, which is what bounded the step (with
-    every MFMA compiled out of conv_direct it still took 51 of 60 ms).
+    Why (tools/graph_launch_floor.py, tools/graph_per_lane.py, tools/lane_handoff.py on MI355X / ROCm 7.2): a replayed
+    graph that is ONE chain of kernels dispatches a node every 1.55 us (pre-built AQL packets); a graph with parallel
+    branches falls off that path - every node costs 2.6-3.2 us and the branches' nodes are issued one after the other,
+    whatever queue they run on (4 chains of 300 tiny kernels: 3.8 ms, against 0.46 ms for one chain) - while
+    single-chain graphs replayed on four streams dispatch a kernel every 0.6-0.9 us.  The AdvMix step launches ~3,500
+    kernels from four lanes.  Stream events between separately replayed graphs are no alternative (~20 us per
+    hand-off, issued by the host): the hand-offs are KERNELS here - at a fork the main lane's chain signals a counter the
+    side lanes' chains wait on, at the join the side lanes signal and the main lane waits (advmix_lane_signal / _wait:
+    monotonic counters, each lane counts its own replays, bounded spin, error flag).
 
-    While ``ops.TAPE`` is set, GroupFn closes the open capture at every fork, captures each lane's members into a graph
-    of their own on the lane's stream, and reopens a capture on the main stream after the join; the fork / join
-    become ``wait`` items replayed with stream.wait_stream().  Everything runs on the calling thread
-    (torch.autograd.set_multithreading_enabled(False)), so captures begin and end on one thread.  All graphs share one
-    memory pool and are replayed in capture order."""
+    While ``ops.TAPE`` is set, GroupFn (``_run_lanes``) ends the open capture at every fork, captures each side lane's
+    members into a graph of their own on the lane's stream and continues on the main stream.  Everything runs on the
+    calling thread (torch.autograd.set_multithreading_enabled(False)), so captures begin and end on one thread.  All
+    graphs share one memory pool; a replay launches them in capture order from one native loop
+    (advmix_graph_launch_many).  The lanes need hardware queues of their own (GPU_MAX_HW_QUEUES >= 5, set by
+    advmix_amd/__init__.py): a waiting kernel at the head of a queue holds back whatever is queued behind it."""
+
+    MAX_SYNC = 4096
 
     def __init__(self, device=None):
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
         self.main = torch.cuda.Stream(device=self.device)
-        self.items = []              # ('graph', CUDAGraph, stream) | ('wait', waiter stream, waited stream)
+        self.items = []              # (CUDAGraph, stream)
         self.pool = None
         self._open = None
         self.mode = dict(capture_error_mode='thread_local')
+        # hand-off state: [epoch per lane (16)] [fork counters] [join counters]; err flag
+        self.sync = torch.zeros(16 + 2 * self.MAX_SYNC, dtype=torch.int64, device=self.device)
+        self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.n_sync = 0
+        self._ticked = set()
+        self._launch = None
+
+    def _ptr(self, idx):
+        return ctypes.c_void_p(self.sync.data_ptr() + 8 * idx)
 
     # ---- capture ---------------------------------------------------------------------------
-    def open(self, stream):
+    def open(self, stream, lane):
         assert self._open is None
         g = torch.cuda.CUDAGraph()
         ctx = torch.cuda.stream(stream)
@@ -912,6 +926,9 @@ class Tape:
         else:
             g.capture_begin(pool=self.pool, **self.mode)
         self._open = (g, stream, ctx)
+        if lane not in self._ticked:                       # the lane's first graph of a replay counts the replay
+            self._ticked.add(lane)
+            call('advmix_lane_tick', self._ptr(lane), ctypes.c_void_p(stream.cuda_stream))
 
     def close(self):
         g, stream, ctx = self._open
@@ -919,14 +936,34 @@ class Tape:
         ctx.__exit__(None, None, None)
         if self.pool is None:
             self.pool = g.pool()
-        self.items.append(('graph', g, stream))
+        self.items.append((g, stream))
         self._open = None
+        self._launch = None
 
-    def wait(self, waiter, waited):
-        self.items.append(('wait', waiter, waited))
+    def fork_join(self, side, run_lane):
+        """A fork into lanes [main] + side and the join after it, around ``run_lane(lane index, stream)``."""
+        k = self.n_sync
+        self.n_sync += 1
+        if k >= self.MAX_SYNC:
+            raise RuntimeError('Tape: more than %d fork/join points' % self.MAX_SYNC)
+        fork, join = self._ptr(16 + k), self._ptr(16 + self.MAX_SYNC + k)
+        err = ctypes.c_void_p(self.err.data_ptr())
+        call('advmix_lane_signal', fork, ctypes.c_void_p(self.main.cuda_stream))     # in the open main capture
+        self.close()
+        for l, s_ in enumerate(side, start=1):
+            self.open(s_, l)
+            h = ctypes.c_void_p(s_.cuda_stream)
+            call('advmix_lane_wait', fork, self._ptr(l), 1, err, h)
+            run_lane(l, s_)
+            call('advmix_lane_signal', join, h)
+            self.close()
+        self.open(self.main, 0)
+        run_lane(0, self.main)
+        call('advmix_lane_wait', join, self._ptr(0), len(side), err, ctypes.c_void_p(self.main.cuda_stream))
 
     def capture(self, fn):
-        """Run ``fn`` once under capture; returns its result.  The tape can be replayed afterwards."""
+        """Run ``fn`` once under capture; returns its result.  May be called several times (segments); replay(lo, hi)
+        replays a range of items, always in capture order."""
         global TAPE
         import gc
         torch.cuda.synchronize(self.device)
@@ -935,7 +972,7 @@ class Tape:
         TAPE = self
         try:
             with torch.autograd.set_multithreading_enabled(False):
-                self.open(self.main)
+                self.open(self.main, 0)
                 try:
                     r = fn()
                 finally:
@@ -949,20 +986,32 @@ class Tape:
     # ---- replay ----------------------------------------------------------------------------
     def replay(self, lo=0, hi=None):
         """Replay items [lo, hi) (default: all).  The tape's main stream first waits for the caller's current stream and
-        the caller's stream waits for it afterwards, so a tape slice behaves like one stream-ordered operation."""
+        the caller's stream waits for it afterwards, so a tape slice behaves like one stream-ordered operation (every
+        side lane's work is joined into the main lane by a device-side hand-off inside the slice)."""
+        hi = len(self.items) if hi is None else hi
+        key = (lo, hi)
+        if self._launch is None or self._launch[0] != key:
+            n = hi - lo
+            execs = (ctypes.c_void_p * n)(*[it[0].raw_cuda_graph_exec() for it in self.items[lo:hi]])
+            streams = (ctypes.c_void_p * n)(*[it[1].cuda_stream for it in self.items[lo:hi]])
+            self._launch = (key, execs, streams, n)
+            self._cache = getattr(self, '_cache', {})
+            self._cache[key] = self._launch
         cur = torch.cuda.current_stream(self.device)
         self.main.wait_stream(cur)
-        for it in self.items[lo:hi]:
-            if it[0] == 'graph':
-                with torch.cuda.stream(it[2]):
-                    it[1].replay()
-            else:
-                it[1].wait_stream(it[2])
+        _, execs, streams, n = self._launch
+        call('advmix_graph_launch_many', execs, streams, n)
         cur.wait_stream(self.main)
+
+    def check(self):
+        """Raise if a hand-off timed out (reads one int from the device: call it where the host synchronises anyway)."""
+        if int(self.err.item()) != 0:
+            raise RuntimeError('advmix_amd: a lane hand-off timed out (two lanes on one hardware queue? '
+                               'GPU_MAX_HW_QUEUES must be >= 5 before the first HIP call)')
 
     @property
     def n_graphs(self):
-        return sum(1 for it in self.items if it[0] == 'graph')
+        return len(self.items)
 
 
 TAPE = None
@@ -997,7 +1046,11 @@ class GraphSeq:
 
     def replay(self, seg):
         if self.tape is not None:
-            self.tape.replay(*self.segs[seg])
+            key = self.segs[seg]
+            cached = getattr(self.tape, '_cache', {}).get(key)
+            if cached is not None:
+                self.tape._launch = cached
+            self.tape.replay(*key)
         else:
             self.graphs[seg].replay()
 
@@ -1027,19 +1080,12 @@ def _run_lanes(dev, n, nl, run_member):
             cur.wait_stream(s_)
         return
     assert cur == tape.main, 'Tape: GroupFn must run on the tape\'s main stream'
-    tape.close()                                           # everything before the fork: one graph on the main stream
-    streams = [tape.main] + side
-    for s_ in side:
-        tape.wait(s_, tape.main)
-    for l in range(nl):
-        tape.open(streams[l])
-        h = ctypes.c_void_p(streams[l].cuda_stream)
+
+    def run_lane(l, stream):
+        h = ctypes.c_void_p(stream.cuda_stream)
         for i in range(l, n, nl):
             run_member(i, h, l)
-        tape.close()
-    for s_ in side:
-        tape.wait(tape.main, s_)
-    tape.open(tape.main)
+    tape.fork_join(side, run_lane)
 
 
 # =============================================================================================

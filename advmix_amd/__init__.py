@@ -6,9 +6,10 @@ that computes) does, and raises if ``libadvmix_hip.so`` has not been built.
 """
 import os as _os
 
-# The launch lanes of a step replay on streams of their own and hand work to each other with kernels that WAIT on a
-# counter (ops.Tape).  Two lanes sharing one hardware queue would deadlock (bounded: the wait times out and raises), so
+# ADVMIX_TAPE=1 (off by default): the launch lanes of a step replay on streams of their own and hand work to each other
+# with kernels that WAIT on a counter (ops.Tape).  Two lanes sharing one hardware queue would deadlock (bounded: the wait times out and raises), so
 # the HIP runtime must be allowed more hardware queues than its default of 4 before it creates the first one.
-_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+if _os.environ.get('ADVMIX_TAPE', '0') == '1':
+    _os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 __version__ = '0.2.0'

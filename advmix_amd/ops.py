@@ -1015,7 +1015,12 @@ class Tape:
 
 
 TAPE = None
-USE_TAPE = __import__('os').environ.get('ADVMIX_TAPE', '1') != '0'    # runners: lane tapes (1) or one multi-branch graph (0)
+# Runners: one multi-branch HIP graph per segment (default) or lane tapes (ADVMIX_TAPE=1).  Measured on the headline step
+# (same box, ms per step): 1 lane 74.9 graph / 78.1 tape; 2 lanes 66.1 / 66.1; 4 lanes 59.5 / 68.2.  The tape dispatches
+# ~3,500 kernels with 2 ms of host time instead of 46 ms and its hand-offs never timed out, but four free-running
+# queues slow each other down more than they gain: the runtime's one-node-at-a-time issue of a multi-branch graph happens
+# to interleave the lanes' kernels better.  Kept as an option and as the record of that experiment.
+USE_TAPE = __import__('os').environ.get('ADVMIX_TAPE', '0') == '1'
 
 
 class GraphSeq:

@@ -606,7 +606,10 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
     p.nsplit = 1;
     switch (pick_cfg(Mmax, p.Co, phases, nch, &ns)) {
         case CFG_128x32: LAUNCHD(1, 1, 4, 1, false); break;
-        case CFG_128x64: LAUNCHD(1, 2, 4, 1, false); break;
+        case CFG_128x64:
+            if (p.bnb_c) return -2;                        // two tiles per wave: no room to prefetch the BatchNorm-backward
+            LAUNCHD(1, 2, 4, 1, false);                    // operands, and loaded in the epilogue they cost more than the
+            break;                                         // separate statistics pass (HRNet-W48: 150.5 vs 153.2 images/s)
         case CFG_64x64: LAUNCHD(1, 1, 2, 2, false); break;
         case CFG_32x32_WAVE_SPLIT: LAUNCHD(1, 1, 1, 1, false); break;      // four waves share K in the workgroup
         case CFG_64x32_WAVE_SPLIT2: LAUNCHD(1, 1, 2, 1, false); break;     // two wave pairs share K
@@ -647,7 +650,11 @@ int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const 
     // fp64 atomics at the memory side (3x3 32->32 @64x48, 768 workgroups: 30.8 us with 16 slots, 23.1 with 64), while
     // every consumer workgroup has to reduce all of them again - 64 only where the contention is real.
     int ns = stats_nbg && *stats_nbg > 0 ? *stats_nbg : advmix_opts().stat_slots;
-    if (ns <= 0) ns = cdiv(Mmax, 128) >= 256 ? 64 : 16;
+    if (ns <= 0) {                                         // (longer kernels spread their atomics over more time:
+        int ph_, nch_;                                     //  HRNet-W48 384x288 is faster with fewer slots to re-read)
+        direct::problem_shape(mode, Ci, R, S, stride, Ci % 32 == 0 ? 32 : 16, &ph_, &nch_);
+        ns = cdiv(Mmax, 128) >= 256 ? (nch_ <= 12 ? 64 : 32) : 16;
+    }
     if (ns > 64 || (ns & (ns - 1))) ns = 16;
     p.stats_nbg = ns;
     bool bnb = false;

@@ -278,10 +278,11 @@ __global__ __launch_bounds__(256) void deconv4x4s2_narrow_kernel(const float* __
 
 AdvmixOpts& advmix_opts() {
     static AdvmixOpts o = [] {
-        AdvmixOpts d{1, 1, 1, 0, 0, 0};
+        AdvmixOpts d{1, 1, 1, 0, 0, 1, 0};
         const char* e;
         if ((e = getenv("ADVMIX_CONV")) && e[0] == 'i') d.direct = 0;
         if ((e = getenv("ADVMIX_WGRAD"))) d.wgrad_direct = e[0] != '0';
+        if ((e = getenv("ADVMIX_WGRAD_LDS"))) d.wgrad_lds = atoi(e);
         if ((e = getenv("ADVMIX_KSPLIT_WG"))) d.ksplit_wg = e[0] != '0';
         if ((e = getenv("ADVMIX_STAT_SLOTS"))) d.stat_slots = atoi(e);
         return d;
@@ -311,6 +312,7 @@ extern "C" int advmix_set_option(const char* name, int value) {
     AdvmixOpts& o = advmix_opts();
     if (!strcmp(name, "direct")) o.direct = value;
     else if (!strcmp(name, "wgrad_direct")) o.wgrad_direct = value;
+    else if (!strcmp(name, "wgrad_lds")) o.wgrad_lds = value;
     else if (!strcmp(name, "ksplit_wg")) o.ksplit_wg = value;
     else if (!strcmp(name, "stat_slots")) o.stat_slots = value;
     else if (!strcmp(name, "trace_shapes")) o.trace_shapes = value;

@@ -66,6 +66,7 @@ struct AdvmixOpts {
     int ksplit_wg;         // 1: layers with too few tiles split K inside the workgroup (fused epilogue kept), 0: across the grid
     int trace_shapes;      // 1: log every MFMA launch's shape (advmix_trace_launch)
     int deterministic;     // 1: conv_direct never splits K across the grid (fp32 atomics); see ops.py set_deterministic
+    int wgrad_lds;         // 1: LDS-patch weight gradient for 3x3 s1 32->32 when the batch fills the chip, 2: whenever eligible
     int stat_slots;        // fp64 slots per channel the statistics epilogues fold their workgroup sums onto (power of 2 <= 64; 0 = by grid size)
 };
 AdvmixOpts& advmix_opts();
@@ -79,3 +80,9 @@ void advmix_trace_launch(const char* kernel, dim3 grid, const char* kind, int N,
 // wgrad_direct.hip: both operands loaded in fragment layout; -1 = not eligible
 int advmix_wgrad_direct_dispatch(const float* a, const float* b, float* dw, int N, int Ha, int Wa, int Ca, int Hb,
                                  int Wb, int Cb, int R, int S, int stride, int pad, hipStream_t st);
+
+// wgrad_lds.hip: 3x3 s1 32->32 with both operands staged once in LDS; -1 = not eligible.  With ``part`` the workgroups
+// store their partial tiles ([*nslices][32*9*32], slab order, summed by the caller) instead of adding them to dw atomically.
+int advmix_wgrad_lds_dispatch(const float* a, const float* b, float* dw, int N, int Ha, int Wa, int Ca, int Hb, int Wb,
+                              int Cb, int R, int S, int stride, int pad, float* part, int64_t part_floats, int* nslices,
+                              hipStream_t st);

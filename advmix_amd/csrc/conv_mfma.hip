@@ -495,6 +495,20 @@ static int wgrad_impl(const float* a, const float* b, float* dw, int N, int Ha, 
                       int R, int S, int stride, int pad, float* part, int64_t part_floats, void* stream) {
     if (!a || !b || !dw || N <= 0 || Ca <= 0 || Cb <= 0 || stride < 1) return ADVMIX_EINVAL;
     if (Ha != (Hb + 2 * pad - R) / stride + 1 || Wa != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
+    {
+        int ns = 0;
+        int rc = advmix_wgrad_lds_dispatch(a, b, dw, N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad, part, part_floats, &ns,
+                                           (hipStream_t)stream);
+        if (rc >= 0) {
+            if (rc == ADVMIX_OK && ns > 0) {
+                const int64_t total = (int64_t)Ca * R * S * Cb;
+                hipLaunchKernelGGL(reduce_slices_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                   part, ns, total, dw);
+                ADVMIX_CHECK_LAUNCH();
+            }
+            return rc;
+        }
+    }
     if (!part) {
         int rc = advmix_wgrad_direct_dispatch(a, b, dw, N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad, (hipStream_t)stream);
         if (rc >= 0) return rc;

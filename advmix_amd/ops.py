@@ -902,8 +902,8 @@ class Tape:
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
         self.main = torch.cuda.Stream(device=self.device)
         self.items = []              # (CUDAGraph, stream)
-        self.pool = None
-        self._open = None
+        self.pools = {}              # lane -> memory pool shared by the lane's graphs
+        self._caps = {}              # lane -> (CUDAGraph, stream) under capture in the current segment
         self.mode = dict(capture_error_mode='thread_local')
         # hand-off state: [epoch per lane (16)] [fork counters] [join counters]; err flag
         self.sync = torch.zeros(16 + 2 * self.MAX_SYNC, dtype=torch.int64, device=self.device)
@@ -916,28 +916,28 @@ class Tape:
         return ctypes.c_void_p(self.sync.data_ptr() + 8 * idx)
 
     # ---- capture ---------------------------------------------------------------------------
-    def open(self, stream, lane):
-        assert self._open is None
+    def _begin(self, stream, lane):
+        """Start the capture of ``lane``'s graph for the current segment on ``stream`` (stays open until the segment
+        ends: several captures are under way at once, one per lane, with no event edges between them)."""
         g = torch.cuda.CUDAGraph()
-        ctx = torch.cuda.stream(stream)
-        ctx.__enter__()
-        if self.pool is None:
-            g.capture_begin(**self.mode)
-        else:
-            g.capture_begin(pool=self.pool, **self.mode)
-        self._open = (g, stream, ctx)
-        if lane not in self._ticked:                       # the lane's first graph of a replay counts the replay
-            self._ticked.add(lane)
-            call('advmix_lane_tick', self._ptr(lane), ctypes.c_void_p(stream.cuda_stream))
+        with torch.cuda.stream(stream):
+            if lane not in self.pools:                     # torch allows one capture at a time per pool: a pool per lane
+                self.pools[lane] = torch.cuda.graph_pool_handle()
+            g.capture_begin(pool=self.pools[lane], **self.mode)
+            if lane not in self._ticked:                   # the lane's first graph of a replay counts the replay
+                self._ticked.add(lane)
+                call('advmix_lane_tick', self._ptr(lane), ctypes.c_void_p(stream.cuda_stream))
+        self._caps[lane] = (g, stream)
 
-    def close(self):
-        g, stream, ctx = self._open
-        g.capture_end()
-        ctx.__exit__(None, None, None)
-        if self.pool is None:
-            self.pool = g.pool()
-        self.items.append((g, stream))
-        self._open = None
+    def _end_all(self):
+        """End every open capture back to back (nothing may allocate in between: the allocator's capture filters of
+        graphs sharing a pool are dropped first-begun-first, whichever capture ends)."""
+        for lane in sorted(self._caps):
+            g, stream = self._caps[lane]
+            with torch.cuda.stream(stream):
+                g.capture_end()
+            self.items.append((g, stream))
+        self._caps = {}
         self._launch = None
 
     def fork_join(self, side, run_lane):
@@ -948,16 +948,16 @@ class Tape:
             raise RuntimeError('Tape: more than %d fork/join points' % self.MAX_SYNC)
         fork, join = self._ptr(16 + k), self._ptr(16 + self.MAX_SYNC + k)
         err = ctypes.c_void_p(self.err.data_ptr())
-        call('advmix_lane_signal', fork, ctypes.c_void_p(self.main.cuda_stream))     # in the open main capture
-        self.close()
+        call('advmix_lane_signal', fork, ctypes.c_void_p(self.main.cuda_stream))
         for l, s_ in enumerate(side, start=1):
-            self.open(s_, l)
-            h = ctypes.c_void_p(s_.cuda_stream)
-            call('advmix_lane_wait', fork, self._ptr(l), 1, err, h)
-            run_lane(l, s_)
-            call('advmix_lane_signal', join, h)
-            self.close()
-        self.open(self.main, 0)
+            if l not in self._caps:
+                self._begin(s_, l)
+            assert self._caps[l][1] == s_
+            with torch.cuda.stream(s_):
+                h = ctypes.c_void_p(s_.cuda_stream)
+                call('advmix_lane_wait', fork, self._ptr(l), 1, err, h)
+                run_lane(l, s_)
+                call('advmix_lane_signal', join, h)
         run_lane(0, self.main)
         call('advmix_lane_wait', join, self._ptr(0), len(side), err, ctypes.c_void_p(self.main.cuda_stream))
 
@@ -971,13 +971,12 @@ class Tape:
         prev = TAPE
         TAPE = self
         try:
-            with torch.autograd.set_multithreading_enabled(False):
-                self.open(self.main, 0)
+            with torch.autograd.set_multithreading_enabled(False), torch.cuda.stream(self.main):
+                self._begin(self.main, 0)
                 try:
                     r = fn()
                 finally:
-                    if self._open is not None:
-                        self.close()
+                    self._end_all()
         finally:
             TAPE = prev
         torch.cuda.synchronize(self.device)
@@ -1023,6 +1022,9 @@ TAPE = None
 USE_TAPE = __import__('os').environ.get('ADVMIX_TAPE', '0') == '1'
 
 
+_REPLAY_SIDE = __import__('os').environ.get('ADVMIX_REPLAY_SIDE', '0') == '1'     # experiment
+
+
 class GraphSeq:
     """What the runners capture into: a Tape (default) or, with ADVMIX_TAPE=0, plain torch.cuda.graph captures (one
     multi-branch HIP graph per ``capture`` call) sharing one pool.  ``capture(fn)`` returns (segment id, fn's result);
@@ -1056,6 +1058,14 @@ class GraphSeq:
             if cached is not None:
                 self.tape._launch = cached
             self.tape.replay(*key)
+        elif _REPLAY_SIDE:
+            cur = torch.cuda.current_stream()
+            if not hasattr(self, '_side'):
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                self.graphs[seg].replay()
+            cur.wait_stream(self._side)
         else:
             self.graphs[seg].replay()
 

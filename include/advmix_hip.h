@@ -35,8 +35,8 @@ extern "C" {
 #define ADVMIX_ACT_LEAKY02 2   /* LeakyReLU(0.2), lib/models/Unet_generator.py:42 */
 
 int advmix_version(void);
-/* dispatch knobs for A/B runs and tests: "direct" (0 = first-generation conv only), "wgrad_direct", "ksplit_wg"
- * (K split inside the workgroup vs across the grid), "stat_slots" (fp64 slots per channel of the statistics
+/* dispatch knobs for A/B runs and tests: "direct" (0 = first-generation conv only), "wgrad_direct", "wgrad_lds"
+ * (0 off, 1 when the batch fills the chip, 2 whenever eligible), "ksplit_wg" (K split inside the workgroup vs across the grid), "stat_slots" (fp64 slots per channel of the statistics
  * epilogues), "deterministic" (1: no K split across the grid), "trace_shapes" (measurement aid, see common.h).
  * Unknown name -> ADVMIX_EINVAL. */
 int advmix_set_option(const char* name, int value);

@@ -61,6 +61,8 @@ CONV_CASES = [
     (16, 128, 32, 24, 128, 3, 2, 1, False), # stride-2 fuse conv: wave-split forward, phase-decomposed input gradient
     (8, 128, 64, 64, 128, 1, 1, 0, True),   # enough rows for the 128x64 tile in both directions
     (32, 64, 32, 24, 64, 3, 1, 1, False),   # HRNet's second branch at the bench batch: 64x32 tiles, K split between wave pairs
+    (32, 32, 64, 48, 32, 3, 1, 1, False),   # HRNet's first branch at the bench batch: LDS-patch weight gradient, 8 rows per workgroup
+    (3, 32, 12, 15, 32, 3, 1, 1, True),     # LDS-patch weight gradient when forced: 4 rows per workgroup, odd width
 ]
 
 
@@ -69,12 +71,47 @@ def conv_path(request):
     """Force each generation of the conv kernels in turn (advmix_set_option)."""
     from advmix_amd.ops import set_option
     set_option('wgrad_direct', {'igemm': 0, 'auto': 1}.get(request.param, 2))   # 2 = force where eligible
+    set_option('wgrad_lds', {'igemm': 0, 'auto': 1, 'direct': 0}.get(request.param, 2))
     set_option('direct', 0 if request.param == 'igemm' else 1)
     set_option('ksplit_wg', 1 if request.param in ('direct_wg', 'auto') else 0)  # K split inside the workgroup
     yield request.param
     set_option('ksplit_wg', 1)
     set_option('direct', 1)
     set_option('wgrad_direct', 1)
+    set_option('wgrad_lds', 1)
+
+
+def test_weight_gradient_lds_patch_kernel_and_its_ordered_partials():
+    """3x3 s1 32->32 (advmix_conv_wgrad / _det -> wgrad3x3_c32): atomics and ordered partials against torch, the
+    ordered variant bit-identical run to run and adding to what dw already holds."""
+    import ctypes
+    from advmix_amd._lib import call, lib
+    ops = _ops()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for (B, H, W, mode) in ((32, 64, 48, 1), (4, 8, 10, 2), (2, 4, 7, 2)):
+        ops.set_option('wgrad_lds', mode)
+        x = rnd(B, 32, H, W, seed=11)
+        dy = rnd(B, 32, H, W, seed=12)
+        wr = torch.zeros(32, 32, 3, 3, dtype=x.dtype, requires_grad=True)
+        F.conv2d(x, wr, None, 1, 1).backward(dy)
+        ref = wr.grad.permute(0, 2, 3, 1).contiguous()                   # [co][kh][kw][ci]
+        xd = x.float().to(dev()).permute(0, 2, 3, 1).contiguous()
+        dyd = dy.float().to(dev()).permute(0, 2, 3, 1).contiguous()
+        geom = (B, H, W, 32, H, W, 32, 3, 3, 1, 1)
+        dw = torch.zeros(32, 3, 3, 32, device=dev())
+        call('advmix_conv_wgrad', P(dyd), P(xd), P(dw), *geom, st)
+        check('dw atomics', dw.cpu(), ref, 2e-4)
+        nb = int(lib.advmix_wgrad_det_ws_bytes(32, 32, 3, 3))
+        ws = torch.empty(nb // 4, device=dev())
+        outs = []
+        for _ in range(2):
+            d2 = torch.ones(32, 3, 3, 32, device=dev())
+            call('advmix_conv_wgrad_det', P(dyd), P(xd), P(d2), *geom, P(ws), nb, st)
+            outs.append(d2.cpu())
+        assert torch.equal(outs[0], outs[1])
+        check('dw ordered', outs[0] - 1, ref, 2e-4)
+    ops.set_option('wgrad_lds', 1)
 
 
 def test_conv_tile_configuration_table():

@@ -5,7 +5,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd); D=$R/tools/_dbg; mkdir -p $D
 NAME=$1; SRC=$2; DEFS=$3
 objs=""
-for f in conv_mfma conv_direct wgrad_direct norm pointwise advmix_ops postproc inputpipe nms; do
+for f in conv_mfma conv_direct wgrad_direct wgrad_lds norm pointwise advmix_ops postproc inputpipe nms; do
   if [ $f = $SRC ]; then
     /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -std=c++17 -Wno-unused-result $DEFS -c $R/advmix_amd/csrc/$f.hip -o $D/$f.$NAME.o
     objs="$objs $D/$f.$NAME.o"

@@ -876,25 +876,35 @@ class Chain:
 # Lane tapes: HIP-graph capture as a SEQUENCE of single-stream graphs
 # =============================================================================================
 class Tape:
-    """Captures a function as per-lane SEQUENCES of single-stream HIP graphs with device-side hand-offs between the
-    lanes, instead of one graph with parallel branches.
+    """Captures a function as ONE single-stream HIP graph per launch lane (and segment) with device-side hand-offs
+    between the lanes, instead of one graph with parallel branches.
 
     Why (tools/graph_launch_floor.py, tools/graph_per_lane.py, tools/lane_handoff.py on MI355X / ROCm 7.2): a replayed
     graph that is ONE chain of kernels dispatches a node every 1.55 us (pre-built AQL packets); a graph with parallel
-    branches falls off that path - every node costs 2.6-3.2 us and the branches' nodes are issued one after the other,
-    whatever queue they run on (4 chains of 300 tiny kernels: 3.8 ms, against 0.46 ms for one chain) - while
-    single-chain graphs replayed on four streams dispatch a kernel every 0.6-0.9 us.  The AdvMix step launches ~3,500
-    kernels from four lanes.  Stream events between separately replayed graphs are no alternative (~20 us per
-    hand-off, issued by the host): the hand-offs are KERNELS here - at a fork the main lane's chain signals a counter the
-    side lanes' chains wait on, at the join the side lanes signal and the main lane waits (advmix_lane_signal / _wait:
+    branches falls off that path - every node costs 2.6-3.2 us and the branches' nodes are issued one after the other
+    by the host, whatever queue they run on - while single-chain graphs replayed on four streams dispatch a kernel
+    every 0.6-0.9 us.  Stream events between separately replayed graphs are no alternative (~20 us per hand-off,
+    issued by the host): the hand-offs are KERNELS here - at a fork the main lane's chain signals a counter the side
+    lanes' chains wait on, at the join the side lanes signal and the main lane waits (advmix_lane_signal / _wait:
     monotonic counters, each lane counts its own replays, bounded spin, error flag).
 
-    While ``ops.TAPE`` is set, GroupFn (``_run_lanes``) ends the open capture at every fork, captures each side lane's
-    members into a graph of their own on the lane's stream and continues on the main stream.  Everything runs on the
-    calling thread (torch.autograd.set_multithreading_enabled(False)), so captures begin and end on one thread.  All
-    graphs share one memory pool; a replay launches them in capture order from one native loop
-    (advmix_graph_launch_many).  The lanes need hardware queues of their own (GPU_MAX_HW_QUEUES >= 5, set by
-    advmix_amd/__init__.py): a waiting kernel at the head of a queue holds back whatever is queued behind it."""
+    While ``ops.TAPE`` is set, GroupFn (``_run_lanes``) records each side lane's members into that lane's own capture,
+    opened at the lane's first fork of the segment and kept open to the segment's end: several stream captures are
+    under way at once on one thread, with no event edges between them (torch allows one capture per memory pool at a
+    time, so every lane has its own pool).  Everything runs on the calling thread
+    (torch.autograd.set_multithreading_enabled(False)).  A replay launches the segment's graphs - main lane first -
+    from one native loop (advmix_graph_launch_many).
+
+    Every lane needs a hardware queue of its OWN: a lane's whole segment sits in its queue behind its first wait, so two
+    lanes sharing a queue dead-lock (bounded: the waits time out after seconds and raise the error flag).  The HIP
+    runtime creates 4 queues by default and reads GPU_MAX_HW_QUEUES when it is loaded - export GPU_MAX_HW_QUEUES=8
+    BEFORE the process imports torch; setting it from Python afterwards has no effect.
+
+    Measured on the headline step (same box, ms per step; r2o logs): 4 lanes 63.2 tape / 59.2 one multi-branch graph
+    per segment; 2 lanes 65.7 / 64.8; 1 lane 77.5 / 74.3 (the same single chain: a graph replayed on a created stream
+    is that much slower than on the default stream - 77.7 vs 74.3 with the plain runner replaying on a side stream).
+    With 8 hardware queues the multi-branch graph itself takes 100.9 ms.  So dispatch is not what bounds the step
+    (DESIGN.md section 3); the tape stays as an option and as the record of the experiment."""
 
     MAX_SYNC = 4096
 
@@ -1005,8 +1015,8 @@ class Tape:
     def check(self):
         """Raise if a hand-off timed out (reads one int from the device: call it where the host synchronises anyway)."""
         if int(self.err.item()) != 0:
-            raise RuntimeError('advmix_amd: a lane hand-off timed out (two lanes on one hardware queue? '
-                               'GPU_MAX_HW_QUEUES must be >= 5 before the first HIP call)')
+            raise RuntimeError('advmix_amd: a lane hand-off timed out (two lanes on one hardware queue? export '
+                               'GPU_MAX_HW_QUEUES=8 before the process imports torch)')
 
     @property
     def n_graphs(self):
@@ -1014,15 +1024,9 @@ class Tape:
 
 
 TAPE = None
-# Runners: one multi-branch HIP graph per segment (default) or lane tapes (ADVMIX_TAPE=1).  Measured on the headline step
-# (same box, ms per step): 1 lane 74.9 graph / 78.1 tape; 2 lanes 66.1 / 66.1; 4 lanes 59.5 / 68.2.  The tape dispatches
-# ~3,500 kernels with 2 ms of host time instead of 46 ms and its hand-offs never timed out, but four free-running
-# queues slow each other down more than they gain: the runtime's one-node-at-a-time issue of a multi-branch graph happens
-# to interleave the lanes' kernels better.  Kept as an option and as the record of that experiment.
+# Runners: one multi-branch HIP graph per segment (default) or lane tapes (ADVMIX_TAPE=1 with GPU_MAX_HW_QUEUES=8 in the
+# environment; slower - see Tape).
 USE_TAPE = __import__('os').environ.get('ADVMIX_TAPE', '0') == '1'
-
-
-_REPLAY_SIDE = __import__('os').environ.get('ADVMIX_REPLAY_SIDE', '0') == '1'     # experiment
 
 
 class GraphSeq:
@@ -1058,14 +1062,6 @@ class GraphSeq:
             if cached is not None:
                 self.tape._launch = cached
             self.tape.replay(*key)
-        elif _REPLAY_SIDE:
-            cur = torch.cuda.current_stream()
-            if not hasattr(self, '_side'):
-                self._side = torch.cuda.Stream()
-            self._side.wait_stream(cur)
-            with torch.cuda.stream(self._side):
-                self.graphs[seg].replay()
-            cur.wait_stream(self._side)
         else:
             self.graphs[seg].replay()
 

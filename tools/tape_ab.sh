@@ -12,7 +12,10 @@ except Exception as e:
     print('$tag failed', e); print(open('gpurun_out/r2o/b_$tag.err').read()[-3500:])
 PY
 }
+run L4_T0 ADVMIX_LANES=4 ADVMIX_TAPE=0
 run L4_T1_Q8 ADVMIX_LANES=4 ADVMIX_TAPE=1 GPU_MAX_HW_QUEUES=8
-run L3_T1_Q8 ADVMIX_LANES=3 ADVMIX_TAPE=1 GPU_MAX_HW_QUEUES=8
+run L4_T0_Q8 ADVMIX_LANES=4 ADVMIX_TAPE=0 GPU_MAX_HW_QUEUES=8
+run L2_T0 ADVMIX_LANES=2 ADVMIX_TAPE=0
 run L2_T1_Q8 ADVMIX_LANES=2 ADVMIX_TAPE=1 GPU_MAX_HW_QUEUES=8
-run L4_T1_Q6 ADVMIX_LANES=4 ADVMIX_TAPE=1 GPU_MAX_HW_QUEUES=6
+run L1_T0 ADVMIX_LANES=1 ADVMIX_TAPE=0
+run L1_T1_Q8 ADVMIX_LANES=1 ADVMIX_TAPE=1 GPU_MAX_HW_QUEUES=8

@@ -78,6 +78,19 @@ for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here == header/library drift
     _fn.argtypes = _args
     _fn.restype = ctypes.c_int
+
+
+class ConvProblem(ctypes.Structure):
+    """advmix_conv_problem (include/advmix_hip.h)."""
+    _fields_ = [('x', _p), ('w', _p), ('bias', _p), ('y', _p)] + \
+               [(k, _i) for k in ('N', 'Hx', 'Wx', 'Cx', 'Hy', 'Wy', 'Cy', 'R', 'S', 'stride', 'pad')] + \
+               [('bn_gamma', _p), ('bn_beta', _p), ('bn_rm', _p), ('bn_rv', _p), ('bn_eps', _f), ('residual', _p),
+                ('act', _i), ('stats', _p), ('stats_ns', _i),
+                ('bnb_y', _p), ('bnb_c', _p), ('bnb_mean', _p), ('bnb_invstd', _p), ('bnb_act', _i)]
+
+
+lib.advmix_conv_group.argtypes = [_i, _i, ctypes.POINTER(ConvProblem), _p]
+lib.advmix_conv_group.restype = ctypes.c_int
 lib.advmix_norm_ws_bytes.argtypes = [_i, _i]
 lib.advmix_norm_ws_bytes.restype = ctypes.c_int64
 lib.advmix_wgrad_det_ws_bytes.argtypes = [_i, _i, _i, _i]

@@ -59,6 +59,17 @@ int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const 
                                 int stride, int pad, int64_t Mmax, hipStream_t st, int bt = 0,
                                 const ConvEpi* epi = nullptr, int* stats_nbg = nullptr);
 
+// conv_direct.hip: 2-4 problems of one kind in one launch; -1 = cannot be served as one launch (nothing launched)
+struct ConvProb {
+    const float *x, *w, *bias;
+    float* y;
+    int N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad;      // x / y sides as in advmix_conv_direct_dispatch
+    int64_t Mmax;
+    const ConvEpi* epi;                                    // or null
+    int stats_nbg;                                         // in: slots to use (0 = default), out: slots used
+};
+int advmix_conv_direct_group(int mode, int bt, int n, ConvProb* probs, hipStream_t st);
+
 // runtime-tunable dispatch options (advmix_set_option / ADVMIX_* environment at first use)
 struct AdvmixOpts {
     int direct;            // 1: conv_direct allowed, 0: first-generation conv_igemm only

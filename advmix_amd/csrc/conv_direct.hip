@@ -90,10 +90,22 @@ struct MS {
     static __device__ __forceinline__ int row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
 };
 
+// LDS floats of one weight buffer (two are used) for a tile configuration - shared by the kernels that instantiate
+// conv_body (conv_direct: one configuration; conv_group: the largest of its configurations)
+template <int TM, int TN, int WM, int WN, int KC>
+struct Geo {
+    static constexpr int WK = 4 / (WM * WN);
+    static constexpr int RM = TM * (32 / MR), RN = TN * (32 / MR);
+    static constexpr int BN = 32 * TN * WN;
+    static constexpr int LDB = KC + 4;
+    static constexpr int RED = WK > 1 ? 4 * RM * RN * MS::NR * 64 : 0;
+    static constexpr int BSZ = (WK * BN * LDB * 2 > RED) ? WK * BN * LDB : (RED + 1) / 2;
+};
+
+// One workgroup's tile (bx, by) of slice / phase bz.  ``Bs0``: 2 * Geo::BSZ floats of LDS, ``taptab``: 64 int4.
 template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT, bool EPI>
-// (min 3 waves / SIMD for the BatchNorm-backward variants: left free, the register allocator spreads their three
-// prefetched epilogue operands over 254 VGPRs = one wave per SIMD; the other variants keep their 52-108)
-__global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(ConvD p) {
+__device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int by, const int bz, float* const Bs0,
+                                          int4* const taptab) {
     // WK waves of the workgroup split K BETWEEN THEM (WM x WN x WK = 4 waves): the low-resolution layers have too
     // few output tiles to fill the chip; instead of slicing K across workgroups (SPLIT: zero-fill + fp32 atomics,
     // no fused epilogue) a 32x32 tile is computed by four waves that each take every fourth K chunk and meet
@@ -112,8 +124,8 @@ __global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(C
     constexpr int RED = WK > 1 ? 4 * RM * RN * MS::NR * 64 : 0;           // floats of the cross-wave reduction (4 waves)
     constexpr int BSZ = (WK * BN * LDB * 2 > RED) ? WK * BN * LDB : (RED + 1) / 2;
 
-    __shared__ __attribute__((aligned(16))) float Bs[2][BSZ];
-    __shared__ int4 taptab[64];
+    static_assert(BSZ == Geo<TM, TN, WM, WN, KC>::BSZ, "Geo mirrors these constants");
+    float (*const Bs)[BSZ] = reinterpret_cast<float (*)[BSZ]>(Bs0);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -121,12 +133,12 @@ __global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(C
     const int wk = wid / (WM * WN), wmn = wid % (WM * WN);
     const int wm = wmn / WN, wn = wmn % WN;
 
-    int Hp, Wp, Th, Tw, rh = 0, rw = 0, phh = 0, phw = 0, zsl = blockIdx.z;
+    int Hp, Wp, Th, Tw, rh = 0, rw = 0, phh = 0, phw = 0, zsl = bz;
     if (MODE == 0) {
         Hp = p.Ho; Wp = p.Wo; Th = p.R; Tw = p.S;
     } else {
-        const int phase = blockIdx.z / p.nsplit;
-        zsl = blockIdx.z - phase * p.nsplit;
+        const int phase = bz / p.nsplit;
+        zsl = bz - phase * p.nsplit;
         rh = phase / p.stride; rw = phase % p.stride;
         Hp = p.Ho > rh ? (p.Ho - rh + p.stride - 1) / p.stride : 0;
         Wp = p.Wo > rw ? (p.Wo - rw + p.stride - 1) / p.stride : 0;
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(C
         Tw = phw < p.S ? (p.S - phw + p.stride - 1) / p.stride : 0;
     }
     const int Mp = p.N * Hp * Wp;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = by * BN;
     if (m0 >= Mp) return;
     const int ntaps = Th * Tw;
     const int cpt = p.Ci / KC;                              // chunks per tap
@@ -409,9 +421,9 @@ __global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(C
     }
 
 #ifdef CD_CLK
-    if (tid == 0 && blockIdx.x < 8192 && blockIdx.y == 0 && blockIdx.z == 0) {   // shader cycles / 100 MHz ticks of the main loop
-        g_cd_clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk_t0;
-        g_cd_clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    if (tid == 0 && bx < 8192 && by == 0 && bz == 0) {   // shader cycles / 100 MHz ticks of the main loop
+        g_cd_clk[2 * bx] = __builtin_amdgcn_s_memtime() - clk_t0;
+        g_cd_clk[2 * bx + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
     }
 #endif
     // ---- epilogue -----------------------------------------------------------------------------
@@ -527,16 +539,63 @@ __global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(C
             }
             // the per-workgroup sums are folded onto stats_nbg slots per column (768 workgroups on the
             // dominant shape -> 12 atomics per address), which norm_finalize reduces and re-zeroes
-            const int pb = blockIdx.x % p.stats_nbg;
+            const int pb = bx % p.stats_nbg;
             atomicAdd(p.stats + (int64_t)(n0 + tid) * p.stats_nbg + pb, d1);
             atomicAdd(p.stats + ((int64_t)p.Co + n0 + tid) * p.stats_nbg + pb, d2);
         }
     }
 }
 
+template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT, bool EPI>
+// (min 3 waves / SIMD for the BatchNorm-backward variants: left free, the register allocator spreads their three
+// prefetched epilogue operands over 254 VGPRs = one wave per SIMD; the other variants keep their 52-108)
+__global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(ConvD p) {
+    __shared__ __attribute__((aligned(16))) float Bs[2 * Geo<TM, TN, WM, WN, KC>::BSZ];
+    __shared__ int4 taptab[64];
+    conv_body<TM, TN, WM, WN, KC, MODE, SPLIT, BT, EPI>(p, blockIdx.x, blockIdx.y, blockIdx.z, Bs, taptab);
+}
+
 // Tile configuration for a problem (the only place that decides it; advmix_conv_direct_config reports it).
 enum Cfg { CFG_128x32 = 1, CFG_128x64 = 2, CFG_64x64 = 3, CFG_64x64_GRID_SPLIT = 4, CFG_32x32_WAVE_SPLIT = 5,
            CFG_64x32_WAVE_SPLIT2 = 6 };
+
+// Several problems of one kind (same MODE / KC / BT / EPI, stride 1, whole-K tiles) in ONE launch: block b belongs to
+// problem i with start[i] <= b < start[i + 1] and computes that problem's tile (b' % gx, b' / gx) with the problem's own
+// tile configuration.  HRNet's branches run the same layer at 2-4 resolutions: one launch of 1,000-1,800 workgroups
+// instead of four of 380-770 on four streams (kernel boundaries and ramps paid once; long and short tiles interleave).
+struct ConvG {
+    int n;
+    int start[5];
+    int cfg[4];
+    int gx[4];
+    ConvD p[4];
+};
+
+template <int A, int B> struct Max2 { static constexpr int v = A > B ? A : B; };
+
+template <int MODE, int KC, bool BT, bool EPI>
+__global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_group(ConvG g) {
+    constexpr int BSZ = Max2<Max2<Max2<Geo<1, 1, 4, 1, KC>::BSZ, Geo<1, 2, 4, 1, KC>::BSZ>::v,
+                                  Max2<Geo<1, 1, 2, 2, KC>::BSZ, Geo<1, 1, 1, 1, KC>::BSZ>::v>::v,
+                             Geo<1, 1, 2, 1, KC>::BSZ>::v;
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
+    __shared__ int4 taptab[64];
+    const int b = blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < g.n && b >= g.start[k]) i = k;
+    const int local = b - g.start[i], gx = g.gx[i];
+    const int by = local / gx, bx = local - by * gx;
+    switch (g.cfg[i]) {
+        case CFG_128x32: conv_body<1, 1, 4, 1, KC, MODE, false, BT, EPI>(g.p[i], bx, by, 0, Bs, taptab); break;
+        case CFG_128x64: conv_body<1, 2, 4, 1, KC, MODE, false, BT, EPI>(g.p[i], bx, by, 0, Bs, taptab); break;
+        case CFG_64x64: conv_body<1, 1, 2, 2, KC, MODE, false, BT, EPI>(g.p[i], bx, by, 0, Bs, taptab); break;
+        case CFG_32x32_WAVE_SPLIT: conv_body<1, 1, 1, 1, KC, MODE, false, BT, EPI>(g.p[i], bx, by, 0, Bs, taptab); break;
+        case CFG_64x32_WAVE_SPLIT2: conv_body<1, 1, 2, 1, KC, MODE, false, BT, EPI>(g.p[i], bx, by, 0, Bs, taptab); break;
+        default: break;
+    }
+}
 
 // share of the chip's workgroup slots n workgroups fill when every CU takes ceil(n / 256) of them
 static double fill(int64_t n) { return n <= 0 ? 0.0 : (double)n / (256.0 * (double)((n + 255) / 256)); }
@@ -549,6 +608,8 @@ static Cfg pick_cfg(int64_t Mmax, int Co, int phases, int nch, int* nsplit) {
         if (force == 5 && nch >= 8) return CFG_32x32_WAVE_SPLIT;
         return CFG_128x32;
     }
+    static const int force_all = [] { const char* e = getenv("ADVMIX_CFG"); return e ? atoi(e) : 0; }();   // measurement aid
+    if (force_all == 2 || force_all == 3 || (force_all == 5 && nch >= 8) || (force_all == 6 && nch >= 4)) return (Cfg)force_all;
     if ((int64_t)cdiv(Mmax, 128) * cdiv(Co, 64) * phases >= 512) return CFG_128x64;
     const int64_t b64 = (int64_t)cdiv(Mmax, 64) * cdiv(Co, 64) * phases;
     int ns = 1;
@@ -628,13 +689,12 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
 
 }  // namespace direct
 
-// Returns -1 when the problem is not eligible (caller falls back to conv_igemm), -2 when only the fused
-// epilogue is not available for this shape (K-split configuration).
-// bt != 0 (mode 1 only): w is k-major [Ci(k)][R][S][Co(n)] instead of [Co][R][S][Ci].
-int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const float* bias, float* y,
-                                int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
-                                int stride, int pad, int64_t Mmax, hipStream_t st, int bt, const ConvEpi* epi,
-                                int* stats_nbg) {
+// Checks a problem and fills its descriptor: 0, or -1 when the problem is not eligible (caller falls back to conv_igemm),
+// -2 when only the fused epilogue is not available.  ``*bnb``: the epilogue is the BatchNorm-backward one.
+static int prepare(int mode, const float* x, const float* w, const float* bias, float* y,
+                   int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
+                   int stride, int pad, int64_t Mmax, int bt, const ConvEpi* epi, const int* stats_nbg,
+                   direct::ConvD* out, bool* bnb_out) {
     if (Ci % 16 != 0 || R * S > 64) return -1;
     if (bt && (mode != 1 || Co % 4 != 0)) return -1;
     if (epi && mode != 0 && (epi->gamma || epi->act)) return -2;                 // mode 1: addend and/or BN-backward sums
@@ -667,7 +727,20 @@ int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const 
             p.bnb_act = epi->bnb_act;
         }
     }
-    int rc;
+    *out = p;
+    *bnb_out = bnb;
+    return 0;
+}
+
+// bt != 0 (mode 1 only): w is k-major [Ci(k)][R][S][Co(n)] instead of [Co][R][S][Ci].
+int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const float* bias, float* y,
+                                int N, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S,
+                                int stride, int pad, int64_t Mmax, hipStream_t st, int bt, const ConvEpi* epi,
+                                int* stats_nbg) {
+    direct::ConvD p;
+    bool bnb = false;
+    int rc = prepare(mode, x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, Mmax, bt, epi, stats_nbg, &p, &bnb);
+    if (rc < 0) return rc;
 #define LAUNCH_KC(MODE_, BT_, EPI_)                                                             \
     (Ci % 32 == 0 ? direct::launch<MODE_, 32, BT_, EPI_>(p, Mmax, st) : direct::launch<MODE_, 16, BT_, EPI_>(p, Mmax, st))
     if (bt && bnb)
@@ -683,6 +756,88 @@ int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const 
 #undef LAUNCH_KC
     if (stats_nbg) *stats_nbg = p.stats_nbg;
     return rc;
+}
+
+// 2-4 problems in one launch (direct::conv_group).  -1: the group cannot be served as one launch (different kernel
+// kinds, a stride, a problem that needs the grid K split or the first-generation kernel, no room for the BatchNorm-
+// backward operands): nothing was launched.  Forward problems (mode 0) all carry an epilogue descriptor or none does;
+// transposed-gather problems (mode 1, weights in their own layout) are all BatchNorm-backward ones or none is.
+int advmix_conv_direct_group(int mode, int bt, int n, ConvProb* pr, hipStream_t st) {
+    if (n < 2 || n > 4) return -1;
+    direct::ConvG g;
+    g.n = n;
+    bool bnb0 = false, epi0 = pr[0].epi != nullptr;
+    const int KC = pr[0].Ci % 32 == 0 ? 32 : 16;
+    int order[4] = {0, 1, 2, 3};
+    int work[4], gy[4];
+    for (int i = 0; i < n; ++i) {
+        ConvProb& q = pr[i];
+        if (q.stride != 1 || (q.Ci % 32 == 0 ? 32 : 16) != KC || (mode == 0 && (q.epi != nullptr) != epi0)) return -1;
+        bool bnb = false;
+        direct::ConvD d;
+        if (prepare(mode, q.x, q.w, q.bias, q.y, q.N, q.Hi, q.Wi, q.Ci, q.Ho, q.Wo, q.Co, q.R, q.S, q.stride, q.pad, q.Mmax,
+                    bt, q.epi, &q.stats_nbg, &d, &bnb) < 0)
+            return -1;
+        if (i == 0) bnb0 = bnb;
+        if (bnb != bnb0) return -1;
+        int phases, nch, ns;
+        direct::problem_shape(mode, q.Ci, q.R, q.S, q.stride, KC, &phases, &nch);
+        const direct::Cfg c = direct::pick_cfg(q.Mmax, q.Co, phases, nch, &ns);
+        if (phases != 1 || c == direct::CFG_64x64_GRID_SPLIT || (c == direct::CFG_128x64 && bnb)) return -1;
+        int bm, bn, wk;
+        switch (c) {
+            case direct::CFG_128x32: bm = 128; bn = 32; wk = 1; break;
+            case direct::CFG_128x64: bm = 128; bn = 64; wk = 1; break;
+            case direct::CFG_64x64: bm = 64; bn = 64; wk = 1; break;
+            case direct::CFG_32x32_WAVE_SPLIT: bm = 32; bn = 32; wk = 4; break;
+            default: bm = 64; bn = 32; wk = 2; break;      // CFG_64x32_WAVE_SPLIT2
+        }
+        d.nsplit = 1;
+        g.p[i] = d;
+        g.cfg[i] = (int)c;
+        g.gx[i] = cdiv(q.Mmax, bm);
+        gy[i] = cdiv(q.Co, bn);
+        work[i] = nch * (c == direct::CFG_128x64 ? 2 : 1) / wk;     // MFMA chunks per wave of a tile: longest first
+        q.stats_nbg = d.stats_nbg;
+    }
+    for (int a = 0; a < n; ++a)                            // order: longest-running tiles first
+        for (int b = a + 1; b < n; ++b)
+            if (work[order[b]] > work[order[a]]) { int t = order[a]; order[a] = order[b]; order[b] = t; }
+    direct::ConvG h = g;
+    int start = 0;
+    for (int k = 0; k < n; ++k) {
+        const int i = order[k];
+        h.p[k] = g.p[i]; h.cfg[k] = g.cfg[i]; h.gx[k] = g.gx[i];
+        h.start[k] = start;
+        start += g.gx[i] * gy[i];
+    }
+    for (int k = n; k < 5; ++k) h.start[k] = start;
+    dim3 grid(start);
+#define LAUNCHG(MODE_, BT_, EPI_)                                                                         \
+    do {                                                                                                  \
+        if (KC == 32) hipLaunchKernelGGL((direct::conv_group<MODE_, 32, BT_, EPI_>), grid, dim3(256), 0, st, h); \
+        else hipLaunchKernelGGL((direct::conv_group<MODE_, 16, BT_, EPI_>), grid, dim3(256), 0, st, h);   \
+    } while (0)
+    if (mode == 0 && !bt) {
+        if (epi0) LAUNCHG(0, false, true); else LAUNCHG(0, false, false);
+    } else if (mode == 1 && bt) {
+        if (bnb0) LAUNCHG(1, true, true); else LAUNCHG(1, true, false);
+    } else {
+        return -1;
+    }
+#undef LAUNCHG
+    if (advmix_opts().trace_shapes) {
+        double fl = 0;
+        for (int i = 0; i < n; ++i)
+            fl += 2.0 * pr[i].N * (mode == 0 ? (double)pr[i].Ho * pr[i].Wo : (double)pr[i].Hi * pr[i].Wi) * pr[i].Co * pr[i].Ci *
+                  pr[i].R * pr[i].S;
+        char nm[64];
+        snprintf(nm, sizeof nm, "conv_group<%d, %d, %s, %s>", mode, KC, bt ? "true" : "false",
+                 (mode == 0 ? epi0 : bnb0) ? "true" : "false");
+        advmix_trace_launch(nm, grid, mode == 0 ? "fwd group" : "dgrad group", pr[0].N, pr[0].Hi, pr[0].Wi, pr[0].Ci, pr[0].Ho,
+                            pr[0].Wo, pr[0].Co, pr[0].R, pr[0].S, 1, fl);
+    }
+    return hipGetLastError() == hipSuccess ? ADVMIX_OK : ADVMIX_ELAUNCH;
 }
 
 // Which conv_direct tile configuration a problem gets (tests assert that the shapes meant to exercise a

@@ -467,6 +467,45 @@ extern "C" int advmix_conv_fwd(const float* x, const float* w, const float* bias
     return launch_igemm<0>(p, (int64_t)N * Ho * Wo, (hipStream_t)stream);
 }
 
+extern "C" int advmix_conv_group(int kind, int n, advmix_conv_problem* pr, void* stream) {
+    if (!pr || n < 2 || n > 4 || (kind != 0 && kind != 1) || !use_direct()) return ADVMIX_EINVAL;
+    ConvProb q[4];
+    ConvEpi e[4];
+    for (int i = 0; i < n; ++i) {
+        const advmix_conv_problem& a = pr[i];
+        if (!a.x || !a.w || !a.y || a.N <= 0 || a.Cx <= 0 || a.Cy <= 0 || a.stride != 1) return ADVMIX_EINVAL;
+        if (a.stats && a.stats_ns < 0) return ADVMIX_EINVAL;
+        if (kind == 0) {
+            if (a.Hy != a.Hx + 2 * a.pad - a.R + 1 || a.Wy != a.Wx + 2 * a.pad - a.S + 1) return ADVMIX_EINVAL;
+            if ((a.bn_gamma != nullptr) != (a.bn_beta && a.bn_rm && a.bn_rv)) return ADVMIX_EINVAL;
+            const bool has = a.bn_gamma || a.residual || a.act || a.stats;
+            e[i] = ConvEpi{a.bn_gamma, a.bn_beta, a.bn_rm, a.bn_rv, a.residual, a.bn_eps, a.act, a.stats,
+                           nullptr, nullptr, nullptr, nullptr, 0};
+            q[i] = ConvProb{a.x, a.w, a.bias, a.y, a.N, a.Hx, a.Wx, a.Cx, a.Hy, a.Wy, a.Cy, a.R, a.S, 1, a.pad,
+                            (int64_t)a.N * a.Hy * a.Wy, has ? &e[i] : nullptr, a.stats_ns};
+        } else {
+            if (a.Hx != a.Hy + 2 * a.pad - a.R + 1 || a.Wx != a.Wy + 2 * a.pad - a.S + 1) return ADVMIX_EINVAL;
+            const bool bnb = a.stats != nullptr;
+            if (bnb && (!a.bnb_c || !a.bnb_mean || !a.bnb_invstd || (a.bnb_act != ADVMIX_ACT_NONE && !a.bnb_y)))
+                return ADVMIX_EINVAL;
+            e[i] = ConvEpi{nullptr, nullptr, nullptr, nullptr, a.residual, 0.f, 0, bnb ? a.stats : nullptr,
+                           bnb ? a.bnb_y : nullptr, bnb ? a.bnb_c : nullptr, bnb ? a.bnb_mean : nullptr,
+                           bnb ? a.bnb_invstd : nullptr, bnb ? a.bnb_act : 0};
+            q[i] = ConvProb{a.x, a.w, nullptr, a.y, a.N, a.Hx, a.Wx, a.Cx, a.Hy, a.Wy, a.Cy, a.R, a.S, 1, a.pad,
+                            (int64_t)a.N * a.Hy * a.Wy, (bnb || a.residual) ? &e[i] : nullptr, a.stats_ns};
+        }
+    }
+    if (kind == 1) {                                       // addend-only and plain problems share a kernel (EPI = false)
+        bool any_bnb = false, all_bnb = true;
+        for (int i = 0; i < n; ++i) { const bool b = pr[i].stats != nullptr; any_bnb |= b; all_bnb &= b; }
+        if (any_bnb && !all_bnb) return ADVMIX_EINVAL;
+    }
+    int rc = advmix_conv_direct_group(kind, kind, n, q, (hipStream_t)stream);
+    if (rc < 0) return ADVMIX_EINVAL;
+    for (int i = 0; i < n; ++i) pr[i].stats_ns = q[i].stats_nbg;
+    return rc;
+}
+
 extern "C" int advmix_conv_tr(const float* x, const float* wt, const float* bias, float* y,
                               int N, int Hs, int Ws, int Ck, int Hb, int Wb, int Cn,
                               int R, int S, int stride, int pad, void* stream) {

@@ -130,6 +130,33 @@ int advmix_conv_wgrad_det(const float* a, const float* b, float* dw,
 int64_t advmix_wgrad_det_ws_bytes(int Ca, int Cb, int R, int S);
 int advmix_bias_grad_det(const float* dy, float* db, int64_t rows, int C, void* ws, int64_t ws_bytes, void* stream);
 
+/* Grouped launch: 2-4 convolution problems of ONE kind in one kernel launch (HRNet runs the same layer on 2-4
+ * branches of different resolution - pose_hrnet.py:247-265 - each too small to fill the chip on its own).
+ * kind 0: every problem is an advmix_conv_fwd_ex (x = input, y = output; residual / eval BatchNorm / act / stats as
+ *         there; either every problem uses the fused epilogue fields or none does);
+ * kind 1: every problem is an advmix_conv_tr_w_add (x = upstream gradient [N,Hx,Wx,Cx], y = input gradient, residual =
+ *         addend) or every problem is an advmix_conv_tr_w_bnb (bnb_* and stats set).
+ * Stride 1 only.  stats_ns: in = slots per channel to use (0 = library default), out = slots used.
+ * ADVMIX_EINVAL: the group cannot be served as one launch (NOTHING was launched): launch the problems one by one.
+ * (Measured in DESIGN.md section 3: 0.51 of the fp32 matrix peak on HRNet-W32's four 3x3 branch convs at B = 32, against
+ * 0.42 for the four launches back to back; the step runner keeps its four launch lanes, which do as well.) */
+typedef struct advmix_conv_problem {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    int N, Hx, Wx, Cx, Hy, Wy, Cy, R, S, stride, pad;
+    const float *bn_gamma, *bn_beta, *bn_rm, *bn_rv;
+    float bn_eps;
+    const float* residual;
+    int act;
+    double* stats;
+    int stats_ns;
+    const float *bnb_y, *bnb_c, *bnb_mean, *bnb_invstd;
+    int bnb_act;
+} advmix_conv_problem;
+int advmix_conv_group(int kind, int n, advmix_conv_problem* problems, void* stream);
+
 /* out[B][T][A] = in[A][T][B]  (weight re-layout for advmix_conv_tr) */
 int advmix_transpose_w(const float* in, float* out, int A, int T, int B, void* stream);
 

@@ -114,6 +114,83 @@ def test_weight_gradient_lds_patch_kernel_and_its_ordered_partials():
     ops.set_option('wgrad_lds', 1)
 
 
+@pytest.mark.parametrize('mode', ['fwd_stats', 'fwd_eval', 'dgrad_add', 'dgrad_bnb'])
+def test_grouped_conv_launch_equals_single_launches(mode):
+    """advmix_conv_group: 2-4 problems of one kind in one launch produce bit-identical outputs (and the same channel
+    sums) as the single-problem entry points; what cannot be one launch is refused with nothing launched."""
+    import ctypes
+    from advmix_amd._lib import call, lib, ConvProblem
+    _ops()
+    d = dev()
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    A = lambda t: t.data_ptr()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    B = 32                                                                   # (smaller batches need the grid K split)
+    shapes = [(32, 32, 24), (64, 32, 24), (128, 16, 12), (256, 8, 6)]        # 3x3, C -> C: 128x32, 64x32 and 32x32 K-split tiles
+    g = torch.Generator().manual_seed(5)
+    R = lambda *s_: torch.randn(*s_, generator=g).to(d)
+    T = []
+    for (C, H, W) in shapes:
+        T.append(dict(C=C, H=H, W=W, x=R(B, H, W, C), w=R(C, 3, 3, C) * 0.05, res=R(B, H, W, C), yy=R(B, H, W, C),
+                      cc=R(B, H, W, C), g=R(C).abs() + 0.5, b=R(C), rm=R(C) * 0.1, rv=R(C).abs() + 0.5,
+                      mean=R(C) * 0.1, invstd=R(C).abs() + 0.5))
+    kind = 0 if mode.startswith('fwd') else 1
+    outs = []
+    for grouped in (False, True):
+        arr = (ConvProblem * len(T))()
+        res = []
+        for i, t in enumerate(T):
+            C, H, W = t['C'], t['H'], t['W']
+            y = torch.full((B, H, W, C), float('nan'), device=d)
+            slots = torch.zeros(2 * C * 64, device=d, dtype=torch.float64)
+            geom = (B, H, W, C, H, W, C, 3, 3, 1, 1)
+            nbg = ctypes.c_int(0)
+            q = arr[i]
+            q.x, q.w, q.y = A(t['x']), A(t['w']), A(y)
+            q.N, q.Hx, q.Wx, q.Cx, q.Hy, q.Wy, q.Cy, q.R, q.S, q.stride, q.pad = geom
+            if mode == 'fwd_stats':
+                q.stats = A(slots)
+                if not grouped:
+                    call('advmix_conv_fwd_ex', P(t['x']), P(t['w']), None, P(y), *geom, None, None, None, None, 0.0, None, 0,
+                         P(slots), ctypes.byref(nbg), st)
+            elif mode == 'fwd_eval':
+                q.bn_gamma, q.bn_beta, q.bn_rm, q.bn_rv, q.bn_eps = A(t['g']), A(t['b']), A(t['rm']), A(t['rv']), 1e-5
+                q.residual, q.act = A(t['res']), 1
+                if not grouped:
+                    call('advmix_conv_fwd_ex', P(t['x']), P(t['w']), None, P(y), *geom, P(t['g']), P(t['b']), P(t['rm']),
+                         P(t['rv']), 1e-5, P(t['res']), 1, None, None, st)
+            elif mode == 'dgrad_add':
+                q.residual = A(t['res']) if i % 2 == 0 else 0                 # with and without an addend in one launch
+                if not grouped:
+                    call('advmix_conv_tr_w_add', P(t['x']), P(t['w']), P(t['res']) if i % 2 == 0 else None, P(y), *geom, st)
+            else:
+                q.residual, q.stats = A(t['res']), A(slots)
+                q.bnb_y, q.bnb_c, q.bnb_mean, q.bnb_invstd, q.bnb_act = A(t['yy']), A(t['cc']), A(t['mean']), A(t['invstd']), 1
+                if not grouped:
+                    call('advmix_conv_tr_w_bnb', P(t['x']), P(t['w']), P(t['res']), P(y), *geom, P(t['yy']), P(t['cc']),
+                         P(t['mean']), P(t['invstd']), 1, P(slots), ctypes.byref(nbg), st)
+            res.append([y, slots, nbg.value])
+        if grouped:
+            assert lib.advmix_conv_group(kind, len(T), arr, st) == 0
+            for i in range(len(T)):
+                res[i][2] = arr[i].stats_ns
+            bad = (ConvProblem * 2)()                                       # a strided problem: refused, nothing launched
+            for k in range(2):
+                ctypes.memmove(ctypes.byref(bad[k]), ctypes.byref(arr[k]), ctypes.sizeof(ConvProblem))
+            bad[1].stride = 2
+            assert lib.advmix_conv_group(kind, 2, bad, st) == 1
+        torch.cuda.synchronize()
+        outs.append(res)
+    for i, t in enumerate(T):
+        (y0, s0, n0), (y1, s1, n1) = outs[0][i], outs[1][i]
+        assert not torch.isnan(y1).any()
+        assert torch.equal(y0, y1), 'problem %d' % i
+        if mode in ('fwd_stats', 'dgrad_bnb'):
+            a = s0[:2 * t['C'] * n0].view(2, t['C'], n0).sum(-1)
+            b = s1[:2 * t['C'] * n1].view(2, t['C'], n1).sum(-1)
+            assert n0 > 0 and n1 > 0 and torch.allclose(a, b, rtol=1e-9, atol=1e-7)
+
+
 def test_conv_tile_configuration_table():
     """The shapes the tests rely on to reach a kernel variant really get it (advmix_conv_direct_config)."""
     from advmix_amd._lib import lib

@@ -246,9 +246,11 @@ __global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restr
     }
 }
 
-template <int WM, int WN, bool VEC>
+// TM x TN 32x32 tiles per wave (default 1 x 1): the U-Net's weight gradients (hundreds of output channels x thousands of
+// tap-channels) take 128 x 128 per workgroup - one LDS read per MFMA instead of two, half the staging per FLOP.
+template <int WM, int WN, bool VEC, int TM = 1, int TN = 1>
 __global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
-    constexpr int BMw = 32 * WM, BNw = 32 * WN;
+    constexpr int BMw = 32 * WM * TM, BNw = 32 * WN * TN;
     constexpr int KS = 32;                             // pixels per step (16 MFMAs per wave between barriers)
     constexpr int ASL = (KS * BMw / 4 + 255) / 256;    // float4 slots per thread
     constexpr int BSL = (KS * BNw / 4 + 255) / 256;
@@ -346,9 +348,13 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
             if (b_in[i]) *reinterpret_cast<f32x4*>(&Bs[buf][b_k[i] * BNw + b_c[i]]) = rb[i];
     };
 
-    f32x16 acc;
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
     // Branch-free steady state (a tile past the slice loads zeros, so the prefetch is unconditional): the first
     // version's "if (more) load" made the compiler shuttle the accumulator AGPR -> VGPR -> AGPR around the branch
@@ -360,28 +366,40 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
     for (int pt = p_lo; pt < p_hi; pt += KS) {
         load_tile(pt + KS);
         __builtin_amdgcn_sched_barrier(0);
-        float av[KS / 2], bv[KS / 2];
+        float av[KS / 2][TM], bv[KS / 2][TN];
 #pragma unroll
         for (int kk = 0; kk < KS / 2; ++kk) {
-            av[kk] = As[buf][(kk * 2 + lh) * BMw + wm * 32 + l31];
-            bv[kk] = Bs[buf][(kk * 2 + lh) * BNw + wn * 32 + l31];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) av[kk][t] = As[buf][(kk * 2 + lh) * BMw + (wm * TM + t) * 32 + l31];
+#pragma unroll
+            for (int u = 0; u < TN; ++u) bv[kk][u] = Bs[buf][(kk * 2 + lh) * BNw + (wn * TN + u) * 32 + l31];
         }
 #pragma unroll
-        for (int kk = 0; kk < KS / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
+        for (int kk = 0; kk < KS / 2; ++kk)
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int u = 0; u < TN; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][t], bv[kk][u], acc[t][u], 0, 0, 0);
         store_tile(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
 
-    const int j = j0 + wn * 32 + l31;
-    if (j >= Ntot) return;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (co >= p.Ca) continue;
-        if (p.part) p.part[((int64_t)blockIdx.z * p.Ca + co) * Ntot + j] = acc[r];
-        else atomicAdd(p.dw + (int64_t)co * Ntot + j, acc[r]);
-    }
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+            const int j = j0 + (wn * TN + u) * 32 + l31;
+            if (j >= Ntot) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int co = co0 + (wm * TM + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co >= p.Ca) continue;
+                if (p.part) p.part[((int64_t)blockIdx.z * p.Ca + co) * Ntot + j] = acc[t][u][r];
+                else atomicAdd(p.dw + (int64_t)co * Ntot + j, acc[t][u][r]);
+            }
+        }
 }
 
 __global__ void transpose_w_kernel(const float* __restrict__ in, float* __restrict__ out, int A, int T, int B) {
@@ -530,6 +548,11 @@ static int wgrad_target_blocks() {
     return v;
 }
 
+static bool wgrad_big() {
+    static int v = [] { const char* e = getenv("ADVMIX_WGRAD_BIG"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
+
 static int wgrad_impl(const float* a, const float* b, float* dw, int N, int Ha, int Wa, int Ca, int Hb, int Wb, int Cb,
                       int R, int S, int stride, int pad, float* part, int64_t part_floats, void* stream) {
     if (!a || !b || !dw || N <= 0 || Ca <= 0 || Cb <= 0 || stride < 1) return ADVMIX_EINVAL;
@@ -558,25 +581,27 @@ static int wgrad_impl(const float* a, const float* b, float* dw, int N, int Ha, 
     const bool vec = (Ca % 4 == 0) && (Cb % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
     int nslices = 1;
-#define LAUNCHW(WM_, WN_, V_)                                                             \
+#define LAUNCHW(WM_, WN_, V_) LAUNCHW2(WM_, WN_, V_, 1, 1)
+#define LAUNCHW2(WM_, WN_, V_, TM_, TN_)                                                   \
     do {                                                                                  \
-        int tiles = cdiv(Ca, 32 * WM_) * cdiv(Ntot, 32 * WN_);                            \
+        int tiles = cdiv(Ca, 32 * WM_ * TM_) * cdiv(Ntot, 32 * WN_ * TN_);                \
         int64_t ns = wgrad_target_blocks() / tiles;                                       \
         if (ns < 1) ns = 1;                                                               \
         int64_t maxs = (P + 63) / 64;                                                     \
         if (ns > maxs) ns = maxs;                                                         \
         int64_t chunk = ((P + ns - 1) / ns + 31) / 32 * 32;                               \
         p.chunk = (int)chunk;                                                             \
-        dim3 g(cdiv(Ca, 32 * WM_), cdiv(Ntot, 32 * WN_), cdiv(P, chunk));                 \
+        dim3 g(cdiv(Ca, 32 * WM_ * TM_), cdiv(Ntot, 32 * WN_ * TN_), cdiv(P, chunk));     \
         nslices = (int)g.z;                                                               \
         if (part) {                                                                       \
             if ((int64_t)nslices * Ca * Ntot > part_floats) return ADVMIX_EINVAL;         \
             if (hipMemsetAsync(part, 0, sizeof(float) * (size_t)nslices * Ca * Ntot, st) != hipSuccess) return ADVMIX_ELAUNCH; \
         }                                                                                 \
-        hipLaunchKernelGGL((conv_wgrad<WM_, WN_, V_>), g, dim3(256), 0, st, p);           \
+        hipLaunchKernelGGL((conv_wgrad<WM_, WN_, V_, TM_, TN_>), g, dim3(256), 0, st, p); \
         if (advmix_opts().trace_shapes) {                                                 \
             char nm[64];                                                                  \
-            snprintf(nm, sizeof nm, "conv_wgrad<%d, %d, %s>", WM_, WN_, V_ ? "true" : "false"); \
+            if (TM_ * TN_ == 1) snprintf(nm, sizeof nm, "conv_wgrad<%d, %d, %s>", WM_, WN_, V_ ? "true" : "false"); \
+            else snprintf(nm, sizeof nm, "conv_wgrad<%d, %d, %s, %d, %d>", WM_, WN_, V_ ? "true" : "false", TM_, TN_); \
             advmix_trace_launch(nm, g, "wgrad", N, Hb, Wb, Cb, Ha, Wa, Ca, R, S, stride,  \
                                 2.0 * N * (double)Ha * Wa * Ca * Cb * R * S);             \
         }                                                                                 \
@@ -585,10 +610,13 @@ static int wgrad_impl(const float* a, const float* b, float* dw, int N, int Ha, 
         if (vec) LAUNCHW(1, 4, true); else LAUNCHW(1, 4, false);
     } else if (Ntot <= 32) {
         if (vec) LAUNCHW(4, 1, true); else LAUNCHW(4, 1, false);
+    } else if (vec && !part && wgrad_big() && Ca >= 128 && Ntot >= 512 && (double)P * Ca * Ntot >= 1.0e10) {
+        LAUNCHW2(2, 2, true, 2, 2);                        // 128 x 128 per workgroup (the U-Net's 4x4 convs)
     } else {
         if (vec) LAUNCHW(2, 2, true); else LAUNCHW(2, 2, false);
     }
 #undef LAUNCHW
+#undef LAUNCHW2
     if (part) {
         const int64_t total = (int64_t)Ca * Ntot;
         int blocks = (int)((total + 255) / 256);

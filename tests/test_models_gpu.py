@@ -572,25 +572,33 @@ def _dp_one_rank_worker():
         data = ([x.cuda().contiguous() for x in v], t.cuda(), w.cuda())
         sync = GradSync(force=True, bucket_mb=0.25)
         assert sync.active
-        # (1) gradients of phase a: plain backward vs pieces + all-reduces
-        cfg, D1, G1, T1, crit, oD1, oG1, _ = _tiny_setup(lr=1e-4)
-        cfg, D2, G2, T2, crit2, oD2, oG2, _ = _tiny_setup(lr=1e-4)
-        sync.broadcast_state([D2, G2, T2], [oD2, oG2])
-        l1, _ = advmix_phase_a(args, D1, G1, T1, crit, oD1, *data)
-        cuts = sync.cuts_for(D2)
-        assert len(cuts) == 2 and 0 < cuts[0][1] < cuts[1][1] < oD2.flat_grads.numel()
-        l2, _, pieces, _pg = advmix_phase_a(args, D2, G2, T2, crit2, oD2, *data, (cuts, sync.cuts_for(G2)))
-        done = []
-        for piece in pieces:
-            lo, hi = piece()
-            sync.reduce_async(oD2.flat_grads, lo, hi)
-            done.append((lo, hi))
-        sync.finish()
-        torch.cuda.synchronize()
+        # (1) gradients of phase a: plain backward vs pieces + all-reduces.  In the deterministic mode (ordered partial
+        # sums instead of fp32 atomics), so the comparison sees the piece-wise path and not the run-to-run noise of the
+        # atomics (with them, 1e-4 of the largest gradient is exceeded once in a few dozen runs).
+        from advmix_amd import ops as _o
+        _o.set_deterministic(True)
+        try:
+            cfg, D1, G1, T1, crit, oD1, oG1, _ = _tiny_setup(lr=1e-4)
+            cfg, D2, G2, T2, crit2, oD2, oG2, _ = _tiny_setup(lr=1e-4)
+            sync.broadcast_state([D2, G2, T2], [oD2, oG2])
+            l1, _ = advmix_phase_a(args, D1, G1, T1, crit, oD1, *data)
+            cuts = sync.cuts_for(D2)
+            assert len(cuts) == 2 and 0 < cuts[0][1] < cuts[1][1] < oD2.flat_grads.numel()
+            l2, _, pieces, _pg = advmix_phase_a(args, D2, G2, T2, crit2, oD2, *data, (cuts, sync.cuts_for(G2)))
+            done = []
+            for piece in pieces:
+                lo, hi = piece()
+                sync.reduce_async(oD2.flat_grads, lo, hi)
+                done.append((lo, hi))
+            sync.finish()
+            torch.cuda.synchronize()
+        finally:
+            _o.set_deterministic(False)
         assert [d[1] for d in done] == [oD2.flat_grads.numel(), cuts[1][1], cuts[0][1]] and done[-1][0] == 0
         assert abs(float(l1) - float(l2)) <= 1e-6 * max(1.0, abs(float(l1)))
         g1, g2 = oD1.flat_grads, oD2.flat_grads
-        assert float((g1 - g2).abs().max()) <= 1e-4 * float(g1.abs().max())
+        err, ref = float((g1 - g2).abs().max()), float(g1.abs().max())
+        assert err <= 1e-5 * ref, (err, ref)
         assert float(g2.abs().max()) > 0
         # (2) the whole step, eager: synced pieces vs plain
         cfg, D1, G1, T1, crit, oD1, oG1, _ = _tiny_setup(lr=1e-4)

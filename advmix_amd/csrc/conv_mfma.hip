@@ -600,8 +600,7 @@ static int wgrad_impl(const float* a, const float* b, float* dw, int N, int Ha, 
         hipLaunchKernelGGL((conv_wgrad<WM_, WN_, V_, TM_, TN_>), g, dim3(256), 0, st, p); \
         if (advmix_opts().trace_shapes) {                                                 \
             char nm[64];                                                                  \
-            if (TM_ * TN_ == 1) snprintf(nm, sizeof nm, "conv_wgrad<%d, %d, %s>", WM_, WN_, V_ ? "true" : "false"); \
-            else snprintf(nm, sizeof nm, "conv_wgrad<%d, %d, %s, %d, %d>", WM_, WN_, V_ ? "true" : "false", TM_, TN_); \
+            snprintf(nm, sizeof nm, "conv_wgrad<%d, %d, %s, %d, %d>", WM_, WN_, V_ ? "true" : "false", TM_, TN_); \
             advmix_trace_launch(nm, g, "wgrad", N, Hb, Wb, Cb, Ha, Wa, Ca, R, S, stride,  \
                                 2.0 * N * (double)Ha * Wa * Ca * Cb * R * S);             \
         }                                                                                 \

@@ -30,6 +30,7 @@ SIGNATURES = {
     'advmix_conv_tr_w': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_direct_config': [_i] * 9,
     'advmix_deconv4x4s2_narrow': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    'advmix_conv_tr_narrow': [_p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_tr_w_add': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_tr_w_bnb': [_p, _p, _p, _p] + [_i] * 11 + [_p, _p, _p, _p, _i, _p, _p, _p],
     'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],

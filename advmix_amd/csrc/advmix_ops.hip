@@ -274,6 +274,97 @@ __global__ __launch_bounds__(256) void deconv4x4s2_narrow_kernel(const float* __
     }
 }
 
+// Transposed gather with a NARROW output (<= 4 channels): the input gradient of a network's first conv (3 image
+// channels; needed when the images come from the generator) computed 32 MFMA columns for 3 (3x3 s2 64->3 @256x192,
+// B = 32: 242 us; 7x7 s2: 743 us).  Here the Ck / 4 lanes of a pixel each take 4 upstream channels (a wave reads whole
+// 256-byte pixel rows: one thread per pixel with 16-byte loads from 64 different rows per instruction is L1-bound
+// and no faster than the MFMA kernel), the taps come from LDS as float4 (co padded to 4) laid out so that a lane
+// group reads 16-byte neighbours (k-major rows put 16 lanes on two banks: 8-way conflicts, 190 us), four pixels per
+// lane share them, the lanes meet in a shuffle tree.
+template <int CO, int L>                                   // L = Ck / 4 lanes per pixel
+__global__ __launch_bounds__(256) void conv_tr_narrow_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             float* __restrict__ y, int N, int Hs, int Ws, int Ck, int Hb,
+                                                             int Wb, int R, int S, int stride, int pad) {
+    extern __shared__ __attribute__((aligned(16))) float wl_[];
+    f32x4* wl = reinterpret_cast<f32x4*>(wl_);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < R * S * Ck; i += 256) {
+        const int tap = i / Ck, ck = i - tap * Ck;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < CO; ++o) v[o] = w[((int64_t)ck * R * S + tap) * CO + o];
+        wl[(tap * 4 + (ck & 3)) * (Ck >> 2) + (ck >> 2)] = v;  // [tap][k % 4][k / 4]: a lane group reads 16-byte neighbours
+    }
+    __syncthreads();
+    const int cl = tid & (L - 1), c4 = cl * 4;
+    // branch-free loads: an invalid pixel gets an out-of-range buffer offset and reads as zeros (a select around a
+    // plain load compiles to a branch and a wait per load: four serialized round trips per tap)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, N * Hs * Ws * Ck * 4, 0x00020000);
+    // Positions in stride-phase coordinates: output pixel (a * stride + rh, b * stride + rw).  A lane group takes PB = 4
+    // consecutive b of one (n, a) - the taps it reads from LDS serve four pixels, the four upstream rows per tap are
+    // contiguous - for every phase in turn (the phases share upstream rows; the taps of one pass are uniform over the
+    // workgroup).  A workgroup stages the taps once and walks many positions.
+    constexpr int PB = 4;
+    const int Ha = (Hb + stride - 1) / stride, Wa = (Wb + stride - 1) / stride, Wq = (Wa + PB - 1) / PB;
+    const int Pq = N * Ha * Wq, HWq = Ha * Wq;               // (32-bit: the host checks the tensor sizes)
+    for (int p = blockIdx.x * (256 / L) + tid / L; p < Pq; p += gridDim.x * (256 / L)) {
+        const int n = p / HWq;
+        const int rem = p - n * HWq;
+        const int a_ = rem / Wq, b0 = (rem - a_ * Wq) * PB;
+        for (int rh = 0; rh < stride; ++rh) {
+            const int hb = a_ * stride + rh;
+            if (hb >= Hb) continue;
+            for (int rw = 0; rw < stride; ++rw) {
+                float s[PB][CO];
+#pragma unroll
+                for (int j = 0; j < PB; ++j)
+#pragma unroll
+                    for (int o = 0; o < CO; ++o) s[j][o] = 0.f;
+                for (int kh = (rh + pad) % stride; kh < R; kh += stride) {
+                    const int hs = (hb + pad - kh) / stride;         // exact: kh = (hb + pad) mod stride
+                    if (hb + pad < kh || hs >= Hs) continue;
+                    for (int kw = (rw + pad) % stride; kw < S; kw += stride) {
+                        const int ws0 = (b0 * stride + rw + pad - kw) / stride;   // exact; may be -1 at the left border
+                        f32x4 v[PB];
+#pragma unroll
+                        for (int j = 0; j < PB; ++j) {
+                            const int ws = ws0 + j;
+                            const bool ok = ws >= 0 && ws < Ws && b0 * stride + rw + pad >= kw - j * stride;
+                            v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                rx, ok ? (unsigned)((((n * Hs + hs) * Ws + ws) * Ck + c4) * 4) : 0x80000000u, 0, 0));
+                        }
+                        const f32x4* wt = wl + ((kh * S + kw) * 4) * L + cl;       // [tap][e][lane]: conflict-free
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const f32x4 wv = wt[e * L];
+#pragma unroll
+                            for (int j = 0; j < PB; ++j)
+#pragma unroll
+                                for (int o = 0; o < CO; ++o) s[j][o] = fmaf(v[j][e], wv[o], s[j][o]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < PB; ++j)
+#pragma unroll
+                    for (int o = 0; o < CO; ++o)
+#pragma unroll
+                        for (int off = L >> 1; off > 0; off >>= 1) s[j][o] += __shfl_xor(s[j][o], off, 64);
+                if (cl == 0) {
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) {
+                        const int wb = (b0 + j) * stride + rw;
+                        if (wb < Wb) {
+#pragma unroll
+                            for (int o = 0; o < CO; ++o) y[(((int64_t)n * Hb + hb) * Wb + wb) * CO + o] = s[j][o];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 AdvmixOpts& advmix_opts() {
@@ -391,6 +482,38 @@ extern "C" int advmix_adam(float* p, const float* g, float* m, float* v, int64_t
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step);
     hipLaunchKernelGGL(adam_kernel, dim3(stream_blocks(n)), dim3(256), 0, st, p, g, m, v, n, hyper, step);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+// y[N,Hb,Wb,Cn] = conv_transpose(x[N,Hs,Ws,Ck], w[Ck][R][S][Cn]) for Cn <= 4 (a Conv2d's input gradient with the
+// weights in their own layout, as advmix_conv_tr_w).  ADVMIX_EINVAL (nothing launched) for other shapes.
+extern "C" int advmix_conv_tr_narrow(const float* x, const float* w, float* y, int N, int Hs, int Ws, int Ck, int Hb,
+                                     int Wb, int Cn, int R, int S, int stride, int pad, void* stream) {
+    if (!x || !w || !y || N <= 0 || Ck <= 0 || stride < 1) return ADVMIX_EINVAL;
+    const int L = Ck / 4;                                    // lanes per pixel
+    if (Cn < 1 || Cn > 4 || Ck % 4 != 0 || (L != 16 && L != 32) || stride > 8) return ADVMIX_EINVAL;
+    if (Hs != (Hb + 2 * pad - R) / stride + 1 || Ws != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
+    const size_t lds = (size_t)R * S * Ck * 16;
+    if (lds > 64 * 1024) return ADVMIX_EINVAL;
+    if ((int64_t)N * Hb * Wb * 4 >= 0x7fffffffLL || (int64_t)N * Hs * Ws * Ck >= 0x7fffffffLL) return ADVMIX_EINVAL;
+    const int64_t P = (int64_t)N * cdiv(Hb, stride) * cdiv(cdiv(Wb, stride), 4);   // positions of 4 pixels in stride-phase coordinates
+    int64_t gx = (P + 256 / L - 1) / (256 / L);
+    if (gx > 3072) gx = 3072;
+    dim3 g((unsigned)gx);
+    hipStream_t st = (hipStream_t)stream;
+#define NARROW(CO_)                                                                                               \
+    do {                                                                                                          \
+        if (L == 16) hipLaunchKernelGGL((conv_tr_narrow_kernel<CO_, 16>), g, dim3(256), lds, st, x, w, y, N, Hs, Ws, Ck, Hb, Wb, R, S, stride, pad); \
+        else hipLaunchKernelGGL((conv_tr_narrow_kernel<CO_, 32>), g, dim3(256), lds, st, x, w, y, N, Hs, Ws, Ck, Hb, Wb, R, S, stride, pad); \
+    } while (0)
+    switch (Cn) {
+        case 1: NARROW(1); break;
+        case 2: NARROW(2); break;
+        case 3: NARROW(3); break;
+        default: NARROW(4); break;
+    }
+#undef NARROW
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }

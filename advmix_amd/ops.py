@@ -253,6 +253,12 @@ def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_
             return dx
         if rc != 1:                                        # 1 = EINVAL: not served (a tensor of 2 GiB or more) -> first-generation kernel
             raise RuntimeError('advmix_conv_tr_w_add failed: %d' % rc)
+    if Ci <= 4:                                               # a network's first conv: 3 image channels
+        rc = lib.advmix_conv_tr_narrow(_p(dy), _p(w), _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, st)
+        if rc == 0:
+            return dx if add_to is None else _add(st, keep(dx), add_to)
+        if rc != 1:
+            raise RuntimeError('advmix_conv_tr_narrow failed: %d' % rc)
     wt = _wt(st, w, Co, R * S, Ci)
     call('advmix_conv_tr', _p(dy), _p(wt), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, st)
     return dx if add_to is None else _add(st, keep(dx), add_to)

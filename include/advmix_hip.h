@@ -101,6 +101,13 @@ int advmix_conv_tr_w_bnb(const float* x, const float* w, const float* addend, fl
                          const float* bn_y, const float* bn_c, const float* bn_mean, const float* bn_invstd,
                          int act, double* stats, int* stats_ns, void* stream);
 
+/* Transposed gather with <= 4 output channels: the input gradient of a network's FIRST conv (3 image channels; taken
+ * when the images come from the generator - lib/core/function.py:146-160 back-propagates loss_G through the frozen
+ * student into G).  Arguments as advmix_conv_tr_w without the bias; one thread per output pixel instead of 32 MFMA
+ * columns for 3.  ADVMIX_EINVAL (nothing launched): Cn > 4, Ck not 64 or 128, R*S*Ck > 4096. */
+int advmix_conv_tr_narrow(const float* x, const float* w, float* y, int N, int Hs, int Ws, int Ck, int Hb, int Wb, int Cn,
+                          int R, int S, int stride, int pad, void* stream);
+
 /* ConvTranspose2d(Cin, Cout <= 4, kernel 4, stride 2, padding 1) forward for NARROW outputs - the U-Net's last layer
  * (Unet_generator.py:51-57, 128 -> 3): a VALU kernel bound by reading x once instead of an MFMA tile 32 columns wide.
  * w in its own layout [Cin][4][4][Cout]; x [N,Hi,Wi,Cin] -> y [N,2Hi,2Wi,Cout].  ADVMIX_EINVAL for other shapes. */

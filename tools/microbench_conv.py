@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time one conv configuration through the C ABI directly (ctypes, ~3 us/call of host overhead,
 so the HIP-event average is the kernel's launch-to-launch time, not Python's).
-usage: microbench_conv.py B Ci H W Co k stride pad [mode=fwd|fwd_stats|dgrad|wgrad] [iters]"""
+usage: microbench_conv.py B Ci H W Co k stride pad [mode=fwd|fwd_stats|dgrad|dgrad_narrow|dgrad_bt|dgrad_bt_add|dgrad_bnb|wgrad] [iters]"""
 import ctypes, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -28,6 +28,8 @@ elif mode == 'fwd':
     run = lambda: call('advmix_conv_fwd', P(x), P(w), None, P(y), B, H, W, Ci, Ho, Wo, Co, k, k, s, p, st)
 elif mode == 'dgrad':        # weights pre-transposed to [Ci][R][S][Co] (one re-layout launch per use, or a mirror per step)
     run = lambda: call('advmix_conv_tr', P(y), P(wt), None, P(x), B, Ho, Wo, Co, H, W, Ci, k, k, s, p, st)
+elif mode == 'dgrad_narrow':  # <= 4 input channels (a network's first conv): one thread per pixel
+    run = lambda: call('advmix_conv_tr_narrow', P(y), P(w), P(x), B, Ho, Wo, Co, H, W, Ci, k, k, s, p, st)
 elif mode == 'dgrad_bt':     # weights in their own layout, scattered into the LDS image (what the step launches)
     run = lambda: call('advmix_conv_tr_w_add', P(y), P(w), None, P(x), B, Ho, Wo, Co, H, W, Ci, k, k, s, p, st)
 elif mode == 'dgrad_bt_add':

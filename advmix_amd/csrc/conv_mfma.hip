@@ -299,6 +299,21 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
         }
     }
 
+    // Each B slot's pixel advances by KS per step: (n, ha, wa) are carried along instead of being divided out of the pixel
+    // index on every step (two integer divisions per slot and step were ~600 VALU cycles per 1024 MFMA cycles and wave).
+    const int HWa = p.Ha * p.Wa;
+    const int step_n = KS / HWa;                                         // KS pixels = step_n images + step_h rows +
+    const int step_h = (KS - step_n * HWa) / p.Wa;                       // step_w columns (one carry each: branch-free)
+    const int step_w = KS - step_n * HWa - step_h * p.Wa;
+    int b_n[BSL], b_ha[BSL], b_wa[BSL];
+#pragma unroll
+    for (int i = 0; i < BSL; ++i) {
+        const int pix = p_lo + b_k[i];
+        b_n[i] = pix / HWa;
+        const int rem = pix - b_n[i] * HWa;
+        b_ha[i] = rem / p.Wa;
+        b_wa[i] = rem - b_ha[i] * p.Wa;
+    }
     f32x4 ra[ASL], rb[BSL];
     auto load_tile = [&](int pt) {
 #pragma unroll
@@ -318,11 +333,13 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
         for (int i = 0; i < BSL; ++i) {
             int pix = pt + b_k[i];
             bool ok = b_in[i] && pix < p_hi;
-            int pp = ok ? pix : 0;
-            int n = pp / (p.Ha * p.Wa);
-            int rem = pp - n * (p.Ha * p.Wa);
-            int ha = rem / p.Wa, wa = rem - ha * p.Wa;
-            int hb0 = ha * p.stride, wb0 = wa * p.stride;
+            const int n = b_n[i], ha = b_ha[i], wa = b_wa[i];           // of pixel pt + b_k[i] (load_tile is called with
+            int hb0 = ha * p.stride, wb0 = wa * p.stride;              // pt = p_lo, p_lo + KS, ... in order)
+            const int w2 = wa + step_w, cw = w2 >= p.Wa;
+            const int h2 = ha + step_h + cw, ch = h2 >= p.Ha;
+            b_wa[i] = w2 - (cw ? p.Wa : 0);
+            b_ha[i] = h2 - (ch ? p.Ha : 0);
+            b_n[i] = n + step_n + ch;
             if (VEC) {
                 int hb = hb0 + b_dh[i][0], wb = wb0 + b_dw[i][0];
                 bool v = ok && b_jv[i][0] && (unsigned)hb < (unsigned)p.Hb && (unsigned)wb < (unsigned)p.Wb;

@@ -35,6 +35,23 @@ def _cfg(net, extra, J):
     return CfgNode({'MODEL': {'NAME': net, 'EXTRA': extra, 'NUM_JOINTS': J, 'INIT_WEIGHTS': True, 'PRETRAINED': ''}})
 
 
+def test_product_path_fails_loudly_without_the_hip_library(tmp_path):
+    """No CPU fallback: with the library missing, importing anything that computes raises - it does not route through
+    torch or the oracle."""
+    import subprocess, sys
+    code = ('import sys; sys.path.insert(0, %r)\n'
+            'try:\n    import advmix_amd.ops\n    print("IMPORTED")\n'
+            'except ImportError as e:\n    print("RAISED", "no CPU fallback" in str(e))\n' % ROOT)
+    env = dict(os.environ, ADVMIX_SO=str(tmp_path / 'missing.so'))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, env=env)
+    assert 'RAISED True' in out.stdout, (out.stdout, out.stderr[-2000:])
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'advmix_amd')):       # and nothing under the package imports the checker
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), os.path.join(dirpath, f)
+
+
 def test_model_mirrors_register_reference_keys():
     from oracle import configs
     from advmix_amd import models

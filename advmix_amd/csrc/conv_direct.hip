@@ -29,6 +29,13 @@ extern "C" int advmix_dbg_clk(unsigned long long* out, int n) {
 }
 #endif
 
+#ifdef CD_PRELOAD                   /* measurement build (tools/build_variant.sh pre conv_direct -DCD_PRELOAD): what a BatchNorm + ReLU applied
+                                       to the A fragments on load costs the forward kernel (DESIGN.md section 8, item 2 b) */
+static const float* g_pre_scale = nullptr;
+static const float* g_pre_shift = nullptr;
+extern "C" int advmix_dbg_preload(const float* scale, const float* shift) { g_pre_scale = scale; g_pre_shift = shift; return 0; }
+#endif
+
 namespace direct {
 
 struct ConvD {
@@ -54,6 +61,9 @@ struct ConvD {
     // (dy, y, c) and its finalize launch disappear (norm.hip: norm_bwd_apply_slots consumes the slots).
     const float *bnb_y, *bnb_c, *bnb_mean, *bnb_invstd;
     int bnb_act;
+#ifdef CD_PRELOAD
+    const float *pre_scale, *pre_shift;   // per input channel: A = max(x * scale + shift, 0), 0 outside the image
+#endif
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -280,6 +290,16 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
     // 3x3 32->32 conv and 47 % vs 60 % on the 128x64 tile (130 VGPRs -> 2 waves/SIMD), i.e. the
     // kernel is not bound by load latency per wave.
     f32x4 A0[RM][KQ], A1[RM][KQ], Br[BSL];
+#ifdef CD_PRELOAD
+    __shared__ __attribute__((aligned(16))) float pre_ss[2][512];
+    const bool pre_on = MODE == 0 && p.pre_scale != nullptr && p.Ci <= 512;
+    if (pre_on) {
+        for (int i = tid; i < p.Ci; i += 256) { pre_ss[0][i] = p.pre_scale[i]; pre_ss[1][i] = p.pre_shift[i]; }
+        __syncthreads();
+    }
+    bool okA[RM];
+    int c0A = 0;
+#endif
     MS::acc_t acc[RM][RN];
 #pragma unroll
     for (int t = 0; t < RM; ++t)
@@ -316,6 +336,10 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
         for (int t = 0; t < RM; ++t) {
             int hi = a_h[t] + tt.x, wi = a_w[t] + tt.y;
             bool ok = live && a_ok[t] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
+#ifdef CD_PRELOAD
+            okA[t] = ok;
+            c0A = c0;
+#endif
             unsigned off = ok ? (unsigned)(((a_nb[t] + hi * p.Wi + wi) * p.Ci + c0 + lh * 4) * 4) : OOB;
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
@@ -388,6 +412,27 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
         }
     };
 
+#ifdef CD_PRELOAD
+    // applied to the set just issued (flags / channel base of that issue): BatchNorm + ReLU of the producer on load
+    auto transform = [&](f32x4 (&A)[RM][KQ]) {
+        if (!pre_on) return;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(&pre_ss[0][c0A + q * (4 * KL) + lh * 4]);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(&pre_ss[1][c0A + q * (4 * KL) + lh * 4]);
+#pragma unroll
+            for (int t = 0; t < RM; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = fmaxf(fmaf(A[t][q][j], sc[j], sh[j]), 0.f);
+                    A[t][q][j] = okA[t] ? v : 0.f;
+                }
+        }
+    };
+#define CD_TRANSFORM(A_) transform(A_)
+#else
+#define CD_TRANSFORM(A_)
+#endif
     const int nch = (ch_hi - ch_lo + WK - 1) / WK;         // steps
     if (nch > 0) {
         // Steady-state loop with NO conditional load issue and one body: the conditional "issue the next chunk
@@ -398,6 +443,7 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
         // v_accvgpr moves.  The last chunk is peeled; the in-flight set is copied into the multiply set with
         // 16 register moves per chunk.
         issue(A0);
+        CD_TRANSFORM(A0);
         stage(0);
 #if !(defined(CD_DBG) && (CD_DBG & 2))
         __syncthreads();
@@ -411,6 +457,7 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
 #if !(defined(CD_DBG) && (CD_DBG & 2))
             __syncthreads();
 #endif
+            CD_TRANSFORM(A1);
 #pragma unroll
             for (int t = 0; t < RM; ++t)
 #pragma unroll
@@ -727,6 +774,10 @@ static int prepare(int mode, const float* x, const float* w, const float* bias, 
             p.bnb_act = epi->bnb_act;
         }
     }
+#ifdef CD_PRELOAD
+    p.pre_scale = mode == 0 ? g_pre_scale : nullptr;
+    p.pre_shift = mode == 0 ? g_pre_shift : nullptr;
+#endif
     *out = p;
     *bnb_out = bnb;
     return 0;

@@ -4,8 +4,10 @@ GPU, synthetic inputs resident in HBM, random-init weights), fp32.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hrnet_w32|resnet50|hrnet_w48]
 
-N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N bench.py
---gpus N ...` (one rank per GPU, RCCL); per-GPU work is fixed (weak scaling).  A "step" is the
+N > 1: either the driver's `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, or plain
+`python bench.py --gpus N`, which starts its own N ranks (advmix_amd/launch.py: one fresh process per GPU before
+anything touches the GPU; exits non-zero if fewer than N GPUs are visible - it never silently runs one rank).
+One rank per GPU, RCCL; per-GPU work is fixed (weak scaling); `rccl_ranks` in the line is dist.get_world_size().  A "step" is the
 body of train_advmix's batch loop (lib/core/function.py:137-171): G fwd, softmax-mix, D step
 (heat-map + KD loss, backward, Adam), G step through the updated frozen D (backward, Adam),
 loss.item() and the PCK accuracy read-out - nothing is skipped inside the timed region.
@@ -302,7 +304,7 @@ def bench_validate(a, device, rank, world):
     fwd_gflop = {'hrnet_w32': 15.290, 'hrnet_w48': 70.613, 'resnet50': 10.853}[a.workload]
     value = a.batch * world * a.steps / dt
     line = {'metric': 'images/sec validate batch, flip test (%s)' % a.workload, 'value': round(value, 2),
-            'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'unit': 'images/sec', 'n_gpus': world, 'rccl_ranks': _ranks(), 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic (N(0,1) images, Gaussian targets, random boxes), random-init weights',
@@ -428,6 +430,12 @@ def bench_nms(a, device, rank, world):
     return line
 
 
+def _ranks():
+    """Ranks in the RCCL process group as torch.distributed sees them (1 when no group was needed)."""
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 def cpu_baseline(workload, budget_s=25.0, hard_timeout_s=240.0, path="train"):
     """The CPU oracle's AdvMix step on this host (bounded sample: B=4, 1 warm-up + a few timed
     steps), in a CPU-only child process with a hard timeout so the bench always finishes."""
@@ -446,6 +454,35 @@ def cpu_baseline(workload, budget_s=25.0, hard_timeout_s=240.0, path="train"):
                 'sample': 'cpu oracle exceeded the %.0fs hard timeout' % hard_timeout_s}
 
 
+def rendezvous(a, backend, rank, world, local):
+    """--path rendezvous: the launcher's self-test.  Every rank joins the process group, one all-reduce checks that
+    all ``world`` ranks are really there, rank 0 prints a JSON line.  With the default backend (nccl = RCCL) each rank
+    binds its own GPU; ADVMIX_BENCH_BACKEND=gloo runs the same path on CPU (tests/test_host_cpu.py)."""
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29555')
+    if backend == 'nccl':
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+        torch.cuda.set_device(local)
+        device = torch.device('cuda', local)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    else:
+        device = torch.device('cpu')
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], device=device)
+    dist.all_reduce(t)
+    ok = float(t.item()) == world * (world + 1) / 2
+    ranks = dist.get_world_size()
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'metric': 'rendezvous', 'n_gpus': a.gpus, 'rccl_ranks': ranks, 'backend': backend,
+                          'allreduce_ok': ok}), flush=True)
+    if not ok:
+        raise SystemExit(4)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -454,9 +491,10 @@ def main():
     ap.add_argument('--workload', default='hrnet_w32', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=32, help='images per GPU (TRAIN.BATCH_SIZE_PER_GPU)')
     ap.add_argument('--exec', dest='exec_mode', default='graph', choices=['graph', 'eager'])
-    ap.add_argument('--path', default='train', choices=['train', 'validate', 'inputs', 'nms'],
+    ap.add_argument('--path', default='train', choices=['train', 'validate', 'inputs', 'nms', 'rendezvous'],
                     help='train = the headline AdvMix step; validate = the validate() batch body (SURVEY 8 f1); '
-                         'inputs = the device input pipeline (SURVEY 8 f2)')
+                         'inputs = the device input pipeline (SURVEY 8 f2); rendezvous = start the ranks, one all-reduce, '
+                         'report (launcher self-test; ADVMIX_BENCH_BACKEND=gloo runs it without GPUs)')
     ap.add_argument('--through-loop', action='store_true',
                     help='time core.function.train_advmix itself (the drop-in entry point): pinned host batches, H2D copies, '
                          'graph replay, loss.item(), accuracy - the reference loop body lib/core/function.py:107-197')
@@ -470,11 +508,23 @@ def main():
         os.environ['ADVMIX_TRACE_SHAPES'] = os.path.abspath(a.dump_shapes)
 
     import torch.distributed as dist
+    backend = os.environ.get('ADVMIX_BENCH_BACKEND', 'nccl')      # 'gloo' only for --path rendezvous (CPU launcher test)
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        # One command, N ranks (the reference's multi-GPU entry is one command too: GPUS in the YAML ->
+        # nn.DataParallel, tools/train.py:69,106,109).  This parent has NOT touched the GPU; it starts one fresh
+        # process per GPU, relays rank 0's JSON line and fails loudly rather than run fewer ranks than asked for.
+        from advmix_amd.launch import spawn_ranks
+        need = not (a.path == 'rendezvous' and backend == 'gloo')
+        raise SystemExit(spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], a.gpus, need_gpus=need))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, a.gpus))
+    if a.path == 'rendezvous':
+        return rendezvous(a, backend, rank, world, local)
+    if backend != 'nccl':
+        raise SystemExit('ADVMIX_BENCH_BACKEND=%s is only for --path rendezvous' % backend)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local)
@@ -601,8 +651,8 @@ def main():
         line = {
             'metric': 'images/sec AdvMix train step (HRNet-W32 256x192)' if a.workload == 'hrnet_w32'
             else 'images/sec AdvMix train step (%s)' % a.workload,
-            'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'rccl_ranks': _ranks(), 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic (N(0,1) views, Gaussian targets), random-init weights',
             'config': {'workload': '%s_%dx%d_advmix' % (a.workload, H, W), 'batch_per_gpu': a.batch,
                        'global_batch': a.batch * world, 'generator': 'UnetGenerator(9,3,%d)' % downs,

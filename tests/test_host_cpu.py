@@ -238,3 +238,42 @@ def test_grid_params_replays_the_reference_draws():
             assert (got is None and want is None) or list(got) == want, (tag, b, got, want)
     g, tmp = gaussian_patch(2)
     assert g.shape == (13, 13) and tmp == 6 and g[6, 6] == 1.0 and g.dtype == np.float32
+
+
+def _run_bench(argv, env_extra, timeout=300):
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + argv, capture_output=True, text=True,
+                          timeout=timeout, env=env, cwd=ROOT)
+
+
+def test_bench_launches_its_own_ranks_over_gloo():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts two ranks itself (advmix_amd/launch.py,
+    replacing GPUS -> nn.DataParallel, tools/train.py:69,106,109); the launcher self-test path runs on gloo here."""
+    out = _run_bench(['--gpus', '2', '--path', 'rendezvous'], {'ADVMIX_BENCH_BACKEND': 'gloo'})
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['allreduce_ok'] is True
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked():
+    """Fewer GPUs than --gpus (none here; one on the 1-GPU box): non-zero exit and no JSON line, never a silent single
+    rank.  A WORLD_SIZE that disagrees with --gpus is refused too."""
+    out = _run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0'], {})
+    assert out.returncode != 0 and 'refusing to run fewer ranks' in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    out = _run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0'], {'WORLD_SIZE': '1'})
+    assert out.returncode != 0 and 'WORLD_SIZE 1 != --gpus 2' in (out.stderr + out.stdout)
+
+
+def test_launcher_stops_the_job_when_a_rank_fails():
+    from advmix_amd.launch import spawn_ranks
+    code = ('import os, sys, time\n'
+            'r = int(os.environ["RANK"]); assert os.environ["WORLD_SIZE"] == "3" and os.environ["LOCAL_RANK"] == str(r)\n'
+            'sys.exit(7) if r == 1 else time.sleep(60)\n')
+    import time
+    t0 = time.time()
+    rc = spawn_ranks([sys.executable, '-c', code], 3, need_gpus=False)
+    assert rc == 7 and time.time() - t0 < 30

@@ -62,10 +62,6 @@ SIGNATURES = {
     'advmix_adam': [_p, _p, _p, _p, _l, _p, _p, _p],
     'advmix_sgd': [_p, _p, _p, _l, _p, _p],
     'advmix_fill': [_p, _f, _l, _p],
-    'advmix_graph_launch_many': [_p, _p, _i],
-    'advmix_lane_tick': [_p, _p],
-    'advmix_lane_signal': [_p, _p],
-    'advmix_lane_wait': [_p, _p, ctypes.c_uint64, _p, _p],
     'advmix_make_views': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     'advmix_render_targets': [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'advmix_flip_w': [_p, _p, _i, _i, _i, _i, _i, _p],

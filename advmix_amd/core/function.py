@@ -239,6 +239,13 @@ def _log(config, epoch, i, n, batch_time, data_time, losses, acc, bs, writer_dic
         writer_dict['train_global_steps'] = global_steps + 1
 
 
+def _capturable(optimizers, tensors):
+    """The graph runners need the flat optimizers of get_optimizer (flat_state / flat_grads / sync_hyper) and batches
+    that are already on the GPU; a plain torch.optim optimizer handed to the drop-in signature takes the eager step."""
+    return all(hasattr(o, 'flat_state') and hasattr(o, 'sync_hyper') for o in optimizers) \
+        and all(torch.is_tensor(t) and t.is_cuda for t in tensors)
+
+
 def train(config, args, train_loader, model, criterion, optimizer, epoch,
           output_dir, tb_log_dir, writer_dict, grad_sync=None):
     batch_time, data_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
@@ -252,7 +259,7 @@ def train(config, args, train_loader, model, criterion, optimizer, epoch,
         data_time.update(time.time() - end)
         x = x.contiguous()
         runner = None
-        if GRAPH_EXEC:
+        if GRAPH_EXEC and _capturable([optimizer], [x, target, target_weight]):
             from ..graph import PlainGraphRunner
             sig = (tuple(x.shape), tuple(target.shape), tuple(target_weight.shape), id(grad_sync))
             runner = _runner_for('plain', (model, criterion, optimizer), sig, lambda: PlainGraphRunner(
@@ -286,7 +293,7 @@ def train_advmix(config, args, train_loader, models, criterion, optimizers, epoc
         inputs = [v.contiguous() for v in dev[:3]]
         target, target_weight = dev[3], dev[4]
         runner = None
-        if GRAPH_EXEC:
+        if GRAPH_EXEC and _capturable([optimizer, optimizer_G], inputs + [target, target_weight]):
             from ..graph import AdvMixGraphRunner
             sig = (tuple(inputs[0].shape), tuple(target.shape), tuple(target_weight.shape), float(args.alpha),
                    float(args.adv_loss_weight), id(grad_sync))

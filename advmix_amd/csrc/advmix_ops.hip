@@ -496,7 +496,8 @@ extern "C" int advmix_conv_tr_narrow(const float* x, const float* w, float* y, i
     if (Hs != (Hb + 2 * pad - R) / stride + 1 || Ws != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
     const size_t lds = (size_t)R * S * Ck * 16;
     if (lds > 64 * 1024) return ADVMIX_EINVAL;
-    if ((int64_t)N * Hb * Wb * 4 >= 0x7fffffffLL || (int64_t)N * Hs * Ws * Ck >= 0x7fffffffLL) return ADVMIX_EINVAL;
+    // byte sizes (the buffer resource's num_records and the per-load offsets are 32-bit BYTE quantities)
+    if ((int64_t)N * Hb * Wb * 4 * 4 >= 0x7fffffffLL || (int64_t)N * Hs * Ws * Ck * 4 >= 0x7fffffffLL) return ADVMIX_EINVAL;
     const int64_t P = (int64_t)N * cdiv(Hb, stride) * cdiv(cdiv(Wb, stride), 4);   // positions of 4 pixels in stride-phase coordinates
     int64_t gx = (P + 256 / L - 1) / (256 / L);
     if (gx > 3072) gx = 3072;

@@ -322,61 +322,3 @@ extern "C" int advmix_scale_dev(float* y, const float* x, const float* s_dev, fl
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }
-
-
-// ---- device-side hand-offs between launch lanes (ops.Tape) ------------------------------------------------------------
-// Every lane of a tape replays a chain of single-stream HIP graphs on its own stream; where one lane's work depends on
-// another's, the producer's chain holds a SIGNAL kernel and the consumer's a WAIT kernel instead of a stream event (an
-// event between streams costs ~20 us of latency on this platform and would have to be issued by the host between graph
-// launches).  Counters only grow: a signal adds 1 to its counter; the waiter's target is (replays of ITS OWN lane so far)
-// x (signals per replay) - each lane counts its replays itself (lane_tick), so nothing is ever reset and no ordering
-// between the lanes' launches is assumed.  The spin is bounded: on timeout the kernel raises ``err`` and returns (a lost
-// hand-off shows up as a wrong result + error flag, never as a hung GPU).
-__global__ void lane_tick_kernel(unsigned long long* epoch) { *epoch += 1ULL; }
-
-__global__ void lane_signal_kernel(unsigned long long* counter) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_fetch_add(counter, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ void lane_wait_kernel(const unsigned long long* counter, const unsigned long long* epoch,
-                                 unsigned long long per_replay, int* err) {
-    const unsigned long long target = *epoch * per_replay;
-    long long spins = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1LL << 24)) { *err = 1; break; }    // ~ a second: give up instead of hanging the queue
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-
-extern "C" int advmix_lane_tick(unsigned long long* epoch, void* stream) {
-    if (!epoch) return ADVMIX_EINVAL;
-    hipLaunchKernelGGL(lane_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, epoch);
-    ADVMIX_CHECK_LAUNCH();
-    return ADVMIX_OK;
-}
-
-extern "C" int advmix_lane_signal(unsigned long long* counter, void* stream) {
-    if (!counter) return ADVMIX_EINVAL;
-    hipLaunchKernelGGL(lane_signal_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter);
-    ADVMIX_CHECK_LAUNCH();
-    return ADVMIX_OK;
-}
-
-extern "C" int advmix_lane_wait(const unsigned long long* counter, const unsigned long long* epoch,
-                                unsigned long long per_replay, int* err, void* stream) {
-    if (!counter || !epoch || !err) return ADVMIX_EINVAL;
-    hipLaunchKernelGGL(lane_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, epoch, per_replay, err);
-    ADVMIX_CHECK_LAUNCH();
-    return ADVMIX_OK;
-}
-
-// Replays a tape: hipGraphLaunch(execs[i], streams[i]) for i = 0..n-1 from one native loop (each launch from Python -
-// stream context + CUDAGraph.replay() - costs ~29 us of host time, a step has a few hundred).
-extern "C" int advmix_graph_launch_many(void* const* execs, void* const* streams, int n) {
-    if (!execs || !streams || n < 0) return ADVMIX_EINVAL;
-    for (int i = 0; i < n; ++i)
-        if (hipGraphLaunch((hipGraphExec_t)execs[i], (hipStream_t)streams[i]) != hipSuccess) return ADVMIX_ELAUNCH;
-    return ADVMIX_OK;
-}

@@ -5,9 +5,8 @@ backward passes); driven eagerly from Python it is launch-bound.  The step has s
 so it is captured ONCE into HIP graphs (hipStreamBeginCapture via torch.cuda.CUDAGraph - every
 kernel in libadvmix_hip.so is capture-safe: no allocation, no sync) and replayed per batch.
 
-Captured through ops.GraphSeq: by default one HIP graph with parallel branches per segment (the launch lanes' streams
-fork and join inside the capture); with ADVMIX_TAPE=1 as lane tapes (ops.Tape: one single-chain graph per lane and
-segment, device-side hand-offs) - measured slower, kept as an option.
+Captured through ops.GraphSeq: one HIP graph with parallel branches per segment (the launch lanes' streams fork and
+join inside the capture).
 Single GPU: two segments (phase a: G fwd ... D bwd; phase b: Adam(D) ... G bwd, Adam(G)).
 With data parallelism the step is cut into seven graphs, one per piece of a backward pass (core.function.
 _backward_pieces): [G fwd, mix, D fwd, T fwd, losses, top third of D's bwd] | [middle third] | [bottom third] |

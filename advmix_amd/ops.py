@@ -846,7 +846,11 @@ class Chain:
             if dst in pre:                                 # go is already g = dL/dy * act'(y), sums in the slots
                 kw['pre'] = pre.pop(dst)
             bnb = None
-            if k in plan and nin[0] and any(rec[plan[k]][3]) and rec[plan[k]][1]:
+            # The epilogue must see the COMPLETE dL/dy: every other contribution rides in as the addend, which only
+            # happens on the fan-in-fused path.  With ADVMIX_FANIN=0 a pending gradient of the slot would be added
+            # AFTER the epilogue had multiplied this conv's share by act'(y) and summed it - so no epilogue then.
+            if k in plan and nin[0] and any(rec[plan[k]][3]) and rec[plan[k]][1] \
+                    and (FANIN_FUSED or refs[0][1] not in grad):
                 jsp, jsc, jex, _jn = rec[plan[k]]
                 bnb = ConvBN.bnb_target(saved[jsp:jsp + jsc], jex, subs[plan[k]][2])
                 if bnb is not None:
@@ -878,178 +882,17 @@ class Chain:
 
 
 
-# =============================================================================================
-# Lane tapes: HIP-graph capture as a SEQUENCE of single-stream graphs
-# =============================================================================================
-class Tape:
-    """Captures a function as ONE single-stream HIP graph per launch lane (and segment) with device-side hand-offs
-    between the lanes, instead of one graph with parallel branches.
-
-    Why (tools/graph_launch_floor.py, tools/graph_per_lane.py, tools/lane_handoff.py on MI355X / ROCm 7.2): a replayed
-    graph that is ONE chain of kernels dispatches a node every 1.55 us (pre-built AQL packets); a graph with parallel
-    branches falls off that path - every node costs 2.6-3.2 us and the branches' nodes are issued one after the other
-    by the host, whatever queue they run on - while single-chain graphs replayed on four streams dispatch a kernel
-    every 0.6-0.9 us.  Stream events between separately replayed graphs are no alternative (~20 us per hand-off,
-    issued by the host): the hand-offs are KERNELS here - at a fork the main lane's chain signals a counter the side
-    lanes' chains wait on, at the join the side lanes signal and the main lane waits (advmix_lane_signal / _wait:
-    monotonic counters, each lane counts its own replays, bounded spin, error flag).
-
-    While ``ops.TAPE`` is set, GroupFn (``_run_lanes``) records each side lane's members into that lane's own capture,
-    opened at the lane's first fork of the segment and kept open to the segment's end: several stream captures are
-    under way at once on one thread, with no event edges between them (torch allows one capture per memory pool at a
-    time, so every lane has its own pool).  Everything runs on the calling thread
-    (torch.autograd.set_multithreading_enabled(False)).  A replay launches the segment's graphs - main lane first -
-    from one native loop (advmix_graph_launch_many).
-
-    Every lane needs a hardware queue of its OWN: a lane's whole segment sits in its queue behind its first wait, so two
-    lanes sharing a queue dead-lock (bounded: the waits time out after seconds and raise the error flag).  The HIP
-    runtime creates 4 queues by default and reads GPU_MAX_HW_QUEUES when it is loaded - export GPU_MAX_HW_QUEUES=8
-    BEFORE the process imports torch; setting it from Python afterwards has no effect.
-
-    Measured on the headline step (same box, ms per step; r2o logs): 4 lanes 63.2 tape / 59.2 one multi-branch graph
-    per segment; 2 lanes 65.7 / 64.8; 1 lane 77.5 / 74.3 (the same single chain: a graph replayed on a created stream
-    is that much slower than on the default stream - 77.7 vs 74.3 with the plain runner replaying on a side stream).
-    With 8 hardware queues the multi-branch graph itself takes 100.9 ms.  So dispatch is not what bounds the step
-    (DESIGN.md section 3); the tape stays as an option and as the record of the experiment."""
-
-    MAX_SYNC = 4096
-
-    def __init__(self, device=None):
-        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
-        self.main = torch.cuda.Stream(device=self.device)
-        self.items = []              # (CUDAGraph, stream)
-        self.pools = {}              # lane -> memory pool shared by the lane's graphs
-        self._caps = {}              # lane -> (CUDAGraph, stream) under capture in the current segment
-        self.mode = dict(capture_error_mode='thread_local')
-        # hand-off state: [epoch per lane (16)] [fork counters] [join counters]; err flag
-        self.sync = torch.zeros(16 + 2 * self.MAX_SYNC, dtype=torch.int64, device=self.device)
-        self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self.n_sync = 0
-        self._ticked = set()
-        self._launch = None
-
-    def _ptr(self, idx):
-        return ctypes.c_void_p(self.sync.data_ptr() + 8 * idx)
-
-    # ---- capture ---------------------------------------------------------------------------
-    def _begin(self, stream, lane):
-        """Start the capture of ``lane``'s graph for the current segment on ``stream`` (stays open until the segment
-        ends: several captures are under way at once, one per lane, with no event edges between them)."""
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(stream):
-            if lane not in self.pools:                     # torch allows one capture at a time per pool: a pool per lane
-                self.pools[lane] = torch.cuda.graph_pool_handle()
-            g.capture_begin(pool=self.pools[lane], **self.mode)
-            if lane not in self._ticked:                   # the lane's first graph of a replay counts the replay
-                self._ticked.add(lane)
-                call('advmix_lane_tick', self._ptr(lane), ctypes.c_void_p(stream.cuda_stream))
-        self._caps[lane] = (g, stream)
-
-    def _end_all(self):
-        """End every open capture back to back (nothing may allocate in between: the allocator's capture filters of
-        graphs sharing a pool are dropped first-begun-first, whichever capture ends)."""
-        for lane in sorted(self._caps):
-            g, stream = self._caps[lane]
-            with torch.cuda.stream(stream):
-                g.capture_end()
-            self.items.append((g, stream))
-        self._caps = {}
-        self._launch = None
-
-    def fork_join(self, side, run_lane):
-        """A fork into lanes [main] + side and the join after it, around ``run_lane(lane index, stream)``."""
-        k = self.n_sync
-        self.n_sync += 1
-        if k >= self.MAX_SYNC:
-            raise RuntimeError('Tape: more than %d fork/join points' % self.MAX_SYNC)
-        fork, join = self._ptr(16 + k), self._ptr(16 + self.MAX_SYNC + k)
-        err = ctypes.c_void_p(self.err.data_ptr())
-        call('advmix_lane_signal', fork, ctypes.c_void_p(self.main.cuda_stream))
-        for l, s_ in enumerate(side, start=1):
-            if l not in self._caps:
-                self._begin(s_, l)
-            assert self._caps[l][1] == s_
-            with torch.cuda.stream(s_):
-                h = ctypes.c_void_p(s_.cuda_stream)
-                call('advmix_lane_wait', fork, self._ptr(l), 1, err, h)
-                run_lane(l, s_)
-                call('advmix_lane_signal', join, h)
-        run_lane(0, self.main)
-        call('advmix_lane_wait', join, self._ptr(0), len(side), err, ctypes.c_void_p(self.main.cuda_stream))
-
-    def capture(self, fn):
-        """Run ``fn`` once under capture; returns its result.  May be called several times (segments); replay(lo, hi)
-        replays a range of items, always in capture order."""
-        global TAPE
-        import gc
-        torch.cuda.synchronize(self.device)
-        gc.collect()
-        prev = TAPE
-        TAPE = self
-        try:
-            with torch.autograd.set_multithreading_enabled(False), torch.cuda.stream(self.main):
-                self._begin(self.main, 0)
-                try:
-                    r = fn()
-                finally:
-                    self._end_all()
-        finally:
-            TAPE = prev
-        torch.cuda.synchronize(self.device)
-        return r
-
-    # ---- replay ----------------------------------------------------------------------------
-    def replay(self, lo=0, hi=None):
-        """Replay items [lo, hi) (default: all).  The tape's main stream first waits for the caller's current stream and
-        the caller's stream waits for it afterwards, so a tape slice behaves like one stream-ordered operation (every
-        side lane's work is joined into the main lane by a device-side hand-off inside the slice)."""
-        hi = len(self.items) if hi is None else hi
-        key = (lo, hi)
-        if self._launch is None or self._launch[0] != key:
-            n = hi - lo
-            execs = (ctypes.c_void_p * n)(*[it[0].raw_cuda_graph_exec() for it in self.items[lo:hi]])
-            streams = (ctypes.c_void_p * n)(*[it[1].cuda_stream for it in self.items[lo:hi]])
-            self._launch = (key, execs, streams, n)
-            self._cache = getattr(self, '_cache', {})
-            self._cache[key] = self._launch
-        cur = torch.cuda.current_stream(self.device)
-        self.main.wait_stream(cur)
-        _, execs, streams, n = self._launch
-        call('advmix_graph_launch_many', execs, streams, n)
-        cur.wait_stream(self.main)
-
-    def check(self):
-        """Raise if a hand-off timed out (reads one int from the device: call it where the host synchronises anyway)."""
-        if int(self.err.item()) != 0:
-            raise RuntimeError('advmix_amd: a lane hand-off timed out (two lanes on one hardware queue? export '
-                               'GPU_MAX_HW_QUEUES=8 before the process imports torch)')
-
-    @property
-    def n_graphs(self):
-        return len(self.items)
-
-
-TAPE = None
-# Runners: one multi-branch HIP graph per segment (default) or lane tapes (ADVMIX_TAPE=1 with GPU_MAX_HW_QUEUES=8 in the
-# environment; slower - see Tape).
-USE_TAPE = __import__('os').environ.get('ADVMIX_TAPE', '0') == '1'
-
-
 class GraphSeq:
-    """What the runners capture into: a Tape (default) or, with ADVMIX_TAPE=0, plain torch.cuda.graph captures (one
-    multi-branch HIP graph per ``capture`` call) sharing one pool.  ``capture(fn)`` returns (segment id, fn's result);
-    ``replay(segment id)`` replays that segment."""
+    """What the runners capture into: plain torch.cuda.graph captures (one multi-branch HIP graph per ``capture`` call: the
+    launch lanes' streams fork and join inside the capture) sharing one memory pool.  ``capture(fn)`` returns (segment
+    id, fn's result); ``replay(segment id)`` replays that segment.  (Rounds 1-2 also had per-lane single-chain graphs
+    with device-side hand-offs, "lane tapes": 2 ms instead of 46 ms of host time per step and a SLOWER step, 63.2 vs
+    59.2 ms - DESIGN.md section 3; removed in round 3, the code is in history at 72f4536.)"""
 
     def __init__(self, device):
-        self.tape = Tape(device) if USE_TAPE else None
-        self.graphs, self.segs, self.pool = [], [], None
+        self.graphs, self.pool = [], None
 
     def capture(self, fn):
-        if self.tape is not None:
-            lo = len(self.tape.items)
-            r = self.tape.capture(fn)
-            self.segs.append((lo, len(self.tape.items)))
-            return len(self.segs) - 1, r
         g = torch.cuda.CUDAGraph()
         kw = dict(capture_error_mode='thread_local')
         if self.pool is not None:
@@ -1062,18 +905,11 @@ class GraphSeq:
         return len(self.graphs) - 1, r
 
     def replay(self, seg):
-        if self.tape is not None:
-            key = self.segs[seg]
-            cached = getattr(self.tape, '_cache', {}).get(key)
-            if cached is not None:
-                self.tape._launch = cached
-            self.tape.replay(*key)
-        else:
-            self.graphs[seg].replay()
+        self.graphs[seg].replay()
 
     @property
     def n_graphs(self):
-        return self.tape.n_graphs if self.tape is not None else len(self.graphs)
+        return len(self.graphs)
 
 
 def _lane_order(n, nl):
@@ -1082,27 +918,17 @@ def _lane_order(n, nl):
 
 
 def _run_lanes(dev, n, nl, run_member):
-    """Fork, run member i on lane i % nl via ``run_member(i, stream handle, lane)``, join.  Eager or inside an
-    ordinary capture: real stream fork / join.  On a Tape: one graph per lane."""
+    """Fork, run member i on lane i % nl via ``run_member(i, stream handle, lane)``, join (real stream fork / join,
+    eager or inside a capture)."""
     cur = torch.cuda.current_stream(dev)
     side = _lanes(dev, nl - 1)
-    tape = TAPE
-    if tape is None or nl == 1:
-        for s_ in side:
-            s_.wait_stream(cur)
-        handles = [ctypes.c_void_p(cur.cuda_stream)] + [ctypes.c_void_p(s_.cuda_stream) for s_ in side]
-        for i in _lane_order(n, nl):
-            run_member(i, handles[i % nl], i % nl)
-        for s_ in side:
-            cur.wait_stream(s_)
-        return
-    assert cur == tape.main, 'Tape: GroupFn must run on the tape\'s main stream'
-
-    def run_lane(l, stream):
-        h = ctypes.c_void_p(stream.cuda_stream)
-        for i in range(l, n, nl):
-            run_member(i, h, l)
-    tape.fork_join(side, run_lane)
+    for s_ in side:
+        s_.wait_stream(cur)
+    handles = [ctypes.c_void_p(cur.cuda_stream)] + [ctypes.c_void_p(s_.cuda_stream) for s_ in side]
+    for i in _lane_order(n, nl):
+        run_member(i, handles[i % nl], i % nl)
+    for s_ in side:
+        cur.wait_stream(s_)
 
 
 # =============================================================================================

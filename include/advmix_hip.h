@@ -170,17 +170,6 @@ int advmix_transpose_w(const float* in, float* out, int A, int T, int B, void* s
 /* db[c] += sum over rows of dy[rows, C] */
 int advmix_bias_grad(const float* dy, float* db, int64_t rows, int C, void* stream);
 
-/* ---- hand-offs between launch lanes replayed as separate HIP graphs (advmix_amd/ops.py::Tape): counters only grow;
- * a waiter's target is its own lane's replay count x the signals it expects per replay.  Bounded spin; *err = 1 on
- * timeout.  Replaces the stream events of a multi-stream capture. */
-int advmix_lane_tick(unsigned long long* epoch, void* stream);
-int advmix_lane_signal(unsigned long long* counter, void* stream);
-int advmix_lane_wait(const unsigned long long* counter, const unsigned long long* epoch,
-                     unsigned long long per_replay, int* err, void* stream);
-
-/* hipGraphLaunch(execs[i], streams[i]) for i in [0, n): the native replay loop of a lane tape */
-int advmix_graph_launch_many(void* const* execs, void* const* streams, int n);
-
 /* ---- normalisation: replaces nn.BatchNorm2d (train / eval, pose_hrnet.py:34 etc.) and
  * nn.InstanceNorm2d(affine=False) (Unet_generator.py:19,43,45).  groups = 1 -> BatchNorm
  * over all N*H*W rows; groups = N -> InstanceNorm over H*W rows of each image.

@@ -268,6 +268,49 @@ def test_network_parity_at_the_benchmarked_batch():
     print(tag, 'worst err/bound ratios', {k: round(x, 3) for k, x in rep.items()})
 
 
+@pytest.mark.parametrize('tag', ['hrnet_tiny', 'resnet18_tiny'])
+def test_gradient_fan_in_by_separate_add_gives_the_same_gradients(tag):
+    """with ADVMIX_FANIN=0 the gradients pending for a slot are NOT folded into the consumer's input-gradient
+    epilogue, so that epilogue must not carry the producer's BatchNorm backward either (it would multiply a partial
+    gradient by act'(y) and sum it).  Full and input-only backward, fan-in fused vs separate: same gradients, and the
+    BatchNorm-backward epilogue still taken wherever the gradient is complete."""
+    from oracle.posenet import calibrate
+    from oracle.synth import synth_batch
+    from advmix_amd import ops
+    from advmix_amd.core.loss import JointsMSELoss
+    from advmix_amd.core.function import set_require_grad
+    net, extra, J, B, H, W, _ = CASES[tag]
+    D, T, G = build_states(net, extra, J)
+    views, tgt, tw = synth_batch(tag, B, J, H, W)
+    calibrate(net, D, views[2], extra)
+    cfg, mD, _, _ = product_models(net, extra, J, D, T, G)
+    mD.train()
+    res = {}
+    try:
+        for fused in (True, False):
+            ops.FANIN_FUSED = fused
+            for frozen in (False, True):
+                set_require_grad(mD, not frozen)
+                for p in mD.parameters():
+                    p.grad = None
+                x = views[1].cuda().requires_grad_(True)
+                n0 = ops.COUNTERS['bnb']
+                JointsMSELoss(True)(mD(x), tgt.cuda(), tw.cuda()).backward()
+                g = {'x': x.grad.detach().clone()}
+                if not frozen:
+                    g.update({k: p.grad.detach().clone() for k, p in mD.named_parameters()})
+                res[fused, frozen] = (g, ops.COUNTERS['bnb'] - n0)
+    finally:
+        ops.FANIN_FUSED = True
+        set_require_grad(mD, True)
+    for frozen in (False, True):
+        (ga, na), (gb, nb) = res[True, frozen], res[False, frozen]
+        assert na > 0 and 0 < nb <= na, (na, nb)
+        for k in ga:
+            sc = float(ga[k].abs().max()) + 1e-30
+            assert float((ga[k] - gb[k]).abs().max()) <= 2e-4 * sc, (k, frozen, float((ga[k] - gb[k]).abs().max()), sc)
+
+
 def test_smoke_entry():
     run_smoke('hrnet_tiny', iters=2)
     run_smoke('resnet18_tiny', iters=1)

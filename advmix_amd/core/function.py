@@ -239,6 +239,33 @@ def _log(config, epoch, i, n, batch_time, data_time, losses, acc, bs, writer_dic
         writer_dict['train_global_steps'] = global_steps + 1
 
 
+_AUTO_SYNC = {}
+
+
+def _auto_sync(models, optimizers, grad_sync):
+    """The reference's call sites (tools/train.py:291-296) pass no ``grad_sync``: when the process is one rank of an
+    initialised process group (one process per GPU instead of nn.DataParallel), the loops create the GradSync themselves
+    - once per set of models - and make every replica start from rank 0's state, which is what DataParallel's
+    per-forward weight broadcast did implicitly."""
+    import torch.distributed as dist
+    if grad_sync is not None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+        return grad_sync
+    key = tuple(id(m) for m in models)
+    hit = _AUTO_SYNC.get(key)
+    if hit is None or any(a is not b for a, b in zip(hit[1], models)):
+        from ..dp import GradSync
+        gs = GradSync()
+        gs.broadcast_state(list(models), list(optimizers))
+        hit = _AUTO_SYNC[key] = (gs, tuple(models))
+    return hit[0]
+
+
+def _net(m):
+    """The network inside a DataParallel-shaped wrapper (dp.Replica), or ``m`` itself."""
+    from ..dp import unwrap
+    return unwrap(m)
+
+
 def _capturable(optimizers, tensors):
     """The graph runners need the flat optimizers of get_optimizer (flat_state / flat_grads / sync_hyper) and batches
     that are already on the GPU; a plain torch.optim optimizer handed to the drop-in signature takes the eager step."""
@@ -251,7 +278,9 @@ def train(config, args, train_loader, model, criterion, optimizer, epoch,
     batch_time, data_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
     if isinstance(model, list):
         model = model[0]
+    model = _net(model)
     model.train()
+    grad_sync = _auto_sync([model], [optimizer], grad_sync)
     end = time.time()
     n = len(train_loader) if hasattr(train_loader, '__len__') else -1
     pick = lambda b: [b[0], b[1][0] if isinstance(b[1], (list, tuple)) else b[1], b[2]]     # noqa: E731  (:48-51)
@@ -281,10 +310,11 @@ def train(config, args, train_loader, model, criterion, optimizer, epoch,
 def train_advmix(config, args, train_loader, models, criterion, optimizers, epoch,
                  output_dir, tb_log_dir, writer_dict, grad_sync=None):
     batch_time, data_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
-    model = models[0].train()
-    model_G = models[1].train()
-    model_teacher = models[2].eval()
+    model = _net(models[0]).train()
+    model_G = _net(models[1]).train()
+    model_teacher = _net(models[2]).eval()
     optimizer, optimizer_G = optimizers[0], optimizers[1]
+    grad_sync = _auto_sync([model, model_G, model_teacher], [optimizer, optimizer_G], grad_sync)
     end = time.time()
     n = len(train_loader) if hasattr(train_loader, '__len__') else -1
     pick = lambda b: [b[0][0], b[0][1], b[0][2], b[1][0], b[2][0]]                        # noqa: E731  (:129-133)
@@ -342,6 +372,7 @@ def validate(config, args, val_loader, val_dataset, model, criterion, output_dir
     if cpu:
         raise RuntimeError('advmix_amd: validate() has no CPU path (the reference\'s cpu=True debug mode)')
     batch_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter()
+    model = _net(model)
     model.eval()
     num_samples = len(val_dataset)
     all_preds = np.zeros((num_samples, config.MODEL.NUM_JOINTS, 3), dtype=np.float32)

@@ -135,3 +135,36 @@ class GradSync:
         place and discards the others).  Here rank 0's buffers ARE that shard's statistics: only rank 0 writes
         checkpoints, and nothing is averaged."""
         return (dist.get_rank(self.group) if self.world > 1 else 0) == 0
+
+
+class Replica(torch.nn.Module):
+    """What ``torch.nn.DataParallel(model, device_ids=cfg.GPUS)`` becomes with one process per GPU: a wrapper that
+    keeps DataParallel's SHAPE - ``.module``, ``module.``-prefixed state-dict keys, ``forward`` delegating to the wrapped
+    network - and none of its mechanics (no scatter / replicate / gather: this process owns one GPU and one replica;
+    gradients are exchanged by GradSync).  The reference's wiring relies on that shape: tools/train.py:198-235 prefixes
+    the keys of ``--load_from_D`` / ``--load_from_G`` checkpoints with ``module.`` before matching them against
+    ``model.state_dict()``, :315,325,337 save ``model.module.state_dict()``, and AUTO_RESUME reloads the prefixed
+    ``state_dict`` (:244).  Binding it as ``torch.nn.DataParallel`` lets tools/train.py:69,
+    106,109 run unchanged.  Attributes the wrapper does not have (``plan_cuts``, ``init_weights``, ...) resolve on
+    the wrapped network."""
+
+    def __init__(self, module, device_ids=None, output_device=None, dim=0):
+        super().__init__()
+        self.module = module
+        self.device_ids = list(device_ids) if device_ids is not None else None      # recorded, not used: one GPU per process
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            if name == 'module':
+                raise
+            return getattr(super().__getattr__('module'), name)
+
+
+def unwrap(model):
+    """The network inside a Replica / DataParallel-shaped wrapper (or the model itself)."""
+    return model.module if isinstance(model, Replica) else model

@@ -255,6 +255,9 @@ def save_checkpoint(states, is_best, output_dir, filename='checkpoint.pth', suff
     alone (tools/train.py:311-337); parameters and Adam state are identical on every rank (dp.GradSync)."""
     if grad_sync is not None and not grad_sync.checkpoint_rank():
         return
+    import torch.distributed as dist
+    if grad_sync is None and dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+        return                                              # the reference's call sites pass no grad_sync (tools/train.py:311-328)
     if suffix != '':
         torch.save(states, os.path.join(output_dir, filename[:-4] + '_' + suffix + '.pth'))
         if is_best and 'state_dict' in states:

@@ -277,3 +277,65 @@ def test_launcher_stops_the_job_when_a_rank_fails():
     t0 = time.time()
     rc = spawn_ranks([sys.executable, '-c', code], 3, need_gpus=False)
     assert rc == 7 and time.time() - t0 < 30
+
+
+def test_replica_keeps_dataparallels_shape():
+    """dp.Replica: ``.module``, ``module.``-prefixed keys (what tools/train.py:198-235 match --load_from_D against),
+    forward / attribute delegation; the loops unwrap it."""
+    import torch.nn as nn
+    from advmix_amd.dp import Replica, unwrap
+    net = nn.Sequential(nn.Conv2d(3, 4, 1), nn.BatchNorm2d(4))
+    net.plan_cuts = lambda n: ['cuts', n]
+    r = Replica(net, device_ids=(0, 1, 2, 3))
+    assert r.module is net and unwrap(r) is net and unwrap(net) is net
+    assert sorted(r.state_dict()) == sorted('module.' + k for k in net.state_dict())
+    r.load_state_dict({'module.' + k: v + 1 if v.is_floating_point() else v for k, v in net.state_dict().items()})
+    x = torch.randn(2, 3, 4, 4)
+    assert torch.equal(r(x), net(x)) and r.plan_cuts(3) == ['cuts', 3]
+    r.eval()
+    assert not net.training
+    with pytest.raises(AttributeError):
+        r.no_such_attribute
+
+
+_WORKER_AUTO = r'''
+import os, sys, torch, torch.nn as nn, torch.distributed as dist
+sys.path.insert(0, %r)
+rank = int(os.environ['RANK'])
+from advmix_amd.core import function as F
+net = lambda: nn.Sequential(nn.Conv2d(3, 4, 3, padding=1), nn.BatchNorm2d(4))
+torch.manual_seed(7 + rank)
+D, G, T = net(), net(), net()
+oD, oG = torch.optim.Adam(D.parameters(), 1e-2), torch.optim.Adam(G.parameters(), 1e-2)
+ok = F._auto_sync([D, G, T], [oD, oG], None) is None            # no process group: single GPU, nothing to do
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ['MASTER_PORT'], rank=rank, world_size=2)
+gs = F._auto_sync([D, G, T], [oD, oG], None)
+ok = ok and gs is not None and gs.active and F._auto_sync([D, G, T], [oD, oG], None) is gs    # created once
+def same(t):
+    got = [torch.zeros_like(t), torch.zeros_like(t)]
+    dist.all_gather(got, t.contiguous())
+    return torch.equal(got[0], got[1])
+ok = ok and all(same(p.data) for m in (D, G, T) for p in m.parameters())       # rank 0's state everywhere
+mine = object()
+ok = ok and F._auto_sync([D, G, T], [oD, oG], mine) is mine      # an explicit grad_sync wins
+from advmix_amd.utils.utils import save_checkpoint
+save_checkpoint({'state_dict': D.state_dict(), 'best_state_dict': D.state_dict()}, True, sys.argv[1], suffix='D%%d' %% rank)
+dist.barrier()
+ok = ok and os.path.exists(os.path.join(sys.argv[1], 'checkpoint_D0.pth')) \
+    and not os.path.exists(os.path.join(sys.argv[1], 'checkpoint_D1.pth'))      # rank 0 writes, rank 1 returns
+dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+'''
+
+
+def test_loops_create_their_own_grad_sync_under_a_process_group(tmp_path):
+    """The reference's call sites pass no grad_sync (tools/train.py:291-296, 311-328): under an initialised process
+    group the loops create it once and broadcast rank 0's state; save_checkpoint writes on rank 0 only."""
+    script = tmp_path / 'wa.py'
+    script.write_text(_WORKER_AUTO % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29617')
+        procs.append(subprocess.Popen([sys.executable, str(script), str(tmp_path)], env=env))
+    for p in procs:
+        assert p.wait(timeout=180) == 0

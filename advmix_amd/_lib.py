@@ -22,6 +22,7 @@ _p, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 # name -> argtypes, mirrors include/advmix_hip.h line by line
 SIGNATURES = {
     'advmix_version': [],
+    'advmix_build_flags': [],
     'advmix_set_option': [ctypes.c_char_p, _i],
     'advmix_conv_fwd': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_fwd_ex': [_p, _p, _p, _p] + [_i] * 11 + [_p, _p, _p, _p, _f, _p, _i, _p, _p, _p],

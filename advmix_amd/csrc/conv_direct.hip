@@ -22,19 +22,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 
-#ifdef CD_CLK                       /* diagnostic build (tools/build_variant.sh clk conv_direct -DCD_CLK): in-kernel shader clock */
-__device__ unsigned long long g_cd_clk[2 * 8192];
-extern "C" int advmix_dbg_clk(unsigned long long* out, int n) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cd_clk), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : 2;
-}
-#endif
 
-#ifdef CD_PRELOAD                   /* measurement build (tools/build_variant.sh pre conv_direct -DCD_PRELOAD): what a BatchNorm + ReLU applied
-                                       to the A fragments on load costs the forward kernel (DESIGN.md section 8, item 2 b) */
-static const float* g_pre_scale = nullptr;
-static const float* g_pre_shift = nullptr;
-extern "C" int advmix_dbg_preload(const float* scale, const float* shift) { g_pre_scale = scale; g_pre_shift = shift; return 0; }
-#endif
 
 namespace direct {
 
@@ -61,9 +49,6 @@ struct ConvD {
     // (dy, y, c) and its finalize launch disappear (norm.hip: norm_bwd_apply_slots consumes the slots).
     const float *bnb_y, *bnb_c, *bnb_mean, *bnb_invstd;
     int bnb_act;
-#ifdef CD_PRELOAD
-    const float *pre_scale, *pre_shift;   // per input channel: A = max(x * scale + shift, 0), 0 outside the image
-#endif
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -228,10 +213,6 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
     __syncthreads();                                       // taptab visible
-#ifdef CD_CLK
-    unsigned long long clk_t0 = 0, clk_r0 = 0;
-    if (tid == 0) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
-#endif
 
     // ---- epilogue geometry, and its operands fetched NOW ------------------------------------------------------------
     constexpr int RSL = MS::NR / WK;                       // accumulator registers a wave finishes itself
@@ -263,11 +244,7 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
     // Loaded in the epilogue they were a pure memory phase with the matrix pipe idle, every wave of the launch at once:
     // 3x3 32->32 @64x48 input gradient 23.5 us, + addend 28.0, + BatchNorm-backward sums 36.1.  Single-tile waves only
     // (16 registers per operand).
-#ifdef CD_NO_PRE
-    constexpr bool PRE = false;
-#else
     constexpr bool PRE = RM * RN == 1 && !SPLIT;
-#endif
     const bool pre_a_on = PRE && p.res != nullptr && (MODE == 1 || EPI);
     const bool pre_c_on = PRE && EPI && MODE == 1;
     const bool pre_y_on = pre_c_on && p.bnb_act != ADVMIX_ACT_NONE;
@@ -290,16 +267,6 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
     // 3x3 32->32 conv and 47 % vs 60 % on the 128x64 tile (130 VGPRs -> 2 waves/SIMD), i.e. the
     // kernel is not bound by load latency per wave.
     f32x4 A0[RM][KQ], A1[RM][KQ], Br[BSL];
-#ifdef CD_PRELOAD
-    __shared__ __attribute__((aligned(16))) float pre_ss[2][512];
-    const bool pre_on = MODE == 0 && p.pre_scale != nullptr && p.Ci <= 512;
-    if (pre_on) {
-        for (int i = tid; i < p.Ci; i += 256) { pre_ss[0][i] = p.pre_scale[i]; pre_ss[1][i] = p.pre_shift[i]; }
-        __syncthreads();
-    }
-    bool okA[RM];
-    int c0A = 0;
-#endif
     MS::acc_t acc[RM][RN];
 #pragma unroll
     for (int t = 0; t < RM; ++t)
@@ -336,22 +303,12 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
         for (int t = 0; t < RM; ++t) {
             int hi = a_h[t] + tt.x, wi = a_w[t] + tt.y;
             bool ok = live && a_ok[t] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
-#ifdef CD_PRELOAD
-            okA[t] = ok;
-            c0A = c0;
-#endif
             unsigned off = ok ? (unsigned)(((a_nb[t] + hi * p.Wi + wi) * p.Ci + c0 + lh * 4) * 4) : OOB;
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
-#if defined(CD_DBG) && (CD_DBG & 1)                  /* throughput experiments (tools/conv_limiter.sh): no A loads */
-                float fv = __builtin_bit_cast(float, off + q);
-                A[t][q] = f32x4{fv, fv, fv, fv};
-#else
                 A[t][q] = bload(xr, off + q * (16 * KL));
-#endif
             }
         }
-#if !(defined(CD_DBG) && (CD_DBG & 2))
 #pragma unroll
         for (int i = 0; i < BSL; ++i) {
             const int cb = WK == 1 ? ck : cur + b_kk[i];
@@ -363,14 +320,10 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
                               : b_off[i] + (BT ? (unsigned)(((c0b * p.R * p.S + tq.w) * p.Co) * 4)
                                              : (unsigned)((tq.z + c0b) * 4)));
         }
-#endif
         cur += WK;
         advance(a_tap, a_c0);
     };
     auto stage = [&](int buf) {
-#if defined(CD_DBG) && (CD_DBG & 2)                  /* no weight staging at all */
-        return;
-#endif
 #pragma unroll
         for (int i = 0; i < BSL; ++i)
             if (tid + 256 * i < BCH * WK) {
@@ -389,13 +342,8 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
             f32x4 b[RN];
 #pragma unroll
             for (int u = 0; u < RN; ++u) {
-#if defined(CD_DBG) && (CD_DBG & 2)
-                float fb = __builtin_bit_cast(float, (unsigned)(buf + q + u + lane));
-                b[u] = f32x4{fb, fb, fb, fb};
-#else
                 b[u] = *reinterpret_cast<const f32x4*>(
                     &Bs[buf][wk * (BN * LDB) + (wn * TN * 32 + u * MR + l31) * LDB + q * (4 * KL) + lh * 4]);
-#endif
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -403,36 +351,11 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
                 for (int t = 0; t < RM; ++t)
 #pragma unroll
                     for (int u = 0; u < RN; ++u) {
-#if defined(CD_DBG) && (CD_DBG & 8)                  /* no MFMAs: how much of the STEP is matrix-pipe time? */
-                        acc[t][u][0] += A[t][q][j] * b[u][j];
-#else
                         acc[t][u] = MS::mma(A[t][q][j], b[u][j], acc[t][u]);
-#endif
                     }
         }
     };
 
-#ifdef CD_PRELOAD
-    // applied to the set just issued (flags / channel base of that issue): BatchNorm + ReLU of the producer on load
-    auto transform = [&](f32x4 (&A)[RM][KQ]) {
-        if (!pre_on) return;
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(&pre_ss[0][c0A + q * (4 * KL) + lh * 4]);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(&pre_ss[1][c0A + q * (4 * KL) + lh * 4]);
-#pragma unroll
-            for (int t = 0; t < RM; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = fmaxf(fmaf(A[t][q][j], sc[j], sh[j]), 0.f);
-                    A[t][q][j] = okA[t] ? v : 0.f;
-                }
-        }
-    };
-#define CD_TRANSFORM(A_) transform(A_)
-#else
-#define CD_TRANSFORM(A_)
-#endif
     const int nch = (ch_hi - ch_lo + WK - 1) / WK;         // steps
     if (nch > 0) {
         // Steady-state loop with NO conditional load issue and one body: the conditional "issue the next chunk
@@ -443,21 +366,15 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
         // v_accvgpr moves.  The last chunk is peeled; the in-flight set is copied into the multiply set with
         // 16 register moves per chunk.
         issue(A0);
-        CD_TRANSFORM(A0);
-        stage(0);
-#if !(defined(CD_DBG) && (CD_DBG & 2))
+            stage(0);
         __syncthreads();
-#endif
         int buf = 0;
         for (int ci = 0; ci + 1 < nch; ++ci) {
             issue(A1);                                     // chunk ci + 1 in flight ...
             __builtin_amdgcn_sched_barrier(0);             // (the scheduler otherwise sinks the weight load below the MFMAs)
             compute(A0, buf);                              // ... while chunk ci is multiplied
             stage(buf ^ 1);
-#if !(defined(CD_DBG) && (CD_DBG & 2))
             __syncthreads();
-#endif
-            CD_TRANSFORM(A1);
 #pragma unroll
             for (int t = 0; t < RM; ++t)
 #pragma unroll
@@ -467,12 +384,6 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
         compute(A0, buf);
     }
 
-#ifdef CD_CLK
-    if (tid == 0 && bx < 8192 && by == 0 && bz == 0) {   // shader cycles / 100 MHz ticks of the main loop
-        g_cd_clk[2 * bx] = __builtin_amdgcn_s_memtime() - clk_t0;
-        g_cd_clk[2 * bx + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
-    }
-#endif
     // ---- epilogue -----------------------------------------------------------------------------
     // BN column sums: the WM waves that share a column meet in LDS (the weight buffer is free now), so a
     // workgroup issues ONE pair of fp64 atomics per column instead of one per wave
@@ -535,9 +446,6 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
                 const int off = elem_off(t, u, r_lo + r, valid);
                 const unsigned boff = valid ? (unsigned)off * 4u : OOB;
                 float v = acc[t][u][r] + bv;
-#if defined(CD_DBG) && (CD_DBG & 4)                  /* no output stores (kept alive by an impossible value) */
-                if (v != 123456.789f) continue;
-#endif
                 // transposed gather (input gradients): an addend, e.g. the other gradient of a tensor with two
                 // consumers, rides in the epilogue instead of a separate add kernel (slice 0 only under SPLIT)
                 if (addend) v += PRE ? pre_a[r] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, boff, 0, 0));
@@ -774,10 +682,6 @@ static int prepare(int mode, const float* x, const float* w, const float* bias, 
             p.bnb_act = epi->bnb_act;
         }
     }
-#ifdef CD_PRELOAD
-    p.pre_scale = mode == 0 ? g_pre_scale : nullptr;
-    p.pre_shift = mode == 0 ? g_pre_shift : nullptr;
-#endif
     *out = p;
     *bnb_out = bnb;
     return 0;
@@ -889,6 +793,27 @@ int advmix_conv_direct_group(int mode, int bt, int n, ConvProb* pr, hipStream_t 
                             pr[0].Wo, pr[0].Co, pr[0].R, pr[0].S, 1, fl);
     }
     return hipGetLastError() == hipSuccess ? ADVMIX_OK : ADVMIX_ELAUNCH;
+}
+
+// Bit mask of the measurement switches this library was compiled with: 0 for the shipped library (__graft_entry__.build()
+// and advmix_amd/_lib.py assert it).  1 = CD_DBG (parts of the kernel compiled out), 2 = CD_PRELOAD, 4 = CD_CLK, 8 =
+// CD_NO_PRE - all four exist only in tools/variants/conv_direct_dbg.patch - and 16 = a store cache policy other than sc1.
+extern "C" int advmix_build_flags(void) {
+    int f = 0;
+#ifdef CD_DBG
+    f |= 1;
+#endif
+#ifdef CD_PRELOAD
+    f |= 2;
+#endif
+#ifdef CD_CLK
+    f |= 4;
+#endif
+#ifdef CD_NO_PRE
+    f |= 8;
+#endif
+    if (CD_STORE_AUX != 16) f |= 16;
+    return f;
 }
 
 // Which conv_direct tile configuration a problem gets (tests assert that the shapes meant to exercise a

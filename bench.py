@@ -641,7 +641,9 @@ def main():
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    if not (lv == lv) and os.environ.get('ADVMIX_BENCH_ALLOW_NAN') != '1':     # (debug builds with work compiled out)
+    from advmix_amd._lib import lib as _hiplib
+    variant = _hiplib.advmix_build_flags()                  # non-zero: a tools/build_variant.sh library (ADVMIX_SO=...)
+    if not (lv == lv) and not variant:
         raise SystemExit('loss is NaN')
 
     line = None
@@ -661,8 +663,10 @@ def main():
                        'step_gflop_per_image': gflop_img},
             'step_tflops_per_gpu': round(value / world * gflop_img / 1e3, 2),
             'step_frac_of_fp32_mfma_peak': round(value / world * gflop_img / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
-            'last_loss_D': round(lv, 6),
+            'last_loss_D': round(lv, 6) if lv == lv else None,
         }
+        if variant:
+            line['INVALID_variant_build_flags'] = variant   # measurement build: never a benchmark result
         if not a.no_roofline:
             line['roofline'] = time_conv_family(a.batch, device)
         if world == 1 and not a.no_cpu_baseline:

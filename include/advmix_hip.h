@@ -35,6 +35,9 @@ extern "C" {
 #define ADVMIX_ACT_LEAKY02 2   /* LeakyReLU(0.2), lib/models/Unet_generator.py:42 */
 
 int advmix_version(void);
+/* 0 for the shipped library; non-zero bits name the measurement switches a variant build was compiled with
+ * (tools/build_variant.sh, tools/variants/): such a library must never be benchmarked or shipped as the product. */
+int advmix_build_flags(void);
 /* dispatch knobs for A/B runs and tests: "direct" (0 = first-generation conv only), "wgrad_direct", "wgrad_lds"
  * (0 off, 1 when the batch fills the chip, 2 whenever eligible), "ksplit_wg" (K split inside the workgroup vs across the grid), "stat_slots" (fp64 slots per channel of the statistics
  * epilogues), "deterministic" (1: no K split across the grid), "trace_shapes" (measurement aid, see common.h).

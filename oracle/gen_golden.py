@@ -276,6 +276,50 @@ def gen_b32(M):
     gen_advmix(M, (B32_CASE + (1,),), 'b32_advmix_steps.npz', 'b32_advmix_checksums.json', plain=False)
 
 
+# every benchmarked network at a batch that reaches the tile configurations conv_direct dispatches at B = 32
+# (tests/test_models_gpu.py asserts the configuration sets): ResNet-50 256x192 at B = 32 itself, HRNet-W48 384x288 at
+# B = 16 (configurations {2, 3, 6} like B = 32; the CPU oracle at B = 32 would need ~40 GB)
+BENCH_TILE_CASES = (('resnet50_b32', 'pose_resnet', configs.RES50, 17, 32, 256, 192),
+                    ('hrnet_w48_b16', 'pose_hrnet', configs.HRNET_W48, 17, 16, 384, 288))
+# BASELINE.json configs[0] (C1), literally: pose_resnet50 256x192, MPII's 16 joints, batch 4, the plain ``train`` loop
+C1_CASE = ('c1_resnet50_j16_b4', 'pose_resnet', configs.RES50, 16, 4, 256, 192)
+
+
+def gen_benchtiles(M):
+    gen_forward(M, BENCH_TILE_CASES, 'benchtiles_forward.npz')
+
+
+def gen_c1(M):
+    """C1: two iterations of the REAL ``train`` loop (function.py:30-95) at J = 16, B = 4."""
+    fn = M['core.function']
+    tag, net, extra, J, B, H, W = C1_CASE
+    cfg, D, _, _ = build_ref_models(M, net, extra, J, 6, salt=20)
+    calib = synth_batch(tag + '.calib', B, J, H, W)[0][0]
+    calibrate_ref(D, calib)
+    optD = torch.optim.Adam(D.parameters(), lr=1e-3)
+    crit = Rec(M['core.loss'].JointsMSELoss(True))
+    pb, outs = [], []
+    for it in range(2):
+        v, t, w = synth_batch('%s.plain%d' % (tag, it), B, J, H, W)
+        pb.append((v[0], [t, t], w, {}))
+    hook = D.register_forward_hook(lambda m, i, o: outs.append(o.detach().clone()))
+    wd = {'writer': types.SimpleNamespace(add_scalar=lambda *a, **k: None), 'train_global_steps': 0}
+    cfg['PRINT_FREQ'] = 10 ** 9
+    fn.save_debug_images = lambda *a, **k: None
+    fn.train(cfg, None, pb, D, crit, optD, 0, '/tmp', '/tmp', wd)
+    hook.remove()
+    res = {tag + '.plain_losses': np.array(crit.vals)}
+    for it in range(2):
+        res['%s.out.it%d' % (tag, it)] = strided(outs[it], 2048)
+    sdD = D.state_dict()
+    meta = {tag: {'plain_D': checksum(sdD, [k for k in sdD if sdD[k].is_floating_point()]),
+                  'nbt': int(sdD['bn1.num_batches_tracked'])}}
+    np.savez_compressed(os.path.join(OUT, 'c1_plain_steps.npz'), **res)
+    with open(os.path.join(OUT, 'c1_plain_checksums.json'), 'w') as f:
+        json.dump(meta, f)
+    print('c1', crit.vals, flush=True)
+
+
 def gen_nms(M):
     nm = M['nms.nms']
     rng = np.random.Generator(np.random.Philox(key=77))
@@ -499,7 +543,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     M = import_reference()
-    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe', 'c4', 'b32']
+    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe', 'c4', 'b32', 'benchtiles', 'c1']
     for w in which:
         globals()['gen_' + w](M)
         print('done', w, flush=True)

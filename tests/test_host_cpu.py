@@ -27,6 +27,9 @@ def test_library_exports_every_header_symbol():
              'advmix_conv_group'}                                          # struct argument, bound separately
     assert names - sizes == set(L.SIGNATURES), (names ^ set(L.SIGNATURES))
     assert L.lib.advmix_version() == 1
+    assert L.lib.advmix_build_flags() == 0                 # the shipped library carries no measurement switches
+    src = open(os.path.join(ROOT, 'advmix_amd', 'csrc', 'conv_direct.hip')).read()
+    assert not re.search(r'#\s*if.*CD_(DBG|PRELOAD|CLK|NO_PRE)', src.split('advmix_build_flags')[0])   # one code path in the hot kernel
     assert L.lib.advmix_norm_ws_bytes(1, 64) == 512 * 2 * 64 * 8 + 2 * 64 * 4
 
 

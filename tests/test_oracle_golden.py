@@ -187,6 +187,50 @@ def test_forward_at_the_benchmarked_batch_matches_reference():
     close([float(loss)], g[tag + '.loss'], 1e-5, 1e-4)
 
 
+BENCH_TILE_CASES = {      # oracle/gen_golden.py::BENCH_TILE_CASES - the other two benchmarked networks at benchmark-sized batches
+    'resnet50_b32': ('pose_resnet', configs.RES50, 17, 32, 256, 192),
+    'hrnet_w48_b16': ('pose_hrnet', configs.HRNET_W48, 17, 16, 384, 288),
+}
+
+
+@pytest.mark.parametrize('tag', sorted(BENCH_TILE_CASES))
+def test_forward_of_the_other_benchmarked_networks_matches_reference(tag):
+    """ResNet-50 256x192 at B = 32 (C2) and HRNet-W48 384x288 at B = 16 (C4): eval forward, train forward, loss and
+    running statistics against the REAL reference's vectors at those batches (tests/golden/benchtiles_forward.npz)."""
+    net, extra, J, B, H, W = BENCH_TILE_CASES[tag]
+    g = gold_npz('benchtiles_forward.npz')
+    D, _, _ = build_states(net, extra, J, unet_downs=5 if 'w48' in tag else 6)
+    views, tgt, tw = synth_batch(tag, B, J, H, W)
+    calibrate(net, D, views[2], extra)
+    with torch.no_grad():
+        ye = posenet_forward(net, D, views[0], extra, False)
+        yt = posenet_forward(net, D, views[1], extra, True)
+        loss = joints_loss(yt, tgt, tw, True)
+    close(strided(ye), g[tag + '.eval_out'])
+    close(strided(yt), g[tag + '.train_out'])
+    close([float(loss)], g[tag + '.loss'], 1e-5, 1e-4)
+    for key in g.files:
+        if key.startswith(tag + '.bn.'):
+            close(D[key[len(tag) + 4:]].detach().numpy(), g[key], 1e-4, 1e-3)
+
+
+def test_c1_plain_loop_literally_matches_reference():
+    """BASELINE.json configs[0] as written: pose_resnet50 256x192, J = 16 (MPII), B = 4, the plain ``train`` loop
+    (function.py:30-95), two iterations of the REAL reference: losses, heat-maps, post-step parameter checksums."""
+    tag, net, extra, J, B, H, W = 'c1_resnet50_j16_b4', 'pose_resnet', configs.RES50, 16, 4, 256, 192
+    g, meta = gold_npz('c1_plain_steps.npz'), gold_json('c1_plain_checksums.json')[tag]
+    D, _, _ = build_states(net, extra, J, salt=20)
+    calibrate(net, D, synth_batch(tag + '.calib', B, J, H, W)[0][0], extra)
+    optD = Adam(D, trainable(D))
+    for it in range(2):
+        v, t, w = synth_batch('%s.plain%d' % (tag, it), B, J, H, W)
+        r = plain_step(net, extra, D, optD, v[0], t, w)
+        close([float(r['loss'])], [g[tag + '.plain_losses'][it]], 1e-4, 1e-3)
+        close(strided(r['out'], 2048), g['%s.out.it%d' % (tag, it)], 2e-3 if it else 1e-3, 2e-3 if it else 1e-3)
+    assert int(D['bn1.num_batches_tracked']) == meta['nbt']
+    checksum_close(checksum(D, meta['plain_D'].keys()), meta['plain_D'])
+
+
 # ---- validation path (SURVEY.md 8 f1): oracle/validate.py against the real reference's outputs ----------------
 
 from oracle import validate as oval                                   # noqa: E402

@@ -55,7 +55,15 @@ WORKLOADS = {
     'resnet50': ('pose_resnet', {'FINAL_CONV_KERNEL': 1, 'DECONV_WITH_BIAS': False, 'NUM_DECONV_LAYERS': 3,
                                  'NUM_DECONV_FILTERS': [256, 256, 256], 'NUM_DECONV_KERNELS': [4, 4, 4],
                                  'NUM_LAYERS': 50}, 17, 256, 192, 6, 91.77),
+    # BASELINE.json configs[4] (C5) as far as it can be built: the reference has NO HigherHRNet model, loss or grouping
+    # code (README.md:72-73 lists its accuracy; tools/test_corruption.py:147 is a dead branch), so there is no oracle.
+    # This is the HRNet-W32 trunk + UnetGenerator(9,3,6) AdvMix step at 512x512 - the 128x128x32 ... 16x16x256 shapes of
+    # that resolution - as a THROUGHPUT-ONLY line, never the headline.  GFLOP / image: the 256x192 counts x (512*512)/
+    # (256*192): 6 * 81.55 + 3 * 48.19 - 1.43.
+    'hrnet_w32_512': ('pose_hrnet', hrnet_extra(HRNET_STAGES['hrnet_w32']), 17, 512, 512, 6, 632.4),
 }
+NO_ORACLE = {'hrnet_w32_512': 'no oracle - the reference has no HigherHRNet code (README.md:72-73); trunk + generator '
+                              'step only, no associative-embedding head / grouping; throughput only'}
 
 
 def synth(B, J, H, W, device, seed):
@@ -130,7 +138,7 @@ def _latest_pmc():
         return round(json.load(f)['hbm_bytes_per_launch']), os.path.relpath(files[-1], ROOT)
 
 
-def time_conv_family(B, device, iters=100):
+def time_conv_family(B, device, iters=100, family=None):
     """The roofline object.  The step's time is the MFMA convs' (SURVEY 8 d3), and no single launch dominates: the four
     branch resolutions of HRNet-W32 each run the same 1.81 GFLOP 3x3 conv, as forward (+ BatchNorm column sums, or +
     eval BatchNorm + ReLU for the teacher), input gradient (+ the BatchNorm-backward sums of its producer) and weight
@@ -146,7 +154,8 @@ def time_conv_family(B, device, iters=100):
     members, hbm = [], []
     tot_f = tot_t = 0.0
     dominant = None
-    for C, H, W in CONV_FAMILY:
+    family = family or CONV_FAMILY
+    for C, H, W in family:
         rows = B * H * W
         x = torch.randn(B, H, W, C, device=device)
         w = torch.randn(C, 3, 3, C, device=device) * (9 * C) ** -0.5
@@ -181,10 +190,10 @@ def time_conv_family(B, device, iters=100):
                  'tflops': round(flops / (ms * 1e-3) / 1e12, 2), 'frac': round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                  'launches_per_step_weight': wgt}
             members.append(m)
-            if C == 32 and kind == 'fwd+BN-sums':
+            if C == family[0][0] and kind == 'fwd+BN-sums':
                 dominant = dict(m, us_per_launch_runs=[round(v * 1e3, 2) for v in rr],
                                 algorithmic_gflop_per_launch=round(flops / 1e9, 3))
-        if C in (32, 128):                                  # the two BatchNorm kernels left on the train path
+        if C in (family[0][0], family[2][0]):               # the two BatchNorm kernels left on the train path
             res = torch.randn_like(x)
             nbt = torch.zeros((), dtype=torch.int64, device=device)
             call('advmix_conv_fwd_ex', P(x), P(w), None, P(c2), *geom, None, None, None, None, 0.0, None, 0, P(slots),
@@ -202,11 +211,12 @@ def time_conv_family(B, device, iters=100):
                 hbm.append({'kernel': '%s rows %d x C %d' % (name, rows, C), 'us_per_launch': round(ms * 1e3, 2),
                             'algorithmic_bytes_per_launch': nbytes, 'achieved_GBps': round(nbytes / (ms * 1e-3) / 1e9, 1),
                             'frac_of_8TBps': round(nbytes / (ms * 1e-3) / 1e9 / 8000.0, 4)})
-    traffic, src = _latest_pmc() if B == 32 else (None, None)
+    traffic, src = _latest_pmc() if (B == 32 and family == CONV_FAMILY) else (None, None)
     agg = tot_f / tot_t / 1e12
-    algo_bytes = 2 * B * 64 * 48 * 32 * 4 + 9 * 32 * 32 * 4
+    C0, H0, W0 = family[0]
+    algo_bytes = 2 * B * H0 * W0 * C0 * 4 + 9 * C0 * C0 * 4
     return {'bound': 'mfma',
-            'kernel': 'conv_direct / conv_wgrad family: 3x3 s1 C->C at the four HRNet-W32 branch resolutions x '
+            'kernel': 'conv_direct / conv_wgrad family: 3x3 s1 C->C at the four HRNet branch resolutions of this workload x '
                       '{fwd+BN sums, fwd+BN eval, dgrad+BN-bwd sums, wgrad}, launch-count weighted',
             'achieved': round(agg, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(agg / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -301,7 +311,7 @@ def bench_validate(a, device, rank, world):
         dt = float(tmax.item())
     if rank != 0:
         return None
-    fwd_gflop = {'hrnet_w32': 15.290, 'hrnet_w48': 70.613, 'resnet50': 10.853}[a.workload]
+    fwd_gflop = {'hrnet_w32': 15.290, 'hrnet_w48': 70.613, 'resnet50': 10.853, 'hrnet_w32_512': 81.55}[a.workload]
     value = a.batch * world * a.steps / dt
     line = {'metric': 'images/sec validate batch, flip test (%s)' % a.workload, 'value': round(value, 2),
             'unit': 'images/sec', 'n_gpus': world, 'rccl_ranks': _ranks(), 'steps': a.steps, 'warmup': a.warmup,
@@ -661,14 +671,20 @@ def main():
                        'parallelism': 'dp%d' % world, 'exec': 'hipgraph' if a.exec_mode == 'graph' else 'eager',
                        'entry': loop_note or 'graph.AdvMixGraphRunner.step (inputs resident in HBM)',
                        'step_gflop_per_image': gflop_img},
+        }
+        if a.workload in NO_ORACLE:
+            line['config']['parity'] = NO_ORACLE[a.workload]
+        line.update({
             'step_tflops_per_gpu': round(value / world * gflop_img / 1e3, 2),
             'step_frac_of_fp32_mfma_peak': round(value / world * gflop_img / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
             'last_loss_D': round(lv, 6) if lv == lv else None,
-        }
+        })
         if variant:
             line['INVALID_variant_build_flags'] = variant   # measurement build: never a benchmark result
         if not a.no_roofline:
-            line['roofline'] = time_conv_family(a.batch, device)
+            widths = HRNET_STAGES.get('hrnet_w48' if a.workload == 'hrnet_w48' else 'hrnet_w32')
+            line['roofline'] = time_conv_family(a.batch, device, family=tuple(
+                (c, (H // 4) >> i, (W // 4) >> i) for i, c in enumerate(widths)))
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(a.workload)
 

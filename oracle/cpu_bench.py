@@ -139,7 +139,8 @@ def main():
     from oracle.synth import synth_batch
     W = {'hrnet_w32': ('pose_hrnet', configs.HRNET_W32, 17, 256, 192, 6),
          'hrnet_w48': ('pose_hrnet', configs.HRNET_W48, 17, 384, 288, 5),
-         'resnet50': ('pose_resnet', configs.RES50, 17, 256, 192, 6)}
+         'resnet50': ('pose_resnet', configs.RES50, 17, 256, 192, 6),
+         'hrnet_w32_512': ('pose_hrnet', configs.HRNET_W32, 17, 512, 512, 6)}    # (bench.py: throughput only, no reference code)
     net, extra, J, H, Wd, downs = W[workload]
     detinit.mark_transposed(unet_transposed_names(9, 3, downs))
     D = detinit.fill_state_dict(posenet_spec(net, extra, J))

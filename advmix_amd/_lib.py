@@ -49,6 +49,7 @@ SIGNATURES = {
     'advmix_act_bwd': [_p, _i, _p, _i, _p, _i, _l, _i, _i, _p],
     'advmix_fuse_sum': [_p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
     'advmix_fuse_sum_bwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'advmix_fuse_sum_bwd_bnb': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p],
     'advmix_maxpool3x3s2': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'advmix_maxpool3x3s2_bwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'advmix_scale_dev': [_p, _p, _p, _f, _l, _p],
@@ -65,6 +66,7 @@ SIGNATURES = {
     'advmix_fill': [_p, _f, _l, _p],
     'advmix_make_views': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     'advmix_render_targets': [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'advmix_autoaug': [_p, _p, _p, _p, _i, _i, _i, _p],
     'advmix_flip_w': [_p, _p, _i, _i, _i, _i, _i, _p],
     'advmix_flip_merge': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'advmix_final_preds': [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p],

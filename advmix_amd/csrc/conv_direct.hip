@@ -95,12 +95,15 @@ struct Geo {
     static constexpr int LDB = KC + 4;
     static constexpr int RED = WK > 1 ? 4 * RM * RN * MS::NR * 64 : 0;
     static constexpr int BSZ = (WK * BN * LDB * 2 > RED) ? WK * BN * LDB : (RED + 1) / 2;
+    static constexpr int TP = 36;                          // pitch of the epilogue's wave-private transposer (floats)
+    static constexpr int TSZ = 4 * (2 * MS::NR / WK) * TP; // four waves x the 2 * NR / WK rows a wave finishes x 32 columns
 };
 
-// One workgroup's tile (bx, by) of slice / phase bz.  ``Bs0``: 2 * Geo::BSZ floats of LDS, ``taptab``: 64 int4.
+// One workgroup's tile (bx, by) of slice / phase bz.  ``Bs0``: 2 * Geo::BSZ floats of LDS, ``Ts0``: Geo::TSZ floats,
+// ``taptab``: 64 int4.
 template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT, bool EPI>
 __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int by, const int bz, float* const Bs0,
-                                          int4* const taptab) {
+                                          float* const Ts0, int4* const taptab) {
     // WK waves of the workgroup split K BETWEEN THEM (WM x WN x WK = 4 waves): the low-resolution layers have too
     // few output tiles to fill the chip; instead of slicing K across workgroups (SPLIT: zero-fill + fp32 atomics,
     // no fused epilogue) a 32x32 tile is computed by four waves that each take every fourth K chunk and meet
@@ -239,26 +242,45 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
         const int hi_ = rem / Wp, wi_ = rem - hi_ * Wp;
         return ((n * p.Ho + rh + hi_ * p.stride) * p.Wo + rw + wi_ * p.stride) * p.Co + col;
     };
+    // 16-byte view of a wave's share of tile (t, u): chunk q = 8 rows x 32 columns, lane -> (row 8q + lane / 8 of the
+    // 2 * RSL rows the wave finishes, 4 consecutive columns).  The accumulator layout (one column, 16 scattered rows per
+    // lane) costs 16 four-byte memory instructions per lane and operand; through a wave-private LDS transposer the same
+    // bytes move as RSL / 4 sixteen-byte ones - the skeleton of this kernel is bound by vector-memory ISSUE, not bytes.
+    constexpr int TQ = RSL / 4;
+    constexpr int TP = Geo<TM, TN, WM, WN, KC>::TP;
+    const bool t128 = !SPLIT && (p.Co & 3) == 0;           // uniform: rows of the output are 16-byte aligned
+    int e_lane = lane;
+    auto chunk_off = [&](int t, int u, int q, bool& valid) -> int {
+        const int col = n0 + wn * TN * 32 + u * MR + ((e_lane & 7) << 2);
+        int m = m0 + wm * TM * 32 + t * MR + 2 * r_lo + 8 * q + (e_lane >> 3);
+        valid = m < Mp && col < p.Co;
+        if (!valid) m = 0;
+        if (MODE == 0 || p.stride == 1) return m * p.Co + col;
+        const int n = m / (Hp * Wp);
+        const int rem = m - n * (Hp * Wp);
+        const int hi_ = rem / Wp, wi_ = rem - hi_ * Wp;
+        return ((n * p.Ho + rh + hi_ * p.stride) * p.Wo + rw + wi_ * p.stride) * p.Co + col;
+    };
     // The epilogue's READ operands - the residual (forward) / the addend (input gradient), and for the BatchNorm-
     // backward epilogue the producer's c and y - are requested before the main loop and sit in registers until it ends.
     // Loaded in the epilogue they were a pure memory phase with the matrix pipe idle, every wave of the launch at once:
     // 3x3 32->32 @64x48 input gradient 23.5 us, + addend 28.0, + BatchNorm-backward sums 36.1.  Single-tile waves only
     // (16 registers per operand).
     constexpr bool PRE = RM * RN == 1 && !SPLIT;
-    const bool pre_a_on = PRE && p.res != nullptr && (MODE == 1 || EPI);
-    const bool pre_c_on = PRE && EPI && MODE == 1;
+    const bool pre_a_on = PRE && t128 && p.res != nullptr && (MODE == 1 || EPI);
+    const bool pre_c_on = PRE && t128 && EPI && MODE == 1;
     const bool pre_y_on = pre_c_on && p.bnb_act != ADVMIX_ACT_NONE;
-    float pre_a[RSL], pre_c[RSL], pre_y[RSL];
+    f32x4 pq_a[TQ], pq_c[TQ], pq_y[TQ];
 #pragma unroll
-    for (int r = 0; r < RSL; ++r) {
-        pre_a[r] = 0.f; pre_c[r] = 0.f; pre_y[r] = 0.f;
+    for (int q = 0; q < TQ; ++q) {
+        pq_a[q] = f32x4{0.f, 0.f, 0.f, 0.f}; pq_c[q] = pq_a[q]; pq_y[q] = pq_a[q];
         if (PRE) {
             bool valid;
-            const int off = elem_off(0, 0, r_lo + r, valid);
+            const int off = chunk_off(0, 0, q, valid);
             const unsigned boff = valid ? (unsigned)off * 4u : OOB;
-            if (pre_a_on) pre_a[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, boff, 0, 0));
-            if (pre_c_on) pre_c[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cr, boff, 0, 0));
-            if (pre_y_on) pre_y[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yyr, boff, 0, 0));
+            if (pre_a_on) pq_a[q] = bload(rr, boff);
+            if (pre_c_on) pq_c[q] = bload(cr, boff);
+            if (pre_y_on) pq_y[q] = bload(yyr, boff);
         }
     }
 
@@ -415,8 +437,33 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
     }
     // The offsets of the prefetched operands are NOT kept across the main loop (16 more live registers per lane): the
     // epilogue recomputes them from lane ids the compiler cannot connect to the earlier ones.
-    asm volatile("" : "+v"(e_l31), "+v"(e_lh));
+    asm volatile("" : "+v"(e_l31), "+v"(e_lh), "+v"(e_lane));
     if (stats) __syncthreads();                            // every wave is done reading Bs
+    // The wave-private transposer: 2 * RSL rows x 32 columns at a 36-float pitch (16-byte aligned rows; a 4-byte access
+    // of the accumulator layout - row MS::row(r, lh), column l31 - is bank-conflict free per half wave).  LDS accesses
+    // of ONE wave execute in issue order, so a write followed by a read of other lanes' data needs no barrier - only
+    // that the compiler keeps the order (the accesses go through one pointer it cannot prove disjoint, plus a
+    // scheduling fence).
+    float* const Tx = Ts0 + wid * (2 * RSL * TP);
+    auto wave_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    float pre_a[RSL], pre_c[RSL], pre_y[RSL];
+    auto to_acc_layout = [&](const f32x4 (&q)[TQ], float (&o)[RSL]) {
+#pragma unroll
+        for (int i = 0; i < TQ; ++i)
+            *reinterpret_cast<f32x4*>(&Tx[(8 * i + (lane >> 3)) * TP + ((lane & 7) << 2)]) = q[i];
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < RSL; ++r) o[r] = Tx[MS::row(r, lh) * TP + l31];
+        wave_fence();
+    };
+#pragma unroll
+    for (int r = 0; r < RSL; ++r) { pre_a[r] = 0.f; pre_c[r] = 0.f; pre_y[r] = 0.f; }
+    if (PRE) {
+        if (pre_a_on) to_acc_layout(pq_a, pre_a);
+        if (pre_c_on) to_acc_layout(pq_c, pre_c);
+        if (pre_y_on) to_acc_layout(pq_y, pre_y);
+    }
     // Straight-line stores: out-of-tile lanes get an out-of-range offset and the hardware drops their write
     // (reads return 0), so there is no per-element branch.  The first version branched around every store, and
     // the compiler's s_waitcnt for the bias value at each re-convergence (vmcnt(0) - which on gfx9 also counts
@@ -437,18 +484,48 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
         float bb_mu = 0.f, bb_is = 0.f;
         if (bnb && cvalid) { bb_mu = p.bnb_mean[col]; bb_is = p.bnb_invstd[col]; }
         const float bb_slope = act_neg_slope(p.bnb_act);
+        // element offsets in the accumulator layout are only needed on the scalar path (Co % 4 != 0, K split across
+        // the grid): everything else moves in 16-byte chunks through the transposer
+        const bool op_a = addend || (EPI && MODE == 0 && p.res != nullptr);
+        const bool need_off = !t128;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int t = 0; t < RM; ++t) {
+            // read operands that were not prefetched (multi-tile waves): 16-byte loads now, same transposer
+            float oa[RSL], oc[RSL], oy[RSL];
+#pragma unroll
+            for (int r = 0; r < RSL; ++r) { oa[r] = pre_a[r]; oc[r] = pre_c[r]; oy[r] = pre_y[r]; }
+            if (t128 && !PRE) {
+                const bool la = op_a, lc = bnb, ly = bnb && p.bnb_act != ADVMIX_ACT_NONE;
+                f32x4 qa[TQ], qc[TQ], qy[TQ];
+#pragma unroll
+                for (int q = 0; q < TQ; ++q) {
+                    bool valid;
+                    const int off = chunk_off(t, u, q, valid);
+                    const unsigned boff = valid ? (unsigned)off * 4u : OOB;
+                    qa[q] = qc[q] = qy[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (la) qa[q] = bload(rr, boff);
+                    if (lc) qc[q] = bload(cr, boff);
+                    if (ly) qy[q] = bload(yyr, boff);
+                }
+                if (la) to_acc_layout(qa, oa);
+                if (lc) to_acc_layout(qc, oc);
+                if (ly) to_acc_layout(qy, oy);
+            }
+            float vo[RSL];
 #pragma unroll
             for (int r = 0; r < RSL; ++r) {
-                bool valid;
-                const int off = elem_off(t, u, r_lo + r, valid);
-                const unsigned boff = valid ? (unsigned)off * 4u : OOB;
+                bool valid = (m0 + wm * TM * 32 + t * MR + MS::row(r_lo + r, e_lh)) < Mp && cvalid;
+                unsigned boff = OOB;
+                int off = 0;
+                if (need_off) {
+                    off = elem_off(t, u, r_lo + r, valid);
+                    boff = valid ? (unsigned)off * 4u : OOB;
+                }
                 float v = acc[t][u][r] + bv;
                 // transposed gather (input gradients): an addend, e.g. the other gradient of a tensor with two
                 // consumers, rides in the epilogue instead of a separate add kernel (slice 0 only under SPLIT)
-                if (addend) v += PRE ? pre_a[r] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, boff, 0, 0));
+                if (addend) v += t128 ? oa[r] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, boff, 0, 0));
                 if (SPLIT) {
                     if (valid) atomicAdd(p.y + off, v);
                     continue;
@@ -456,18 +533,33 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
                 if (EPI && MODE == 0) {
                     if (valid) { s1 += v; s2 += v * v; }
                     if (bn) v = (v - bn_m) * bn_is * bn_g + bn_b;
-                    if (p.res) v += PRE ? pre_a[r] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, boff, 0, 0));
+                    if (p.res) v += t128 ? oa[r] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, boff, 0, 0));
                     v = act_fwd(v, p.act);
                 }
                 if (bnb) {                                  // out-of-tile lanes load 0 and contribute 0
-                    const float cv = PRE ? pre_c[r] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cr, boff, 0, 0));
+                    const float cv = t128 ? oc[r] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cr, boff, 0, 0));
                     if (p.bnb_act != ADVMIX_ACT_NONE) {
-                        const float yv = PRE ? pre_y[r] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yyr, boff, 0, 0));
+                        const float yv = t128 ? oy[r] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yyr, boff, 0, 0));
                         v = yv > 0.f ? v : v * bb_slope;
                     }
                     if (valid) { s1 += v; s2 += v * ((cv - bb_mu) * bb_is); }
                 }
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, boff, 0, CD_STORE_AUX);
+                vo[r] = v;
+                if (!t128) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, boff, 0, CD_STORE_AUX);
+            }
+            if (!SPLIT && t128) {                           // the tile leaves as RSL / 4 sixteen-byte stores per lane
+#pragma unroll
+                for (int r = 0; r < RSL; ++r) Tx[MS::row(r, lh) * TP + l31] = vo[r];
+                wave_fence();
+#pragma unroll
+                for (int q = 0; q < TQ; ++q) {
+                    bool valid;
+                    const int off = chunk_off(t, u, q, valid);
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&Tx[(8 * q + (lane >> 3)) * TP + ((lane & 7) << 2)]);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w4), yr, valid ? (unsigned)off * 4u : OOB, 0,
+                                                           CD_STORE_AUX);
+                }
+                wave_fence();
             }
         }
         if (stats) {                                        // wave-uniform branch: every lane shuffles
@@ -506,8 +598,9 @@ template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT,
 // prefetched epilogue operands over 254 VGPRs = one wave per SIMD; the other variants keep their 52-108)
 __global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(ConvD p) {
     __shared__ __attribute__((aligned(16))) float Bs[2 * Geo<TM, TN, WM, WN, KC>::BSZ];
+    __shared__ __attribute__((aligned(16))) float Ts[Geo<TM, TN, WM, WN, KC>::TSZ];
     __shared__ int4 taptab[64];
-    conv_body<TM, TN, WM, WN, KC, MODE, SPLIT, BT, EPI>(p, blockIdx.x, blockIdx.y, blockIdx.z, Bs, taptab);
+    conv_body<TM, TN, WM, WN, KC, MODE, SPLIT, BT, EPI>(p, blockIdx.x, blockIdx.y, blockIdx.z, Bs, Ts, taptab);
 }
 
 // Tile configuration for a problem (the only place that decides it; advmix_conv_direct_config reports it).
@@ -534,6 +627,7 @@ __global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_group(Co
                                   Max2<Geo<1, 1, 2, 2, KC>::BSZ, Geo<1, 1, 1, 1, KC>::BSZ>::v>::v,
                              Geo<1, 1, 2, 1, KC>::BSZ>::v;
     __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
+    __shared__ __attribute__((aligned(16))) float Ts[Geo<1, 1, 4, 1, KC>::TSZ];     // (WK = 1: the largest)
     __shared__ int4 taptab[64];
     const int b = blockIdx.x;
     int i = 0;
@@ -543,11 +637,11 @@ __global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_group(Co
     const int local = b - g.start[i], gx = g.gx[i];
     const int by = local / gx, bx = local - by * gx;
     switch (g.cfg[i]) {
-        case CFG_128x32: conv_body<1, 1, 4, 1, KC, MODE, false, BT, EPI>(g.p[i], bx, by, 0, Bs, taptab); break;
-        case CFG_128x64: conv_body<1, 2, 4, 1, KC, MODE, false, BT, EPI>(g.p[i], bx, by, 0, Bs, taptab); break;
-        case CFG_64x64: conv_body<1, 1, 2, 2, KC, MODE, false, BT, EPI>(g.p[i], bx, by, 0, Bs, taptab); break;
-        case CFG_32x32_WAVE_SPLIT: conv_body<1, 1, 1, 1, KC, MODE, false, BT, EPI>(g.p[i], bx, by, 0, Bs, taptab); break;
-        case CFG_64x32_WAVE_SPLIT2: conv_body<1, 1, 2, 1, KC, MODE, false, BT, EPI>(g.p[i], bx, by, 0, Bs, taptab); break;
+        case CFG_128x32: conv_body<1, 1, 4, 1, KC, MODE, false, BT, EPI>(g.p[i], bx, by, 0, Bs, Ts, taptab); break;
+        case CFG_128x64: conv_body<1, 2, 4, 1, KC, MODE, false, BT, EPI>(g.p[i], bx, by, 0, Bs, Ts, taptab); break;
+        case CFG_64x64: conv_body<1, 1, 2, 2, KC, MODE, false, BT, EPI>(g.p[i], bx, by, 0, Bs, Ts, taptab); break;
+        case CFG_32x32_WAVE_SPLIT: conv_body<1, 1, 1, 1, KC, MODE, false, BT, EPI>(g.p[i], bx, by, 0, Bs, Ts, taptab); break;
+        case CFG_64x32_WAVE_SPLIT2: conv_body<1, 1, 2, 1, KC, MODE, false, BT, EPI>(g.p[i], bx, by, 0, Bs, Ts, taptab); break;
         default: break;
     }
 }
@@ -622,10 +716,9 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
     p.nsplit = 1;
     switch (pick_cfg(Mmax, p.Co, phases, nch, &ns)) {
         case CFG_128x32: LAUNCHD(1, 1, 4, 1, false); break;
-        case CFG_128x64:
-            if (p.bnb_c) return -2;                        // two tiles per wave: no room to prefetch the BatchNorm-backward
-            LAUNCHD(1, 2, 4, 1, false);                    // operands, and loaded in the epilogue they cost more than the
-            break;                                         // separate statistics pass (HRNet-W48: 150.5 vs 153.2 images/s)
+        case CFG_128x64:                                   // two tiles per wave: no registers to prefetch the BatchNorm-
+            LAUNCHD(1, 2, 4, 1, false);                    // backward operands; they are loaded in the epilogue, 16 bytes
+            break;                                         // per lane and access (round 3; scalar loads lost to the separate pass)
         case CFG_64x64: LAUNCHD(1, 1, 2, 2, false); break;
         case CFG_32x32_WAVE_SPLIT: LAUNCHD(1, 1, 1, 1, false); break;      // four waves share K in the workgroup
         case CFG_64x32_WAVE_SPLIT2: LAUNCHD(1, 1, 2, 1, false); break;     // two wave pairs share K
@@ -738,7 +831,7 @@ int advmix_conv_direct_group(int mode, int bt, int n, ConvProb* pr, hipStream_t 
         int phases, nch, ns;
         direct::problem_shape(mode, q.Ci, q.R, q.S, q.stride, KC, &phases, &nch);
         const direct::Cfg c = direct::pick_cfg(q.Mmax, q.Co, phases, nch, &ns);
-        if (phases != 1 || c == direct::CFG_64x64_GRID_SPLIT || (c == direct::CFG_128x64 && bnb)) return -1;
+        if (phases != 1 || c == direct::CFG_64x64_GRID_SPLIT) return -1;
         int bm, bn, wk;
         switch (c) {
             case direct::CFG_128x32: bm = 128; bn = 32; wk = 1; break;

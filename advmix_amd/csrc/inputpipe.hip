@@ -121,6 +121,108 @@ __global__ __launch_bounds__(256) void render_targets_kernel(const double* __res
     if (threadIdx.x == 0) tw[bj] = jw ? w * jw[j] : w;
 }
 
+// ---- the AutoAugment view on the device (lib/dataset/advaug.py:10-108, applied per sample at JointsDataset.py:124) ------
+// ImageNetPolicy's table (advaug.py:22-35) only reaches five Pillow operations: ImageOps.equalize / posterize / solarize /
+// invert (256-entry look-up tables) and ImageEnhance.Sharpness (3x3 SMOOTH filter + Image.blend).  The worker keeps the
+// draws (Python's ``random``: dataset.advaug.autoaug_params) and ships (code, parameter) pairs; one workgroup per image
+// applies up to two operations back to back, bit for bit what Pillow computes:
+//   equalize   per band: histogram h, step = (sum of non-zero bins - last non-zero bin) / 255, lut[i] = min(255, n / step)
+//              with n = step / 2 + h[0] + ... + h[i-1]; identity when <= 1 non-zero bin or step == 0 (ImageOps.py);
+//   posterize  i & mask;   solarize  i < threshold ? i : 255 - i (threshold is a float);   invert  255 - i;
+//   sharpness  d = SMOOTH(im): float32, 0.5 + row below + row itself + row above, each ((a*k0 + b*k1) + c*k2), k = {1,1,1,
+//              1,5,1,1,1,1} / 13.0f, truncated, borders copied (Filter.c); out = d + alpha * (im - d) in float32, truncated,
+//              clipped to 0..255 when alpha is outside [0, 1] (Blend.c).  No fused multiply-adds anywhere (x86-64 Pillow
+//              has none): aa_mul.
+enum { AA_NONE = 0, AA_EQUALIZE = 1, AA_POSTERIZE = 2, AA_SOLARIZE = 3, AA_INVERT = 4, AA_SHARPNESS = 5 };
+
+// a product the compiler cannot fuse into a following add (hipcc contracts a * b + c into v_fmac_f32 by default, and the
+// __fmul_rn / __fadd_rn intrinsics are plain operators to it): the value passes through an empty asm
+__device__ __forceinline__ float aa_mul(float a, float b) {
+    float m = a * b;
+    asm volatile("" : "+v"(m));
+    return m;
+}
+
+__device__ __forceinline__ uint8_t aa_clip8(float v) { return v <= 0.f ? 0 : (v >= 255.f ? 255 : (uint8_t)(int)v); }
+
+__global__ __launch_bounds__(1024) void autoaug_kernel(const uint8_t* __restrict__ base, const int32_t* __restrict__ ops,
+                                                       uint8_t* __restrict__ tmp, uint8_t* __restrict__ out, int H, int W) {
+    __shared__ unsigned hist[3][256];
+    __shared__ uint8_t lut[3][256];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int64_t n = (int64_t)H * W * 3;
+    const uint8_t* src = base + b * n;
+    int code[2] = {ops[b * 4], ops[b * 4 + 2]}, par[2] = {ops[b * 4 + 1], ops[b * 4 + 3]};
+    const int nops = (code[0] != AA_NONE) + (code[1] != AA_NONE);
+    if (nops == 0) {                                        // neither operation fired: the view is the crop itself
+        for (int64_t i = tid; i < n; i += nt) out[b * n + i] = src[i];
+        return;
+    }
+    int done = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (code[k] == AA_NONE) continue;
+        uint8_t* dst = (done + 1 == nops ? out : tmp) + b * n;
+        if (code[k] == AA_SHARPNESS) {
+            const float alpha = __builtin_bit_cast(float, par[k]);
+            const float k1 = __fdiv_rn(1.0f, 13.0f), k5 = __fdiv_rn(5.0f, 13.0f);
+            const int W3 = W * 3;
+            for (int64_t i = tid; i < n; i += nt) {
+                const int y = (int)(i / W3), r = (int)(i - (int64_t)y * W3), x = r / 3;
+                const int im = src[i];
+                int d = im;
+                if (y > 0 && y < H - 1 && x > 0 && x < W - 1) {
+                    const uint8_t* p1 = src + i + W3;       // row below
+                    const uint8_t* p0 = src + i;
+                    const uint8_t* pm = src + i - W3;       // row above
+                    float ss = 0.5f;
+                    ss = __fadd_rn(ss, __fadd_rn(__fadd_rn(aa_mul((float)p1[-3], k1), aa_mul((float)p1[0], k1)), aa_mul((float)p1[3], k1)));
+                    ss = __fadd_rn(ss, __fadd_rn(__fadd_rn(aa_mul((float)p0[-3], k1), aa_mul((float)p0[0], k5)), aa_mul((float)p0[3], k1)));
+                    ss = __fadd_rn(ss, __fadd_rn(__fadd_rn(aa_mul((float)pm[-3], k1), aa_mul((float)pm[0], k1)), aa_mul((float)pm[3], k1)));
+                    d = aa_clip8(ss);
+                }
+                uint8_t o;
+                if (alpha == 0.0f) o = (uint8_t)d;
+                else if (alpha == 1.0f) o = (uint8_t)im;
+                else {
+                    const float t = __fadd_rn((float)d, aa_mul(alpha, (float)(im - d)));
+                    o = (alpha >= 0.f && alpha <= 1.f) ? (uint8_t)(int)t : aa_clip8(t);
+                }
+                dst[i] = o;
+            }
+        } else {
+            if (code[k] == AA_EQUALIZE) {
+                for (int i = tid; i < 768; i += nt) hist[i >> 8][i & 255] = 0;
+                __syncthreads();
+                for (int64_t i = tid; i < n; i += nt) atomicAdd(&hist[i % 3][src[i]], 1u);
+                __syncthreads();
+                if (tid < 3) {                              // 256 serial steps per band: nothing next to the passes over the image
+                    unsigned total = 0, last = 0;
+                    int nz = 0;
+                    for (int i = 0; i < 256; ++i) { const unsigned h = hist[tid][i]; if (h) { ++nz; total += h; last = h; } }
+                    const unsigned step = nz <= 1 ? 0 : (total - last) / 255;
+                    unsigned acc = step / 2;
+                    for (int i = 0; i < 256; ++i) {
+                        unsigned v = step ? acc / step : (unsigned)i;
+                        lut[tid][i] = (uint8_t)(v > 255 ? 255 : v);      // Image.point clips the table
+                        acc += hist[tid][i];
+                    }
+                }
+            } else if (tid < 256) {
+                int v = tid;
+                if (code[k] == AA_POSTERIZE) v = tid & par[k];
+                else if (code[k] == AA_SOLARIZE) v = ((float)tid < __builtin_bit_cast(float, par[k])) ? tid : 255 - tid;
+                else v = 255 - tid;                         // AA_INVERT
+                lut[0][tid] = lut[1][tid] = lut[2][tid] = (uint8_t)v;
+            }
+            __syncthreads();
+            for (int64_t i = tid; i < n; i += nt) dst[i] = lut[i % 3][src[i]];
+        }
+        ++done;
+        src = dst;
+        __syncthreads();                                    // (workgroup-scope fence: the second operation reads what this one wrote)
+    }
+}
+
 }  // namespace
 
 extern "C" int advmix_make_views(const uint8_t* base, const uint8_t* aug, const int32_t* grid, const float* mean,
@@ -147,6 +249,17 @@ extern "C" int advmix_render_targets(const double* joints, const double* vis, co
     if (H <= 0 || W <= 0 || Hh <= 0 || Wh <= 0) return ADVMIX_EINVAL;
     hipLaunchKernelGGL(render_targets_kernel, dim3(B * J), dim3(256), 0, (hipStream_t)stream, joints, vis, grid, g,
                        tmp_size, joints_weight, target, target_weight, vis_out, J, H, W, Hh, Wh);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+// The AutoAugment view of a batch: out[b] = op2(op1(base[b])) with ops[b] = {code1, param1, code2, param2} (int32;
+// code 0 = operation did not fire; posterize: param = the bit mask; solarize / sharpness: param = the float's bits -
+// threshold / blend factor).  ``tmp``: B*H*W*3 bytes of scratch (images that take two operations).  One workgroup per image.
+extern "C" int advmix_autoaug(const uint8_t* base, const int32_t* ops, uint8_t* tmp, uint8_t* out, int B, int H, int W,
+                              void* stream) {
+    if (!base || !ops || !tmp || !out || B <= 0 || H <= 0 || W <= 0) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(autoaug_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, base, ops, tmp, out, H, W);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }

@@ -47,6 +47,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     }
 }
 
+struct d4s { double v[4]; };
+
 struct FuseArgs {
     const float* in[4];
     float* din[4];
@@ -107,6 +109,139 @@ __global__ __launch_bounds__(256) void pool_sum_kernel(const float* __restrict__
                 s += reinterpret_cast<const f32x4*>(g)[off];
             }
         reinterpret_cast<f32x4*>(din)[i] = s;
+    }
+}
+
+// ---- fuse-sum backward in ONE launch, with the BatchNorm-backward sums of the sources -----------------------------------
+// HRNet's fuse layers end in conv -> BN (no activation) -> sum with the other branches -> ReLU (pose_hrnet.py:196-265).
+// The gradient of each BN output comes out of this kernel - g = dy * act'(y) for the sources at the sum's resolution, its
+// 2^s x 2^s block sum for the up-sampled ones - so the kernel also leaves the two channel sums their BatchNorm backward
+// needs (sum g_j, sum g_j * xhat_j) in the source's fp64 slots: norm_bwd_apply_slots then replaces the separate
+// statistics pass + finalize + apply (the last 53 conv + BN pairs per HRNet-W32 backward pass that still took those).
+// One launch instead of mask_grad + a pool_sum per source: segment 0 of the grid writes g, segment k the pooled gradient
+// of one up-sampled source straight from (dy, y) - no dependency between segments.
+struct FuseBwdArgs {
+    int n;                       // segments: 0 = g at full resolution, k >= 1 = pooled source src[k]
+    int start[6];                // first block of each segment (start[n] = grid size)
+    int shift[5];                // per segment (segment 0: 0)
+    float* out[5];               // segment 0: g (may be null if nobody needs it), k: the source's gradient
+    // BatchNorm-backward targets.  Segment 0 serves up to three same-resolution sources (tc0[i]), segment k one.
+    int nt0;
+    const float* tc0[3]; const float* tmean0[3]; const float* tinvstd0[3]; double* tslots0[3];
+    const float* tc[5]; const float* tmean[5]; const float* tinvstd[5]; double* tslots[5];
+    int ns;                      // slots per channel and statistic in use
+};
+
+__global__ __launch_bounds__(256) void fuse_bwd_kernel(FuseBwdArgs a, const float* __restrict__ dy,
+                                                       const float* __restrict__ y, int N, int H, int W, int CV, int act) {
+    __shared__ d4s red[256];
+    const int tid = threadIdx.x;
+    int seg = 0;
+#pragma unroll
+    for (int k = 1; k < 5; ++k)
+        if (k < a.n && (int)blockIdx.x >= a.start[k]) seg = k;
+    const int blk = blockIdx.x - a.start[seg], nblk = a.start[seg + 1] - a.start[seg];
+    const int C = CV * 4, cv = tid % CV;                  // 256 % CV == 0: a thread keeps its four channels
+    const int64_t stride = (int64_t)nblk * 256;
+    const float slope = act_neg_slope(act);
+    double s1[4] = {0, 0, 0, 0}, s2[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    int nt;
+    const float* tc[3]; f32x4 mu[3], is[3]; double* tsl[3];
+    if (seg == 0) {
+        nt = a.nt0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < nt) {
+                tc[i] = a.tc0[i]; tsl[i] = a.tslots0[i];
+                mu[i] = *reinterpret_cast<const f32x4*>(a.tmean0[i] + cv * 4);
+                is[i] = *reinterpret_cast<const f32x4*>(a.tinvstd0[i] + cv * 4);
+            }
+        const int64_t total = (int64_t)N * H * W * CV;
+        float* const g = a.out[0];
+        for (int64_t i = (int64_t)blk * 256 + tid; i < total; i += stride) {
+            f32x4 d = reinterpret_cast<const f32x4*>(dy)[i];
+            const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = yv[e] > 0.f ? d[e] : d[e] * slope;
+            if (g) reinterpret_cast<f32x4*>(g)[i] = d;
+            if (nt > 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s1[e] += (double)d[e];
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    if (t < nt) {
+                        const f32x4 cvv = reinterpret_cast<const f32x4*>(tc[t])[i];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s2[t][e] += (double)d[e] * (double)((cvv[e] - mu[t][e]) * is[t][e]);
+                    }
+            }
+        }
+    } else {
+        nt = a.tc[seg] ? 1 : 0;
+        if (nt) {
+            tc[0] = a.tc[seg]; tsl[0] = a.tslots[seg];
+            mu[0] = *reinterpret_cast<const f32x4*>(a.tmean[seg] + cv * 4);
+            is[0] = *reinterpret_cast<const f32x4*>(a.tinvstd[seg] + cv * 4);
+        }
+        const int sh = a.shift[seg], Hs = H >> sh, Ws = W >> sh, f = 1 << sh;
+        const int64_t total = (int64_t)N * Hs * Ws * CV;
+        float* const din = a.out[seg];
+        for (int64_t i = (int64_t)blk * 256 + tid; i < total; i += stride) {
+            const int64_t pix = i / CV;
+            const int ws = (int)(pix % Ws);
+            const int64_t q = pix / Ws;
+            const int hs = (int)(q % Hs), n = (int)(q / Hs);
+            f32x4 s = {0, 0, 0, 0};
+            for (int dh = 0; dh < f; ++dh)
+                for (int dw = 0; dw < f; ++dw) {
+                    const int64_t off = (((int64_t)n * H + (hs * f + dh)) * W + (ws * f + dw)) * CV + cv;
+                    f32x4 d = reinterpret_cast<const f32x4*>(dy)[off];
+                    const f32x4 yv = reinterpret_cast<const f32x4*>(y)[off];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] = yv[e] > 0.f ? d[e] : d[e] * slope;
+                    s += d;
+                }
+            reinterpret_cast<f32x4*>(din)[i] = s;
+            if (nt) {
+                const f32x4 cvv = reinterpret_cast<const f32x4*>(tc[0])[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1[e] += (double)s[e];
+                    s2[0][e] += (double)s[e] * (double)((cvv[e] - mu[0][e]) * is[0][e]);
+                }
+            }
+        }
+    }
+    if (nt == 0) return;                                    // uniform over the segment's blocks
+    // block reduction per channel group (threads tid % CV == cv), one quantity at a time; then fp64 atomics into the
+    // slots of every target: sum g is shared by the targets of segment 0
+    const int pb = blk % a.ns;
+#pragma unroll
+    for (int qn = 0; qn < 4; ++qn) {                        // (unrolled: statically indexed accumulators)
+        if (qn > nt) break;
+        d4s v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v.v[e] = qn == 0 ? s1[e] : s2[qn == 0 ? 0 : qn - 1][e];
+        red[tid] = v;
+        __syncthreads();
+        if (tid < CV) {
+            d4s acc = red[tid];
+            for (int k = tid + CV; k < 256; k += CV)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc.v[e] += red[k].v[e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ch = tid * 4 + e;
+                if (qn == 0) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        if (t < nt) atomicAdd(tsl[t] + (int64_t)ch * a.ns + pb, acc.v[e]);
+                } else {
+                    atomicAdd(tsl[qn == 0 ? 0 : qn - 1] + ((int64_t)C + ch) * a.ns + pb, acc.v[e]);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -264,6 +399,65 @@ extern "C" int advmix_fuse_sum_bwd(const float* dy, const float* y, float* g_out
         hipLaunchKernelGGL(pool_sum_kernel, dim3(stream_blocks(t)), dim3(256), 0, st, g_out, dins[j], N, H, W, C / 4,
                            shifts[j]);
     }
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+// advmix_fuse_sum_bwd in one launch + the BatchNorm-backward channel sums of the sources that are conv + BN outputs.
+// bnb_c[j] != null: source j is the output (no activation) of a train-mode conv + BN whose raw conv output is bnb_c[j],
+// saved statistics bnb_mean[j] / bnb_invstd[j]; its sums are ADDED to bnb_slots[j] ([2][C][ns] fp64, pre-zeroed).
+// g_out may be null when no same-resolution source needs a gradient.  ADVMIX_EINVAL: shape not served (C / 4 must
+// divide 256, at most three same-resolution targets) - nothing launched, use advmix_fuse_sum_bwd.
+extern "C" int advmix_fuse_sum_bwd_bnb(const float* dy, const float* y, float* g_out, float* const* dins,
+                                       const int* shifts, int n_in, int N, int H, int W, int C, int act,
+                                       const float* const* bnb_c, const float* const* bnb_mean,
+                                       const float* const* bnb_invstd, double* const* bnb_slots, int ns, void* stream) {
+    if (!dy || !y || !dins || !shifts || n_in < 1 || n_in > 4 || C % 4 != 0 || !bnb_c || !bnb_mean || !bnb_invstd ||
+        !bnb_slots)
+        return ADVMIX_EINVAL;
+    const int CV = C / 4;
+    if (CV > 256 || 256 % CV != 0 || ns < 1 || ns > ADVMIX_STAT_SLOTS_MAX || (ns & (ns - 1))) return ADVMIX_EINVAL;
+    FuseBwdArgs a{};
+    a.ns = ns;
+    a.n = 1;
+    a.shift[0] = 0;
+    a.out[0] = g_out;
+    int64_t work[5];
+    work[0] = (int64_t)N * H * W * CV;
+    bool need0 = g_out != nullptr;
+    for (int j = 0; j < n_in; ++j) {
+        if (shifts[j] < 0 || (H % (1 << shifts[j])) || (W % (1 << shifts[j]))) return ADVMIX_EINVAL;
+        const bool tgt = bnb_c[j] != nullptr;
+        if (tgt && (!bnb_mean[j] || !bnb_invstd[j] || !bnb_slots[j])) return ADVMIX_EINVAL;
+        if (shifts[j] == 0) {
+            if (!tgt) continue;
+            if (a.nt0 >= 3 || !g_out) return ADVMIX_EINVAL;
+            a.tc0[a.nt0] = bnb_c[j]; a.tmean0[a.nt0] = bnb_mean[j]; a.tinvstd0[a.nt0] = bnb_invstd[j];
+            a.tslots0[a.nt0] = bnb_slots[j];
+            ++a.nt0;
+        } else {
+            if (!dins[j]) continue;
+            const int k = a.n++;
+            a.shift[k] = shifts[j];
+            a.out[k] = dins[j];
+            work[k] = work[0] >> (2 * shifts[j]);
+            if (tgt) { a.tc[k] = bnb_c[j]; a.tmean[k] = bnb_mean[j]; a.tinvstd[k] = bnb_invstd[j]; a.tslots[k] = bnb_slots[j]; }
+        }
+    }
+    int start = 0;
+    for (int k = 0; k < a.n; ++k) {
+        a.start[k] = start;
+        if (k == 0 && !need0) continue;                     // nobody needs g: segment 0 gets no blocks
+        // pooled segments read f x f inputs per output: fewer elements per block
+        int64_t per = k == 0 ? 1024 : (1024 >> (2 * a.shift[k]) > 64 ? 1024 >> (2 * a.shift[k]) : 64);
+        int64_t b = (work[k] + per - 1) / per;
+        if (b > 1024) b = 1024;
+        if (b < 1) b = 1;
+        start += (int)b;
+    }
+    for (int k = a.n; k < 6; ++k) a.start[k] = start;
+    if (start == 0) return ADVMIX_OK;
+    hipLaunchKernelGGL(fuse_bwd_kernel, dim3(start), dim3(256), 0, (hipStream_t)stream, a, dy, y, N, H, W, CV, act);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }

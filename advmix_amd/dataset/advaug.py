@@ -63,3 +63,80 @@ def make_views(base_u8, aug_u8=None, grid=None, mean=IMAGENET_MEAN, std=IMAGENET
          ctypes.cast(s, ctypes.c_void_p), P(views[0]), P(views[1]), P(views[2]), B, H, W,
          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     return views
+
+
+# ---- the AutoAugment view (ImageNetPolicy, advaug.py:10-108) ---------------------------------------------------------
+# The reference applies PIL operations in the DataLoader workers (MixCombine, advaug.py:180-187): at ~540 images/s per
+# GPU that is ~4,300 PIL AutoAugment calls a second for an 8-GPU node.  Here the worker only DRAWS (Python's ``random``,
+# the same calls in the same order: ``autoaug_params``) and the operations run on the device, bit-identical to Pillow.
+# The policy table only ever reaches these five operations.
+AA_EQUALIZE, AA_POSTERIZE, AA_SOLARIZE, AA_INVERT, AA_SHARPNESS = 1, 2, 3, 4, 5
+_AA_CODE = {'equalize': AA_EQUALIZE, 'posterize': AA_POSTERIZE, 'solarize': AA_SOLARIZE, 'invert': AA_INVERT,
+            'sharpness': AA_SHARPNESS}
+# advaug.py:22-35: (p1, operation1, magnitude_idx1, p2, operation2, magnitude_idx2)
+IMAGENET_POLICIES = (
+    (0.8, 'equalize', 8, 0.6, 'equalize', 3), (0.6, 'posterize', 7, 0.6, 'posterize', 6),
+    (0.4, 'equalize', 7, 0.2, 'solarize', 4), (0.6, 'solarize', 3, 0.6, 'equalize', 7),
+    (0.8, 'posterize', 5, 1.0, 'equalize', 2), (0.6, 'equalize', 8, 0.4, 'posterize', 6),
+    (0.0, 'equalize', 7, 0.8, 'equalize', 8), (0.6, 'invert', 4, 1.0, 'equalize', 8),
+    (0.4, 'sharpness', 7, 0.6, 'invert', 8), (0.4, 'equalize', 7, 0.2, 'solarize', 4),
+    (0.6, 'invert', 4, 1.0, 'equalize', 8), (0.8, 'equalize', 8, 0.6, 'equalize', 3),
+)
+# advaug.py:50-65, the ``ranges`` rows of the reachable operations
+_AA_RANGES = {'posterize': np.round(np.linspace(8, 4, 10), 0).astype(int), 'solarize': np.linspace(256, 0, 10),
+              'sharpness': np.linspace(0.0, 0.9, 10)}
+
+
+def autoaug_params(rng=None):
+    """The random draws of ``ImageNetPolicy.__call__`` + ``SubPolicy.__call__`` (advaug.py:38-40, 102-105) in their
+    order - ``randint(0, 11)``; ``random()`` against p1; ``choice([-1, 1])`` if the first operation is sharpness and
+    fires; ``random()`` against p2; ``choice`` likewise - on ``rng`` (default: Python's ``random`` module, which is what
+    the reference uses).  Returns the (code, parameter) pairs that fire, in order (zero, one or two)."""
+    import random as _random
+    rng = _random if rng is None else rng
+    p1, op1, m1, p2, op2, m2 = IMAGENET_POLICIES[rng.randint(0, len(IMAGENET_POLICIES) - 1)]
+    out = []
+    for p, op, m in ((p1, op1, m1), (p2, op2, m2)):
+        if rng.random() < p:
+            mag = _AA_RANGES[op][m] if op in _AA_RANGES else 0
+            if op == 'sharpness':
+                mag = 1 + mag * rng.choice([-1, 1])
+            out.append((_AA_CODE[op], float(mag)))
+    return out
+
+
+def pack_autoaug(params, device):
+    """int32 [B,4] device table {code1, param1, code2, param2} for a batch of ``autoaug_params`` results: posterize's
+    parameter becomes its bit mask (ImageOps.posterize), solarize's threshold and sharpness's factor travel as float32
+    bits (Pillow converts both to a C float)."""
+    t = np.zeros((len(params), 4), dtype=np.int32)
+    for i, ops in enumerate(params):
+        if len(ops) > 2:
+            raise ValueError('a sub-policy applies at most two operations')
+        for k, (code, par) in enumerate(ops):
+            t[i, 2 * k] = code
+            if code == AA_POSTERIZE:
+                t[i, 2 * k + 1] = ~(2 ** (8 - int(par)) - 1)
+            elif code == AA_SOLARIZE:
+                # ``i < threshold`` is evaluated in Python (double) by ImageOps.solarize for integer i: any float32 between
+                # the same two integers decides identically, so the float32 nearest the threshold is exact
+                t[i, 2 * k + 1] = np.float32(par).view(np.int32)
+            elif code == AA_SHARPNESS:
+                t[i, 2 * k + 1] = np.float32(par).view(np.int32)
+    return torch.from_numpy(t).to(device)
+
+
+def auto_augment(base_u8, ops):
+    """The AutoAugment view of a batch of uint8 crops [B,H,W,3] (CUDA) for the packed draws ``ops`` (``pack_autoaug``):
+    what ``np.array(ImageNetPolicy()(Image.fromarray(crop)))`` returns for the same draws, computed on the device."""
+    if not base_u8.is_cuda or base_u8.dtype != torch.uint8 or base_u8.dim() != 4 or base_u8.shape[3] != 3:
+        raise TypeError('auto_augment needs a uint8 CUDA tensor [B,H,W,3]')
+    base_u8 = base_u8.contiguous()
+    B, H, W, _ = base_u8.shape
+    if ops.shape != (B, 4) or ops.dtype != torch.int32 or not ops.is_cuda:
+        raise TypeError('ops must be the int32 [B,4] table of pack_autoaug')
+    out, tmp = torch.empty_like(base_u8), torch.empty_like(base_u8)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())              # noqa: E731
+    call('advmix_autoaug', P(base_u8), P(ops.contiguous()), P(tmp), P(out), B, H, W,
+         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    return out

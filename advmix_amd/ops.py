@@ -83,6 +83,14 @@ STAT_SLOTS = 64          # capacity reserved per channel and statistic; a launch
 STAT_SLOTS_ASK = int(__import__('os').environ.get('ADVMIX_STAT_SLOTS', '0'))   # 0 = the kernel's choice
 
 
+# Side channels between members of DIFFERENT launch groups (the autograd graph only carries tensors):
+#  _BNB_FWD: output tensor (data_ptr) of a train-mode ConvBN whose only consumer is a fuse sum -> what that sum's backward
+#            needs to leave the BatchNorm-backward channel sums in the layer's slots (ConvBN.fwd -> FuseSum.fwd);
+#  _BNB_PRE: (gradient tensor data_ptr, arena id, slot offset) -> slot count: "this gradient's two channel sums are
+#            already in your backward slots" (FuseSum.bwd -> ConvBN.bwd).
+_BNB_FWD, _BNB_PRE = {}, {}
+
+
 class StatArena:
     """The fp64 statistics slots of ONE network: for every conv -> train-mode BatchNorm pair a forward set
     (column sum / sum of squares of the conv output, written by the conv's epilogue) and a backward set (sum g,
@@ -109,6 +117,9 @@ class StatArena:
         call('advmix_fill', ctypes.c_void_p(self.t.data_ptr()), 0.0, 2 * self.size, _st())
         self.pass_id += 1
         self.dirty.clear()
+        for reg in (_BNB_FWD, _BNB_PRE):                   # hand-offs of an earlier pass that nobody picked up
+            for k in [k for k, v in reg.items() if v[0] is self]:
+                del reg[k]
 
     def ptr(self, off):
         return ctypes.c_void_p(self.t.data_ptr() + 8 * off)
@@ -479,6 +490,10 @@ class ConvBN:
             call('advmix_norm_apply', _p(c), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), _p(y),
                  Co, 1, rows, Co, act, st)
         extra = (residual is not None, arena, arena.pass_id if arena is not None else 0, bwd_off)
+        if len(meta) > 9 and meta[9] and arena is not None and arena.t is not None and act == ACT_NONE and any(needs) \
+                and BNB_FUSED and not DETERMINISTIC:
+            # the only consumer is a fuse sum in another launch group: its backward can produce this layer's sums
+            _BNB_FWD[y.data_ptr()] = (arena, arena.pass_id, bwd_off, c, mean, invstd)
         return (y,), (x, w, c, y, mean, invstd, gamma, beta), extra
 
     ADD_TO = True
@@ -507,6 +522,10 @@ class ConvBN:
         Ho, Wo = y.shape[2], y.shape[3]
         rows = B * Ho * Wo
         need_res = has_res and needs[7]
+        if not pre and arena is not None:                   # sums left by the backward of a fuse sum in another group
+            hit = _BNB_PRE.pop((dy.data_ptr(), id(arena), bwd_off), None)
+            if hit is not None and hit[0] is arena and hit[1] == _pass:
+                pre = hit[2]
         dc = keep(empty_nhwc(B, Co, Ho, Wo, x.device))
         dres = None
         dg = _grad_buf(gamma, st) if needs[2] else None
@@ -618,7 +637,10 @@ class CatAct:
 
 class FuseSum:
     NHWC = None      # inputs made dense NHWC BEFORE the lanes fork (None = all)
-    """y = act(sum_j nearest_up_{2^shift_j}(in_j))  (pose_hrnet.py:206,254-265). meta=(act, shifts)."""
+    """y = act(sum_j nearest_up_{2^shift_j}(in_j))  (pose_hrnet.py:206,254-265). meta=(act, shifts).
+    Backward: ONE launch writes g = dy * act'(y) and the block-summed gradients of the up-sampled sources; for sources
+    that are train-mode conv + BN outputs (the fuse layers, registered by ConvBN.fwd in ``_BNB_FWD``) it also leaves
+    their BatchNorm-backward channel sums in their slots, so that ConvBN.bwd needs norm_bwd_apply_slots only."""
 
     @staticmethod
     def fwd(st, lane, t, meta, needs):
@@ -630,7 +652,13 @@ class FuseSum:
         ptrs = (ctypes.c_void_p * n)(*[v.data_ptr() for v in ins])
         sh = (ctypes.c_int * n)(*shifts)
         call('advmix_fuse_sum', ptrs, sh, n, _p(y), B, H, W, C, act, st)
-        return (y,), (y,), None
+        targets = [None] * n
+        for j, v in enumerate(ins):
+            tg = _BNB_FWD.pop(v.data_ptr(), None)
+            if tg is not None and needs[j] and tg[0].pass_id == tg[1] and tuple(tg[3].shape) == tuple(v.shape) \
+                    and tg[3].stride() == v.stride():
+                targets[j] = tg
+        return (y,), (y,), (targets if any(tg is not None for tg in targets) else None)
 
     @staticmethod
     def bwd(st, lane, saved, extra, meta, grads, needs):
@@ -639,7 +667,8 @@ class FuseSum:
         dy = nhwc(grads[0])
         B, C, H, W = y.shape
         n = len(shifts)
-        g = keep(empty_nhwc(B, C, H, W, y.device))
+        need_g = any(needs[j] and s == 0 for j, s in enumerate(shifts))
+        g = keep(empty_nhwc(B, C, H, W, y.device)) if need_g else None
         outs = []
         for j, s in enumerate(shifts):
             if not needs[j]:
@@ -651,6 +680,31 @@ class FuseSum:
         ptrs = (ctypes.c_void_p * n)(*[(o.data_ptr() if (o is not None and s > 0) else None)
                                       for o, s in zip(outs, shifts)])
         sh = (ctypes.c_int * n)(*shifts)
+        if BNB_FUSED and not DETERMINISTIC and act in (ACT_NONE, ACT_RELU, ACT_LEAKY):
+            tgs = [None] * n
+            for j, tg in enumerate(extra or ()):
+                if tg is not None and outs[j] is not None and tg[0].claim_bwd(tg[2], tg[1]):
+                    tgs[j] = tg
+            NS = 16
+            vp = ctypes.c_void_p * n
+            rc = lib.advmix_fuse_sum_bwd_bnb(
+                _p(dy), _p(y), _p(g), ptrs, sh, n, B, H, W, C, act,
+                vp(*[(tg[3].data_ptr() if tg else None) for tg in tgs]), vp(*[(tg[4].data_ptr() if tg else None) for tg in tgs]),
+                vp(*[(tg[5].data_ptr() if tg else None) for tg in tgs]),
+                vp(*[(tg[0].t.data_ptr() + 8 * tg[2] if tg else None) for tg in tgs]), NS, st)
+            if rc == 0:
+                for j, tg in enumerate(tgs):
+                    if tg is not None:
+                        _BNB_PRE[(outs[j].data_ptr(), id(tg[0]), tg[2])] = (tg[0], tg[1], NS)
+                        COUNTERS['fuse_bnb'] = COUNTERS.get('fuse_bnb', 0) + 1
+                return tuple(outs)
+            for tg in tgs:                                  # not served (rc 1): release the slot claims, separate kernels
+                if tg is not None:
+                    tg[0].dirty.discard(tg[2])
+            if rc != 1:
+                raise RuntimeError('advmix_fuse_sum_bwd_bnb failed: %d' % rc)
+        if g is None:
+            g = keep(empty_nhwc(B, C, H, W, y.device))
         call('advmix_fuse_sum_bwd', _p(dy), _p(y), _p(g), ptrs, sh, n, B, H, W, C, act, st)
         return tuple(outs)
 

@@ -349,6 +349,16 @@ class PlanNet(nn.Module):
         # fp64 statistics slots (ops.StatArena): a forward and a backward set per conv + BatchNorm pair
         self._arena = ops.StatArena()
         self._stat_off = {}
+        # conv + BN outputs whose ONLY consumer is a fuse sum (HRNet's fuse layers): the sum's backward produces their
+        # BatchNorm-backward channel sums (ops.FuseSum.bwd)
+        uses, fuse_srcs = {}, set()
+        for st in plan.steps:
+            for s_ in self._srcs(st):
+                uses[s_] = uses.get(s_, 0) + 1
+            if st[0] == 'fuse':
+                fuse_srcs.update(st[1])
+        self._fuse_only = {st[1] for st in plan.steps if st[0] == 'bn' and st[3] in fuse_srcs and uses.get(st[3], 0) == 1
+                           and st[3] != plan.out and st[5] == ACT_NONE}
         ch_of = {name: shape[0] for name, shape, kind in plan.params if kind == 'bn_w'}
         for st in plan.steps:
             if st[0] == 'bn':
@@ -569,7 +579,8 @@ class PlanNet(nn.Module):
                     (slots[s], T[cname + '.weight'], T[bname + '.weight'], T[bname + '.bias'],
                      T[bname + '.running_mean'], T[bname + '.running_var'], T[bname + '.num_batches_tracked'],
                      slots[res] if res is not None else None),
-                    (stride, pad, act, train, BN_MOMENTUM, BN_EPS, self._arena) + self._stat_off[bname])
+                    (stride, pad, act, train, BN_MOMENTUM, BN_EPS, self._arena) + self._stat_off[bname]
+                    + (bname in self._fuse_only,))
         if k in ('conv', 'deconv'):
             _, name, s, d, stride, pad, hb = st
             return (ops.Conv if k == 'conv' else ops.Deconv,

@@ -236,6 +236,15 @@ int advmix_fuse_sum(const float* const* ins_host, const int* shifts_host, int n_
 int advmix_fuse_sum_bwd(const float* dy, const float* y, float* g_out, float* const* dins_host,
                         const int* shifts_host, int n_in, int N, int H, int W, int C, int act,
                         void* stream);
+/* The same in ONE launch, leaving the BatchNorm-backward channel sums (sum g_j, sum g_j * xhat_j) of the sources that
+ * are outputs of a train-mode conv + BN (pose_hrnet.py:196-232: the fuse layers end in BN without activation) in
+ * their fp64 slots [2][C][ns] (pre-zeroed, added to): advmix_norm_bwd_apply_slots then finishes that BatchNorm's
+ * backward in one launch.  bnb_c[j] == NULL: source j has no such target.  ADVMIX_EINVAL = shape not served, nothing
+ * launched (use advmix_fuse_sum_bwd). */
+int advmix_fuse_sum_bwd_bnb(const float* dy, const float* y, float* g_out, float* const* dins_host,
+                            const int* shifts_host, int n_in, int N, int H, int W, int C, int act,
+                            const float* const* bnb_c_host, const float* const* bnb_mean_host,
+                            const float* const* bnb_invstd_host, double* const* bnb_slots_host, int ns, void* stream);
 int advmix_maxpool3x3s2(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C,
                         int Ho, int Wo, void* stream);
 int advmix_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W,
@@ -297,6 +306,15 @@ int advmix_make_views(const uint8_t* base, const uint8_t* aug, const int32_t* gr
 int advmix_render_targets(const double* joints, const double* vis, const int32_t* grid, const float* g,
                           int tmp_size, const float* joints_weight, float* target, float* target_weight,
                           double* vis_out, int B, int J, int H, int W, int Hh, int Wh, void* stream);
+
+/* The AutoAugment view on the device: ImageNetPolicy (lib/dataset/advaug.py:10-108; applied per sample by MixCombine,
+ * advaug.py:180-187, from JointsDataset.py:124).  The policy table only reaches equalize / posterize / solarize / invert
+ * (Pillow ImageOps look-up tables) and sharpness (ImageFilter.SMOOTH + Image.blend); results are bit-identical to
+ * Pillow's.  base / out / tmp: uint8 [B,H,W,3]; ops: int32 [B][4] = {code1, param1, code2, param2}, code 0 = none,
+ * 1 equalize, 2 posterize (param = bit mask), 3 solarize (param = float bits of the threshold), 4 invert,
+ * 5 sharpness (param = float bits of the blend factor).  The worker draws (advmix_amd.dataset.advaug.autoaug_params). */
+int advmix_autoaug(const uint8_t* base, const int32_t* ops, uint8_t* tmp, uint8_t* out, int B, int H, int W,
+                   void* stream);
 
 /* ---- validate(): flip test and final predictions ----------------------------------------
  * Replace the numpy round trips of lib/core/function.py:240-261,285-287, lib/utils/transforms.py:16-41,57-107

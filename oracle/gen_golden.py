@@ -538,12 +538,69 @@ def gen_inputpipe(M):
         json.dump(meta, f)
 
 
+AUTOAUG_CASES = (('small', 48, 64, 48), ('coco', 6, 256, 192), ('odd', 6, 33, 21))
+
+
+def gen_autoaug(M):
+    """The AutoAugment view (SURVEY 8 f2 remainder) from the REAL ``ImageNetPolicy`` (advaug.py:10-108, constructed as
+    MixCombine does, :175) on synthetic crops: per sample Python's ``random`` is seeded, the real policy is applied to
+    the PIL image (as JointsDataset / MixCombine do, advaug.py:184-186), and the draws are replayed through
+    oracle.autoaug.draw_policy from the same state.  Stores the outputs (uint8) and the replayed draws.
+    ``np.int`` (removed in numpy 1.24) is shimmed for advaug.py:56."""
+    import random
+    import zlib
+    from PIL import Image
+    from oracle import autoaug as oa
+    from oracle import inputpipe as ip
+    if not hasattr(np, 'int'):
+        np.int = int
+    for m, attrs in (('pycocotools', {}), ('pycocotools.coco', {'COCO': None}),
+                     ('pycocotools.cocoeval', {'COCOeval': None}), ('json_tricks', {}),
+                     ('imagecorruptions', {'corrupt': None, 'get_corruption_names': None})):
+        mod = types.ModuleType(m)
+        for k, v in attrs.items():
+            setattr(mod, k, v)
+        sys.modules.setdefault(m, mod)
+    pkg = types.ModuleType('dataset')
+    pkg.__path__ = [os.path.join(REF, 'lib', 'dataset')]
+    sys.modules.setdefault('dataset', pkg)
+    import dataset.advaug as adv
+    policy = adv.MixCombine().autoaug
+    res, meta = {}, {}
+    seen = set()
+    for tag, B, H, W in AUTOAUG_CASES:
+        base, _, _, _ = ip.synth_samples('aa.' + tag, B, 1, H, W)
+        if tag == 'small':
+            base[0] = 77                                    # one colour: equalize leaves it alone (len(histo) <= 1)
+            base[1] = (base[1] // 128) * 200                # two levels
+            base[2, :, :, 1] = base[2, :, :, 0] // 64 * 60  # few levels in one band: step == 0 for small images
+        draws, crcs = [], []
+        for b in range(B):
+            seed = 4242 + 31 * b + H
+            random.seed(seed)
+            st = random.getstate()
+            out = np.array(policy(Image.fromarray(base[b].astype(np.uint8))))
+            random.setstate(st)
+            ops = oa.draw_policy(random)
+            draws.append([[int(c), float(p)] for c, p in ops])
+            seen.update(c for c, _ in ops)
+            crcs.append(zlib.crc32(np.ascontiguousarray(out).tobytes()))
+            if tag == 'odd':                                # full outputs for the small case, CRC-32 of the bytes for all
+                res['%s.out%d' % (tag, b)] = out
+        meta[tag] = {'draws': draws, 'crc32': crcs}
+        print('autoaug', tag, draws, flush=True)
+    assert seen == {1, 2, 3, 4, 5}, seen                    # every reachable operation is covered by some sample
+    np.savez_compressed(os.path.join(OUT, 'autoaug.npz'), **res)
+    with open(os.path.join(OUT, 'autoaug.json'), 'w') as f:
+        json.dump(meta, f)
+
+
 def main():
     logging.basicConfig(level=logging.WARNING)
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     M = import_reference()
-    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe', 'c4', 'b32', 'benchtiles', 'c1']
+    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe', 'c4', 'b32', 'benchtiles', 'c1', 'autoaug']
     for w in which:
         globals()['gen_' + w](M)
         print('done', w, flush=True)

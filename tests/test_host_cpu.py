@@ -342,3 +342,26 @@ def test_loops_create_their_own_grad_sync_under_a_process_group(tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script), str(tmp_path)], env=env))
     for p in procs:
         assert p.wait(timeout=180) == 0
+
+
+def test_autoaug_params_replays_the_reference_draws():
+    """dataset.advaug.autoaug_params consumes Python's ``random`` exactly like ImageNetPolicy / SubPolicy (advaug.py:
+    38-40, 102-105): same seeds -> the draws recorded from the REAL policy; pack_autoaug encodes them for the device."""
+    import random
+    import numpy as np
+    from oracle.gen_golden import AUTOAUG_CASES
+    from advmix_amd.dataset.advaug import autoaug_params, pack_autoaug, AA_POSTERIZE, AA_SOLARIZE, AA_SHARPNESS
+    meta = gold_json('autoaug.json')
+    n = 0
+    for tag, B, H, W in AUTOAUG_CASES:
+        for b in range(B):
+            random.seed(4242 + 31 * b + H)
+            got = autoaug_params()                             # default: the ``random`` module itself
+            assert [[int(c), float(p)] for c, p in got] == meta[tag]['draws'][b], (tag, b)
+            n += len(got)
+    assert n > 40
+    t = pack_autoaug([[(AA_POSTERIZE, 5.0), (AA_SOLARIZE, 170.66666666666669)], [(AA_SHARPNESS, 1.7000000000000002)], []],
+                     torch.device('cpu')).numpy()
+    assert t.shape == (3, 4) and t.dtype == np.int32
+    assert t[0, 1] == ~7 and t[0, 3:4].view(np.float32)[0] == np.float32(170.66666666666669)
+    assert t[1, 0] == AA_SHARPNESS and t[1, 1:2].view(np.float32)[0] == np.float32(1.7000000000000002) and not t[2].any()

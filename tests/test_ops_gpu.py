@@ -423,6 +423,13 @@ def _plan_reference(plan, sd, x):
             if res is not None:
                 o = o + slots[res]
             slots[d_] = F.relu(o) if act == 1 else o
+        elif st[0] == 'fuse':
+            _, xs, shifts, d_, act = st
+            o = 0
+            for s_, sh in zip(xs, shifts):
+                t = slots[s_]
+                o = o + (F.interpolate(t, scale_factor=2 ** sh, mode='nearest') if sh else t)
+            slots[d_] = F.relu(o) if act == 1 else o
         else:
             raise ValueError(st[0])
     return slots[plan.out]
@@ -492,6 +499,121 @@ def test_chain_bn_backward_fused_into_dgrad_epilogue(frozen):
         assert float((a - b).abs().max()) <= 5e-5 * scale, (k, float((a - b).abs().max()), scale)
         frac = float(((a - ref).abs() <= 1e-3 * scale).double().mean())
         assert frac >= 0.999, (k, frac)                       # (a flipped ReLU mask moves isolated elements)
+
+
+@pytest.mark.parametrize('shape', [(4, 32, 16, 12, (0, 0, 1, 2)), (2, 64, 8, 8, (1, 0, 0, 0)), (3, 128, 8, 4, (2, 1, 0)),
+                                   (2, 256, 4, 4, (0,)), (2, 32, 8, 8, (0, 3))])
+def test_fuse_sum_backward_one_launch_with_bn_backward_sums(shape):
+    """advmix_fuse_sum_bwd_bnb: g and the block-summed gradients are BIT-identical to mask_grad + pool_sum
+    (advmix_fuse_sum_bwd); the BatchNorm-backward channel sums it leaves in the fp64 slots of every conv + BN source
+    equal a float64 torch reduction of (g_j, g_j * xhat_j)."""
+    import ctypes
+    from advmix_amd._lib import lib, call
+    d = dev()
+    B, C, H, W, shifts = shape
+    n = len(shifts)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())       # noqa: E731
+    dy = rnd(B, H, W, C, seed=1).float().to(d)
+    y = torch.relu(rnd(B, H, W, C, seed=2)).float().to(d)
+    # every source but the first same-resolution one is a conv + BN output with a target
+    tgt = [not (s == 0 and j == shifts.index(0)) for j, s in enumerate(shifts)]
+    if sum(1 for j, s in enumerate(shifts) if s == 0 and tgt[j]) > 3:
+        pytest.skip('more than three same-resolution targets')
+    cs = [rnd(B, H >> s, W >> s, C, seed=10 + j).float().to(d) for j, s in enumerate(shifts)]
+    mean = [rnd(C, seed=20 + j, scale=0.3).float().to(d) for j in range(n)]
+    invstd = [(rnd(C, seed=30 + j).abs() + 0.5).float().to(d) for j in range(n)]
+    NS = 16
+    slots = [torch.zeros(2 * C * NS, dtype=torch.float64, device=d) for _ in range(n)]
+    g0, g1 = torch.empty_like(dy), torch.empty_like(dy)
+    outs0 = [torch.empty(B, H >> s, W >> s, C, device=d) if s > 0 else None for s in shifts]
+    outs1 = [torch.empty(B, H >> s, W >> s, C, device=d) if s > 0 else None for s in shifts]
+    vp = ctypes.c_void_p * n
+    sh = (ctypes.c_int * n)(*shifts)
+    call('advmix_fuse_sum_bwd', P(dy), P(y), P(g0), vp(*[(o.data_ptr() if o is not None else None) for o in outs0]), sh, n,
+         B, H, W, C, 1, st)
+    rc = lib.advmix_fuse_sum_bwd_bnb(P(dy), P(y), P(g1), vp(*[(o.data_ptr() if o is not None else None) for o in outs1]), sh, n,
+                                     B, H, W, C, 1,
+                                     vp(*[(cs[j].data_ptr() if tgt[j] else None) for j in range(n)]),
+                                     vp(*[(mean[j].data_ptr() if tgt[j] else None) for j in range(n)]),
+                                     vp(*[(invstd[j].data_ptr() if tgt[j] else None) for j in range(n)]),
+                                     vp(*[(slots[j].data_ptr() if tgt[j] else None) for j in range(n)]), NS, st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(g0, g1)
+    for a, b in zip(outs0, outs1):
+        assert (a is None and b is None) or torch.equal(a, b)
+    for j, s in enumerate(shifts):
+        sl = slots[j].view(2, C, NS).sum(-1).cpu()
+        if not tgt[j]:
+            assert float(sl.abs().max()) == 0.0
+            continue
+        gj = (g1 if s == 0 else outs1[j]).double().cpu()
+        xh = (cs[j].double().cpu() - mean[j].double().cpu()) * invstd[j].double().cpu()
+        check('sum g src %d' % j, sl[0], gj.sum((0, 1, 2)), 1e-6)
+        check('sum g*xhat src %d' % j, sl[1], (gj * (cs[j].cpu() - mean[j].cpu()).mul(invstd[j].cpu()).double()).sum((0, 1, 2)), 1e-6)
+        assert float((xh - (cs[j].cpu() - mean[j].cpu()).mul(invstd[j].cpu()).double()).abs().max()) < 1e-5
+    # refused without launching: C / 4 does not divide 256
+    assert lib.advmix_fuse_sum_bwd_bnb(P(dy), P(y), P(g1), vp(*[None] * n), sh, n, B, H, W, 24, 1, vp(*[None] * n),
+                                       vp(*[None] * n), vp(*[None] * n), vp(*[None] * n), NS, st) == 1
+
+
+def test_fuse_layer_bn_backward_sums_come_from_the_fuse_sum_backward():
+    """A two-branch HRNet module as launch chains in separate groups: the fuse layers' conv + BN (no activation) feed
+    a fuse sum in ANOTHER group; that sum's backward leaves their BatchNorm-backward sums in the slots
+    (ops.FuseSum.bwd -> ops.ConvBN.bwd through ``_BNB_PRE``).  Fused vs unfused agree to rounding, both with a float64
+    torch interpretation of the plan; full and input-only (G-step) backward."""
+    import advmix_amd.ops as ops
+    from advmix_amd.plan import hrnet_plan, PlanNet
+    extra = {'FINAL_CONV_KERNEL': 1,
+             'STAGE2': {'NUM_MODULES': 1, 'NUM_BRANCHES': 2, 'BLOCK': 'BASIC', 'NUM_BLOCKS': [1, 1], 'NUM_CHANNELS': [32, 64], 'FUSE_METHOD': 'SUM'},
+             'STAGE3': {'NUM_MODULES': 2, 'NUM_BRANCHES': 3, 'BLOCK': 'BASIC', 'NUM_BLOCKS': [1, 1, 1], 'NUM_CHANNELS': [32, 64, 128], 'FUSE_METHOD': 'SUM'},
+             'STAGE4': {'NUM_MODULES': 1, 'NUM_BRANCHES': 4, 'BLOCK': 'BASIC', 'NUM_BLOCKS': [1, 1, 1, 1], 'NUM_CHANNELS': [32, 64, 128, 256], 'FUSE_METHOD': 'SUM'}}
+    P = hrnet_plan(extra, 5)
+    torch.manual_seed(11)
+    net = PlanNet(P)
+    assert len(net._fuse_only) == 2 + 2 * 6 + 3
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if p.dim() == 1 and k.endswith('.weight'):
+                p.uniform_(0.6, 1.4)
+            elif p.dim() == 1:
+                p.normal_(0, 0.2)
+    net = net.to(dev()).train()
+    sd = {k: v.detach().double().cpu().requires_grad_(v.is_floating_point()) for k, v in net.state_dict().items()}
+    B, H, W = 4, 64, 64
+    xin = rnd(B, 3, H, W, seed=91)
+    dyo = rnd(B, 5, H // 4, W // 4, seed=92)
+    xr = xin.clone().requires_grad_(True)
+    yr = _plan_reference(P, sd, xr)
+    yr.backward(dyo)
+    for frozen in (False, True):
+        for p in net.parameters():
+            p.requires_grad = not frozen
+        got = {}
+        for fused in (True, False):
+            ops.BNB_FUSED = fused
+            ops.COUNTERS['fuse_bnb'] = 0
+            try:
+                for p in net.parameters():
+                    p.grad = None
+                xg = cl(xin).requires_grad_(True)
+                y = net(xg)
+                y.backward(cl(dyo))
+                torch.cuda.synchronize()
+            finally:
+                ops.BNB_FUSED = True
+            got[fused] = {'x': xg.grad.detach().cpu().double()}
+            if not frozen:
+                got[fused].update({k: p.grad.detach().cpu().double() for k, p in net.named_parameters()})
+            assert ops.COUNTERS['fuse_bnb'] == (17 if fused else 0), ops.COUNTERS['fuse_bnb']
+        for k in got[True]:
+            ref = xr.grad if k == 'x' else sd[k].grad
+            a, b = got[True][k], got[False][k]
+            scale = max(float(ref.abs().max()), 1e-9)
+            assert float((a - b).abs().max()) <= 1e-4 * scale, (k, frozen, float((a - b).abs().max()), scale)
+            frac = float(((a - ref).abs() <= 2e-3 * scale).double().mean())
+            assert frac >= 0.995, (k, frozen, frac)
 
 
 def test_batch_norm_frozen_params_input_grad_only():
@@ -988,3 +1110,48 @@ def test_edge_cases_empty_single_boundary():
     want_t, want_w = oip.generate_target(jt[0], vis[0], (W, H), (Wh, Hh), 2)
     assert np.array_equal(tgt[0].cpu().numpy(), want_t) and np.array_equal(tw[0].cpu().numpy(), want_w)
     assert 0 < int(want_w.sum()) < len(xs)
+
+
+def test_auto_augment_bit_exact_vs_oracle_and_the_real_policy():
+    """Device AutoAugment (advmix_autoaug) against the numpy oracle - itself pinned to Pillow and to the REAL
+    ImageNetPolicy - on the recorded cases (tests/golden/autoaug.json: the real policy's draws and the CRC-32 of its output
+    bytes), then every operation x every magnitude x both sharpness signs, two operations chained, on random /
+    low-entropy / constant images of even and odd sizes."""
+    import random
+    import zlib
+    import json, os
+    from oracle import autoaug as oa
+    from oracle import inputpipe as ip
+    from oracle.gen_golden import AUTOAUG_CASES
+    from advmix_amd.dataset.advaug import autoaug_params, pack_autoaug, auto_augment
+    d = dev()
+    meta = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'autoaug.json')))
+    for tag, B, H, W in AUTOAUG_CASES:
+        base, _, _, _ = ip.synth_samples('aa.' + tag, B, 1, H, W)
+        if tag == 'small':
+            base[0] = 77
+            base[1] = (base[1] // 128) * 200
+            base[2, :, :, 1] = base[2, :, :, 0] // 64 * 60
+        base = base.astype(np.uint8)
+        params = []
+        for b in range(B):
+            random.seed(4242 + 31 * b + H)
+            params.append(autoaug_params(random))
+            assert [[int(c), float(p)] for c, p in params[-1]] == meta[tag]['draws'][b]
+        out = auto_augment(torch.from_numpy(base).to(d), pack_autoaug(params, d)).cpu().numpy()
+        for b in range(B):
+            assert zlib.crc32(np.ascontiguousarray(out[b]).tobytes()) == meta[tag]['crc32'][b], (tag, b, params[b])
+            assert np.array_equal(out[b], oa.autoaug(base[b], params[b]))
+    rng = np.random.RandomState(17)
+    for H, W in ((24, 32), (33, 21), (3, 3), (2, 7), (64, 48)):
+        imgs = np.stack([rng.randint(0, 256, (H, W, 3)), rng.randint(0, 256, (H, W, 3)) // 64 * 64,
+                         np.full((H, W, 3), 131), np.minimum(rng.randint(0, 256, (H, W, 3)), 30)]).astype(np.uint8)
+        singles = [(oa.EQUALIZE, 0.0), (oa.INVERT, 0.0)]
+        for idx in range(10):
+            singles += [(oa.POSTERIZE, float(oa.magnitude('posterize', idx))), (oa.SOLARIZE, oa.magnitude('solarize', idx)),
+                        (oa.SHARPNESS, 1 + oa.magnitude('sharpness', idx)), (oa.SHARPNESS, 1 - oa.magnitude('sharpness', idx))]
+        chains = [[s] for s in singles] + [[singles[i], singles[(7 * i + 3) % len(singles)]] for i in range(len(singles))] + [[]]
+        for ops in chains:
+            got = auto_augment(torch.from_numpy(imgs).to(d), pack_autoaug([ops] * len(imgs), d)).cpu().numpy()
+            for b in range(len(imgs)):
+                assert np.array_equal(got[b], oa.autoaug(imgs[b], ops)), (H, W, b, ops)

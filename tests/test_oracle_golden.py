@@ -380,3 +380,57 @@ def test_gridmask_and_targets_match_reference():
     base, aug, jt, vis = oip.synth_samples('inp.coco', 3, 17, 256, 192)
     _, tw = oip.generate_target(jt[0], vis[0], (192, 256), (48, 64), 2, jw)
     assert np.array_equal(tw, g['coco.jw.tw0'])
+
+
+# ---- AutoAugment view (SURVEY.md 8 f2 remainder): oracle/autoaug.py against Pillow and the real ImageNetPolicy -----
+
+def test_autoaug_operations_match_pillow_bit_for_bit():
+    """Every reachable operation at every magnitude the policy table uses (and the sharpness signs) against the
+    installed Pillow on random, low-entropy and constant images, odd sizes included."""
+    from PIL import Image, ImageOps, ImageEnhance
+    from oracle import autoaug as oa
+    rng = np.random.RandomState(3)
+    imgs = [rng.randint(0, 256, (h, w, 3)).astype(np.uint8) for h, w in ((3, 3), (17, 31), (64, 48), (40, 57), (2, 9), (9, 1))]
+    imgs.append(np.full((12, 10, 3), 200, np.uint8))
+    imgs.append((rng.randint(0, 256, (30, 30, 3)) // 64 * 64).astype(np.uint8))
+    imgs.append(np.minimum(rng.randint(0, 256, (64, 64, 3)), 40).astype(np.uint8))
+    for a in imgs:
+        im = Image.fromarray(a)
+        assert np.array_equal(oa.apply_op(a, oa.EQUALIZE, 0), np.array(ImageOps.equalize(im)))
+        assert np.array_equal(oa.apply_op(a, oa.INVERT, 0), np.array(ImageOps.invert(im)))
+        for idx in range(10):
+            bits = oa.magnitude('posterize', idx)
+            assert np.array_equal(oa.apply_op(a, oa.POSTERIZE, bits), np.array(ImageOps.posterize(im, bits)))
+            th = oa.magnitude('solarize', idx)
+            assert np.array_equal(oa.apply_op(a, oa.SOLARIZE, th), np.array(ImageOps.solarize(im, th)))
+            for sign in (-1, 1):
+                f = 1 + oa.magnitude('sharpness', idx) * sign
+                assert np.array_equal(oa.apply_op(a, oa.SHARPNESS, f), np.array(ImageEnhance.Sharpness(im).enhance(f))), (a.shape, f)
+
+
+def test_autoaug_matches_the_real_policy_and_replays_its_draws():
+    """tests/golden/autoaug.*: outputs of the REAL ImageNetPolicy (advaug.py:10-108) for seeded ``random`` states; the
+    restated draw order reproduces the recorded draws from the same seeds, the restated operations the recorded bytes."""
+    import random
+    import zlib
+    from oracle import autoaug as oa
+    from oracle import inputpipe as ip
+    from oracle.gen_golden import AUTOAUG_CASES
+    meta, g = gold_json('autoaug.json'), gold_npz('autoaug.npz')
+    seen = set()
+    for tag, B, H, W in AUTOAUG_CASES:
+        base, _, _, _ = ip.synth_samples('aa.' + tag, B, 1, H, W)
+        if tag == 'small':
+            base[0] = 77
+            base[1] = (base[1] // 128) * 200
+            base[2, :, :, 1] = base[2, :, :, 0] // 64 * 60
+        for b in range(B):
+            random.seed(4242 + 31 * b + H)
+            ops = oa.draw_policy(random)
+            assert [[int(c), float(p)] for c, p in ops] == meta[tag]['draws'][b], (tag, b)
+            out = oa.autoaug(base[b].astype(np.uint8), ops)
+            assert zlib.crc32(np.ascontiguousarray(out).tobytes()) == meta[tag]['crc32'][b], (tag, b, ops)
+            if tag == 'odd':
+                assert np.array_equal(out, g['%s.out%d' % (tag, b)])
+            seen.update(c for c, _ in ops)
+    assert seen == {1, 2, 3, 4, 5}

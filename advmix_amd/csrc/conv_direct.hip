@@ -49,6 +49,7 @@ struct ConvD {
     // (dy, y, c) and its finalize launch disappear (norm.hip: norm_bwd_apply_slots consumes the slots).
     const float *bnb_y, *bnb_c, *bnb_mean, *bnb_invstd;
     int bnb_act;
+    int xcd_remap;          // 1: row-tile order remapped so that each XCD (and its L2) owns a CONTIGUOUS range of row tiles
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -145,7 +146,15 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
         Tw = phw < p.S ? (p.S - phw + p.stride - 1) / p.stride : 0;
     }
     const int Mp = p.N * Hp * Wp;
-    const int m0 = bx * BM, n0 = by * BN;
+    // Workgroups are dealt to the 8 XCDs round-robin in launch order, so neighbouring row tiles - which share their 3x3
+    // halo rows - land on eight different L2s and each fetches the halo from HBM again (dominant conv: 22.2 MB read for
+    // 12.6 MB of input, x1.76 = (128 + 2 * 48) / 128 pixels per tile, profiles/r02c_pmc_conv32_epi.json).  With the
+    // row-tile index remapped (tile = (bx % 8) * (gx / 8) + bx / 8) XCD k works through tiles [k * gx / 8, (k + 1) * gx / 8)
+    // in order: a tile's halo is what its predecessor on the SAME XCD just loaded.
+    int bxr = bx;
+    if (p.xcd_remap && (gridDim.x & 7) == 0 && gridDim.x >= 16 && bx < (int)gridDim.x)
+        bxr = (bx & 7) * ((int)gridDim.x >> 3) + (bx >> 3);
+    const int m0 = bxr * BM, n0 = by * BN;
     if (m0 >= Mp) return;
     const int ntaps = Th * Tw;
     const int cpt = p.Ci / KC;                              // chunks per tap
@@ -716,9 +725,14 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
     p.nsplit = 1;
     switch (pick_cfg(Mmax, p.Co, phases, nch, &ns)) {
         case CFG_128x32: LAUNCHD(1, 1, 4, 1, false); break;
-        case CFG_128x64:                                   // two tiles per wave: no registers to prefetch the BatchNorm-
-            LAUNCHD(1, 2, 4, 1, false);                    // backward operands; they are loaded in the epilogue, 16 bytes
-            break;                                         // per lane and access (round 3; scalar loads lost to the separate pass)
+        case CFG_128x64: {                                 // two tiles per wave: no registers to prefetch the BatchNorm-
+            // backward operands; they are loaded in the epilogue, 16 bytes per lane and access (round 3; as scalar loads
+            // they lost to the separate statistics pass).  ADVMIX_BNB128=0: A/B switch back to that pass.
+            static const int bnb128 = [] { const char* e = getenv("ADVMIX_BNB128"); return e ? atoi(e) : 1; }();
+            if (p.bnb_c && !bnb128) return -2;
+            LAUNCHD(1, 2, 4, 1, false);
+            break;
+        }
         case CFG_64x64: LAUNCHD(1, 1, 2, 2, false); break;
         case CFG_32x32_WAVE_SPLIT: LAUNCHD(1, 1, 1, 1, false); break;      // four waves share K in the workgroup
         case CFG_64x32_WAVE_SPLIT2: LAUNCHD(1, 1, 2, 1, false); break;     // two wave pairs share K
@@ -753,7 +767,9 @@ static int prepare(int mode, const float* x, const float* w, const float* bias, 
     if (xb >= 0x7fffffffLL || wb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return -1;
     direct::ConvD p{x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, (int)xb, (int)wb, (int)yb, 1,
                     nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0,
-                    nullptr, nullptr, nullptr, nullptr, 0};
+                    nullptr, nullptr, nullptr, nullptr, 0, 0};
+    static const int xcd_remap = [] { const char* e = getenv("ADVMIX_XCD_REMAP"); return e ? atoi(e) : 1; }();
+    p.xcd_remap = xcd_remap;
     // Slots per channel the workgroup sums are folded onto: many row blocks hammering few addresses serialise the
     // fp64 atomics at the memory side (3x3 32->32 @64x48, 768 workgroups: 30.8 us with 16 slots, 23.1 with 64), while
     // every consumer workgroup has to reduce all of them again - 64 only where the contention is real.
@@ -841,6 +857,7 @@ int advmix_conv_direct_group(int mode, int bt, int n, ConvProb* pr, hipStream_t 
             default: bm = 64; bn = 32; wk = 2; break;      // CFG_64x32_WAVE_SPLIT2
         }
         d.nsplit = 1;
+        d.xcd_remap = 0;                                  // (block ranges per problem: the launch-order argument does not hold)
         g.p[i] = d;
         g.cfg[i] = (int)c;
         g.gx[i] = cdiv(q.Mmax, bm);

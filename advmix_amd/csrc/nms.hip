@@ -90,6 +90,29 @@ __global__ void oks_matrix_kernel(const double* __restrict__ kpts, const double*
     ious[(int64_t)i * n + j] = K ? s / K : 0.0;
 }
 
+// Greedy pass of oks_nms (lib/nms/nms.py:97-125) on the device: candidates in ``order`` (score-descending, the host's
+// argsort - numpy's tie order is part of the result); a candidate survives unless an EARLIER SURVIVOR has OKS > thresh
+// with it (the reference keeps ``oks_ovr <= thresh``).  One workgroup; position p of the order is decided in round p
+// (uniform), then all threads strike the later positions it suppresses.  Only the kept indices leave the GPU.
+__global__ __launch_bounds__(256) void oks_greedy_kernel(const double* __restrict__ ious, const int* __restrict__ order, int n,
+                                                         double thresh, int* __restrict__ keep, int* __restrict__ count) {
+    extern __shared__ int dead[];                          // [n]
+    for (int j = threadIdx.x; j < n; j += blockDim.x) dead[j] = 0;
+    __syncthreads();
+    int kept = 0;
+    for (int p = 0; p < n; ++p) {
+        if (!dead[p]) {                                    // uniform: dead[] is only written between barriers
+            const int i = order[p];
+            if (threadIdx.x == 0) keep[kept] = i;
+            ++kept;
+            for (int q = p + 1 + threadIdx.x; q < n; q += blockDim.x)
+                if (!(ious[(int64_t)i * n + order[q]] <= thresh)) dead[q] = 1;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = kept;
+}
+
 }  // namespace
 
 extern "C" int advmix_nms_mask(const float* boxes_dev, int n, float thresh, uint64_t* mask_dev, void* stream) {
@@ -142,6 +165,17 @@ extern "C" int advmix_oks_matrix(const double* kpts, const double* areas, const 
     if (!kpts || !areas || !sigmas || !ious || n <= 0 || K <= 0 || K > 128) return ADVMIX_EINVAL;   // (numpy recurses past 128)
     hipLaunchKernelGGL(oks_matrix_kernel, dim3(cdiv(n, 64), n), dim3(64), 0, (hipStream_t)stream, kpts, areas, sigmas,
                        n, K, ious);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+// oks_nms's greedy pass on the device (see oks_greedy_kernel).  ious: [n][n] fp64 from advmix_oks_matrix; order: int32
+// [n] candidate indices, best first; keep_out: int32 [n]; count_out: int32 [1].  n <= 8192.
+extern "C" int advmix_oks_greedy(const double* ious, const int* order, int n, double thresh, int* keep_out, int* count_out,
+                                 void* stream) {
+    if (!ious || !order || !keep_out || !count_out || n <= 0 || n > 8192) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(oks_greedy_kernel, dim3(1), dim3(256), n * sizeof(int), (hipStream_t)stream, ious, order, n, thresh,
+                       keep_out, count_out);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }

@@ -80,7 +80,7 @@ def gpu_nms_wrapper(thresh, device_id):
 _SIGMAS = np.array([.26, .25, .25, .35, .35, .79, .79, .72, .72, .62, .62, 1.07, 1.07, .87, .87, .89, .89]) / 10.0
 
 
-def _oks_matrix(kpts, areas, sigmas):
+def _oks_matrix(kpts, areas, sigmas, device=False):
     n, K = kpts.shape[0], kpts.shape[1] // 3
     sig = _SIGMAS if not isinstance(sigmas, np.ndarray) else sigmas
     k = torch.from_numpy(np.ascontiguousarray(kpts, dtype=np.float64)).cuda()
@@ -90,7 +90,7 @@ def _oks_matrix(kpts, areas, sigmas):
     P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
     call('advmix_oks_matrix', P(k), P(a), P(s), n, K, P(out),
          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-    return out.cpu().numpy()
+    return out if device else out.cpu().numpy()
 
 
 def _unpack(kpts_db):
@@ -107,15 +107,18 @@ def oks_nms(kpts_db, thresh, sigmas=None, in_vis_thre=None):
     if in_vis_thre is not None:
         raise NotImplementedError('in_vis_thre is unused by the reference caller')
     scores, kpts, areas = _unpack(kpts_db)
-    M = _oks_matrix(kpts, areas, sigmas)
-    order = scores.argsort()[::-1]
-    keep = []
-    while order.size > 0:
-        i = order[0]
-        keep.append(i)
-        inds = np.where(M[i, order[1:]] <= thresh)[0]
-        order = order[inds + 1]
-    return keep
+    n = len(scores)
+    M = _oks_matrix(kpts, areas, sigmas, device=True)      # [n, n] fp64, stays on the GPU
+    # candidates best-first: numpy's argsort (its order among equal scores is part of the reference's result); the greedy
+    # pass itself runs on the device (advmix_oks_greedy) and only the kept indices come back
+    order = torch.from_numpy(np.ascontiguousarray(scores.argsort()[::-1], dtype=np.int32)).cuda()
+    keep = torch.empty(n, dtype=torch.int32, device='cuda')
+    cnt = torch.zeros(1, dtype=torch.int32, device='cuda')
+    P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+    call('advmix_oks_greedy', P(M), P(order), n, float(thresh), P(keep), P(cnt),
+         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    out = torch.cat([cnt, keep]).cpu().numpy()
+    return [int(i) for i in out[1:1 + int(out[0])]]
 
 
 def soft_oks_nms(kpts_db, thresh, sigmas=None, in_vis_thre=None):

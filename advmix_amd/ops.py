@@ -194,6 +194,7 @@ def _wt(st, w, A, T, B):
 #          bwd(st, lane, saved, extra, meta, grads, needs) -> input grads (aligned with tensors)
 # =============================================================================================
 BNB_FUSED = __import__('os').environ.get('ADVMIX_BNB', '1') != '0'
+FUSE_BNB = __import__('os').environ.get('ADVMIX_FUSE_BNB', '1') != '0'    # the fuse layers' BatchNorm-backward sums from FuseSum.bwd
 DETERMINISTIC = False
 
 
@@ -491,7 +492,7 @@ class ConvBN:
                  Co, 1, rows, Co, act, st)
         extra = (residual is not None, arena, arena.pass_id if arena is not None else 0, bwd_off)
         if len(meta) > 9 and meta[9] and arena is not None and arena.t is not None and act == ACT_NONE and any(needs) \
-                and BNB_FUSED and not DETERMINISTIC:
+                and BNB_FUSED and FUSE_BNB and not DETERMINISTIC:
             # the only consumer is a fuse sum in another launch group: its backward can produce this layer's sums
             _BNB_FWD[y.data_ptr()] = (arena, arena.pass_id, bwd_off, c, mean, invstd)
         return (y,), (x, w, c, y, mean, invstd, gamma, beta), extra

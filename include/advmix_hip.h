@@ -342,6 +342,11 @@ int advmix_nms_host(int* keep_out, int* num_out, const float* boxes_host, int bo
 /* OKS matrix (float64, lib/nms/nms.py:75-94): ious[n,n] for kpts[n,17*3], areas[n] (device) */
 int advmix_oks_matrix(const double* kpts, const double* areas, const double* sigmas, int n, int K,
                       double* ious, void* stream);
+/* The greedy pass of oks_nms (lib/nms/nms.py:97-125) on the device: ``order`` = candidate indices best-first (the host's
+ * argsort of the scores: numpy's tie order is part of the reference's result); a candidate is kept unless an earlier
+ * kept one has OKS > thresh with it.  keep_out: int32 [n], count_out: int32 [1].  Only the kept indices cross PCIe. */
+int advmix_oks_greedy(const double* ious, const int* order, int n, double thresh, int* keep_out, int* count_out,
+                      void* stream);
 
 #ifdef __cplusplus
 }

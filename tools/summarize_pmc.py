@@ -4,6 +4,9 @@ FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests a
 coalesced streams, so reads are doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact."""
 import collections, csv, glob, json, sys
 root, out = sys.argv[1], sys.argv[2]
+# algorithmic bytes per launch (default: the dominant forward, input + output + weights); the BatchNorm-backward input
+# gradient reads dy, addend, c, y and writes g: 5 tensors
+algo = int(sys.argv[3]) if len(sys.argv) > 3 else 32 * 64 * 48 * 32 * 4 * 2 + 32 * 9 * 32 * 4
 vals = {}
 for sub in ('sq', 'fetch', 'write', 'tcc'):
     fs = glob.glob('%s/%s/*/*_counter_collection.csv' % (root, sub))
@@ -22,7 +25,8 @@ fetch_b = vals.get('FETCH_SIZE', 0) * 1024 * 2
 write_b = vals.get('WRITE_SIZE', 0) * 1024
 res = {'kernel': vals.get('kernel'), 'launches_averaged': 20, 'raw': {k: v for k, v in vals.items() if k != 'kernel'},
        'hbm_read_bytes_corrected': fetch_b, 'hbm_write_bytes': write_b, 'hbm_bytes_per_launch': fetch_b + write_b,
-       'algorithmic_bytes_per_launch': 32 * 64 * 48 * 32 * 4 * 2 + 32 * 9 * 32 * 4,
+       'algorithmic_bytes_per_launch': algo, 'traffic_ratio': (fetch_b + write_b) / algo,
+       'read_ratio_vs_one_input_tensor': fetch_b / (32 * 64 * 48 * 32 * 4),
        'mfma_busy_frac_of_wave_cycles': vals.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(1.0, 4 * vals.get('SQ_WAVE_CYCLES', 1)),
        'wait_any_frac': vals.get('SQ_WAIT_ANY', 0) / max(1.0, vals.get('SQ_WAVE_CYCLES', 1)),
        'wait_inst_any_frac': vals.get('SQ_WAIT_INST_ANY', 0) / max(1.0, vals.get('SQ_WAVE_CYCLES', 1)),

@@ -127,6 +127,15 @@ CONV_FAMILY = ((32, 64, 48), (64, 32, 24), (128, 16, 12), (256, 8, 6))     # HRN
 KIND_WEIGHT = {'fwd+BN-sums': 2, 'fwd+BN-eval+ReLU': 1, 'dgrad+BN-bwd-sums': 2, 'wgrad': 1}
 
 
+def _pmc_file(pattern):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        return json.load(f), os.path.relpath(files[-1], ROOT)
+
+
 def _latest_pmc():
     """HBM bytes per launch of the dominant kernel from this round's rocprofv3 PMC passes (tools/pmc_conv.sh +
     tools/summarize_pmc.py: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate --pmc runs); newest profiles/r*_pmc file."""
@@ -212,6 +221,12 @@ def time_conv_family(B, device, iters=100, family=None):
                             'algorithmic_bytes_per_launch': nbytes, 'achieved_GBps': round(nbytes / (ms * 1e-3) / 1e9, 1),
                             'frac_of_8TBps': round(nbytes / (ms * 1e-3) / 1e9 / 8000.0, 4)})
     traffic, src = _latest_pmc() if (B == 32 and family == CONV_FAMILY) else (None, None)
+    bnb_traffic = None
+    if B == 32 and family == CONV_FAMILY:                   # the input gradient + BatchNorm-backward member (5 tensors of 12.6 MB)
+        d, f = _pmc_file('r*_pmc_conv32_dgrad_bnb.json')
+        if d:
+            bnb_traffic = {'hbm_bytes_per_launch': round(d['hbm_bytes_per_launch']), 'algorithmic_bytes': d['algorithmic_bytes_per_launch'],
+                           'ratio': round(d['hbm_bytes_per_launch'] / d['algorithmic_bytes_per_launch'], 3), 'source': f}
     agg = tot_f / tot_t / 1e12
     C0, H0, W0 = family[0]
     algo_bytes = 2 * B * H0 * W0 * C0 * 4 + 9 * C0 * C0 * 4
@@ -223,6 +238,7 @@ def time_conv_family(B, device, iters=100, family=None):
             'traffic': traffic, 'traffic_unit': 'HBM bytes per launch of the dominant member (rocprofv3 PMC, corrected)',
             'traffic_source': src, 'traffic_algorithmic_bytes': algo_bytes,
             'traffic_ratio': round(traffic / algo_bytes, 3) if traffic else None,
+            'traffic_dgrad_bnb': bnb_traffic,
             'dominant': dominant, 'members': members, 'hbm_kernels': hbm}
 
 

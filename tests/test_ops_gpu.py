@@ -616,7 +616,7 @@ def test_fuse_layer_bn_backward_sums_come_from_the_fuse_sum_backward():
             scale = max(float(ref.abs().max()), 1e-9)
             assert float((a - b).abs().max()) <= 1e-4 * scale, (k, frozen, float((a - b).abs().max()), scale)
             frac = float(((a - ref).abs() <= 2e-2 * scale).double().mean())
-            assert frac >= 0.97, (k, frozen, frac)              # (vs float64 torch: tiny maps, masks within rounding of 0 flip)
+            assert frac >= 1 - max(0.03, 2.0 / a.numel()), (k, frozen, frac)     # (vs float64 torch: tiny maps, masks within rounding of 0 flip)
 
 
 def test_batch_norm_frozen_params_input_grad_only():

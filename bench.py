@@ -349,26 +349,30 @@ def bench_validate(a, device, rank, world):
 
 
 def bench_inputs(a, device, rank, world):
-    """--path inputs: images/sec of the device input pipeline: from the uint8 crops of one batch
-    (clean + AutoAugment) to the three normalised float views (GridMask on the third) and the gaussian
-    targets / target weights.  HBM-bound: 6 B read + 36 B written per pixel by the view kernel."""
+    """--path inputs: images/sec of the device input pipeline: from ONE uint8 crop per sample and the
+    workers' draws to the AutoAugment view (device, round 3), the three normalised float views (GridMask on the third)
+    and the gaussian targets / target weights.  HBM-bound: 6 B read + 36 B written per pixel by the view kernel."""
     import numpy as np
-    from advmix_amd.dataset.advaug import make_views, pack_grid, grid_params
+    import random as pyrandom
+    from advmix_amd.dataset.advaug import make_views, pack_grid, grid_params, auto_augment, pack_autoaug, autoaug_params
     from advmix_amd.dataset.JointsDataset import TargetRenderer
     net, extra, J, H, W, downs, _ = WORKLOADS[a.workload]
     rng = np.random.RandomState(99 + rank)
     base = torch.from_numpy(rng.randint(0, 256, (a.batch, H, W, 3), dtype=np.uint8)).to(device)
-    aug = torch.from_numpy(rng.randint(0, 256, (a.batch, H, W, 3), dtype=np.uint8)).to(device)
     grid = pack_grid([grid_params(H, W, rng=rng) for _ in range(a.batch)], device)
+    prng = pyrandom.Random(7 + rank)
+    aa = pack_autoaug([autoaug_params(prng) for _ in range(a.batch)], device)      # the workers' draws (advaug.py:38-40,102-105)
     joints = np.zeros((a.batch, J, 3)); joints[:, :, 0] = rng.rand(a.batch, J) * W; joints[:, :, 1] = rng.rand(a.batch, J) * H
     vis = np.zeros((a.batch, J, 3)); vis[:, :, :2] = (rng.rand(a.batch, J, 1) < 0.8)
     jd, vd = torch.from_numpy(joints).to(device), torch.from_numpy(vis).to(device)
     rend = TargetRenderer((W, H), (W // 4, H // 4), 2, device=device)
 
     def one_batch():
+        aug = auto_augment(base, aa)                        # the AutoAugment view on the device (round 3)
         views = make_views(base, aug, grid)
         tgt, tw = rend.render(jd, vd)
         return views, tgt, tw
+    aug = auto_augment(base, aa)
 
     for _ in range(a.warmup):
         one_batch()
@@ -391,7 +395,8 @@ def bench_inputs(a, device, rank, world):
                                         ctypes.cast(sd, ctypes.c_void_p), P(v[0]), P(v[1]), P(v[2]), a.batch, H, W, st), 100)
     nbytes = a.batch * H * W * (6 + 36)
     value = a.batch * world * steps / dt
-    line = {'metric': 'images/sec device input pipeline: 3 views + targets (%dx%d)' % (H, W), 'value': round(value, 1),
+    ms_aa, _ = _event_time(lambda: auto_augment(base, aa), 100)
+    line = {'metric': 'images/sec device input pipeline: AutoAugment + 3 views + targets (%dx%d)' % (H, W), 'value': round(value, 1),
             'unit': 'images/sec', 'n_gpus': world, 'steps': steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'u8->f32', 'data': 'synthetic uint8 crops resident in HBM, random joints',
@@ -399,7 +404,8 @@ def bench_inputs(a, device, rank, world):
             'roofline': {'bound': 'hbm', 'kernel': 'make_views_kernel', 'achieved': round(nbytes / (ms * 1e-3) / 1e9, 1),
                          'peak': 8000.0, 'unit': 'GB/s', 'frac': round(nbytes / (ms * 1e-3) / 1e9 / 8000.0, 4),
                          'traffic': None, 'us_per_launch': round(ms * 1e3, 2),
-                         'algorithmic_bytes_per_launch': nbytes}}
+                         'algorithmic_bytes_per_launch': nbytes},
+            'autoaug_us_per_batch': round(ms_aa * 1e3, 2)}
     if world == 1 and not a.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(a.workload, path='inputs')
     return line

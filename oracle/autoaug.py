@@ -133,3 +133,22 @@ def autoaug(a, ops):
     for code, param in ops:
         a = apply_op(a, code, param)
     return a
+
+
+def autoaug_pil(a, ops):
+    """The same view through Pillow itself, the way the reference computes it (SubPolicy.func, advaug.py:82-95) - what
+    bench.py's cpu_baseline times for the input pipeline (the numpy restatement above is for checking, not for speed)."""
+    from PIL import Image, ImageOps, ImageEnhance
+    im = Image.fromarray(a)
+    for code, param in ops:
+        if code == EQUALIZE:
+            im = ImageOps.equalize(im)
+        elif code == POSTERIZE:
+            im = ImageOps.posterize(im, int(param))
+        elif code == SOLARIZE:
+            im = ImageOps.solarize(im, param)
+        elif code == INVERT:
+            im = ImageOps.invert(im)
+        elif code == SHARPNESS:
+            im = ImageEnhance.Sharpness(im).enhance(param)
+    return np.array(im)

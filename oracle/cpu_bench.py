@@ -73,11 +73,14 @@ def inputs_main(workload, budget, cores):
     B, J = 32, 17
     base, aug, jt, vis = ip.synth_samples('bench.cpu.inp', B, J, H, W)
     rng = np.random.RandomState(5)
+    import random
+    from oracle import autoaug as oa
+    prng = random.Random(5)
 
     def batch():
         for b in range(B):
             v0 = ip.to_tensor_normalize(base[b])
-            ip.to_tensor_normalize(aug[b])
+            ip.to_tensor_normalize(oa.autoaug_pil(base[b], oa.draw_policy(prng)))  # the AutoAugment view through PIL (advaug.py:180-187)
             ip.grid_aug(ip.to_tensor_normalize(base[b]), jt[b], vis[b], ip.grid_draws(H, W, 0.5, 0.7, 1, rng), J)
             ip.generate_target(jt[b], vis[b], (W, H), (W // 4, H // 4), 2)
         return v0
@@ -88,7 +91,7 @@ def inputs_main(workload, budget, cores):
         n += 1
     dt = time.time() - t0
     print(json.dumps({'value': round(B * n / dt, 1), 'unit': 'images/sec', 'cores': 1, 'kind': 'port',
-                      'sample': 'per-sample host pipeline (3x ToTensor+Normalize, GridMask, generate_target), %dx%d, '
+                      'sample': 'per-sample host pipeline (AutoAugment, 3x ToTensor+Normalize, GridMask, generate_target), %dx%d, '
                                 '%d batches of %d in one process (a DataLoader worker)' % (H, W, n, B)}), flush=True)
 
 

@@ -35,12 +35,49 @@ def build(force=False, verbose=True):
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed on ' + s)
+    linked = False
     if force or procs or _stale(SO, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', SO] + objs
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+        linked = True
+    _record(hipcc, [s for s, _ in procs], linked)
     return SO
+
+
+def _record(hipcc, compiled, linked):
+    """advmix_amd/build_info.json: what THIS call compiled / linked and what the library on disk was built from (source
+    hashes at build time), so that a reader of the tree can tell whether the .so the tests loaded matches the sources
+    next to it (build(force=False) reuses objects by mtime and nothing recorded it)."""
+    import hashlib
+    import json
+    import time
+
+    def sha(path):
+        with open(path, 'rb') as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    info_path = os.path.join(HERE, 'build_info.json')
+    try:
+        with open(info_path) as f:
+            info = json.load(f)
+    except (OSError, ValueError):
+        info = {'objects': {}}
+    for s in compiled:
+        info['objects'][s] = {'source_sha256_16': sha(os.path.join(CSRC, s)), 'compiled_at': time.strftime('%Y-%m-%d %H:%M:%S')}
+    hdrs = {h: sha(os.path.join(HERE, *h.split('/'))) for h in ('csrc/common.h', '../include/advmix_hip.h')}
+    info.update({'last_call': {'at': time.strftime('%Y-%m-%d %H:%M:%S'), 'compiled': compiled, 'linked': linked},
+                 'headers_sha256_16': hdrs, 'flags': FLAGS,
+                 'sources_now': {s: sha(os.path.join(CSRC, s)) for s in SOURCES},
+                 'library_sha256_16': sha(SO) if os.path.exists(SO) else None})
+    info['up_to_date'] = all(info['objects'].get(s, {}).get('source_sha256_16') == h for s, h in info['sources_now'].items())
+    try:
+        info['hipcc'] = subprocess.run([hipcc, '--version'], capture_output=True, text=True).stdout.strip().splitlines()[0]
+    except OSError:
+        pass
+    with open(info_path, 'w') as f:
+        json.dump(info, f, indent=1, sort_keys=True)
+    return info
 
 
 if __name__ == '__main__':

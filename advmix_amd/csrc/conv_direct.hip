@@ -631,7 +631,8 @@ struct ConvG {
 template <int A, int B> struct Max2 { static constexpr int v = A > B ? A : B; };
 
 template <int MODE, int KC, bool BT, bool EPI>
-__global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_group(ConvG g) {
+// (the BatchNorm-backward group holds the largest configuration's registers: two waves per SIMD is what fits)
+__global__ __launch_bounds__(256, (EPI && MODE == 1) ? 2 : 1) void conv_group(ConvG g) {
     constexpr int BSZ = Max2<Max2<Max2<Geo<1, 1, 4, 1, KC>::BSZ, Geo<1, 2, 4, 1, KC>::BSZ>::v,
                                   Max2<Geo<1, 1, 2, 2, KC>::BSZ, Geo<1, 1, 1, 1, KC>::BSZ>::v>::v,
                              Geo<1, 1, 2, 1, KC>::BSZ>::v;

@@ -88,29 +88,32 @@ struct MS {
 
 // LDS floats of one weight buffer (two are used) for a tile configuration - shared by the kernels that instantiate
 // conv_body (conv_direct: one configuration; conv_group: the largest of its configurations)
-template <int TM, int TN, int WM, int WN, int KC>
+template <int TM, int TN, int WM, int WN, int KC, int NW = 4>
 struct Geo {
-    static constexpr int WK = 4 / (WM * WN);
+    static constexpr int WK = NW / (WM * WN);
     static constexpr int RM = TM * (32 / MR), RN = TN * (32 / MR);
     static constexpr int BN = 32 * TN * WN;
     static constexpr int LDB = KC + 4;
-    static constexpr int RED = WK > 1 ? 4 * RM * RN * MS::NR * 64 : 0;
+    static constexpr int RED = WK > 1 ? NW * RM * RN * MS::NR * 64 : 0;
     static constexpr int BSZ = (WK * BN * LDB * 2 > RED) ? WK * BN * LDB : (RED + 1) / 2;
     static constexpr int TP = 36;                          // pitch of the epilogue's wave-private transposer (floats)
-    static constexpr int TSZ = 4 * (2 * MS::NR / WK) * TP; // four waves x the 2 * NR / WK rows a wave finishes x 32 columns
+    static constexpr int TSZ = NW * (2 * MS::NR / WK) * TP; // NW waves x the 2 * NR / WK rows a wave finishes x 32 columns
 };
 
 // One workgroup's tile (bx, by) of slice / phase bz.  ``Bs0``: 2 * Geo::BSZ floats of LDS, ``Ts0``: Geo::TSZ floats,
 // ``taptab``: 64 int4.
-template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT, bool EPI>
+template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT, bool EPI, int NW = 4>
 __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int by, const int bz, float* const Bs0,
                                           float* const Ts0, int4* const taptab) {
     // WK waves of the workgroup split K BETWEEN THEM (WM x WN x WK = 4 waves): the low-resolution layers have too
     // few output tiles to fill the chip; instead of slicing K across workgroups (SPLIT: zero-fill + fp32 atomics,
     // no fused epilogue) a 32x32 tile is computed by four waves that each take every fourth K chunk and meet
     // in LDS, so the fused BN / residual / activation / statistics epilogue still applies.
-    static_assert(WM * WN == 4 || WM * WN == 2 || WM * WN == 1, "WM x WN x WK = 4 waves");
-    constexpr int WK = 4 / (WM * WN);
+    // NW = 8 (round 3): two row tiles share ONE staging of the weight chunks - the low-resolution layers are bound by
+    // weight traffic (3x3 256->256: 2.36 MB of weights re-read by each of 48 row tiles) - and each is K-split over four waves.
+    static_assert(NW % (WM * WN) == 0 && (NW == 4 || NW == 8), "WM x WN x WK = NW waves");
+    constexpr int NT = 64 * NW;                // threads of the workgroup
+    constexpr int WK = NW / (WM * WN);
     static_assert(!(SPLIT && WK > 1), "one kind of K split at a time");
     constexpr int NSUB = 32 / MR;              // MFMA tiles per 32 rows / 32 columns
     constexpr int KL = 64 / MR;                // k-lanes: lanes that hold different k of the same row
@@ -119,11 +122,11 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
     constexpr int KQ = KC / (4 * KL);          // float4 k-groups per chunk (4 k per k-lane each)
     constexpr int LDB = KC + 4;
     constexpr int BCH = BN * KC / 4;           // float4 staging slots per chunk
-    constexpr int BSL = (BCH * WK + 255) / 256;
-    constexpr int RED = WK > 1 ? 4 * RM * RN * MS::NR * 64 : 0;           // floats of the cross-wave reduction (4 waves)
+    constexpr int BSL = (BCH * WK + NT - 1) / NT;
+    constexpr int RED = WK > 1 ? NW * RM * RN * MS::NR * 64 : 0;          // floats of the cross-wave reduction (all waves)
     constexpr int BSZ = (WK * BN * LDB * 2 > RED) ? WK * BN * LDB : (RED + 1) / 2;
 
-    static_assert(BSZ == Geo<TM, TN, WM, WN, KC>::BSZ, "Geo mirrors these constants");
+    static_assert(BSZ == Geo<TM, TN, WM, WN, KC, NW>::BSZ, "Geo mirrors these constants");
     float (*const Bs)[BSZ] = reinterpret_cast<float (*)[BSZ]>(Bs0);
 
     const int tid = threadIdx.x;
@@ -206,7 +209,7 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
     unsigned b_off[BSL];
 #pragma unroll
     for (int i = 0; i < BSL; ++i) {
-        int s = tid + 256 * i;
+        int s = tid + NT * i;
         b_kk[i] = s / BCH;                                  // which of the WK chunks of a step this slot stages
         s -= b_kk[i] * BCH;
         const bool in = b_kk[i] < WK;
@@ -256,7 +259,7 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
     // lane) costs 16 four-byte memory instructions per lane and operand; through a wave-private LDS transposer the same
     // bytes move as RSL / 4 sixteen-byte ones - the skeleton of this kernel is bound by vector-memory ISSUE, not bytes.
     constexpr int TQ = RSL / 4;
-    constexpr int TP = Geo<TM, TN, WM, WN, KC>::TP;
+    constexpr int TP = Geo<TM, TN, WM, WN, KC, NW>::TP;
     const bool t128 = !SPLIT && (p.Co & 3) == 0;           // uniform: rows of the output are 16-byte aligned
     int e_lane = lane;
     auto chunk_off = [&](int t, int u, int q, bool& valid) -> int {
@@ -357,7 +360,7 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
     auto stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < BSL; ++i)
-            if (tid + 256 * i < BCH * WK) {
+            if (tid + NT * i < BCH * WK) {
                 float* dst = &Bs[buf][b_kk[i] * (BN * LDB)];
                 if (!BT) {
                     *reinterpret_cast<f32x4*>(&dst[b_row[i] * LDB + b_k4[i]]) = Br[i];
@@ -602,19 +605,19 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
     }
 }
 
-template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT, bool EPI>
+template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT, bool EPI, int NW = 4>
 // (min 3 waves / SIMD for the BatchNorm-backward variants: left free, the register allocator spreads their three
 // prefetched epilogue operands over 254 VGPRs = one wave per SIMD; the other variants keep their 52-108)
-__global__ __launch_bounds__(256, (EPI && MODE == 1) ? 3 : 1) void conv_direct(ConvD p) {
-    __shared__ __attribute__((aligned(16))) float Bs[2 * Geo<TM, TN, WM, WN, KC>::BSZ];
-    __shared__ __attribute__((aligned(16))) float Ts[Geo<TM, TN, WM, WN, KC>::TSZ];
+__global__ __launch_bounds__(64 * NW, (EPI && MODE == 1 && NW == 4) ? 3 : 1) void conv_direct(ConvD p) {
+    __shared__ __attribute__((aligned(16))) float Bs[2 * Geo<TM, TN, WM, WN, KC, NW>::BSZ];
+    __shared__ __attribute__((aligned(16))) float Ts[Geo<TM, TN, WM, WN, KC, NW>::TSZ];
     __shared__ int4 taptab[64];
-    conv_body<TM, TN, WM, WN, KC, MODE, SPLIT, BT, EPI>(p, blockIdx.x, blockIdx.y, blockIdx.z, Bs, Ts, taptab);
+    conv_body<TM, TN, WM, WN, KC, MODE, SPLIT, BT, EPI, NW>(p, blockIdx.x, blockIdx.y, blockIdx.z, Bs, Ts, taptab);
 }
 
 // Tile configuration for a problem (the only place that decides it; advmix_conv_direct_config reports it).
 enum Cfg { CFG_128x32 = 1, CFG_128x64 = 2, CFG_64x64 = 3, CFG_64x64_GRID_SPLIT = 4, CFG_32x32_WAVE_SPLIT = 5,
-           CFG_64x32_WAVE_SPLIT2 = 6 };
+           CFG_64x32_WAVE_SPLIT2 = 6, CFG_64x32_K4_W8 = 7 };
 
 // Several problems of one kind (same MODE / KC / BT / EPI, stride 1, whole-K tiles) in ONE launch: block b belongs to
 // problem i with start[i] <= b < start[i + 1] and computes that problem's tile (b' % gx, b' / gx) with the problem's own
@@ -668,7 +671,7 @@ static Cfg pick_cfg(int64_t Mmax, int Co, int phases, int nch, int* nsplit) {
         return CFG_128x32;
     }
     static const int force_all = [] { const char* e = getenv("ADVMIX_CFG"); return e ? atoi(e) : 0; }();   // measurement aid
-    if (force_all == 2 || force_all == 3 || (force_all == 5 && nch >= 8) || (force_all == 6 && nch >= 4)) return (Cfg)force_all;
+    if (force_all == 2 || force_all == 3 || (force_all == 5 && nch >= 8) || (force_all == 6 && nch >= 4) || (force_all == 7 && nch >= 8)) return (Cfg)force_all;
     if ((int64_t)cdiv(Mmax, 128) * cdiv(Co, 64) * phases >= 512) return CFG_128x64;
     const int64_t b64 = (int64_t)cdiv(Mmax, 64) * cdiv(Co, 64) * phases;
     int ns = 1;
@@ -691,6 +694,11 @@ static Cfg pick_cfg(int64_t Mmax, int Co, int phases, int nch, int* nsplit) {
     // 34.8 us but the separate statistics / BN pass and the memset disappear; with fewer tiles (U-Net
     // bottleneck, 4x4 512->512 @4x3: 84 vs 59 us) the grid-level split wins.
     const int64_t b32 = (int64_t)cdiv(Mmax, 32) * cdiv(Co, 32) * phases;
+    // Between one and two 32 x 32 workgroups per CU (3x3 256->256 @8x6, B = 32: 384) the layer is bound by its weights -
+    // 2.36 MB re-staged by each of 48 row tiles: eight-wave workgroups whose two row tiles share ONE staging of every weight
+    // chunk (192 workgroups, the same 1,536 waves): forward + sums 36.2 -> 34.2 us, input gradient + BatchNorm backward
+    // 40.0 -> 36.6 (profiles/r03_exp_tiles_8waves.log); with 768 tiles (128->128 @16x12) the four-wave form stays ahead.
+    if (advmix_opts().ksplit_wg && b32 >= 256 && b32 < 512 && nch >= 8 && Mmax >= 64) return CFG_64x32_K4_W8;
     if (advmix_opts().ksplit_wg && b32 >= 256) return CFG_32x32_WAVE_SPLIT;
     if (advmix_opts().deterministic)                       // the grid split adds with fp32 atomics: order varies run to run
         return advmix_opts().ksplit_wg ? CFG_32x32_WAVE_SPLIT : CFG_64x64;
@@ -709,10 +717,11 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
     static_assert(!EPI || (MODE == 0 && !BT) || (MODE == 1 && BT), "fused epilogues: forward gather, or BN-backward on the k-major transposed gather");
     int phases, nch, ns;
     problem_shape(MODE, p.Ci, p.R, p.S, p.stride, KC, &phases, &nch);
-#define LAUNCHD(TM_, TN_, WM_, WN_, SP_)                                                          \
+#define LAUNCHD(TM_, TN_, WM_, WN_, SP_) LAUNCHW(TM_, TN_, WM_, WN_, SP_, 4)
+#define LAUNCHW(TM_, TN_, WM_, WN_, SP_, NW_)                                                     \
     do {                                                                                          \
         dim3 g(cdiv(Mmax, 32 * TM_ * WM_), cdiv(p.Co, 32 * TN_ * WN_), phases * p.nsplit);        \
-        hipLaunchKernelGGL((conv_direct<TM_, TN_, WM_, WN_, KC, MODE, SP_, BT, (EPI && !SP_)>), g, dim3(256), 0, st, p); \
+        hipLaunchKernelGGL((conv_direct<TM_, TN_, WM_, WN_, KC, MODE, SP_, BT, (EPI && !SP_), NW_>), g, dim3(64 * NW_), 0, st, p); \
         if (advmix_opts().trace_shapes) {                                                         \
             char nm[96];                                                                          \
             snprintf(nm, sizeof nm, "conv_direct<%d, %d, %d, %d, %d, %d, %s, %s, %s>", TM_, TN_, WM_, WN_, KC, MODE, \
@@ -737,6 +746,7 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
         case CFG_64x64: LAUNCHD(1, 1, 2, 2, false); break;
         case CFG_32x32_WAVE_SPLIT: LAUNCHD(1, 1, 1, 1, false); break;      // four waves share K in the workgroup
         case CFG_64x32_WAVE_SPLIT2: LAUNCHD(1, 1, 2, 1, false); break;     // two wave pairs share K
+        case CFG_64x32_K4_W8: LAUNCHW(1, 1, 2, 1, false, 8); break;       // eight waves: two row tiles x four-way K split, weights staged once
         case CFG_64x64_GRID_SPLIT:                                         // K across gridDim.z + atomics
             if (p.bn_gamma || (MODE == 0 && p.res) || p.act || p.stats || p.bnb_c) return -2;   // fused epilogue needs whole-K tiles
             p.nsplit = ns;
@@ -746,6 +756,7 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
             break;
     }
 #undef LAUNCHD
+#undef LAUNCHW
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }
@@ -847,7 +858,9 @@ int advmix_conv_direct_group(int mode, int bt, int n, ConvProb* pr, hipStream_t 
         if (bnb != bnb0) return -1;
         int phases, nch, ns;
         direct::problem_shape(mode, q.Ci, q.R, q.S, q.stride, KC, &phases, &nch);
-        const direct::Cfg c = direct::pick_cfg(q.Mmax, q.Co, phases, nch, &ns);
+        direct::Cfg c = direct::pick_cfg(q.Mmax, q.Co, phases, nch, &ns);
+        if (c == direct::CFG_64x32_K4_W8) c = direct::CFG_32x32_WAVE_SPLIT;   // (a group's workgroups have four waves: the same
+                                                                               //  K split per row tile, bit-identical outputs)
         if (phases != 1 || c == direct::CFG_64x64_GRID_SPLIT) return -1;
         int bm, bn, wk;
         switch (c) {

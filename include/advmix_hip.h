@@ -119,7 +119,8 @@ int advmix_deconv4x4s2_narrow(const float* x, const float* w, const float* bias,
 
 /* Which tile configuration the second-generation conv kernel picks (introspection for tests / tuning):
  * 1 = 128x32, 2 = 128x64, 3 = 64x64, 4 = 64x64 + K split across the grid (atomics), 5 = 32x32 + K split between
- * the four waves of a workgroup, 6 = 64x32 + K split between two wave pairs; -1 = not served.  mode 0: forward, (Ho, Wo) = output size, Ci = reduction channels;
+ * the four waves of a workgroup, 6 = 64x32 + K split between two wave pairs, 7 = 64x32 with eight waves (two row tiles
+ * sharing the weight staging, each K-split four ways); -1 = not served.  mode 0: forward, (Ho, Wo) = output size, Ci = reduction channels;
  * mode 1: input gradient / transposed conv, (Ho, Wo) = the LARGER (gradient) side, Ci = channels reduced over. */
 int advmix_conv_direct_config(int mode, int N, int Ho, int Wo, int Ci, int Co, int R, int S, int stride);
 

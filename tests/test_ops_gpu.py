@@ -57,7 +57,8 @@ CONV_CASES = [
     (2, 64, 20, 24, 48, 3, 1, 1, True),     # 2 channel chunks, ragged tiles, Co % 32 != 0
     (1, 32, 9, 17, 32, 3, 1, 1, False),
     (2, 96, 16, 16, 64, 3, 1, 1, False),
-    (32, 256, 8, 6, 256, 3, 1, 1, True),    # HRNet's lowest branch at the bench batch: 32x32 tiles, K split between waves
+    (32, 256, 8, 6, 256, 3, 1, 1, True),    # HRNet's lowest branch at the bench batch: eight-wave workgroups (two row tiles, K split four ways)
+    (32, 128, 16, 12, 128, 3, 1, 1, False), # HRNet's third branch at the bench batch: 32x32 tiles, K split between four waves
     (16, 128, 32, 24, 128, 3, 2, 1, False), # stride-2 fuse conv: wave-split forward, phase-decomposed input gradient
     (8, 128, 64, 64, 128, 1, 1, 0, True),   # enough rows for the 128x64 tile in both directions
     (32, 64, 32, 24, 64, 3, 1, 1, False),   # HRNet's second branch at the bench batch: 64x32 tiles, K split between wave pairs
@@ -188,7 +189,9 @@ def test_grouped_conv_launch_equals_single_launches(mode):
         if mode in ('fwd_stats', 'dgrad_bnb'):
             a = s0[:2 * t['C'] * n0].view(2, t['C'], n0).sum(-1)
             b = s1[:2 * t['C'] * n1].view(2, t['C'], n1).sum(-1)
-            assert n0 > 0 and n1 > 0 and torch.allclose(a, b, rtol=1e-9, atol=1e-7)
+            # (fp32 per-workgroup partial sums: a group keeps four-wave workgroups where the single launch takes the
+            #  eight-wave form - one row tile per workgroup instead of two - so the fp64 totals differ by fp32 rounding)
+            assert n0 > 0 and n1 > 0 and torch.allclose(a, b, rtol=2e-6, atol=1e-5)
 
 
 def test_conv_tile_configuration_table():
@@ -203,9 +206,10 @@ def test_conv_tile_configuration_table():
     assert cfgq(1, 32, 32, 24, 64, 64, 3, 3, 1) == 6
     assert cfgq(0, 64, 32, 24, 64, 64, 3, 3, 1) == 3          # 64x64 (768 of them)
     assert cfgq(0, 8, 64, 64, 128, 128, 1, 1, 1) == 2 and cfgq(1, 8, 64, 64, 128, 128, 1, 1, 1) == 2   # CONV_CASES[-1]
-    assert cfgq(0, 32, 8, 6, 256, 256, 3, 3, 1) == 5          # wave split, forward
-    assert cfgq(1, 32, 8, 6, 256, 256, 3, 3, 1) == 5          # wave split, input gradient
-    assert cfgq(0, 16, 16, 12, 128, 128, 3, 3, 2) == 5        # the stride-2 case of CONV_CASES (output 16x12)
+    assert cfgq(0, 32, 8, 6, 256, 256, 3, 3, 1) == 7          # eight waves: two row tiles share the weight staging, forward
+    assert cfgq(1, 32, 8, 6, 256, 256, 3, 3, 1) == 7          # ... and input gradient (384 tiles of 32x32: 1.5 per CU)
+    assert cfgq(0, 32, 16, 12, 128, 128, 3, 3, 1) == 5 and cfgq(1, 32, 16, 12, 128, 128, 3, 3, 1) == 5   # 768 tiles: four-wave K split
+    assert cfgq(0, 16, 16, 12, 128, 128, 3, 3, 2) == 7        # the stride-2 case of CONV_CASES (output 16x12, 384 tiles)
     assert cfgq(0, 2, 8, 6, 256, 256, 3, 3, 1) == 4           # too few tiles: grid split + atomics
     assert cfgq(0, 32, 4, 3, 512, 512, 4, 4, 2) == 4          # U-Net bottleneck
     ops.set_option('ksplit_wg', 0)

@@ -43,6 +43,7 @@ SIGNATURES = {
     'advmix_norm_apply': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _i, _p],
     'advmix_norm_apply_slots': [_p, _p, _i, _l, _i, _f, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _p],
     'advmix_norm_bwd_apply_slots': [_p, _p, _p, _p, _p, _p, _i, _l, _i, _p, _p, _p, _p],
+    'advmix_stats_fold': [_p, _i, _i, _p, _p],
     'advmix_bn_eval': [_p, _p, _p, _p, _p, _f, _p, _p, _l, _i, _i, _p],
     'advmix_norm_bwd': [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _p],
     'advmix_act_copy': [_p, _i, _p, _i, _l, _i, _i, _p],

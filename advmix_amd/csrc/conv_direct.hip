@@ -49,6 +49,8 @@ struct ConvD {
     // (dy, y, c) and its finalize launch disappear (norm.hip: norm_bwd_apply_slots consumes the slots).
     const float *bnb_y, *bnb_c, *bnb_mean, *bnb_invstd;
     int bnb_act;
+    int stats_tiles;        // 1 (deterministic mode): every workgroup STORES its column sums in a slot of its own -
+                            // stats[2][Co][stats_nbg] with stats_nbg = row tiles x phases - instead of fp64 atomics
     int xcd_remap;          // 1: row-tile order remapped so that each XCD (and its L2) owns a CONTIGUOUS range of row tiles
 };
 
@@ -598,9 +600,15 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
             }
             // the per-workgroup sums are folded onto stats_nbg slots per column (768 workgroups on the
             // dominant shape -> 12 atomics per address), which norm_finalize reduces and re-zeroes
-            const int pb = bx % p.stats_nbg;
-            atomicAdd(p.stats + (int64_t)(n0 + tid) * p.stats_nbg + pb, d1);
-            atomicAdd(p.stats + ((int64_t)p.Co + n0 + tid) * p.stats_nbg + pb, d2);
+            if (p.stats_tiles) {                            // ordered later by advmix_stats_fold: bit-reproducible
+                const int64_t pb = (int64_t)bz * gridDim.x + bx;
+                p.stats[(int64_t)(n0 + tid) * p.stats_nbg + pb] = d1;
+                p.stats[((int64_t)p.Co + n0 + tid) * p.stats_nbg + pb] = d2;
+            } else {
+                const int pb = bx % p.stats_nbg;
+                atomicAdd(p.stats + (int64_t)(n0 + tid) * p.stats_nbg + pb, d1);
+                atomicAdd(p.stats + ((int64_t)p.Co + n0 + tid) * p.stats_nbg + pb, d2);
+            }
         }
     }
 }
@@ -713,7 +721,7 @@ static void problem_shape(int mode, int Ci, int R, int S, int stride, int KC, in
 }
 
 template <int MODE, int KC, bool BT, bool EPI>
-int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
+int launch(ConvD& p, int64_t Mmax, hipStream_t st, int64_t stats_cap) {
     static_assert(!EPI || (MODE == 0 && !BT) || (MODE == 1 && BT), "fused epilogues: forward gather, or BN-backward on the k-major transposed gather");
     int phases, nch, ns;
     problem_shape(MODE, p.Ci, p.R, p.S, p.stride, KC, &phases, &nch);
@@ -721,6 +729,10 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st) {
 #define LAUNCHW(TM_, TN_, WM_, WN_, SP_, NW_)                                                     \
     do {                                                                                          \
         dim3 g(cdiv(Mmax, 32 * TM_ * WM_), cdiv(p.Co, 32 * TN_ * WN_), phases * p.nsplit);        \
+        if (p.stats_tiles) {                               /* one slot per (phase, row tile); capacity checked here */ \
+            if ((int64_t)g.x * g.z > stats_cap) return -2;                                        \
+            p.stats_nbg = (int)(g.x * g.z);                                                       \
+        }                                                                                         \
         hipLaunchKernelGGL((conv_direct<TM_, TN_, WM_, WN_, KC, MODE, SP_, BT, (EPI && !SP_), NW_>), g, dim3(64 * NW_), 0, st, p); \
         if (advmix_opts().trace_shapes) {                                                         \
             char nm[96];                                                                          \
@@ -779,12 +791,14 @@ static int prepare(int mode, const float* x, const float* w, const float* bias, 
     if (xb >= 0x7fffffffLL || wb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return -1;
     direct::ConvD p{x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, (int)xb, (int)wb, (int)yb, 1,
                     nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0,
-                    nullptr, nullptr, nullptr, nullptr, 0, 0};
+                    nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     static const int xcd_remap = [] { const char* e = getenv("ADVMIX_XCD_REMAP"); return e ? atoi(e) : 1; }();
     p.xcd_remap = xcd_remap;
     // Slots per channel the workgroup sums are folded onto: many row blocks hammering few addresses serialise the
     // fp64 atomics at the memory side (3x3 32->32 @64x48, 768 workgroups: 30.8 us with 16 slots, 23.1 with 64), while
     // every consumer workgroup has to reduce all of them again - 64 only where the contention is real.
+    // *stats_nbg < 0 (deterministic mode): -capacity - one slot per row tile, plain stores (see ConvD::stats_tiles)
+    const bool tiles = epi && epi->stats && stats_nbg && *stats_nbg < 0;
     int ns = stats_nbg && *stats_nbg > 0 ? *stats_nbg : advmix_opts().stat_slots;
     if (ns <= 0) {                                         // (longer kernels spread their atomics over more time:
         int ph_, nch_;                                     //  HRNet-W48 384x288 is faster with fewer slots to re-read)
@@ -793,6 +807,7 @@ static int prepare(int mode, const float* x, const float* w, const float* bias, 
     }
     if (ns > 64 || (ns & (ns - 1))) ns = 16;
     p.stats_nbg = ns;
+    p.stats_tiles = tiles ? 1 : 0;
     bool bnb = false;
     if (epi) {
         p.bn_gamma = epi->gamma; p.bn_beta = epi->beta; p.bn_rm = epi->rm; p.bn_rv = epi->rv; p.res = epi->res;
@@ -815,10 +830,11 @@ int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const 
                                 int* stats_nbg) {
     direct::ConvD p;
     bool bnb = false;
+    const int64_t stats_cap = stats_nbg && *stats_nbg < 0 ? -(int64_t)*stats_nbg : 0;
     int rc = prepare(mode, x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, Mmax, bt, epi, stats_nbg, &p, &bnb);
     if (rc < 0) return rc;
 #define LAUNCH_KC(MODE_, BT_, EPI_)                                                             \
-    (Ci % 32 == 0 ? direct::launch<MODE_, 32, BT_, EPI_>(p, Mmax, st) : direct::launch<MODE_, 16, BT_, EPI_>(p, Mmax, st))
+    (Ci % 32 == 0 ? direct::launch<MODE_, 32, BT_, EPI_>(p, Mmax, st, stats_cap) : direct::launch<MODE_, 16, BT_, EPI_>(p, Mmax, st, stats_cap))
     if (bt && bnb)
         rc = LAUNCH_KC(1, true, true);
     else if (bt)
@@ -871,6 +887,7 @@ int advmix_conv_direct_group(int mode, int bt, int n, ConvProb* pr, hipStream_t 
             default: bm = 64; bn = 32; wk = 2; break;      // CFG_64x32_WAVE_SPLIT2
         }
         d.nsplit = 1;
+        if (d.stats_tiles) return -1;                      // (deterministic per-tile slots: single launches only)
         d.xcd_remap = 0;                                  // (block ranges per problem: the launch-order argument does not hold)
         g.p[i] = d;
         g.cfg[i] = (int)c;

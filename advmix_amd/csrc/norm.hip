@@ -560,6 +560,21 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_slots_kernel(
     }
 }
 
+// Deterministic mode: the conv epilogues STORE one partial per row tile (stats[2][C][cnt], conv_direct.hip
+// ConvD::stats_tiles); one wave per (statistic, channel) adds them in a fixed order - lane l takes l, l + 64, ... in
+// sequence, then a fixed butterfly - and writes the total as slot 0 of the ns = 1 layout [2][C][1] the consumers read.
+__global__ __launch_bounds__(256) void stats_fold_kernel(const double* __restrict__ part, int cnt, int pairs,
+                                                         double* __restrict__ out) {
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pair >= pairs) return;
+    const double* src = part + (int64_t)pair * cnt;
+    double acc = 0.0;
+    for (int i = lane; i < cnt; i += 64) acc += src[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) out[pair] = acc;
+}
+
 // grid for the slot kernels: (row blocks, channel tiles); ~2048 workgroups, at least 4 row-iterations each
 static dim3 slot_grid(int64_t rows, int C) {
     const int nct = cdiv(C, SLOT_CT);
@@ -716,6 +731,16 @@ extern "C" int advmix_norm_bwd_apply_slots(const float* g, const float* c, const
     if (!slots_ok(ns, C)) return ADVMIX_EINVAL;
     hipLaunchKernelGGL(norm_bwd_apply_slots_kernel, slot_grid(rows, C), dim3(256), 0, (hipStream_t)stream, g, c, mean,
                        invstd, gamma, slots, ns, rows, C, dx, dgamma, dbeta);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+// Deterministic mode: fold the per-tile partial sums a conv epilogue stored (partials[2][C][count], see
+// advmix_conv_fwd_ex / advmix_conv_tr_w_bnb with *stats_nbg = -capacity) into slots_out[2][C][1] in a fixed order.
+extern "C" int advmix_stats_fold(const double* partials, int count, int C, double* slots_out, void* stream) {
+    if (!partials || !slots_out || count <= 0 || C <= 0) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(stats_fold_kernel, dim3(cdiv(2 * C, 4)), dim3(256), 0, (hipStream_t)stream, partials, count, 2 * C,
+                       slots_out);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }

@@ -202,8 +202,11 @@ def set_deterministic(on=True):
     """Bit-reproducible mode: every accumulation whose ORDER varies run to run takes its ordered
     form - weight / bias gradients and the loss sum store per-slice partials and add them in slice order
     (advmix_conv_wgrad_det, advmix_bias_grad_det, advmix_joints_loss_det) instead of fp32 atomics; convolutions never
-    split K across the grid; BatchNorm statistics use the block-partial kernels (norm_stats / norm_bwd) instead of the
-    fp64 atomics of the conv epilogues.  Slower (more launches, no epilogue fusion); same results to rounding."""
+    split K across the grid; the conv epilogues STORE one BatchNorm partial per row tile instead of adding fp64 atomics
+    and advmix_stats_fold adds them in a fixed order (round 3: the epilogue fusion stays; rounds 1-2 fell back to the
+    block-partial kernels and an extra pass over the tensor).  The fuse layers' sums (FuseSum.bwd) and shapes the
+    epilogues do not serve take the block-partial kernels.  Slower (a fold launch per BatchNorm, two launches per weight
+    gradient); same results to rounding."""
     global DETERMINISTIC
     DETERMINISTIC = bool(on)
     call('advmix_set_option', b'deterministic', 1 if on else 0)
@@ -233,7 +236,14 @@ def _bias_grad(st, lane, dy, bias, rows, C):
 COUNTERS = {'bnb': 0}       # launches whose epilogue carried a BatchNorm backward (tests assert the path is taken)
 
 
-def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to=None, bnb=None):
+def _det_stats(C, device, lane):
+    """Deterministic mode: where a conv epilogue stores its per-tile partial sums (the lane's scratch; stream-ordered
+    with the fold that follows) and how many tiles fit per (statistic, channel)."""
+    ws = _workspace(device, 0, lane)
+    return ws, WS_BYTES // 8 // (2 * C)
+
+
+def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to=None, bnb=None, lane=0):
     """Input gradient of a conv (+ ``add_to``, another gradient of the same input: summed in the kernel's
     epilogue on the conv_direct path, by advmix_add otherwise).
 
@@ -248,12 +258,19 @@ def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_
         if bnb is not None and BNB_FUSED:
             if tuple(bnb['c'].shape) != tuple(dx.shape) or bnb['c'].stride() != dx.stride():
                 raise RuntimeError('advmix_amd: BatchNorm-backward epilogue on a differently laid out tensor')
-            nsv = ctypes.c_int(STAT_SLOTS_ASK)
+            if DETERMINISTIC:                               # per-tile partials (plain stores) + an ordered fold: no atomics
+                ws, cap = _det_stats(Ci, x.device, lane)
+                nsv, target = ctypes.c_int(-cap), _p(ws)
+            else:
+                nsv, target = ctypes.c_int(STAT_SLOTS_ASK), bnb['slots']
             rc = lib.advmix_conv_tr_w_bnb(_p(dy), _p(w), _p(add_to), _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride,
                                           pad, _p(bnb['y']) if bnb['act'] != ACT_NONE else None, _p(bnb['c']),
-                                          _p(bnb['mean']), _p(bnb['invstd']), bnb['act'], bnb['slots'],
+                                          _p(bnb['mean']), _p(bnb['invstd']), bnb['act'], target,
                                           ctypes.byref(nsv), st)
             if rc == 0:
+                if DETERMINISTIC:
+                    call('advmix_stats_fold', target, nsv.value, Ci, bnb['slots'], st)
+                    nsv.value = 1
                 bnb['done'] = nsv.value
                 COUNTERS['bnb'] += 1
                 return dx
@@ -307,7 +324,7 @@ class Conv:
         Ho, Wo = dy.shape[2], dy.shape[3]
         dx = None
         if needs[0]:
-            dx = _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to, bnb)
+            dx = _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to, bnb, lane)
         if needs[1]:
             _wgrad(st, lane, dy, x, w, (B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad))
         if bias is not None and needs[2]:
@@ -460,16 +477,23 @@ class ConvBN:
         mean = torch.empty(Co, device=x.device, dtype=torch.float32)
         invstd = torch.empty(Co, device=x.device, dtype=torch.float32)
         rc = 1
-        if fused_ok and not DETERMINISTIC:                  # (deterministic mode: block-partial statistics, no fp64 atomics)
+        if fused_ok:
             if arena is not None and arena.t is not None:
                 slots = arena.ptr(fwd_off)
             else:                                           # functional use outside a network: private slots,
                 tmp = keep(torch.empty(2 * Co * STAT_SLOTS, device=x.device, dtype=torch.float64))
                 call('advmix_fill', _p(tmp), 0.0, 2 * tmp.numel(), st)     # zeroed on THIS member's stream
                 slots = _p(tmp)
-            nbg = ctypes.c_int(STAT_SLOTS_ASK)
+            if DETERMINISTIC:                               # no fp64 atomics: the epilogue stores one partial per row tile
+                ws, cap = _det_stats(Co, x.device, lane)    # in the lane's scratch, an ordered fold leaves the totals in
+                nbg, target = ctypes.c_int(-cap), _p(ws)    # the layer's slots (ns = 1) - no extra pass over c
+            else:
+                nbg, target = ctypes.c_int(STAT_SLOTS_ASK), slots
             rc = lib.advmix_conv_fwd_ex(_p(x), _p(w), None, _p(c), *geom, None, None, None, None, 0.0, None, 0,
-                                        slots, ctypes.byref(nbg), st)
+                                        target, ctypes.byref(nbg), st)
+            if rc == 0 and DETERMINISTIC:
+                call('advmix_stats_fold', target, nbg.value, Co, slots, st)
+                nbg.value = 1
             if rc == 0:
                 rc2 = lib.advmix_norm_apply_slots(_p(c), slots, nbg.value, rows, Co, eps, _p(gamma), _p(beta), _p(res),
                                                   _p(y), act, _p(mean), _p(invstd), _p(rmean), _p(rvar), _p(nbt),
@@ -545,7 +569,7 @@ class ConvBN:
                  _p(ws), st)
         dx = None
         if needs[0]:
-            dx = _conv_dgrad(st, dc, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to, bnb)
+            dx = _conv_dgrad(st, dc, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to, bnb, lane)
         if needs[1]:
             _wgrad(st, lane, dc, x, w, (B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad))
         return dx, None, None, None, None, None, None, dres
@@ -886,7 +910,7 @@ class Chain:
     @staticmethod
     def bwd(st, lane, saved, rec, meta, grads, needs):
         subs, ext_slots, out_slots = meta[:3]
-        plan = (meta[3] if len(meta) > 3 else Chain.bnb_plan(subs)) if (BNB_FUSED and not DETERMINISTIC) else {}
+        plan = (meta[3] if len(meta) > 3 else Chain.bnb_plan(subs)) if BNB_FUSED else {}
         grad, pre = {}, {}
         for s_, g in zip(out_slots, grads):
             if g is not None:

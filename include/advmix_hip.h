@@ -204,6 +204,12 @@ int advmix_norm_apply_slots(const float* c, const double* slots, int ns, int64_t
 int advmix_norm_bwd_apply_slots(const float* g, const float* c, const float* mean, const float* invstd,
                                 const float* gamma, const double* slots, int ns, int64_t rows, int C,
                                 float* dx, float* dgamma, float* dbeta, void* stream);
+
+/* Deterministic statistics (bit-reproducible runs, ops.set_deterministic): call advmix_conv_fwd_ex / advmix_conv_tr_w_bnb
+ * with *stats_nbg = -capacity; the epilogue then STORES one partial per row tile, stats[2][C][count] (no atomics), and
+ * returns count in *stats_nbg (ADVMIX_EINVAL, nothing launched, if count > capacity).  advmix_stats_fold adds the partials
+ * in a fixed order into slots_out[2][C][1], which advmix_norm_apply_slots / advmix_norm_bwd_apply_slots read with ns = 1. */
+int advmix_stats_fold(const double* partials, int count, int C, double* slots_out, void* stream);
 /* y = act((x - mean)*invstd*gamma + beta + residual); gamma/beta/residual may be NULL.
  * y rows have stride ldy floats (>= C) so the result can land in a channel slice. */
 int advmix_norm_apply(const float* x, const float* mean, const float* invstd,

@@ -505,6 +505,68 @@ def test_chain_bn_backward_fused_into_dgrad_epilogue(frozen):
         assert frac >= 0.999, (k, frac)                       # (a flipped ReLU mask moves isolated elements)
 
 
+def test_deterministic_mode_keeps_the_statistics_epilogues():
+    """ops.set_deterministic(True) (round 3): the conv epilogues still produce the BatchNorm sums - forward column sums and
+    the BatchNorm-backward sums of the input-gradient conv - but as one STORED partial per row tile, folded in a fixed
+    order (advmix_stats_fold) instead of fp64 atomics: two runs bit-identical in every gradient, the epilogue path taken,
+    results equal to the default (atomic) mode to rounding and to a float64 torch interpretation of the plan."""
+    import advmix_amd.ops as ops
+    from advmix_amd.plan import Plan, PlanNet
+    P = Plan(16)
+    P.tag = 'all'
+    x = P.conv_bn(0, 'stem', 'stem_bn', 32, 3, 1, 1, 1)
+    x = P.block('BASIC', x, 'b0', 32)
+    x = P.block('BOTTLENECK', x, 'b1', 16)
+    x = P.block('BASIC', x, 'b2', 64, 2)
+    P.out = P.conv(x, 'final', 8, 1, 1, 0, bias=True)
+    torch.manual_seed(9)
+    net = PlanNet(P)
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if p.dim() == 1 and k.endswith('.weight'):
+                p.uniform_(0.6, 1.4)
+            elif p.dim() == 1:
+                p.normal_(0, 0.2)
+    net = net.to(dev()).train()
+    sd = {k: v.detach().double().cpu().requires_grad_(v.is_floating_point()) for k, v in net.state_dict().items()}
+    B, H, W = 8, 24, 16
+    xin, dy = rnd(B, 16, H, W, seed=41), rnd(B, 8, H // 2, W // 2, seed=42)
+    xr = xin.clone().requires_grad_(True)
+    _plan_reference(P, sd, xr).backward(dy)
+
+    def run():
+        for p in net.parameters():
+            p.grad = None
+        ops.COUNTERS['bnb'] = 0
+        xg = cl(xin).requires_grad_(True)
+        y = net(xg)
+        y.backward(cl(dy))
+        torch.cuda.synchronize()
+        out = {'x': xg.grad.detach().clone(), 'y': y.detach().clone()}
+        out.update({k: p.grad.detach().clone() for k, p in net.named_parameters()})
+        out.update({k: b.detach().clone() for k, b in net.named_buffers() if b.is_floating_point()})
+        return out, ops.COUNTERS['bnb']
+    try:
+        ops.set_deterministic(True)
+        (a, na), (b, nb) = run(), run()
+    finally:
+        ops.set_deterministic(False)
+    assert na >= 5 and nb == na, (na, nb)                      # the BatchNorm-backward epilogue is taken in deterministic mode
+    for k in a:
+        if 'running_' in k:
+            continue                                           # (momentum updates: two forwards move them twice)
+        assert torch.equal(a[k], b[k]), k                      # bit for bit
+    c, _ = run()                                               # default mode
+    for k in a:
+        if 'running_' in k:
+            continue
+        ref = c[k].double().cpu()
+        scale = max(float(ref.abs().max()), 1e-9)
+        frac = float(((a[k].double().cpu() - ref).abs() <= 1e-3 * scale).double().mean())
+        assert frac >= 1 - max(0.01, 2.0 / ref.numel()), (k, frac)
+    check('y', a['y'], _plan_reference(P, sd, xin.clone()), 2e-4)
+
+
 @pytest.mark.parametrize('shape', [(4, 32, 16, 12, (0, 0, 1, 2)), (2, 64, 8, 8, (1, 0, 0, 0)), (3, 128, 8, 4, (2, 1, 0)),
                                    (2, 256, 4, 4, (0,)), (2, 32, 8, 8, (0, 3))])
 def test_fuse_sum_backward_one_launch_with_bn_backward_sums(shape):

@@ -154,8 +154,14 @@ __global__ __launch_bounds__(1024) void autoaug_kernel(const uint8_t* __restrict
     const uint8_t* src = base + b * n;
     int code[2] = {ops[b * 4], ops[b * 4 + 2]}, par[2] = {ops[b * 4 + 1], ops[b * 4 + 3]};
     const int nops = (code[0] != AA_NONE) + (code[1] != AA_NONE);
+    const bool vec4 = (n & 3) == 0 && ((((uintptr_t)base | (uintptr_t)tmp | (uintptr_t)out)) & 3) == 0;   // (b * n keeps the alignment)
     if (nops == 0) {                                        // neither operation fired: the view is the crop itself
-        for (int64_t i = tid; i < n; i += nt) out[b * n + i] = src[i];
+        if (vec4) {
+            for (int64_t i = (int64_t)tid * 4; i < n; i += (int64_t)nt * 4)
+                *reinterpret_cast<uint32_t*>(out + b * n + i) = *reinterpret_cast<const uint32_t*>(src + i);
+        } else {
+            for (int64_t i = tid; i < n; i += nt) out[b * n + i] = src[i];
+        }
         return;
     }
     int done = 0;
@@ -193,7 +199,16 @@ __global__ __launch_bounds__(1024) void autoaug_kernel(const uint8_t* __restrict
             if (code[k] == AA_EQUALIZE) {
                 for (int i = tid; i < 768; i += nt) hist[i >> 8][i & 255] = 0;
                 __syncthreads();
-                for (int64_t i = tid; i < n; i += nt) atomicAdd(&hist[i % 3][src[i]], 1u);
+                if (vec4) {                                 // four bytes per load
+                    for (int64_t i = (int64_t)tid * 4; i < n; i += (int64_t)nt * 4) {
+                        const uint32_t w4 = *reinterpret_cast<const uint32_t*>(src + i);
+                        const int c0 = (int)(i % 3);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) atomicAdd(&hist[(c0 + j) % 3][(w4 >> (8 * j)) & 255u], 1u);
+                    }
+                } else {
+                    for (int64_t i = tid; i < n; i += nt) atomicAdd(&hist[i % 3][src[i]], 1u);
+                }
                 __syncthreads();
                 if (tid < 3) {                              // 256 serial steps per band: nothing next to the passes over the image
                     unsigned total = 0, last = 0;
@@ -215,7 +230,18 @@ __global__ __launch_bounds__(1024) void autoaug_kernel(const uint8_t* __restrict
                 lut[0][tid] = lut[1][tid] = lut[2][tid] = (uint8_t)v;
             }
             __syncthreads();
-            for (int64_t i = tid; i < n; i += nt) dst[i] = lut[i % 3][src[i]];
+            if (vec4) {
+                for (int64_t i = (int64_t)tid * 4; i < n; i += (int64_t)nt * 4) {
+                    const uint32_t w4 = *reinterpret_cast<const uint32_t*>(src + i);
+                    const int c0 = (int)(i % 3);
+                    uint32_t o = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o |= (uint32_t)lut[(c0 + j) % 3][(w4 >> (8 * j)) & 255u] << (8 * j);
+                    *reinterpret_cast<uint32_t*>(dst + i) = o;
+                }
+            } else {
+                for (int64_t i = tid; i < n; i += nt) dst[i] = lut[i % 3][src[i]];
+            }
         }
         ++done;
         src = dst;

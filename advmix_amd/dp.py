@@ -21,6 +21,10 @@ class GradSync:
         self._side = None
         self.pieces = 3             # the backward pass is cut into this many pieces per network (see reduce_async)
         self._cuts = {}
+        # RCCL ("nccl") averages in the collective; any other backend (gloo: the CPU tests, and the two-ranks-on-one-GPU
+        # test of the whole path) sums and scales
+        self._avg = self.world > 1 and dist.get_backend(group) == 'nccl' or (self.world == 1 and force and
+                                                                            dist.is_initialized() and dist.get_backend(group) == 'nccl')
 
     @property
     def active(self):
@@ -46,10 +50,18 @@ class GradSync:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 for b in range(0, hi - lo, self.bucket_elems):
-                    dist.all_reduce(chunk[b:b + self.bucket_elems], op=dist.ReduceOp.AVG, group=self.group)
+                    self._mean_(chunk[b:b + self.bucket_elems])
         else:
             dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
             chunk.div_(self.world)
+
+    def _mean_(self, t):
+        """In-place mean over the ranks of a device tensor, on the current (side) stream."""
+        if self._avg:
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            t.mul_(1.0 / self.world)
 
     def finish(self):
         """The current stream waits for every reduce_async issued so far."""
@@ -74,8 +86,7 @@ class GradSync:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 for lo in range(0, n, self.bucket_elems):
-                    chunk = flat[lo:min(n, lo + self.bucket_elems)]
-                    dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group)
+                    self._mean_(flat[lo:min(n, lo + self.bucket_elems)])
             cur.wait_stream(side)
         else:
             for lo in range(0, n, self.bucket_elems):

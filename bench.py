@@ -541,12 +541,15 @@ def main():
 
     import torch.distributed as dist
     backend = os.environ.get('ADVMIX_BENCH_BACKEND', 'nccl')      # 'gloo' only for --path rendezvous (CPU launcher test)
+    # ADVMIX_BENCH_SHARE_GPU=1: a FUNCTIONAL run of the N-rank path on a box with fewer GPUs - every rank uses cuda:0 and the
+    # gradient exchange goes over gloo (RCCL refuses two ranks on one device).  The line says so; it is not a scaling number.
+    share_gpu = os.environ.get('ADVMIX_BENCH_SHARE_GPU') == '1'
     if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
         # One command, N ranks (the reference's multi-GPU entry is one command too: GPUS in the YAML ->
         # nn.DataParallel, tools/train.py:69,106,109).  This parent has NOT touched the GPU; it starts one fresh
         # process per GPU, relays rank 0's JSON line and fails loudly rather than run fewer ranks than asked for.
         from advmix_amd.launch import spawn_ranks
-        need = not (a.path == 'rendezvous' and backend == 'gloo')
+        need = not (a.path == 'rendezvous' and backend == 'gloo') and not share_gpu
         raise SystemExit(spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], a.gpus, need_gpus=need))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -557,6 +560,8 @@ def main():
         return rendezvous(a, backend, rank, world, local)
     if backend != 'nccl':
         raise SystemExit('ADVMIX_BENCH_BACKEND=%s is only for --path rendezvous' % backend)
+    if share_gpu:
+        local, backend = 0, 'gloo'
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local)
@@ -565,7 +570,10 @@ def main():
     if world > 1 or force_sync:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29555')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if a.path in ('validate', 'inputs', 'nms'):
         line = {'validate': bench_validate, 'inputs': bench_inputs, 'nms': bench_nms}[a.path](a, device, rank, world)
@@ -696,6 +704,9 @@ def main():
         }
         if a.workload in NO_ORACLE:
             line['config']['parity'] = NO_ORACLE[a.workload]
+        if share_gpu:
+            line['config']['shared_gpu'] = ('all %d ranks on cuda:0, gradient exchange over gloo: a functional run of the '
+                                            'data-parallel path, NOT a scaling measurement' % world)
         line.update({
             'step_tflops_per_gpu': round(value / world * gflop_img / 1e3, 2),
             'step_frac_of_fp32_mfma_peak': round(value / world * gflop_img / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),

@@ -855,6 +855,107 @@ def _dp_one_rank_worker():
         dist.destroy_process_group()
 
 
+def _dp_two_rank_worker():
+    """WORLD SIZE 2 on ONE GPU: both ranks use cuda:0 and exchange over gloo (which all-reduces device tensors through
+    pinned host memory) - RCCL refuses two ranks on one device, and the build pool has no multi-GPU box.  Everything
+    else is the real data-parallel path: ranks start from DIFFERENT weights, ``broadcast_state`` makes them equal, each
+    rank steps on its own batch (eagerly, then through the seven-graph runner), the backward pass runs in pieces with
+    every finished range of the flat gradient buffers averaged on the side stream.  Asserted: the averaged gradient is
+    exactly the mean of the two ranks' own gradients (deterministic mode); parameters and Adam moments of D and G stay
+    BIT-identical across the ranks after every step; BatchNorm statistics and losses stay per replica."""
+    import os
+    import torch.distributed as dist
+    from oracle.synth import synth_batch
+    from advmix_amd import ops as _o
+    from advmix_amd.core.function import advmix_step, advmix_phase_a
+    from advmix_amd.dp import GradSync
+    from advmix_amd.graph import AdvMixGraphRunner
+    rank = int(os.environ['RANK'])
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%s' % os.environ['MASTER_PORT'], rank=rank, world_size=2)
+    torch.cuda.set_device(0)
+
+    def gathered(t):
+        got = [torch.zeros_like(t), torch.zeros_like(t)]
+        dist.all_gather(got, t.contiguous())
+        return got
+
+    def same(t):
+        a, b = gathered(t)
+        return bool(torch.equal(a, b))
+    args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
+    B, J, H, W = 2, 5, 64, 64
+    v, t, w = synth_batch('hrnet_tiny.it%d' % rank, B, J, H, W)             # a different shard per rank
+    data = ([x.cuda().contiguous() for x in v], t.cuda(), w.cuda())
+    cfg, D, G, T, crit, oD, oG, _ = _tiny_setup(salt=10 + 7 * rank, lr=1e-3)  # and different initial weights
+    sync = GradSync(bucket_mb=0.25)
+    assert sync.active and sync.world == 2
+    assert not same(oD.flat_params) and not same(oG.flat_params)
+    sync.broadcast_state([D, G, T], [oD, oG])
+    assert same(oD.flat_params) and same(oG.flat_params) and all(same(b.float()) for b in D.buffers())
+    # (1) the exchanged gradient of the D step = the mean of the ranks' own gradients, bit for bit (ordered sums)
+    _o.set_deterministic(True)
+    try:
+        snap = [x.clone() for x in oD.flat_state()] + [b.clone() for b in D.buffers()]
+        l0, _ = advmix_phase_a(args, D, G, T, crit, oD, *data)             # local gradient, no exchange
+        torch.cuda.synchronize()
+        g0, g1 = gathered(oD.flat_grads.clone())
+        want = (g0 + g1) * 0.5
+        with torch.no_grad():
+            for dst, src in zip(oD.flat_state() + list(D.buffers()), snap):
+                dst.copy_(src)
+        cuts = (sync.cuts_for(D), sync.cuts_for(G))
+        l1, _, pieces, _pg = advmix_phase_a(args, D, G, T, crit, oD, *data, cuts)
+        for piece in pieces:
+            lo, hi = piece()
+            sync.reduce_async(oD.flat_grads, lo, hi)
+        sync.finish()
+        torch.cuda.synchronize()
+        assert float(l0) == float(l1)
+        assert torch.equal(oD.flat_grads, want), float((oD.flat_grads - want).abs().max())
+        assert not torch.equal(g0, g1)
+        with torch.no_grad():
+            for dst, src in zip(oD.flat_state() + list(D.buffers()), snap):
+                dst.copy_(src)
+    finally:
+        _o.set_deterministic(False)
+    # (2) whole steps: eager, then the seven-graph runner
+    losses = []
+    l, o = advmix_step(args, D, G, T, crit, oD, oG, *data, sync)
+    torch.cuda.synchronize()
+    losses.append(float(l))
+    assert all(same(x) for x in oD.flat_state()) and all(same(x) for x in oG.flat_state())
+    runner = AdvMixGraphRunner(args, D, G, T, crit, oD, oG, *data, sync)
+    assert runner.seq.n_graphs == 7
+    for _ in range(2):
+        l, o = runner.step()
+        losses.append(float(l))
+    torch.cuda.synchronize()
+    assert all(same(x) for x in oD.flat_state()) and all(same(x) for x in oG.flat_state())
+    rm = D.state_dict()['bn1.running_mean']
+    assert not same(rm)                                                     # statistics stay per replica
+    la, lb = gathered(torch.tensor(losses, device='cuda'))
+    assert not torch.equal(la, lb) and all(x == x for x in losses)          # each rank's own shard, finite
+    assert sync.checkpoint_rank() == (rank == 0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_path_two_ranks_on_one_gpu_over_gloo():
+    """SURVEY 8 e / a12 with a world size of TWO ("RCCL has never seen N > 1 ranks" - it still has not: no
+    multi-GPU box; this runs the same path with gloo as the transport, both ranks on cuda:0)."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ('import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_models_gpu as t; '
+            't._dp_two_rank_worker(); print("DP_TWO_RANKS_OK")' % (os.path.dirname(here), here))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29641')
+        procs.append(subprocess.Popen([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and 'DP_TWO_RANKS_OK' in so, (so[-2000:], se[-4000:])
+
+
 def test_data_parallel_path_on_one_rank_real_rccl():
     """Runs ``_dp_one_rank_worker`` in a CHILD process: RCCL's communicator setup / teardown and the seven-graph runner
     stay out of the pytest process (a HIP-graph replay after destroy_process_group() in the same process crashed the

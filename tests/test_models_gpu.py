@@ -936,6 +936,26 @@ def _dp_two_rank_worker():
     la, lb = gathered(torch.tensor(losses, device='cuda'))
     assert not torch.equal(la, lb) and all(x == x for x in losses)          # each rank's own shard, finite
     assert sync.checkpoint_rank() == (rank == 0)
+    # (3) the reference's own call site: train_advmix(...) WITHOUT a grad_sync argument, models wrapped like
+    # tools/train.py:69,106,109 wraps them (dp.Replica bound as DataParallel): the loop finds the process group, creates
+    # its GradSync, broadcasts rank 0's state and keeps the replicas identical (core.function._auto_sync)
+    from advmix_amd.core import function as F_
+    from advmix_amd.dp import Replica
+    import logging
+    logging.getLogger(F_.__name__).setLevel(logging.WARNING)
+    cfg, D, G, T, crit, oD, oG, _ = _tiny_setup(salt=30 + 5 * rank, lr=1e-3)
+    cfg['PRINT_FREQ'] = 10 ** 9
+    assert not same(oD.flat_params)
+    batches = []
+    for it in range(3):
+        vv, tt, ww = synth_batch('hrnet_tiny.loop%d.%d' % (rank, it), B, J, H, W)
+        batches.append((vv, [tt, tt, tt], [ww, ww, ww], [{}, {}, {}]))
+    wd = {'writer': types.SimpleNamespace(add_scalar=lambda *a, **k: None), 'train_global_steps': 0}
+    F_.train_advmix(cfg, args, batches, [Replica(D), Replica(G), Replica(T)], crit, [oD, oG], 0, '/tmp', '/tmp', wd)
+    torch.cuda.synchronize()
+    assert all(same(x) for x in oD.flat_state()) and all(same(x) for x in oG.flat_state())
+    assert not same(D.state_dict()['bn1.running_mean'])
+    F_.release_graphs()
     dist.barrier()
     dist.destroy_process_group()
 

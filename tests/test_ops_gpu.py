@@ -1181,6 +1181,43 @@ def test_edge_cases_empty_single_boundary():
     assert 0 < int(want_w.sum()) < len(xs)
 
 
+def test_round3_entry_points_refuse_bad_arguments_without_launching():
+    """The C ABI's error behaviour for the entry points added in round 3: ADVMIX_EINVAL (1), nothing launched, never a
+    crash - null pointers, sizes out of range, a partial-sum buffer that is too small (deterministic statistics)."""
+    import ctypes
+    from advmix_amd._lib import lib
+    d = dev()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())               # noqa: E731
+    u8 = torch.zeros(2, 4, 4, 3, dtype=torch.uint8, device=d)
+    opsb = torch.zeros(2, 4, dtype=torch.int32, device=d)
+    assert lib.advmix_autoaug(None, P(opsb), P(u8), P(u8), 2, 4, 4, st) == 1
+    assert lib.advmix_autoaug(P(u8), P(opsb), P(u8), P(u8), 0, 4, 4, st) == 1
+    f64 = torch.zeros(64, dtype=torch.float64, device=d)
+    i32 = torch.zeros(8, dtype=torch.int32, device=d)
+    assert lib.advmix_oks_greedy(None, P(i32), 4, 0.5, P(i32), P(i32), st) == 1
+    assert lib.advmix_oks_greedy(P(f64), P(i32), 0, 0.5, P(i32), P(i32), st) == 1
+    assert lib.advmix_oks_greedy(P(f64), P(i32), 9000, 0.5, P(i32), P(i32), st) == 1
+    assert lib.advmix_stats_fold(None, 4, 8, P(f64), st) == 1 and lib.advmix_stats_fold(P(f64), 0, 8, P(f64), st) == 1
+    # deterministic statistics: capacity of ONE tile per channel where the launch has 4 row tiles -> refused, y untouched
+    B, H, W, C = 4, 16, 8, 32
+    x = torch.randn(B, H, W, C, device=d)
+    w = torch.randn(C, 3, 3, C, device=d) * 0.05
+    y = torch.full((B, H, W, C), 7.0, device=d)
+    part = torch.zeros(2 * C * 4, dtype=torch.float64, device=d)
+    nbg = ctypes.c_int(-1)
+    rc = lib.advmix_conv_fwd_ex(P(x), P(w), None, P(y), B, H, W, C, H, W, C, 3, 3, 1, 1, None, None, None, None, 0.0, None, 0,
+                                P(part), ctypes.byref(nbg), st)
+    torch.cuda.synchronize()
+    assert rc == 1 and float(y.min()) == 7.0 and float(y.max()) == 7.0
+    nbg = ctypes.c_int(-4)                                     # enough: served, count reported, partials sum to the column sums
+    rc = lib.advmix_conv_fwd_ex(P(x), P(w), None, P(y), B, H, W, C, H, W, C, 3, 3, 1, 1, None, None, None, None, 0.0, None, 0,
+                                P(part), ctypes.byref(nbg), st)
+    torch.cuda.synchronize()
+    assert rc == 0 and nbg.value == 4
+    check('tile partials', part.view(2, C, 4).sum(-1)[0], y.double().sum((0, 1, 2)).cpu(), 1e-5)
+
+
 def test_auto_augment_bit_exact_vs_oracle_and_the_real_policy():
     """Device AutoAugment (advmix_autoaug) against the numpy oracle - itself pinned to Pillow and to the REAL
     ImageNetPolicy - on the recorded cases (tests/golden/autoaug.json: the real policy's draws and the CRC-32 of its output

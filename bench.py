@@ -227,6 +227,13 @@ def time_conv_family(B, device, iters=100, family=None):
         if d:
             bnb_traffic = {'hbm_bytes_per_launch': round(d['hbm_bytes_per_launch']), 'algorithmic_bytes': d['algorithmic_bytes_per_launch'],
                            'ratio': round(d['hbm_bytes_per_launch'] / d['algorithmic_bytes_per_launch'], 3), 'source': f}
+    step_util = None
+    if B == 32 and family == CONV_FAMILY:                   # SQ_VALU_MFMA_BUSY_CYCLES summed over one step (tools/pmc_step.sh)
+        d, f = _pmc_file('r*_pmc_step_mfma.json')
+        if d:
+            step_util = {'mfma_busy_simd_cycles_per_step': round(d['mfma_busy_cycles_per_step']),
+                         'algorithmic_simd_cycles_per_step': round(118.58e9 * 32 / 64),
+                         'utilisation_at_the_profiled_step_time': round(d['mfma_utilisation_of_step'], 4), 'source': f}
     agg = tot_f / tot_t / 1e12
     C0, H0, W0 = family[0]
     algo_bytes = 2 * B * H0 * W0 * C0 * 4 + 9 * C0 * C0 * 4
@@ -239,6 +246,7 @@ def time_conv_family(B, device, iters=100, family=None):
             'traffic_source': src, 'traffic_algorithmic_bytes': algo_bytes,
             'traffic_ratio': round(traffic / algo_bytes, 3) if traffic else None,
             'traffic_dgrad_bnb': bnb_traffic,
+            'step_mfma_utilisation_pmc': step_util,
             'dominant': dominant, 'members': members, 'hbm_kernels': hbm}
 
 

@@ -736,8 +736,8 @@ int launch(ConvD& p, int64_t Mmax, hipStream_t st, int64_t stats_cap) {
         hipLaunchKernelGGL((conv_direct<TM_, TN_, WM_, WN_, KC, MODE, SP_, BT, (EPI && !SP_), NW_>), g, dim3(64 * NW_), 0, st, p); \
         if (advmix_opts().trace_shapes) {                                                         \
             char nm[96];                                                                          \
-            snprintf(nm, sizeof nm, "conv_direct<%d, %d, %d, %d, %d, %d, %s, %s, %s>", TM_, TN_, WM_, WN_, KC, MODE, \
-                     SP_ ? "true" : "false", BT ? "true" : "false", (EPI && !SP_) ? "true" : "false"); \
+            snprintf(nm, sizeof nm, "conv_direct<%d, %d, %d, %d, %d, %d, %s, %s, %s, %d>", TM_, TN_, WM_, WN_, KC, MODE, \
+                     SP_ ? "true" : "false", BT ? "true" : "false", (EPI && !SP_) ? "true" : "false", NW_); \
             advmix_trace_launch(nm, g, MODE == 0 ? (p.stats ? "fwd+sums" : (p.bn_gamma ? "fwd+bn_eval" : "fwd")) \
                                                  : (p.bnb_c ? "dgrad+bnb" : "dgrad"),              \
                                 p.N, p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.Co, p.R, p.S, p.stride,      \

@@ -1181,6 +1181,68 @@ def test_edge_cases_empty_single_boundary():
     assert 0 < int(want_w.sum()) < len(xs)
 
 
+def test_conv_and_conv_bn_on_random_shapes():
+    """Seeded sweep over shapes the fixed cases do not list (ragged row / column tiles, Co % 4 != 0 - the scalar store
+    path -, 1x1 / 3x3 / 4x4, stride 1 and 2, with and without bias or residual, batch sizes that land on every tile
+    configuration): conv2d forward / input gradient / weight gradient and the fused conv + train-mode BatchNorm member
+    against float64 torch."""
+    ops = _ops()
+    rng = np.random.RandomState(2024)
+    seen = set()
+    from advmix_amd._lib import lib
+    for it in range(48):
+        B = int(rng.choice([1, 2, 3, 5, 8, 16, 32]))
+        Ci = int(rng.choice([16, 32, 48, 64, 96, 128, 256]))
+        Co = int(rng.choice([4, 17, 20, 32, 48, 64, 72, 128, 256]))
+        k, s = [(1, 1), (3, 1), (3, 2), (4, 2), (1, 2)][int(rng.randint(5))]
+        pad = {1: 0, 3: 1, 4: 1}[k]
+        H, W = int(rng.randint(max(k, 3), 30)), int(rng.randint(max(k, 3), 26))
+        if B * H * W * max(Ci, Co) > 6e6:
+            B = max(1, int(6e6 // (H * W * max(Ci, Co))))
+        hb = bool(rng.randint(2))
+        x = rnd(B, Ci, H, W, seed=1000 + it)
+        w = rnd(Co, Ci, k, k, seed=2000 + it, scale=(Ci * k * k) ** -0.5)
+        b = rnd(Co, seed=3000 + it) if hb else None
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        br = b.clone().requires_grad_(True) if hb else None
+        yr = F.conv2d(xr, wr, br, s, pad)
+        dy = rnd(*yr.shape, seed=4000 + it)
+        yr.backward(dy)
+        xg, wg = cl(x).requires_grad_(True), torch.nn.Parameter(cl(w))
+        bg = torch.nn.Parameter(b.float().to(dev())) if hb else None
+        y = ops.conv2d(xg, wg, bg, s, pad)
+        tag = 'case %d: B%d %d->%d %dx%d k%d s%d bias %s' % (it, B, Ci, Co, H, W, k, s, hb)
+        check(tag + ' y', y, yr)
+        y.backward(cl(dy))
+        check(tag + ' dx', xg.grad, xr.grad)
+        check(tag + ' dw', wg.grad, wr.grad, 2e-4)
+        Ho, Wo = yr.shape[2], yr.shape[3]
+        seen.add(lib.advmix_conv_direct_config(0, B, Ho, Wo, Ci, Co, k, k, s))
+        if it % 2 == 0 and Co % 4 == 0 and Co >= 16:                       # the fused conv + BatchNorm member on the same problem
+            gam, bet = rnd(Co, seed=5000 + it).abs() + 0.5, rnd(Co, seed=6000 + it, scale=0.2)
+            res = rnd(B, Co, Ho, Wo, seed=7000 + it) if it % 4 == 0 else None
+            x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            g2, b2 = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+            c = F.conv2d(x2, w2, None, s, pad)
+            pre = F.batch_norm(c, None, None, g2, b2, True, 0.1, 1e-5)
+            if res is not None:
+                pre = pre + res
+            xg2, wg2 = cl(x).requires_grad_(True), torch.nn.Parameter(cl(w))
+            gg, bb = torch.nn.Parameter(gam.float().to(dev())), torch.nn.Parameter(bet.float().to(dev()))
+            rm, rv = torch.zeros(Co, device=dev()), torch.ones(Co, device=dev())
+            nbt = torch.zeros((), dtype=torch.int64, device=dev())
+            yb = ops.conv_bn(xg2, wg2, gg, bb, rm, rv, nbt, cl(res) if res is not None else None, s, pad, 1, True)
+            mask = (yb.detach().cpu() > 0).double()
+            check(tag + ' conv_bn y', yb, torch.relu(pre.detach()), 2e-4)
+            if B * Ho * Wo >= 16:                                           # (BatchNorm over a handful of rows is ill-conditioned)
+                (pre * mask).backward(dy)
+                yb.backward(cl(dy))
+                check(tag + ' conv_bn dx', xg2.grad, x2.grad, 2e-3)
+                check(tag + ' conv_bn dw', wg2.grad, w2.grad, 2e-3)
+                check(tag + ' conv_bn dgamma', gg.grad, g2.grad, 2e-3)
+    assert len(seen - {-1}) >= 4, seen                                      # the sweep reached several tile configurations
+
+
 def test_round3_entry_points_refuse_bad_arguments_without_launching():
     """The C ABI's error behaviour for the entry points added in round 3: ADVMIX_EINVAL (1), nothing launched, never a
     crash - null pointers, sizes out of range, a partial-sum buffer that is too small (deterministic statistics)."""

@@ -365,3 +365,16 @@ def test_autoaug_params_replays_the_reference_draws():
     assert t.shape == (3, 4) and t.dtype == np.int32
     assert t[0, 1] == ~7 and t[0, 3:4].view(np.float32)[0] == np.float32(170.66666666666669)
     assert t[1, 0] == AA_SHARPNESS and t[1, 1:2].view(np.float32)[0] == np.float32(1.7000000000000002) and not t[2].any()
+
+
+def test_measurement_variants_patch_still_applies(tmp_path):
+    """tools/variants/conv_direct_dbg.patch (the CD_DBG / CD_PRELOAD / CD_CLK / CD_NO_PRE measurement variants, kept out of
+    the shipped kernel source) applies cleanly to the current conv_direct.hip - it has to be regenerated with the kernel."""
+    import shutil
+    if shutil.which('patch') is None:
+        pytest.skip('no patch(1) here')
+    src = tmp_path / 'conv_direct.hip'
+    shutil.copy(os.path.join(ROOT, 'advmix_amd', 'csrc', 'conv_direct.hip'), src)
+    out = subprocess.run(['patch', '--dry-run', '-s', str(src), os.path.join(ROOT, 'tools', 'variants', 'conv_direct_dbg.patch')],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr

@@ -62,8 +62,9 @@ WORKLOADS = {
     # (256*192): 6 * 81.55 + 3 * 48.19 - 1.43.
     'hrnet_w32_512': ('pose_hrnet', hrnet_extra(HRNET_STAGES['hrnet_w32']), 17, 512, 512, 6, 632.4),
 }
-NO_ORACLE = {'hrnet_w32_512': 'no oracle - the reference has no HigherHRNet code (README.md:72-73); trunk + generator '
-                              'step only, no associative-embedding head / grouping; throughput only'}
+NO_ORACLE = {'hrnet_w32_512': 'no oracle for HigherHRNet - the reference has no such code (README.md:72-73): trunk + generator '
+                              'step only, no associative-embedding head / grouping; the trunk and the generator THEMSELVES are '
+                              'parity-tested at 512x512 (tests: hrnet_w32_512, vectors from the real pose_hrnet / UnetGenerator)'}
 
 
 def synth(B, J, H, W, device, seed):

@@ -285,8 +285,17 @@ BENCH_TILE_CASES = (('resnet50_b32', 'pose_resnet', configs.RES50, 17, 32, 256, 
 C1_CASE = ('c1_resnet50_j16_b4', 'pose_resnet', configs.RES50, 16, 4, 256, 192)
 
 
+# BASELINE.json configs[4] (C5) as far as the reference goes: it has no HigherHRNet code, but its pose_hrnet and
+# UnetGenerator run at 512x512 - the shapes of that configuration (128x128x32 ... 16x16x256 branch maps)
+C5_TRUNK_CASE = ('hrnet_w32_512', 'pose_hrnet', configs.HRNET_W32, 17, 2, 512, 512)
+
+
 def gen_benchtiles(M):
     gen_forward(M, BENCH_TILE_CASES, 'benchtiles_forward.npz')
+
+
+def gen_c5trunk(M):
+    gen_forward(M, (C5_TRUNK_CASE,), 'c5_trunk_forward.npz')
 
 
 def gen_c1(M):
@@ -600,7 +609,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     M = import_reference()
-    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe', 'c4', 'b32', 'benchtiles', 'c1', 'autoaug']
+    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe', 'c4', 'b32', 'benchtiles', 'c1', 'autoaug', 'c5trunk']
     for w in which:
         globals()['gen_' + w](M)
         print('done', w, flush=True)

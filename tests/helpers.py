@@ -19,8 +19,13 @@ CASES = {
     # BASELINE.json configs[3] (C4): HRNet-W48 384x288 with UnetGenerator(9, 3, 5)
     'hrnet_w48': ('pose_hrnet', configs.HRNET_W48, 17, 2, 384, 288, 2),
 }
+# forward / backward vectors only (no loop fixtures): BASELINE.json configs[4] as far as the reference's code goes - its
+# pose_hrnet + UnetGenerator(9, 3, 6) at 512x512 (128x128x32 ... 16x16x256 branch maps); HigherHRNet itself has no code
+FORWARD_ONLY_CASES = {'hrnet_w32_512': ('pose_hrnet', configs.HRNET_W32, 17, 2, 512, 512, 0)}
+ALL_FORWARD = dict(CASES, **FORWARD_ONLY_CASES)
 DOWNS = {'hrnet_w48': 5}                        # U-Net depth per case (default 6; tools/_init_parse.py:132-134)
-GOLD_FILES = {'hrnet_w48': ('c4_forward.npz', 'c4_advmix_steps.npz', 'c4_advmix_checksums.json')}
+GOLD_FILES = {'hrnet_w48': ('c4_forward.npz', 'c4_advmix_steps.npz', 'c4_advmix_checksums.json'),
+              'hrnet_w32_512': ('c5_trunk_forward.npz', None, None)}
 
 
 def gold_files(tag):

@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import CASES, DOWNS, gold_files, gold_json, gold_npz, build_states, checksum_close   # noqa: E402
+from helpers import CASES, ALL_FORWARD, DOWNS, gold_files, gold_json, gold_npz, build_states, checksum_close   # noqa: E402
 
 REPORT = {}      # worst err / bound ratio per checked quantity (printed by the tests)
 # median per-tensor D-gradient error vs the fp32 oracle after a device-side update, per case: 3 x the largest value observed
@@ -38,7 +38,7 @@ def _f64_grads(net, extra, D, names, x, tgt, tw, B, J):
     return dict(zip(names + ['x'], g))
 
 
-@pytest.mark.parametrize('tag', list(CASES))
+@pytest.mark.parametrize('tag', list(ALL_FORWARD))
 def test_forward_backward_vs_oracle_and_golden(tag):
     from oracle.posenet import posenet_forward, calibrate, trainable
     from oracle.unet import unet_forward
@@ -47,7 +47,7 @@ def test_forward_backward_vs_oracle_and_golden(tag):
     from oracle import detinit
     from advmix_amd import ops
     from advmix_amd.core.loss import JointsMSELoss
-    net, extra, J, B, H, W, _ = CASES[tag]
+    net, extra, J, B, H, W, _ = ALL_FORWARD[tag]
     downs = DOWNS.get(tag, 6)
     g = gold_npz(gold_files(tag)[0])
     D, T, G = build_states(net, extra, J, unet_downs=downs)

@@ -11,7 +11,7 @@ from oracle.posenet import posenet_spec, posenet_forward, calibrate, trainable
 from oracle.unet import unet_spec, unet_forward
 from oracle.step import Adam, advmix_step, plain_step
 from oracle.synth import synth_batch, strided, checksum
-from helpers import CASES, DOWNS, gold_files, gold_json, gold_npz, build_states, close, checksum_close, GOLD
+from helpers import CASES, ALL_FORWARD, DOWNS, gold_files, gold_json, gold_npz, build_states, close, checksum_close, GOLD
 from oracle import configs
 
 torch.set_num_threads(8)
@@ -93,9 +93,9 @@ def test_oks_nms_matches_reference():
         assert onms.soft_oks_nms(db, c['thresh']) == c['soft_keep'], name
 
 
-@pytest.mark.parametrize('tag', list(CASES))
+@pytest.mark.parametrize('tag', list(ALL_FORWARD))
 def test_forward_backward_matches_reference(tag):
-    net, extra, J, B, H, W, _ = CASES[tag]
+    net, extra, J, B, H, W, _ = ALL_FORWARD[tag]
     downs = DOWNS.get(tag, 6)
     g = gold_npz(gold_files(tag)[0])
     D, _, G = build_states(net, extra, J, unet_downs=downs)

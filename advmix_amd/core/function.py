@@ -73,6 +73,12 @@ def _backward_pieces(loss, net, cuts, pairs):
     return [make(k) for k in range(len(cuts), -1, -1)]
 
 
+# The teacher's forward rides in the student's launch groups (advmix_phase_a).  Round 1 measured this as a loss (86.3 vs
+# 85.8 ms); with round 3's chains it is a small, repeatable gain on the same box (ResNet-50 41.78 -> 41.13 ms, HRNet-W32
+# 58.22 -> 57.67 ms, profiles/r03_pair_*.log).  ADVMIX_PAIR_TEACHER=0 restores the two separate forwards.
+_PAIR_TEACHER = os.environ.get('ADVMIX_PAIR_TEACHER', '1') == '1'
+
+
 def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, inputs, target, target_weight,
                    cuts=None):
     """function.py:137-154: G forward, softmax-mix, D forward on the detached mix, teacher forward,
@@ -92,13 +98,26 @@ def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, in
     tmp = ops.softmax_mix(logits, inputs)                                 # :138,142-144
     if cuts:
         model.cut_levels = tuple(c[0] for c in cuts[0])
-    D_output_detach = model(tmp.detach())                                 # :146
+    if _PAIR_TEACHER and hasattr(model, 'begin') and hasattr(model_teacher, 'begin') and \
+            len(model._levels) == len(model_teacher._levels):
+        # the student's and the (frozen) teacher's levels as members of the SAME launch groups: a sequential network is
+        # one chain per pass, so the two forwards share the chip on two lanes instead of running one after the other
+        for p_ in model_teacher.parameters():                             # function.py:148: the teacher only ever runs under
+            if p_.requires_grad:                                          # no_grad - nothing reads its gradients (checked per
+                p_.requires_grad = False                                  # call: a state restore may re-arm the flags)
+        ra, rb = model.begin(tmp.detach()), model_teacher.begin(inputs[0])
+        while not ra.done:
+            ma, mb = ra.members(), rb.members()
+            outs = ops.run_group(ma + mb)
+            ra.consume(outs[:len(ma)])
+            rb.consume(outs[len(ma):])
+        D_output_detach, teacher_output = ra.result, rb.result.detach()
+    else:
+        D_output_detach = model(tmp.detach())                             # :146
+        with torch.no_grad():
+            teacher_output = model_teacher(inputs[0])                     # :148-149
     pairs_D = model.last_cuts if cuts else None
     model.cut_levels = ()
-    # (Measured and rejected: letting the teacher's levels ride along in the generator's and the
-    # student's launch groups - 86.3 ms vs 85.8 ms per step; two lanes already saturate the chip.)
-    with torch.no_grad():
-        teacher_output = model_teacher(inputs[0])                         # :148-149
     loss_D_hm = criterion(D_output_detach, target, target_weight)
     loss_D_kd = criterion(D_output_detach, teacher_output, target_weight)
     loss_D = loss_D_hm * (1 - args.alpha) + loss_D_kd * args.alpha        # :151-153

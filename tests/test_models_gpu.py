@@ -701,6 +701,40 @@ def _tiny_setup(salt=10, lr=1e-3):
     return cfg, mD, mG, mT, JointsMSELoss(True), optD, optG, (B, J, H, W)
 
 
+def test_teacher_riding_in_the_students_launch_groups_changes_no_result(monkeypatch):
+    """advmix_phase_a runs the frozen teacher's levels as members of the student's launch groups (default); the two
+    separate forwards of function.py:146-149 (ADVMIX_PAIR_TEACHER=0) must give the same loss and the same D gradients
+    from the same state - the pairing only changes WHICH launches share the chip."""
+    from oracle.synth import synth_batch
+    from advmix_amd import ops
+    from advmix_amd.core import function as F_
+    res = {}
+    ops.set_deterministic(True)                                         # so that G's forward is the same bits in both runs
+    try:
+        for pair in (True, False):
+            monkeypatch.setattr(F_, '_PAIR_TEACHER', pair)
+            cfg, mD, mG, mT, crit, optD, optG, (B, J, H, W) = _tiny_setup()
+            v, t, w = synth_batch('hrnet_tiny.it0', B, J, H, W)
+            args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
+            loss, tmp = F_.advmix_phase_a(args, mD, mG, mT, crit, optD, [x.cuda().contiguous() for x in v], t.cuda(), w.cuda())
+            torch.cuda.synchronize()
+            res[pair] = (float(loss), optD.flat_grads.detach().clone(), tmp.detach().clone(),
+                         {k: b.detach().clone() for k, b in mT.named_buffers()})
+            assert all(p.grad is None for p in mT.parameters())
+    finally:
+        ops.set_deterministic(False)
+    (la, ga, ta, ba), (lb, gb, tb, bb) = res[True], res[False]
+    assert torch.equal(ta, tb)                                          # G's forward is not touched
+    assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb)), (la, lb)
+    scale = float(gb.abs().max())
+    d = (ga - gb).abs()
+    # same arithmetic, possibly another tile configuration where two members were fused into one grouped launch (another
+    # summation order; a ReLU mask can flip at a value that is zero to rounding)
+    assert float((d > 1e-4 * scale).float().mean()) <= 1e-3 and float(d.max()) <= 0.05 * scale, (float(d.max()), scale)
+    for k in ba:                                                        # an eval-mode teacher: no buffer moves
+        assert torch.equal(ba[k], bb[k]), k
+
+
 def test_train_advmix_loop_first_iteration_matches_reference():
     """The loop mirror itself (function.py:107-197): batches in the reference loader's format, meters, the
     tensorboard counter; the first iteration's loss_D equals the number the REAL train_advmix recorded."""

@@ -75,8 +75,21 @@ def _backward_pieces(loss, net, cuts, pairs):
 
 # The teacher's forward rides in the student's launch groups (advmix_phase_a).  Round 1 measured this as a loss (86.3 vs
 # 85.8 ms); with round 3's chains it is a small, repeatable gain on the same box (ResNet-50 41.78 -> 41.13 ms, HRNet-W32
-# 58.22 -> 57.67 ms, profiles/r03_pair_*.log).  ADVMIX_PAIR_TEACHER=0 restores the two separate forwards.
-_PAIR_TEACHER = os.environ.get('ADVMIX_PAIR_TEACHER', '1') == '1'
+# 58.22 -> 57.67 ms, profiles/r03_pair_*.log).  Starting the teacher beside the GENERATOR's forward instead and letting it
+# run on into the student's is no better (41.3 / 57.9 ms, profiles/r03_pair2_*.log); with the teacher's forward removed
+# altogether (not a valid step: a bound) the step takes 37.3 / 51.8 ms - the teacher costs 3.8 / 5.6 ms and sharing
+# launch groups hides 0.6 of them.  ADVMIX_PAIR_TEACHER=0 restores the two separate forwards.
+_PAIR_TEACHER = int(os.environ.get('ADVMIX_PAIR_TEACHER', '1'))
+
+
+def _advance(runs):
+    """One level of each in-flight forward (plan.PlanRun) as ONE launch group."""
+    groups = [r.members() for r in runs]
+    outs = ops.run_group([m for g in groups for m in g])
+    pos = 0
+    for r, g in zip(runs, groups):
+        r.consume(outs[pos:pos + len(g)])
+        pos += len(g)
 
 
 def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, inputs, target, target_weight,
@@ -88,6 +101,13 @@ def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, in
     that the caller can all-reduce each finished gradient range beside the next piece, together with G's cut record
     for advmix_phase_b."""
     G_input = ops.cat_views(inputs)                                       # :137
+    pair = _PAIR_TEACHER if all(hasattr(m, 'begin') for m in (model, model_G, model_teacher)) else 0
+    if pair:
+        # the (frozen) teacher's levels as members of the student's launch groups: a sequential network is one chain per
+        # pass, so the teacher shares the chip with it instead of running on its own afterwards
+        for p_ in model_teacher.parameters():                             # function.py:148: the teacher only ever runs under
+            if p_.requires_grad:                                          # no_grad - nothing reads its gradients (checked per
+                p_.requires_grad = False                                  # call: a state restore may re-arm the flags)
     if cuts:
         model_G.cut_levels = tuple(c[0] for c in cuts[1])
     logits = model_G(G_input)                                             # :138 (softmax fused below)
@@ -98,20 +118,14 @@ def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, in
     tmp = ops.softmax_mix(logits, inputs)                                 # :138,142-144
     if cuts:
         model.cut_levels = tuple(c[0] for c in cuts[0])
-    if _PAIR_TEACHER and hasattr(model, 'begin') and hasattr(model_teacher, 'begin') and \
-            len(model._levels) == len(model_teacher._levels):
-        # the student's and the (frozen) teacher's levels as members of the SAME launch groups: a sequential network is
-        # one chain per pass, so the two forwards share the chip on two lanes instead of running one after the other
-        for p_ in model_teacher.parameters():                             # function.py:148: the teacher only ever runs under
-            if p_.requires_grad:                                          # no_grad - nothing reads its gradients (checked per
-                p_.requires_grad = False                                  # call: a state restore may re-arm the flags)
-        ra, rb = model.begin(tmp.detach()), model_teacher.begin(inputs[0])
-        while not ra.done:
-            ma, mb = ra.members(), rb.members()
-            outs = ops.run_group(ma + mb)
-            ra.consume(outs[:len(ma)])
-            rb.consume(outs[len(ma):])
-        D_output_detach, teacher_output = ra.result, rb.result.detach()
+    if pair:
+        rt = model_teacher.begin(inputs[0])
+        rd = model.begin(tmp.detach())                                    # :146
+        while not rd.done:
+            _advance([rd] if rt.done else [rd, rt])
+        while not rt.done:
+            _advance([rt])
+        D_output_detach, teacher_output = rd.result, rt.result.detach()   # :148-149
     else:
         D_output_detach = model(tmp.detach())                             # :146
         with torch.no_grad():

@@ -8,6 +8,7 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, waits for them a
 failing child's code.  Nothing is re-exec'ed: a process that has initialised the GPU must not be replaced.
 """
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -57,6 +58,26 @@ def spawn_ranks(argv, n, need_gpus=True, timeout_s=None, env_extra=None):
     t0 = time.time()
     code = 0
     live = list(procs)
+
+    def _stop(signum, frame):                               # the parent is being stopped (driver timeout, ^C): take the
+        for q in procs:                                     # ranks along - an orphaned rank would keep its GPU
+            if q.poll() is None:
+                q.terminate()
+        raise SystemExit(128 + signum)
+    old = {}
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        try:
+            old[sg] = signal.signal(sg, _stop)
+        except ValueError:                                  # not the main thread: leave the handlers alone
+            pass
+    try:
+        return _wait(procs, live, code, t0, timeout_s)
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
+
+
+def _wait(procs, live, code, t0, timeout_s):
     while live:
         for p in list(live):
             rc = p.poll()

@@ -282,6 +282,36 @@ def test_launcher_stops_the_job_when_a_rank_fails():
     assert rc == 7 and time.time() - t0 < 30
 
 
+def test_launcher_takes_its_ranks_along_when_it_is_stopped(tmp_path):
+    """SIGTERM to the launching parent (a driver's timeout) must not leave ranks behind holding their GPUs."""
+    import signal, subprocess, time
+    child = ('import os, time\n'
+             'open(os.path.join(%r, "pid%%s" %% os.environ["RANK"]), "w").write(str(os.getpid()))\n'
+             'time.sleep(120)\n' % str(tmp_path))
+    parent = ('import sys; sys.path.insert(0, %r)\n'
+              'from advmix_amd.launch import spawn_ranks\n'
+              'raise SystemExit(spawn_ranks([sys.executable, "-c", %r], 2, need_gpus=False))\n' % (ROOT, child))
+    p = subprocess.Popen([sys.executable, '-c', parent])
+    try:
+        t0 = time.time()
+        while time.time() - t0 < 60 and not all((tmp_path / ('pid%d' % r)).exists() and (tmp_path / ('pid%d' % r)).read_text()
+                                                for r in range(2)):
+            time.sleep(0.1)
+        pids = [int((tmp_path / ('pid%d' % r)).read_text()) for r in range(2)]
+        p.send_signal(signal.SIGTERM)
+        assert p.wait(timeout=30) == 128 + signal.SIGTERM
+        t0 = time.time()
+        alive = pids
+        while alive and time.time() - t0 < 20:
+            alive = [q for q in alive if os.path.exists('/proc/%d' % q) and
+                     'Z' not in open('/proc/%d/stat' % q).read().split(')')[-1].split()[0]]
+            time.sleep(0.1)
+        assert not alive, alive
+    finally:
+        if p.poll() is None:
+            p.kill()
+
+
 def test_replica_keeps_dataparallels_shape():
     """dp.Replica: ``.module``, ``module.``-prefixed keys (what tools/train.py:198-235 match --load_from_D against),
     forward / attribute delegation; the loops unwrap it."""

@@ -74,6 +74,7 @@ SIGNATURES = {
     'advmix_nms_mask': [_p, _i, _f, _p, _p],
     'advmix_nms_host': [_p, _p, _p, _i, _i, _f, _i],
     'advmix_oks_matrix': [_p, _p, _p, _i, _i, _p, _p],
+    'advmix_oks_iou': [_p, _p, _i, _p, _p, _i, _p, _i, _i, ctypes.c_double, _p, _p],
     'advmix_oks_greedy': [_p, _p, _i, ctypes.c_double, _p, _p, _p],
 }
 for _name, _args in SIGNATURES.items():

@@ -57,37 +57,52 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(int n, float thresh, cons
 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the K % 8 tail added one by one; for K < 8 a plain running sum.
 // The kernel adds in exactly that order, so the only difference left against the reference is the last-bit
 // rounding of exp() (device libm vs the host's).
-__global__ void oks_matrix_kernel(const double* __restrict__ kpts, const double* __restrict__ areas,
-                                  const double* __restrict__ sigmas, int n, int K, double* __restrict__ ious) {
+// ``use_vis`` (nms.py:90-92, ``in_vis_thre``): only the joints with d's visibility > vis_thre count - the reference's
+// ``list(vg > t) and list(vd > t)`` IS ``list(vd > t)`` - and numpy sums the COMPACTED terms, so the pairwise order runs
+// over the surviving joints (counted first); no survivor: 0.0.
+template <bool VIS>
+__global__ void oks_matrix_kernel(const double* __restrict__ gk, const double* __restrict__ ga,
+                                  const double* __restrict__ dk, const double* __restrict__ da,
+                                  const double* __restrict__ sigmas, int n, int K, double vis_thre,
+                                  double* __restrict__ ious) {
 #pragma clang fp contract(off)                            /* numpy rounds dx**2, dy**2 and their sum separately: no fma */
-    int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;      // row = person i of g, column = person j of d
     if (j >= n) return;
-    const double* g = kpts + (int64_t)i * K * 3;
-    const double* d = kpts + (int64_t)j * K * 3;
+    const double* g = gk + (int64_t)i * K * 3;
+    const double* d = dk + (int64_t)j * K * 3;
     const double eps = 2.220446049250313e-16;             // np.spacing(1)
-    const double denom = (areas[i] + areas[j]) / 2 + eps;
+    const double denom = (ga[i] + da[j]) / 2 + eps;
     auto term = [&](int k) {
         double var = (sigmas[k] * 2) * (sigmas[k] * 2);
         double dx = d[3 * k] - g[3 * k], dy = d[3 * k + 1] - g[3 * k + 1];
         double e = (dx * dx + dy * dy) / var / denom / 2;
         return exp(-e);
     };
+    int m = K;                                             // terms that enter the sum
+    if (VIS) {
+        m = 0;
+        for (int k = 0; k < K; ++k) m += d[3 * k + 2] > vis_thre;
+    }
     double s = 0.0;
-    if (K < 8) {
-        for (int k = 0; k < K; ++k) s += term(k);
+    if (m < 8) {
+        for (int k = 0; k < K; ++k)
+            if (!VIS || d[3 * k + 2] > vis_thre) s += term(k);
     } else {
+        // c = index among the surviving terms: the first 8 start the eight running sums, c < m - m % 8 add to sum c % 8,
+        // the rest are the tail
         double r[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) r[q] = term(q);
-        int k = 8;
-        for (; k < K - (K % 8); k += 8) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) r[q] += term(k + q);
+        const int body = m - (m % 8);
+        int c = 0, k = 0;
+        for (; c < body; ++k) {
+            if (VIS && !(d[3 * k + 2] > vis_thre)) continue;
+            if (c < 8) r[c] = term(k); else r[c & 7] += term(k);
+            ++c;
         }
         s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; k < K; ++k) s += term(k);
+        for (; k < K; ++k)
+            if (!VIS || d[3 * k + 2] > vis_thre) s += term(k);
     }
-    ious[(int64_t)i * n + j] = K ? s / K : 0.0;
+    ious[(int64_t)i * n + j] = m ? s / m : 0.0;
 }
 
 // Greedy pass of oks_nms (lib/nms/nms.py:97-125) on the device: candidates in ``order`` (score-descending, the host's
@@ -163,8 +178,27 @@ extern "C" int advmix_nms_host(int* keep_out, int* num_out, const float* boxes_h
 extern "C" int advmix_oks_matrix(const double* kpts, const double* areas, const double* sigmas, int n, int K,
                                  double* ious, void* stream) {
     if (!kpts || !areas || !sigmas || !ious || n <= 0 || K <= 0 || K > 128) return ADVMIX_EINVAL;   // (numpy recurses past 128)
-    hipLaunchKernelGGL(oks_matrix_kernel, dim3(cdiv(n, 64), n), dim3(64), 0, (hipStream_t)stream, kpts, areas, sigmas,
-                       n, K, ious);
+    hipLaunchKernelGGL(oks_matrix_kernel<false>, dim3(cdiv(n, 64), n), dim3(64), 0, (hipStream_t)stream, kpts, areas, kpts,
+                       areas, sigmas, n, K, 0.0, ious);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+// oks_iou itself (lib/nms/nms.py:75-94), ng ground-truth persons against nd detections: ious[ng][nd].  use_vis != 0 is the
+// reference's ``in_vis_thre`` (nms.py:90-92): joints of DETECTION j whose visibility d_kpts[j][3k + 2] is not above
+// vis_thre leave the sum and the divisor; a pair with no joint left has OKS 0.
+extern "C" int advmix_oks_iou(const double* g_kpts, const double* g_areas, int ng, const double* d_kpts, const double* d_areas,
+                              int nd, const double* sigmas, int K, int use_vis, double vis_thre, double* ious, void* stream) {
+    if (!g_kpts || !g_areas || !d_kpts || !d_areas || !sigmas || !ious || ng <= 0 || nd <= 0 || K <= 0 || K > 128)
+        return ADVMIX_EINVAL;
+    if (use_vis && vis_thre != vis_thre) return ADVMIX_EINVAL;                                      // NaN threshold
+    const dim3 grid(cdiv(nd, 64), ng);
+    if (use_vis)
+        hipLaunchKernelGGL(oks_matrix_kernel<true>, grid, dim3(64), 0, (hipStream_t)stream, g_kpts, g_areas, d_kpts, d_areas,
+                           sigmas, nd, K, vis_thre, ious);
+    else
+        hipLaunchKernelGGL(oks_matrix_kernel<false>, grid, dim3(64), 0, (hipStream_t)stream, g_kpts, g_areas, d_kpts, d_areas,
+                           sigmas, nd, K, 0.0, ious);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }

@@ -80,16 +80,48 @@ def gpu_nms_wrapper(thresh, device_id):
 _SIGMAS = np.array([.26, .25, .25, .35, .35, .79, .79, .72, .72, .62, .62, 1.07, 1.07, .87, .87, .89, .89]) / 10.0
 
 
-def _oks_matrix(kpts, areas, sigmas, device=False):
-    n, K = kpts.shape[0], kpts.shape[1] // 3
+def _dev64(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+def _oks(gk, ga, dk, da, sigmas, in_vis_thre):
+    """ious[ng, nd] (fp64, on the GPU) of ng persons against nd detections: advmix_oks_iou."""
     sig = _SIGMAS if not isinstance(sigmas, np.ndarray) else sigmas
-    k = torch.from_numpy(np.ascontiguousarray(kpts, dtype=np.float64)).cuda()
-    a = torch.from_numpy(np.ascontiguousarray(areas, dtype=np.float64)).cuda()
-    s = torch.from_numpy(np.ascontiguousarray(sig, dtype=np.float64)).cuda()
-    out = torch.empty((n, n), dtype=torch.float64, device='cuda')
+    K = dk.shape[1] // 3
+    g, a, d, b, s = _dev64(gk), _dev64(ga), _dev64(dk), _dev64(da), _dev64(sig)
+    out = torch.empty((g.shape[0], d.shape[0]), dtype=torch.float64, device='cuda')
     P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
-    call('advmix_oks_matrix', P(k), P(a), P(s), n, K, P(out),
+    call('advmix_oks_iou', P(g), P(a), g.shape[0], P(d), P(b), d.shape[0], P(s), K,
+         0 if in_vis_thre is None else 1, 0.0 if in_vis_thre is None else float(in_vis_thre), P(out),
          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    return out
+
+
+def oks_iou(g, d, a_g, a_d, sigmas=None, in_vis_thre=None):
+    """nms.py:75-94: OKS of one person ``g`` [3K] (area a_g) with each of the detections ``d`` [n, 3K] (areas a_d) ->
+    float64 [n]; with ``in_vis_thre`` only the joints the DETECTION shows above it count (nms.py:90-92)."""
+    d = np.asarray(d, dtype=np.float64)
+    if d.shape[0] == 0:
+        return np.zeros(0)
+    g = np.asarray(g, dtype=np.float64).reshape(1, -1)
+    return _oks(g, np.asarray([a_g], dtype=np.float64), d, np.asarray(a_d, dtype=np.float64), sigmas,
+                in_vis_thre)[0].cpu().numpy()
+
+
+def rescore(overlap, scores, thresh, type='gaussian'):
+    """nms.py:127-136: soft-NMS rescoring.  'linear' scales the scores whose overlap reaches ``thresh`` by
+    (1 - overlap) IN PLACE (as the reference does); anything else is the Gaussian penalty, returned as a new array."""
+    assert overlap.shape[0] == scores.shape[0]
+    if type == 'linear':
+        hit = np.where(overlap >= thresh)[0]
+        scores[hit] = scores[hit] * (1 - overlap[hit])
+        return scores
+    return scores * np.exp(-overlap ** 2 / thresh)
+
+
+def _oks_matrix(kpts, areas, sigmas, device=False, in_vis_thre=None):
+    """Row i = oks_iou(kpts[i], kpts, areas[i], areas, sigmas, in_vis_thre): every pair the greedy passes may ask for."""
+    out = _oks(kpts, areas, kpts, areas, sigmas, in_vis_thre)
     return out if device else out.cpu().numpy()
 
 
@@ -101,14 +133,12 @@ def _unpack(kpts_db):
 
 
 def oks_nms(kpts_db, thresh, sigmas=None, in_vis_thre=None):
-    """nms.py:97-125 (in_vis_thre is never passed by the caller, coco.py:356-364)."""
+    """nms.py:97-125 (the caller, coco.py:356-364, never passes in_vis_thre; it is served all the same)."""
     if len(kpts_db) == 0:
         return []
-    if in_vis_thre is not None:
-        raise NotImplementedError('in_vis_thre is unused by the reference caller')
     scores, kpts, areas = _unpack(kpts_db)
     n = len(scores)
-    M = _oks_matrix(kpts, areas, sigmas, device=True)      # [n, n] fp64, stays on the GPU
+    M = _oks_matrix(kpts, areas, sigmas, device=True, in_vis_thre=in_vis_thre)      # [n, n] fp64, stays on the GPU
     # candidates best-first: numpy's argsort (its order among equal scores is part of the reference's result); the greedy
     # pass itself runs on the device (advmix_oks_greedy) and only the kept indices come back
     order = torch.from_numpy(np.ascontiguousarray(scores.argsort()[::-1], dtype=np.int32)).cuda()
@@ -125,10 +155,8 @@ def soft_oks_nms(kpts_db, thresh, sigmas=None, in_vis_thre=None):
     """nms.py:139-177: gaussian rescoring, re-sort every round, max_dets = 20."""
     if len(kpts_db) == 0:
         return []
-    if in_vis_thre is not None:
-        raise NotImplementedError('in_vis_thre is unused by the reference caller')
     scores, kpts, areas = _unpack(kpts_db)
-    M = _oks_matrix(kpts, areas, sigmas)
+    M = _oks_matrix(kpts, areas, sigmas, in_vis_thre=in_vis_thre)
     order = scores.argsort()[::-1]
     scores = scores[order]
     max_dets = 20

@@ -349,6 +349,12 @@ int advmix_nms_host(int* keep_out, int* num_out, const float* boxes_host, int bo
 /* OKS matrix (float64, lib/nms/nms.py:75-94): ious[n,n] for kpts[n,17*3], areas[n] (device) */
 int advmix_oks_matrix(const double* kpts, const double* areas, const double* sigmas, int n, int K,
                       double* ious, void* stream);
+/* oks_iou itself (lib/nms/nms.py:75-94): ng persons (g) against nd detections (d) -> ious[ng, nd], all float64 on the
+ * device.  use_vis != 0 is ``in_vis_thre`` (nms.py:90-92): joints of DETECTION j whose visibility d_kpts[j][3k+2] is not
+ * above vis_thre leave the sum and the divisor (the reference's ``list(vg > t) and list(vd > t)`` is the detection's mask
+ * alone); no joint left: 0.  ADVMIX_EINVAL for a NaN threshold. */
+int advmix_oks_iou(const double* g_kpts, const double* g_areas, int ng, const double* d_kpts, const double* d_areas,
+                   int nd, const double* sigmas, int K, int use_vis, double vis_thre, double* ious, void* stream);
 /* The greedy pass of oks_nms (lib/nms/nms.py:97-125) on the device: ``order`` = candidate indices best-first (the host's
  * argsort of the scores: numpy's tie order is part of the reference's result); a candidate is kept unless an earlier
  * kept one has OKS > thresh with it.  keep_out: int32 [n], count_out: int32 [1].  Only the kept indices cross PCIe. */

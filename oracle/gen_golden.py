@@ -363,6 +363,36 @@ def gen_nms(M):
 COCO_PAIRS = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]       # coco.py:71-72 (data)
 
 
+def gen_nmsvis(M):
+    """oks_iou / oks_nms / soft_oks_nms WITH ``in_vis_thre`` (nms.py:90-92: only the joints whose visibility exceeds the
+    threshold count - through ``list(vg > t) and list(vd > t)``, i.e. the DETECTION's visibilities alone decide).  The
+    reference's caller never passes it (coco.py:356-364); the argument is part of the interface."""
+    nm = M['nms.nms']
+    rng = np.random.Generator(np.random.Philox(key=78))
+    out = {}
+    for N in (1, 6, 24):
+        for th, vis in ((0.5, 0.2), (0.9, 0.5), (0.9, 0.97), (0.5, 2.0)):      # 2.0: no joint passes -> every OKS is 0
+            k = rng.random((N, 17, 3)) * 100
+            base = rng.random((1, 17, 3)) * 100
+            k[: N // 2] = base + rng.normal(0, 2.0, (N // 2, 17, 3))
+            k[:, :, 2] = rng.random((N, 17))                                     # visibilities in [0, 1)
+            if N >= 6:
+                k[1, :, 2] = 0.0                                                 # a person with no visible joint
+                k[2, :9, 2] = 1.0                                                # >= 8 visible joints: numpy's 8-way sum
+            db = [{'score': float(s), 'keypoints': kk, 'area': float(a)}
+                  for s, kk, a in zip(rng.permutation(N) / N + 0.01, k, rng.random(N) * 4000 + 500)]
+            kf = np.array([e['keypoints'].flatten() for e in db])
+            ar = np.array([e['area'] for e in db])
+            out['N%d_t%g_v%g' % (N, th, vis)] = {
+                'score': [e['score'] for e in db], 'area': [e['area'] for e in db], 'kpts': k.tolist(), 'thresh': th,
+                'in_vis_thre': vis,
+                'iou_row0': [float(v) for v in nm.oks_iou(kf[0], kf, ar[0], ar, None, vis)],
+                'keep': [int(i) for i in nm.oks_nms(db, th, None, vis)],
+                'soft_keep': [int(i) for i in nm.soft_oks_nms(db, th, None, vis)]}
+    with open(os.path.join(OUT, 'nms_vis.json'), 'w') as f:
+        json.dump(out, f)
+
+
 def gen_validate(M):
     """Validation path from the REAL reference: get_final_preds / flip_back on synthetic maps,
     the ``validate`` loop on tiny + full nets, COCODataset.evaluate's rescoring + OKS-NMS.  The one missing
@@ -609,7 +639,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     M = import_reference()
-    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe', 'c4', 'b32', 'benchtiles', 'c1', 'autoaug', 'c5trunk']
+    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe', 'c4', 'b32', 'benchtiles', 'c1', 'autoaug', 'c5trunk', 'nmsvis']
     for w in which:
         globals()['gen_' + w](M)
         print('done', w, flush=True)

@@ -86,8 +86,10 @@ COCO_SIGMAS = np.array([.26, .25, .25, .35, .35, .79, .79, .72, .72, .62, .62,
                         1.07, 1.07, .87, .87, .89, .89]) / 10.0          # nms.py:77
 
 
-def oks_iou(g, d, a_g, a_d, sigmas=None):
-    """nms.py:75-94 with in_vis_thre=None. g:[51], d:[n,51]."""
+def oks_iou(g, d, a_g, a_d, sigmas=None, in_vis_thre=None):
+    """nms.py:75-94. g:[51], d:[n,51].  With ``in_vis_thre`` only some joints count (nms.py:90-92): the reference
+    writes ``ind = list(vg > t) and list(vd > t)`` - Python's ``and`` of two non-empty lists is the SECOND list, so the
+    boolean mask is the detection's visibilities alone (``vd > t``); the ground-truth side never enters."""
     sig = COCO_SIGMAS if sigmas is None else sigmas
     var = (sig * 2) ** 2
     out = np.zeros(d.shape[0])
@@ -95,6 +97,8 @@ def oks_iou(g, d, a_g, a_d, sigmas=None):
         dx = d[n, 0::3] - g[0::3]
         dy = d[n, 1::3] - g[1::3]
         e = (dx ** 2 + dy ** 2) / var / ((a_g + a_d[n]) / 2 + np.spacing(1)) / 2
+        if in_vis_thre is not None and g[2::3].shape[0] > 0:
+            e = e[d[n, 2::3] > in_vis_thre]
         out[n] = np.sum(np.exp(-e)) / e.shape[0] if e.shape[0] else 0.0
     return out
 
@@ -106,7 +110,7 @@ def _unpack(db):
     return sc, kp, ar
 
 
-def oks_nms(db, thresh, sigmas=None):
+def oks_nms(db, thresh, sigmas=None, in_vis_thre=None):
     """nms.py:97-125."""
     if len(db) == 0:
         return []
@@ -116,12 +120,12 @@ def oks_nms(db, thresh, sigmas=None):
     while order.size > 0:
         i, rest = order[0], order[1:]
         keep.append(int(i))
-        ov = oks_iou(kp[i], kp[rest], ar[i], ar[rest], sigmas)
+        ov = oks_iou(kp[i], kp[rest], ar[i], ar[rest], sigmas, in_vis_thre)
         order = rest[ov <= thresh]
     return keep
 
 
-def soft_oks_nms(db, thresh, sigmas=None, max_dets=20):
+def soft_oks_nms(db, thresh, sigmas=None, in_vis_thre=None, max_dets=20):
     """nms.py:139-177 (gaussian rescoring, re-sort every round, max_dets = 20)."""
     if len(db) == 0:
         return []
@@ -131,7 +135,7 @@ def soft_oks_nms(db, thresh, sigmas=None, max_dets=20):
     keep = []
     while order.size > 0 and len(keep) < max_dets:
         i = order[0]
-        ov = oks_iou(kp[i], kp[order[1:]], ar[i], ar[order[1:]], sigmas)
+        ov = oks_iou(kp[i], kp[order[1:]], ar[i], ar[order[1:]], sigmas, in_vis_thre)
         order = order[1:]
         sc = sc[1:] * np.exp(-ov ** 2 / thresh)
         t = sc.argsort()[::-1]

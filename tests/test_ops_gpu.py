@@ -1143,6 +1143,47 @@ def test_dgrad_with_addend_in_epilogue(case):
     del ops._KEEP[:]
 
 
+def test_oks_iou_rescore_and_in_vis_thre_match_the_reference_fixture():
+    """The rest of lib/nms/nms.py's interface: ``oks_iou`` itself (one person against n detections), ``rescore``, and
+    ``in_vis_thre`` through oks_iou / oks_nms / soft_oks_nms - against what the REAL reference returned
+    (tests/golden/nms_vis.json) and against the oracle, including K != 17 with explicit sigmas and < 8 surviving joints."""
+    from helpers import gold_json
+    from oracle import nms as onms
+    from advmix_amd.nms import nms as pn
+    g = gold_json('nms_vis.json')
+    worst = 0.0
+    for name, c in g.items():
+        k = np.array(c['kpts'])
+        db = [{'score': s, 'keypoints': kk, 'area': a} for s, kk, a in zip(c['score'], k, c['area'])]
+        kf, ar = k.reshape(len(db), -1), np.array(c['area'])
+        got = pn.oks_iou(kf[0], kf, ar[0], ar, None, c['in_vis_thre'])
+        want = np.array(c['iou_row0'])
+        assert got.shape == want.shape and got.dtype == np.float64
+        ulp = np.abs(got - want) / np.maximum(np.spacing(np.abs(want)), 5e-324)
+        worst = max(worst, float(ulp.max()))
+        assert ulp.max() <= 2, (name, ulp.max())                      # exp()'s last bit: device libm vs the host's
+        assert ((want == 0) == (got == 0)).all(), name
+        assert [int(i) for i in pn.oks_nms(db, c['thresh'], None, c['in_vis_thre'])] == c['keep'], name
+        assert [int(i) for i in pn.soft_oks_nms(db, c['thresh'], None, c['in_vis_thre'])] == c['soft_keep'], name
+    print('oks_iou with in_vis_thre: max ulp distance to the reference %.1f' % worst)
+    rng = np.random.default_rng(5)
+    for K in (3, 7, 8, 11, 17, 33):                                    # numpy's plain loop (< 8 terms) and its 8-way sum
+        sig = rng.random(K) * 0.1 + 0.02
+        gk, dk = rng.random(3 * K) * 50, rng.random((9, 3 * K)) * 50
+        dk[:, 2::3] = rng.random((9, K))
+        ad = rng.random(9) * 900 + 100
+        for vis in (None, 0.3, 0.8):
+            want = onms.oks_iou(gk, dk, 400.0, ad, sig, vis)
+            got = pn.oks_iou(gk, dk, 400.0, ad, sig, vis)
+            assert np.allclose(got, want, rtol=1e-15, atol=0), (K, vis)
+    assert pn.oks_iou(np.zeros(51), np.zeros((0, 51)), 1.0, np.zeros(0)).shape == (0,)
+    ov, sc = rng.random(12), rng.random(12)
+    assert np.array_equal(pn.rescore(ov, sc.copy(), 0.4), sc * np.exp(-ov ** 2 / 0.4))
+    lin = sc.copy()
+    out = pn.rescore(ov, lin, 0.4, type='linear')
+    assert out is lin and np.array_equal(lin, np.where(ov >= 0.4, sc * (1 - ov), sc))   # in place, like nms.py:131-132
+
+
 def test_edge_cases_empty_single_boundary():
     """Degenerate inputs the reference code paths accept: empty / single-person OKS-NMS, all joints weighted out,
     constant heat-maps (ties -> first index), joints whose gaussian just touches / just misses the heat-map."""
@@ -1261,6 +1302,13 @@ def test_round3_entry_points_refuse_bad_arguments_without_launching():
     assert lib.advmix_oks_greedy(P(f64), P(i32), 0, 0.5, P(i32), P(i32), st) == 1
     assert lib.advmix_oks_greedy(P(f64), P(i32), 9000, 0.5, P(i32), P(i32), st) == 1
     assert lib.advmix_stats_fold(None, 4, 8, P(f64), st) == 1 and lib.advmix_stats_fold(P(f64), 0, 8, P(f64), st) == 1
+    big = torch.zeros(1024, dtype=torch.float64, device=d)
+    ok = lambda *a: lib.advmix_oks_iou(*a)                     # noqa: E731
+    assert ok(None, P(f64), 1, P(big), P(f64), 2, P(f64), 17, 0, 0.0, P(f64), st) == 1
+    assert ok(P(big), P(f64), 0, P(big), P(f64), 2, P(f64), 17, 0, 0.0, P(f64), st) == 1
+    assert ok(P(big), P(f64), 1, P(big), P(f64), 2, P(f64), 129, 0, 0.0, P(f64), st) == 1
+    assert ok(P(big), P(f64), 1, P(big), P(f64), 2, P(f64), 17, 1, float('nan'), P(f64), st) == 1
+    assert ok(P(big), P(f64), 1, P(big), P(f64), 2, P(f64), 17, 1, 0.5, P(f64), st) == 0
     # deterministic statistics: capacity of ONE tile per channel where the launch has 4 row tiles -> refused, y untouched
     B, H, W, C = 4, 16, 8, 32
     x = torch.randn(B, H, W, C, device=d)

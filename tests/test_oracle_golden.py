@@ -93,6 +93,22 @@ def test_oks_nms_matches_reference():
         assert onms.soft_oks_nms(db, c['thresh']) == c['soft_keep'], name
 
 
+def test_oks_with_in_vis_thre_matches_reference():
+    """nms.py:90-92 (the visibility filter of oks_iou, threaded through oks_nms / soft_oks_nms) against what the REAL
+    reference returned (oracle/gen_golden.py::gen_nmsvis), OKS values bit for bit."""
+    g = gold_json('nms_vis.json')
+    assert len(g) == 12
+    for name, c in g.items():
+        k = np.array(c['kpts'])
+        db = [{'score': s, 'keypoints': kk, 'area': a} for s, kk, a in zip(c['score'], k, c['area'])]
+        kf, ar = k.reshape(len(db), -1), np.array(c['area'])
+        row = onms.oks_iou(kf[0], kf, ar[0], ar, None, c['in_vis_thre'])
+        assert row.tolist() == c['iou_row0'], name
+        assert onms.oks_nms(db, c['thresh'], None, c['in_vis_thre']) == c['keep'], name
+        assert onms.soft_oks_nms(db, c['thresh'], None, c['in_vis_thre']) == c['soft_keep'], name
+    assert any(0.0 in c['iou_row0'] for c in g.values())            # the "no joint passes" branch is in the fixture
+
+
 @pytest.mark.parametrize('tag', list(ALL_FORWARD))
 def test_forward_backward_matches_reference(tag):
     net, extra, J, B, H, W, _ = ALL_FORWARD[tag]

@@ -16,7 +16,7 @@ for L in 4 1; do
   S=$(ls $OUT/raw/*/*kernel_stats.csv $OUT/raw/*kernel_stats.csv 2>/dev/null | head -1)
   cp $S $OUT/stats_${L}lane.csv
   if [ $L = 4 ]; then
-    python3 $R/tools/analyze_trace.py $T 0.5 > $OUT/trace_summary_4lanes.txt 2>&1
+    python3 $R/tools/analyze_trace.py $T 0.5 cat_views_kernel 4 > $OUT/trace_summary_4lanes.txt 2>&1   # the last 4 whole replayed steps
   else
     python3 $R/bench.py --dump-shapes $OUT/shapes.csv "$@" > $OUT/dump.log 2>&1
     python3 $R/tools/kernel_shapes.py $T $OUT/shapes.csv $OUT/per_shape_1lane.csv 0.5 > $OUT/per_shape_1lane.txt 2>&1

@@ -1,6 +1,7 @@
 """Mirror of lib/core/evaluate.py:41-99 ``accuracy`` (PCK on heat-map argmax).  The argmax runs
 on the GPU; only [B,J] indices are copied to the host instead of two full heat-map tensors."""
 import numpy as np
+import torch
 
 from .inference import get_max_preds
 
@@ -19,12 +20,8 @@ def dist_acc(dists, thr=0.5):
     return (dists[cal] < thr).sum() * 1.0 / n if n > 0 else -1
 
 
-def accuracy(outputs, target, hm_type='gaussian', thr=0.5, args=None, cfg=None):
-    if hm_type != 'gaussian' or args is not None:
-        raise NotImplementedError('only the gaussian heat-map accuracy is on the hot path')
-    pred, _ = get_max_preds(outputs)
-    gt, _ = get_max_preds(target)
-    h, w = outputs.shape[2], outputs.shape[3]
+def _accuracy_from_preds(pred, gt, h, w, thr):
+    thr = 0.5          # evaluate.py:90 calls dist_acc(dists[idx[i]]) without passing ``thr`` on: the argument has no effect
     norm = np.ones((pred.shape[0], 2)) * np.array([h, w]) / 10
     dists = calc_dists(pred, gt, norm)
     J = dists.shape[0]
@@ -39,3 +36,76 @@ def accuracy(outputs, target, hm_type='gaussian', thr=0.5, args=None, cfg=None):
     if cnt != 0:
         acc[0] = avg_acc
     return acc, avg_acc, cnt, pred
+
+
+_SLOTS = {}        # (device index, B * J) -> [[device buffer, pinned host buffer] x 2, next slot, [owner x 2]]
+
+
+class PendingAccuracy:
+    """``accuracy(outputs, target)`` (evaluate.py:41-99) and optionally ``loss.item()`` (function.py:62,167) split in two:
+    constructing it ENQUEUES the device half - the two heat-map argmaxes written into one packed buffer, the loss scalar
+    beside them, ONE device-to-host copy into pinned memory, an event - and returns at once; ``get()`` waits for the
+    event and does the host half.  The reference reads both synchronously every iteration (two full heat-map tensors
+    to the host); read one iteration late instead, the round trip (≈ 0.5 ms of idle GPU per step) hides behind the next
+    step.  Two slots alternate, so the copy of step k + 1 never lands in the buffer the host still parses for step k."""
+
+    def __init__(self, outputs, target, loss=None, thr=0.5):
+        from .. import ops
+        B, J, H, W = outputs.shape
+        self.shape, self.thr, self.has_loss = (B, J, H, W), thr, loss is not None
+        n = B * J
+        dev = outputs.device
+        key = (dev.index, n)
+        st = _SLOTS.get(key)
+        if st is None:
+            st = _SLOTS[key] = [[(torch.empty(4 * n + 1, dtype=torch.int32, device=dev),
+                                  torch.empty(4 * n + 1, dtype=torch.int32).pin_memory()) for _ in range(2)], 0, [None, None]]
+        buf, self.host = st[0][st[1]]
+        prev = st[2][st[1]]
+        if prev is not None and prev._result is None:     # a third result in flight: parse the slot's owner first
+            prev.get()
+        st[2][st[1]] = self
+        st[1] ^= 1
+        self._result = None
+        f = buf.view(torch.float32)
+        ops.heatmap_argmax(outputs.detach(), out=(buf[0:n], f[n:2 * n]))
+        ops.heatmap_argmax(target.detach().float(), out=(buf[2 * n:3 * n], f[3 * n:4 * n]))
+        if loss is not None:
+            f[4 * n:4 * n + 1].copy_(loss.detach().reshape(1))
+        self.host.copy_(buf, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(dev))
+
+    def get(self):
+        """(acc, avg_acc, cnt, pred, loss value or None) - the first four exactly what ``accuracy`` returns."""
+        if self._result is not None:
+            return self._result
+        self.event.synchronize()
+        B, J, H, W = self.shape
+        n = B * J
+        h = self.host.numpy()
+        hf = h.view(np.float32)
+
+        def preds(idx, mx):
+            idx = idx.astype(np.int64).reshape(B, J)
+            p = np.zeros((B, J, 2), np.float32)
+            p[:, :, 0] = idx % W
+            p[:, :, 1] = np.floor(idx / W)
+            p *= np.tile(np.greater(mx.reshape(B, J, 1), 0.0), (1, 1, 2)).astype(np.float32)      # inference.py:44-47
+            return p
+        pred = preds(h[0:n], hf[n:2 * n])
+        gt = preds(h[2 * n:3 * n], hf[3 * n:4 * n])
+        lv = float(hf[4 * n]) if self.has_loss else None
+        self._result = _accuracy_from_preds(pred, gt, H, W, self.thr) + (lv,)
+        return self._result
+
+
+def accuracy(outputs, target, hm_type='gaussian', thr=0.5, args=None, cfg=None):
+    if hm_type != 'gaussian' or args is not None:
+        raise NotImplementedError('only the gaussian heat-map accuracy is on the hot path')
+    if isinstance(outputs, torch.Tensor) and outputs.is_cuda and isinstance(target, torch.Tensor) and target.is_cuda:
+        return PendingAccuracy(outputs, target, None, thr).get()[:4]       # one device-to-host copy instead of four
+    pred, _ = get_max_preds(outputs)
+    gt, _ = get_max_preds(target)
+    h, w = outputs.shape[2], outputs.shape[3]
+    return _accuracy_from_preds(pred, gt, h, w, thr)

@@ -254,6 +254,34 @@ class _Prefetch:
         return batch, dev
 
 
+class _Deferred:
+    """``loss.item()`` and ``accuracy()`` of iteration i (function.py:62-66 / :167-169), read while iteration i + 1 is
+    already running on the GPU (evaluate.PendingAccuracy); ``flush()`` before anything prints the meters, so a log line
+    shows exactly what the reference's shows."""
+
+    def __init__(self, losses, acc):
+        self.losses, self.acc, self.pending = losses, acc, None
+
+    def push(self, loss, output, target, bs):
+        if torch.is_tensor(output) and output.is_cuda and torch.is_tensor(target) and target.is_cuda:
+            from .evaluate import PendingAccuracy
+            cur = (PendingAccuracy(output, target, loss), bs)      # enqueued behind this iteration's step
+            self.flush()                                           # the previous iteration's numbers: long since there
+            self.pending = cur
+        else:
+            self.flush()
+            self.losses.update(loss.item(), bs)
+            _, avg_acc, cnt, _ = accuracy(output, target)
+            self.acc.update(avg_acc, cnt)
+
+    def flush(self):
+        if self.pending is not None:
+            (p, bs), self.pending = self.pending, None
+            _, avg_acc, cnt, _, lv = p.get()
+            self.losses.update(lv, bs)
+            self.acc.update(avg_acc, cnt)
+
+
 def _log(config, epoch, i, n, batch_time, data_time, losses, acc, bs, writer_dict):
     msg = 'Epoch: [{0}][{1}/{2}]\t' \
           'Time {batch_time.val:.3f}s ({batch_time.avg:.3f}s)\t' \
@@ -314,6 +342,7 @@ def train(config, args, train_loader, model, criterion, optimizer, epoch,
     model = _net(model)
     model.train()
     grad_sync = _auto_sync([model], [optimizer], grad_sync)
+    meters = _Deferred(losses, acc)
     end = time.time()
     n = len(train_loader) if hasattr(train_loader, '__len__') else -1
     pick = lambda b: [b[0], b[1][0] if isinstance(b[1], (list, tuple)) else b[1], b[2]]     # noqa: E731  (:48-51)
@@ -331,13 +360,13 @@ def train(config, args, train_loader, model, criterion, optimizer, epoch,
             loss, outputs = runner.step()
         else:
             loss, outputs = plain_step(model, criterion, optimizer, x, target, target_weight, grad_sync)
-        losses.update(loss.item(), input.size(0))                                        # :62
-        _, avg_acc, cnt, pred = accuracy(outputs, target)
-        acc.update(avg_acc, cnt)
+        meters.push(loss, outputs, target, input.size(0))                                # :62-66, one iteration late
         batch_time.update(time.time() - end)
         end = time.time()
         if i % config.PRINT_FREQ == 0:
+            meters.flush()
             _log(config, epoch, i, n, batch_time, data_time, losses, acc, input.size(0), writer_dict)
+    meters.flush()
 
 
 def train_advmix(config, args, train_loader, models, criterion, optimizers, epoch,
@@ -348,6 +377,7 @@ def train_advmix(config, args, train_loader, models, criterion, optimizers, epoc
     model_teacher = _net(models[2]).eval()
     optimizer, optimizer_G = optimizers[0], optimizers[1]
     grad_sync = _auto_sync([model, model_G, model_teacher], [optimizer, optimizer_G], grad_sync)
+    meters = _Deferred(losses, acc)
     end = time.time()
     n = len(train_loader) if hasattr(train_loader, '__len__') else -1
     pick = lambda b: [b[0][0], b[0][1], b[0][2], b[1][0], b[2][0]]                        # noqa: E731  (:129-133)
@@ -369,13 +399,13 @@ def train_advmix(config, args, train_loader, models, criterion, optimizers, epoc
         else:                                              # another batch shape: eager
             loss_D, output = advmix_step(args, model, model_G, model_teacher, criterion, optimizer,
                                          optimizer_G, inputs, target, target_weight, grad_sync)
-        losses.update(loss_D.item(), inputs[0].size(0))                                  # :167
-        _, avg_acc, cnt, pred = accuracy(output, target)                                 # :168
-        acc.update(avg_acc, cnt)
+        meters.push(loss_D, output, target, inputs[0].size(0))                           # :167-169, one iteration late
         batch_time.update(time.time() - end)
         end = time.time()
         if i % config.PRINT_FREQ == 0:
+            meters.flush()
             _log(config, epoch, i, n, batch_time, data_time, losses, acc, inputs[0].size(0), writer_dict)
+    meters.flush()
 
 
 def validate_batch(config, model, criterion, input, target, target_weight, flip_pairs):

@@ -1171,8 +1171,9 @@ def cat_views(views):
     return out
 
 
-def heatmap_argmax(hm):
-    """(idx int32 [B,J], max [B,J]) of a [B,J,H,W] heat-map; first occurrence (numpy.argmax)."""
+def heatmap_argmax(hm, out=None):
+    """(idx int32 [B,J], max [B,J]) of a [B,J,H,W] heat-map; first occurrence (numpy.argmax).  ``out`` = (idx, max)
+    tensors to write into (contiguous, B * J elements each) instead of fresh ones."""
     if not hm.is_cuda or hm.dtype != torch.float32:
         raise TypeError('heatmap_argmax needs an fp32 CUDA tensor')
     B, J, H, W = hm.shape
@@ -1180,8 +1181,14 @@ def heatmap_argmax(hm):
         fmt = 0
     else:
         hm, fmt = nhwc(hm), 1
-    idx = torch.empty((B, J), device=hm.device, dtype=torch.int32)
-    mx = torch.empty((B, J), device=hm.device, dtype=torch.float32)
+    if out is None:
+        idx = torch.empty((B, J), device=hm.device, dtype=torch.int32)
+        mx = torch.empty((B, J), device=hm.device, dtype=torch.float32)
+    else:
+        idx, mx = out
+        if idx.dtype != torch.int32 or mx.dtype != torch.float32 or idx.numel() != B * J or mx.numel() != B * J \
+                or not idx.is_contiguous() or not mx.is_contiguous():
+            raise TypeError('heatmap_argmax: out = (int32, float32) contiguous tensors of B * J elements')
     call('advmix_heatmap_argmax', _p(hm), fmt, _p(idx), _p(mx), B, J, H * W, _st())
     return idx, mx
 

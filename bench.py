@@ -524,6 +524,9 @@ def rendezvous(a, backend, rank, world, local):
         raise SystemExit(4)
 
 
+SYNC_METRICS = os.environ.get('ADVMIX_SYNC_METRICS') == '1'
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -659,29 +662,39 @@ def main():
         lv, acc = seen.get('train_loss', float('nan')), seen.get('train_acc', 0.0)
         loop_note = 'core.function.train_advmix over pinned host batches (H2D inside the timed region)'
     else:
+        from advmix_amd.core.evaluate import PendingAccuracy
         if a.exec_mode == 'graph':
             runner = AdvMixGraphRunner(args, D, G, T, crit, optD, optG, views, tgt, tw, sync)
 
-            def one_step():
+            def launch():
                 loss_D, out = runner.step()
-                lv = loss_D.item()                                         # function.py:167
-                _, avg_acc, cnt, _ = accuracy(out, runner.target)          # function.py:168
-                return lv, avg_acc
+                return PendingAccuracy(out, runner.target, loss_D)         # function.py:167-168, device half enqueued
         else:
-            def one_step():
+            def launch():
                 loss_D, out = advmix_step(args, D, G, T, crit, optD, optG, views, tgt, tw, sync)
-                lv = loss_D.item()
-                _, avg_acc, cnt, _ = accuracy(out, tgt)
-                return lv, avg_acc
+                return PendingAccuracy(out, tgt, loss_D)
 
-        for _ in range(a.warmup):
-            one_step()
+        def run_steps(n):
+            """n steps; loss.item() and accuracy() of every step are read - one step late, while the next one runs (the
+            loop mirror core.function.train_advmix does the same), the last one before returning."""
+            pend, lv, acc = None, float('nan'), 0.0
+            for _ in range(n):
+                cur = launch()
+                if SYNC_METRICS:                            # A/B switch: read every step's numbers before the next launch
+                    cur.get()
+                if pend is not None:
+                    _, acc, _, _, lv = pend.get()
+                pend = cur
+            if pend is not None:
+                _, acc, _, _, lv = pend.get()
+            return lv, acc
+
+        run_steps(a.warmup)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
-            lv, acc = one_step()
+        lv, acc = run_steps(a.steps)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

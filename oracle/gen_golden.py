@@ -393,6 +393,48 @@ def gen_nmsvis(M):
         json.dump(out, f)
 
 
+def accuracy_cases():
+    """Seeded (outputs, target) pairs for the accuracy fixture - shared by the generator and the tests."""
+    cases = {}
+    o = detinit.normal('acc.o0', (4, 17, 64, 48))
+    t = torch.zeros(4, 17, 64, 48)
+    cx = (detinit.uniform('acc.cx0', (4, 17)) * 48).long().clamp(0, 47)
+    cy = (detinit.uniform('acc.cy0', (4, 17)) * 64).long().clamp(0, 63)
+    for b in range(4):
+        for j in range(17):
+            t[b, j, cy[b, j], cx[b, j]] = 1.0
+            if (b + j) % 3 == 0:                           # prediction on / near the target
+                o[b, j, cy[b, j], min(47, int(cx[b, j]) + (j % 2))] = 9.0
+    cases['coco'] = (o, t)
+    o = detinit.normal('acc.o1', (2, 5, 8, 8))
+    t = detinit.uniform('acc.t1', (2, 5, 8, 8))
+    o[0, 0] = 0.25                                          # constant map: ties -> first index
+    o[0, 1] = -o[0, 1].abs() - 0.1                          # nothing positive: the prediction is zeroed (inference.py:44-47)
+    t[0, 2] = 0.0
+    t[0, 2, 0, 5] = 1.0                                     # target in row 0: invalid (evaluate.py:21)
+    t[1, 2] = 0.0
+    t[1, 2, 1, 1] = 1.0                                     # (1, 1): not > 1 either
+    t[:, 3] = 0.0                                           # a joint nobody annotates: all -1 -> acc -1, not counted
+    t[0, 4] = 0.0
+    t[0, 4, 2, 2] = 1.0
+    o[0, 4] = 0.0
+    o[0, 4, 2, 2] = 1.0                                     # exact hit
+    cases['edge'] = (o, t)
+    return cases
+
+
+def gen_accuracy(M):
+    """evaluate.accuracy (evaluate.py:41-99) from the REAL reference on the seeded cases above."""
+    ev = M['core.evaluate']
+    out = {}
+    for name, (o, t) in accuracy_cases().items():
+        acc, avg, cnt, pred = ev.accuracy(o.clone(), t.clone())
+        out[name] = {'acc': [float(v) for v in acc], 'avg': float(avg), 'cnt': int(cnt), 'pred': pred.tolist()}
+        print('accuracy', name, avg, cnt, flush=True)
+    with open(os.path.join(OUT, 'accuracy_kat.json'), 'w') as f:
+        json.dump(out, f)
+
+
 def gen_validate(M):
     """Validation path from the REAL reference: get_final_preds / flip_back on synthetic maps,
     the ``validate`` loop on tiny + full nets, COCODataset.evaluate's rescoring + OKS-NMS.  The one missing
@@ -639,7 +681,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     M = import_reference()
-    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe', 'c4', 'b32', 'benchtiles', 'c1', 'autoaug', 'c5trunk', 'nmsvis']
+    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe', 'c4', 'b32', 'benchtiles', 'c1', 'autoaug', 'c5trunk', 'nmsvis', 'accuracy']
     for w in which:
         globals()['gen_' + w](M)
         print('done', w, flush=True)

@@ -38,7 +38,9 @@ def max_preds(hm):
 
 
 def accuracy(output, target, thr=0.5):
-    """evaluate.py:41-99 (hm_type gaussian, args None). Returns (acc[J+1], avg, cnt, pred)."""
+    """evaluate.py:41-99 (hm_type gaussian, args None). Returns (acc[J+1], avg, cnt, pred).  ``thr`` is accepted and, as in
+    the reference, NOT used: evaluate.py:90 calls ``dist_acc(dists[idx[i]])`` with dist_acc's own default of 0.5."""
+    thr = 0.5
     out = output.detach().cpu().numpy()
     tgt = target.detach().cpu().numpy()
     pred, _ = max_preds(out)

@@ -1143,6 +1143,33 @@ def test_dgrad_with_addend_in_epilogue(case):
     del ops._KEEP[:]
 
 
+def test_accuracy_and_its_deferred_form_match_the_reference_fixture():
+    """core.evaluate.accuracy (device argmax, ONE packed device-to-host copy) and PendingAccuracy (the same with the loss
+    scalar, read later) against the REAL reference's evaluate.accuracy on seeded heat-maps (ties, all-negative maps,
+    border / missing targets), NCHW and channels-last; three results in flight with two slots."""
+    from helpers import gold_json
+    from oracle.gen_golden import accuracy_cases
+    from advmix_amd.core.evaluate import accuracy, PendingAccuracy
+    g = gold_json('accuracy_kat.json')
+    for name, (o, t) in accuracy_cases().items():
+        for conv in (lambda x: x.cuda().contiguous(), cl):
+            acc, avg, cnt, pred = accuracy(conv(o), conv(t), thr=0.1)          # thr has no effect (evaluate.py:90)
+            assert acc.tolist() == g[name]['acc'] and avg == g[name]['avg'] and cnt == g[name]['cnt'], name
+            assert pred.tolist() == g[name]['pred'], name
+    (o0, t0), (o1, t1) = accuracy_cases()['coco'], accuracy_cases()['edge']
+    loss = torch.tensor(0.625, device=dev())
+    p = [PendingAccuracy(o0.cuda(), t0.cuda(), loss), PendingAccuracy(o0.cuda().flip(0), t0.cuda().flip(0), loss * 2),
+         PendingAccuracy(o0.cuda(), t0.cuda(), loss * 3)]                       # the third re-uses the first one's slot
+    q = PendingAccuracy(o1.cuda(), t1.cuda())                                    # another size: its own slots
+    r = [x.get() for x in p]
+    assert [x[4] for x in r] == [0.625, 1.25, 1.875]
+    assert r[0][0].tolist() == g['coco']['acc'] and r[2][0].tolist() == g['coco']['acc'] and r[0][3].tolist() == g['coco']['pred']
+    assert r[1][3].tolist() == g['coco']['pred'][::-1] and abs(r[1][1] - g['coco']['avg']) < 1e-12
+    assert q.get()[0].tolist() == g['edge']['acc'] and q.get()[4] is None
+    with pytest.raises(NotImplementedError):
+        accuracy(o1.cuda(), t1.cuda(), hm_type='coord')
+
+
 def test_oks_iou_rescore_and_in_vis_thre_match_the_reference_fixture():
     """The rest of lib/nms/nms.py's interface: ``oks_iou`` itself (one person against n detections), ``rescore``, and
     ``in_vis_thre`` through oks_iou / oks_nms / soft_oks_nms - against what the REAL reference returned

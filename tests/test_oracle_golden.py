@@ -93,6 +93,19 @@ def test_oks_nms_matches_reference():
         assert onms.soft_oks_nms(db, c['thresh']) == c['soft_keep'], name
 
 
+def test_accuracy_matches_reference():
+    """evaluate.accuracy (evaluate.py:41-99) on seeded heat-maps incl. ties, all-negative maps, border / missing targets:
+    the oracle against what the REAL reference returned."""
+    from oracle.gen_golden import accuracy_cases
+    from oracle.loss import accuracy as oacc
+    g = gold_json('accuracy_kat.json')
+    for name, (o, t) in accuracy_cases().items():
+        acc, avg, cnt, pred = oacc(o, t)
+        assert acc.tolist() == g[name]['acc'] and avg == g[name]['avg'] and cnt == g[name]['cnt'], name
+        assert pred.tolist() == g[name]['pred'], name
+    assert -1.0 in g['edge']['acc'] and g['edge']['cnt'] < 5
+
+
 def test_oks_with_in_vis_thre_matches_reference():
     """nms.py:90-92 (the visibility filter of oks_iou, threaded through oks_nms / soft_oks_nms) against what the REAL
     reference returned (oracle/gen_golden.py::gen_nmsvis), OKS values bit for bit."""

@@ -11,7 +11,8 @@ namespace {
 
 static int stream_blocks(int64_t total) {
     int64_t b = (total + 255) / 256;
-    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+    const int cap = advmix_stream_cap();
+    return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
 // views are NCHW [N,3,H,W]; out NHWC [N,H,W,9]: G_input = torch.cat(inputs, 1) (function.py:137)

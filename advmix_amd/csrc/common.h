@@ -1,5 +1,6 @@
 // Shared helpers for the gfx950 kernels (device code is CDNA4-only: wave = 64 lanes).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/advmix_hip.h"
@@ -81,6 +82,18 @@ struct AdvmixOpts {
     int stat_slots;        // fp64 slots per channel the statistics epilogues fold their workgroup sums onto (power of 2 <= 64; 0 = by grid size)
 };
 AdvmixOpts& advmix_opts();
+
+// Workgroup cap of the grid-stride streaming kernels (ADVMIX_STREAM_WGS) and of the BatchNorm slot kernels
+// (ADVMIX_SLOT_WGS).  Round 3: narrow HBM-bound launches leave CUs to the MFMA kernels of the other lanes - see DESIGN.md.
+inline int advmix_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : dflt;
+    return v > 0 ? v : dflt;
+}
+inline int advmix_stream_cap() {
+    static const int v = advmix_env_int("ADVMIX_STREAM_WGS", 2048);
+    return v;
+}
 
 // Measurement aid (off unless advmix_set_option("trace_shapes", 1) with ADVMIX_TRACE_SHAPES=<file> in the environment):
 // one CSV line per MFMA launch - kernel template, grid, problem shape, algorithmic FLOPs - so that a rocprofv3 kernel

@@ -581,7 +581,7 @@ static dim3 slot_grid(int64_t rows, int C) {
     const int ctn = C < SLOT_CT ? C : SLOT_CT;
     const int rpi = 256 / (ctn / 4);
     int64_t nb = (rows + 4 * rpi - 1) / (4 * rpi);
-    static const int wgs = [] { const char* e = getenv("ADVMIX_SLOT_WGS"); int v = e ? atoi(e) : 2048; return v > 0 ? v : 2048; }();
+    static const int wgs = advmix_env_int("ADVMIX_SLOT_WGS", 512);
     const int64_t cap = wgs / nct > 0 ? wgs / nct : 1;
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
@@ -594,7 +594,8 @@ static bool slots_ok(int ns, int C) {
 
 static int stream_blocks(int64_t total) {
     int64_t b = (total + 255) / 256;
-    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+    const int cap = advmix_stream_cap();
+    return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
 }  // namespace

@@ -10,7 +10,8 @@ namespace {
 
 static int stream_blocks(int64_t total) {
     int64_t b = (total + 255) / 256;
-    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+    const int cap = advmix_stream_cap();
+    return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
 // input.flip(3) (function.py:241): x dense NCHW; y dense NCHW or NHWC.  Threads walk x in memory order.

@@ -575,7 +575,9 @@ __global__ __launch_bounds__(256) void stats_fold_kernel(const double* __restric
     if (lane == 0) out[pair] = acc;
 }
 
-// grid for the slot kernels: (row blocks, channel tiles); ~2048 workgroups, at least 4 row-iterations each
+// grid for the slot kernels: (row blocks, channel tiles); at least 4 row-iterations each, at most ADVMIX_SLOT_WGS (512)
+// workgroups: 2,048 is the fastest launch on its own (9.1 vs 8.3 us at 98,304 x 32 says otherwise even there), but in the step
+// these HBM-bound launches run beside other lanes' convolutions and a narrower one leaves them the CUs
 static dim3 slot_grid(int64_t rows, int C) {
     const int nct = cdiv(C, SLOT_CT);
     const int ctn = C < SLOT_CT ? C : SLOT_CT;

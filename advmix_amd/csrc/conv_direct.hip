@@ -614,9 +614,12 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
 }
 
 template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT, bool EPI, int NW = 4>
-// (min 3 waves / SIMD for the BatchNorm-backward variants: left free, the register allocator spreads their three
-// prefetched epilogue operands over 254 VGPRs = one wave per SIMD; the other variants keep their 52-108)
-__global__ __launch_bounds__(64 * NW, (EPI && MODE == 1 && NW == 4) ? 3 : 1) void conv_direct(ConvD p) {
+// (left free, the register allocator spreads the BatchNorm-backward variants' three prefetched epilogue operands over 254
+// VGPRs = one wave per SIMD.)  Four waves per SIMD for every variant (4-wave workgroups: 4 per CU, 8-wave: 2): the BatchNorm-backward variants compiled to
+// 138-152 registers = 3 waves per SIMD; capped at 128 (two of them spill 13 / 20 registers) the STEP is 1.8 % faster
+// (56.25 -> 55.26 ms, profiles/r03_ab_launch_bounds.log) - in the step a kernel shares the CUs with other lanes' kernels,
+// and the waves it can keep resident beside them matter more than its own instruction count.  5 / 6 per CU: 58.0 / 57.1 ms.
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void conv_direct(ConvD p) {
     __shared__ __attribute__((aligned(16))) float Bs[2 * Geo<TM, TN, WM, WN, KC, NW>::BSZ];
     __shared__ __attribute__((aligned(16))) float Ts[Geo<TM, TN, WM, WN, KC, NW>::TSZ];
     __shared__ int4 taptab[64];

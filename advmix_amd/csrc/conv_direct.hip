@@ -620,10 +620,16 @@ template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT,
 // (56.25 -> 55.26 ms, profiles/r03_ab_launch_bounds.log) - in the step a kernel shares the CUs with other lanes' kernels,
 // and the waves it can keep resident beside them matter more than its own instruction count.  5 / 6 per CU: 58.0 / 57.1 ms.
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void conv_direct(ConvD p) {
-    __shared__ __attribute__((aligned(16))) float Bs[2 * Geo<TM, TN, WM, WN, KC, NW>::BSZ];
-    __shared__ __attribute__((aligned(16))) float Ts[Geo<TM, TN, WM, WN, KC, NW>::TSZ];
+    using G = Geo<TM, TN, WM, WN, KC, NW>;
+    // K split inside the workgroup (WK > 1): the epilogue starts with a workgroup barrier (the partial tiles meet in the
+    // FIRST weight buffer), so the wave-private transposer can live in the SECOND weight buffer instead of LDS of its
+    // own - 42.5 -> 37.9 KB for the 32x32 tile, i.e. four workgroups per CU instead of three.
+    constexpr bool ALIAS = G::WK > 1 && G::RED <= G::BSZ && G::TSZ <= G::BSZ;   // (the partial tiles must fit the first buffer)
+    __shared__ __attribute__((aligned(16))) float Bs[2 * G::BSZ];
+    __shared__ __attribute__((aligned(16))) float Ts[ALIAS ? 4 : G::TSZ];
     __shared__ int4 taptab[64];
-    conv_body<TM, TN, WM, WN, KC, MODE, SPLIT, BT, EPI, NW>(p, blockIdx.x, blockIdx.y, blockIdx.z, Bs, Ts, taptab);
+    conv_body<TM, TN, WM, WN, KC, MODE, SPLIT, BT, EPI, NW>(p, blockIdx.x, blockIdx.y, blockIdx.z, Bs,
+                                                            ALIAS ? Bs + G::BSZ : Ts, taptab);
 }
 
 // Tile configuration for a problem (the only place that decides it; advmix_conv_direct_config reports it).

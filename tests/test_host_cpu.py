@@ -408,3 +408,25 @@ def test_measurement_variants_patch_still_applies(tmp_path):
     out = subprocess.run(['patch', '--dry-run', '-s', str(src), os.path.join(ROOT, 'tools', 'variants', 'conv_direct_dbg.patch')],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_product_never_touches_the_oracle_or_the_reference_tree():
+    """The oracle is the checker, never the product: nothing under advmix_amd/ imports ``oracle`` or names /root/reference;
+    only bench.py's cpu_baseline leg and __graft_entry__ (smoke / building the checker) may import it, and nothing that
+    runs on the GPU box (GPU tests, smoke, bench) reads /root/reference."""
+    import glob
+    pat = re.compile(r'^\s*(from|import)\s+oracle\b|/root/reference', re.M)
+    for f in glob.glob(os.path.join(ROOT, 'advmix_amd', '**', '*.py'), recursive=True):
+        assert not pat.search(open(f).read()), f
+    for f in glob.glob(os.path.join(ROOT, 'advmix_amd', 'csrc', '*')) + glob.glob(os.path.join(ROOT, 'include', '*.h')):
+        if f.endswith(('.hip', '.h')):
+            assert 'oracle/' not in open(f).read(), f
+    for f in ('bench.py', '__graft_entry__.py', 'tests/test_models_gpu.py', 'tests/test_ops_gpu.py', 'tests/smoke_step.py',
+              'tests/helpers.py', 'tests/conftest.py'):
+        assert '/root/reference' not in open(os.path.join(ROOT, f)).read(), f
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    for m in re.finditer(r'^\s*(from|import)\s+oracle\b.*$', src, re.M):          # every oracle import of bench.py ...
+        head = src[:m.start()]
+        fn = re.findall(r'^def (\w+)\(', head, re.M)[-1]
+        assert fn.startswith('cpu_baseline') or fn in ('cpu_baseline', '_cpu_baseline_worker'), (fn, m.group(0))   # ... is in its CPU leg
+

@@ -283,7 +283,12 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
     constexpr bool PRE = RM * RN == 1 && !SPLIT;
     const bool pre_a_on = PRE && t128 && p.res != nullptr && (MODE == 1 || EPI);
     const bool pre_c_on = PRE && t128 && EPI && MODE == 1;
-    const bool pre_y_on = pre_c_on && p.bnb_act != ADVMIX_ACT_NONE;
+    // The 128-row tile (WM == 4) keeps three operands x 16 registers through its main loop; under the four-waves-per-SIMD
+    // cap that is what spilled (20 registers).  Its y operand - needed only for the activation mask - is fetched in the
+    // epilogue instead (16-byte loads through the same transposer): 29.3 -> 27.1 us alone at 32->32 @64x48, step 55.8 -> 55.6 ms.
+    constexpr bool LATE_Y = PRE && (WM == 4 || WN == 2);       // (the 64x64 four-wave tile spilled the same way)
+    const bool pre_y_on = !LATE_Y && pre_c_on && p.bnb_act != ADVMIX_ACT_NONE;
+    const bool late_y_on = LATE_Y && pre_c_on && p.bnb_act != ADVMIX_ACT_NONE;
     f32x4 pq_a[TQ], pq_c[TQ], pq_y[TQ];
 #pragma unroll
     for (int q = 0; q < TQ; ++q) {
@@ -509,6 +514,16 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
             float oa[RSL], oc[RSL], oy[RSL];
 #pragma unroll
             for (int r = 0; r < RSL; ++r) { oa[r] = pre_a[r]; oc[r] = pre_c[r]; oy[r] = pre_y[r]; }
+            if (LATE_Y && late_y_on) {
+                f32x4 qy[TQ];
+#pragma unroll
+                for (int q = 0; q < TQ; ++q) {
+                    bool valid;
+                    const int off = chunk_off(t, u, q, valid);
+                    qy[q] = bload(yyr, valid ? (unsigned)off * 4u : OOB);
+                }
+                to_acc_layout(qy, oy);
+            }
             if (t128 && !PRE) {
                 const bool la = op_a, lc = bnb, ly = bnb && p.bnb_act != ADVMIX_ACT_NONE;
                 f32x4 qa[TQ], qc[TQ], qy[TQ];

@@ -9,6 +9,25 @@ SO = os.path.join(HERE, 'libadvmix_hip.so')
 SOURCES = ['conv_mfma.hip', 'conv_direct.hip', 'wgrad_direct.hip', 'wgrad_lds.hip', 'norm.hip', 'pointwise.hip', 'advmix_ops.hip', 'postproc.hip', 'inputpipe.hip', 'nms.hip']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-munsafe-fp-atomics', '-std=c++17',
          '-Wno-unused-result']
+# Every kernel must fit its registers: a kernel with scratch (spilled VGPRs) is refused - none of the library's kernels needs
+# any, a spill is always an accident of a register cap, and spilling builds were among the suspects of round 3's
+# two-process NaN hunt (conv_direct.hip, at its launch bounds).  The compiler reports each kernel's scratch; the build reads it.
+RESOURCE_FLAG = '-Rpass-analysis=kernel-resource-usage'
+
+
+def _scratch_users(report):
+    """Kernels with scratch in a -Rpass-analysis=kernel-resource-usage report: [(function, bytes per lane)]."""
+    import re
+    out, name = [], None
+    for line in report.splitlines():
+        m = re.search(r'remark: Function Name: (\S+)', line)
+        if m:
+            name = m.group(1)
+            continue
+        m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', line)
+        if m and int(m.group(1)) > 0:
+            out.append((name, int(m.group(1))))
+    return out
 
 
 def _stale(out, deps):
@@ -28,13 +47,27 @@ def build(force=False, verbose=True):
         obj = os.path.join(CSRC, s.replace('.hip', '.o'))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+            cmd = [hipcc] + FLAGS + [RESOURCE_FLAG, '-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
-            procs.append((s, subprocess.Popen(cmd)))
-    for s, p in procs:
-        if p.wait() != 0:
+            procs.append((s, obj, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+    bad = []
+    for s, obj, p in procs:
+        _, err = p.communicate()
+        other = [ln for ln in err.splitlines() if 'kernel-resource-usage' not in ln]
+        # (the remark lines carry a source excerpt each: print only what is not part of the resource report)
+        msgs = [ln for ln in other if 'warning' in ln or 'error' in ln]
+        if msgs and verbose:
+            print('\n'.join(msgs), flush=True)
+        if p.returncode != 0:
+            sys.stderr.write(err[-4000:])
             raise RuntimeError('hipcc failed on ' + s)
+        users = _scratch_users(err)
+        if users:
+            os.remove(obj)                                  # never link it
+            bad += ['%s: %s uses %d bytes of scratch per lane' % (s, n, b) for n, b in users]
+    if bad:
+        raise RuntimeError('kernels with register spills / scratch are refused (see build.py):\n  ' + '\n  '.join(bad))
     linked = False
     if force or procs or _stale(SO, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', SO] + objs
@@ -42,7 +75,7 @@ def build(force=False, verbose=True):
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
         linked = True
-    _record(hipcc, [s for s, _ in procs], linked)
+    _record(hipcc, [s for s, _, _ in procs], linked)
     return SO
 
 

@@ -193,6 +193,17 @@ def advmix_step(args, model, model_G, model_teacher, criterion, optimizer, optim
 # graphs (graph.AdvMixGraphRunner / PlainGraphRunner) and replay it per batch; a batch of another shape (the ragged
 # last batch of an epoch) runs eagerly.  ADVMIX_EXEC=eager disables the capture.
 GRAPH_EXEC = os.environ.get('ADVMIX_EXEC', 'graph') != 'eager'
+# With MORE THAN ONE rank the step runs eagerly unless ADVMIX_DP_GRAPH=1.  Round 3: the seven-graph data-parallel runner kept
+# two ranks' parameters bit-identical for weeks of tests and then, on the last day, stopped doing so in 20-75 % of the
+# two-ranks-on-one-GPU runs (gloo transport) - exchanged gradients came back as garbage (1e35, then NaN) on the second or
+# third replay; ALWAYS with ADVMIX_LANES=1, never in the eager step of the same test, never with one rank (whose exchange
+# moves nothing; 60-step benchmarks of the seven-graph runner are clean).  Not found in the time left;
+# until it is, multi-rank training takes the path that has never failed.
+DP_GRAPH = os.environ.get('ADVMIX_DP_GRAPH', '0') == '1'
+
+
+def _graph_ok(grad_sync):
+    return GRAPH_EXEC and (DP_GRAPH or grad_sync is None or not grad_sync.active or grad_sync.world == 1)
 _RUNNERS = {}
 
 
@@ -350,7 +361,7 @@ def train(config, args, train_loader, model, criterion, optimizer, epoch,
         data_time.update(time.time() - end)
         x = x.contiguous()
         runner = None
-        if GRAPH_EXEC and _capturable([optimizer], [x, target, target_weight]):
+        if _graph_ok(grad_sync) and _capturable([optimizer], [x, target, target_weight]):
             from ..graph import PlainGraphRunner
             sig = (tuple(x.shape), tuple(target.shape), tuple(target_weight.shape), id(grad_sync))
             runner = _runner_for('plain', (model, criterion, optimizer), sig, lambda: PlainGraphRunner(
@@ -386,7 +397,7 @@ def train_advmix(config, args, train_loader, models, criterion, optimizers, epoc
         inputs = [v.contiguous() for v in dev[:3]]
         target, target_weight = dev[3], dev[4]
         runner = None
-        if GRAPH_EXEC and _capturable([optimizer, optimizer_G], inputs + [target, target_weight]):
+        if _graph_ok(grad_sync) and _capturable([optimizer, optimizer_G], inputs + [target, target_weight]):
             from ..graph import AdvMixGraphRunner
             sig = (tuple(inputs[0].shape), tuple(target.shape), tuple(target_weight.shape), float(args.alpha),
                    float(args.adv_loss_weight), id(grad_sync))

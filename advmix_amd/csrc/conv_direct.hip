@@ -283,10 +283,10 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
     constexpr bool PRE = RM * RN == 1 && !SPLIT;
     const bool pre_a_on = PRE && t128 && p.res != nullptr && (MODE == 1 || EPI);
     const bool pre_c_on = PRE && t128 && EPI && MODE == 1;
-    // The 128-row tile (WM == 4) keeps three operands x 16 registers through its main loop; under the four-waves-per-SIMD
-    // cap that is what spilled (20 registers).  Its y operand - needed only for the activation mask - is fetched in the
-    // epilogue instead (16-byte loads through the same transposer): 29.3 -> 27.1 us alone at 32->32 @64x48, step 55.8 -> 55.6 ms.
-    constexpr bool LATE_Y = PRE && (WM == 4 || WN == 2);       // (the 64x64 four-wave tile spilled the same way)
+    // The 128-row tile (WM == 4) and the 64x64 four-wave tile (WN == 2) keep three operands x 16 registers through the main
+    // loop; their y operand - needed only for the activation mask - is fetched in the epilogue instead (16-byte loads through
+    // the same transposer), which takes 16 registers off the main loop.
+    constexpr bool LATE_Y = PRE && (WM == 4 || WN == 2);
     const bool pre_y_on = !LATE_Y && pre_c_on && p.bnb_act != ADVMIX_ACT_NONE;
     const bool late_y_on = LATE_Y && pre_c_on && p.bnb_act != ADVMIX_ACT_NONE;
     f32x4 pq_a[TQ], pq_c[TQ], pq_y[TQ];
@@ -630,11 +630,14 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
 
 template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT, bool EPI, int NW = 4>
 // (left free, the register allocator spreads the BatchNorm-backward variants' three prefetched epilogue operands over 254
-// VGPRs = one wave per SIMD.)  Four waves per SIMD for every variant (4-wave workgroups: 4 per CU, 8-wave: 2): the BatchNorm-backward variants compiled to
-// 138-152 registers = 3 waves per SIMD; capped at 128 (two of them spill 13 / 20 registers) the STEP is 1.8 % faster
-// (56.25 -> 55.26 ms, profiles/r03_ab_launch_bounds.log) - in the step a kernel shares the CUs with other lanes' kernels,
-// and the waves it can keep resident beside them matter more than its own instruction count.  5 / 6 per CU: 58.0 / 57.1 ms.
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void conv_direct(ConvD p) {
+// VGPRs = one wave per SIMD.)  Four waves per SIMD (4-wave workgroups: 4 per CU, 8-wave: 2) for every variant EXCEPT the
+// BatchNorm-backward ones, which stay at three (138-152 registers).  Capping those at 128 as well was worth 1.8 % of the
+// step (profiles/r03_ab_launch_bounds.log) and was shipped for a few hours of round 3 - until the two-ranks-on-one-GPU
+// data-parallel test, which had passed a dozen times in a row, began to fail in 2-6 of 8 runs: parameters turned NaN on the
+// third graph replay, with spilling builds (13-20 registers of scratch) and with a spill-free one alike, and in 0 of 10 runs
+// with this line.  No single-process test, benchmark or parity check ever saw it; the cause was not found in the time left
+// (DESIGN.md section 8), so the configuration that is known good ships.
+__global__ __launch_bounds__(64 * NW, NW == 4 ? ((EPI && MODE == 1) ? 3 : 4) : 2) void conv_direct(ConvD p) {
     using G = Geo<TM, TN, WM, WN, KC, NW>;
     // K split inside the workgroup (WK > 1): the epilogue starts with a workgroup barrier (the partial tiles meet in the
     // FIRST weight buffer), so the wave-private transposer can live in the SECOND weight buffer instead of LDS of its

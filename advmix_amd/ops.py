@@ -970,6 +970,7 @@ class GraphSeq:
 
     def __init__(self, device):
         self.graphs, self.pool = [], None
+        self._sink = torch.zeros(64, device=device, dtype=torch.float32)
 
     def capture(self, fn):
         g = torch.cuda.CUDAGraph()
@@ -978,6 +979,13 @@ class GraphSeq:
             kw['pool'] = self.pool
         with torch.cuda.graph(g, **kw):
             r = fn()
+            # ONE sink node on the capture stream, after every lane has been joined into it.  A segment whose last
+            # launches sit on side lanes otherwise ends in several leaf nodes, and work that another stream orders behind
+            # the replay (``side.wait_stream(cur)`` of the data-parallel gradient exchange, dp.GradSync.reduce_async) was
+            # seen to start while such a leaf - the last weight gradients of a backward piece - was still running: with two
+            # ranks the exchanged gradients then differed between the ranks in 20-75 % of the runs (round 3,
+            # test_data_parallel_path_two_ranks_on_one_gpu_over_gloo; never with one rank, whose exchange moves nothing).
+            call('advmix_fill', _p(self._sink), 0.0, self._sink.numel(), _st())
         if self.pool is None:
             self.pool = g.pool()
         self.graphs.append(g)

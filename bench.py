@@ -663,6 +663,10 @@ def main():
         loop_note = 'core.function.train_advmix over pinned host batches (H2D inside the timed region)'
     else:
         from advmix_amd.core.evaluate import PendingAccuracy
+        if world > 1 and a.exec_mode == 'graph' and os.environ.get('ADVMIX_DP_GRAPH', '0') != '1':
+            # core.function.DP_GRAPH: with more than one rank the step runs eagerly until the seven-graph runner's
+            # two-rank failure is found; the line says which execution it timed
+            a.exec_mode = 'eager'
         if a.exec_mode == 'graph':
             runner = AdvMixGraphRunner(args, D, G, T, crit, optD, optG, views, tgt, tw, sync)
 

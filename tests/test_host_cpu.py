@@ -430,3 +430,18 @@ def test_product_never_touches_the_oracle_or_the_reference_tree():
         fn = re.findall(r'^def (\w+)\(', head, re.M)[-1]
         assert fn.startswith('cpu_baseline') or fn in ('cpu_baseline', '_cpu_baseline_worker'), (fn, m.group(0))   # ... is in its CPU leg
 
+
+def test_build_refuses_kernels_with_scratch():
+    """advmix_amd/build.py reads the compiler's per-kernel resource report and refuses any kernel with scratch (spilled
+    registers): such kernels passed every single-process test and corrupted a two-process data-parallel run (round 3)."""
+    from advmix_amd import build as b
+    rep = ("x.hip:5:1: remark: Function Name: _Z1av [-Rpass-analysis=kernel-resource-usage]\n"
+           "x.hip:5:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]\n"
+           "x.hip:9:1: remark: Function Name: _Z1bv [-Rpass-analysis=kernel-resource-usage]\n"
+           "x.hip:9:1: remark:     VGPRs Spill: 20 [-Rpass-analysis=kernel-resource-usage]\n"
+           "x.hip:9:1: remark:     ScratchSize [bytes/lane]: 84 [-Rpass-analysis=kernel-resource-usage]\n")
+    assert b._scratch_users(rep) == [('_Z1bv', 84)]
+    assert b._scratch_users('') == [] and b.RESOURCE_FLAG.startswith('-Rpass-analysis')
+    import inspect
+    assert 'RESOURCE_FLAG' in inspect.getsource(b.build) and 'refused' in inspect.getsource(b.build)
+

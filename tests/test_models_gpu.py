@@ -958,13 +958,23 @@ def _dp_two_rank_worker():
     torch.cuda.synchronize()
     losses.append(float(l))
     assert all(same(x) for x in oD.flat_state()) and all(same(x) for x in oG.flat_state())
-    runner = AdvMixGraphRunner(args, D, G, T, crit, oD, oG, *data, sync)
-    assert runner.seq.n_graphs == 7
-    for _ in range(2):
-        l, o = runner.step()
+    for _ in range(2):                                                      # two more steps from the moved state
+        l, o = advmix_step(args, D, G, T, crit, oD, oG, *data, sync)
         losses.append(float(l))
     torch.cuda.synchronize()
     assert all(same(x) for x in oD.flat_state()) and all(same(x) for x in oG.flat_state())
+    if os.environ.get('ADVMIX_TEST_DP_GRAPH') == '1':
+        # KNOWN OPEN ISSUE (round 3): the seven-graph runner with two ranks.  It held this invariant
+        # in every run until the last day of the round and then failed 20-75 % of them (always with ADVMIX_LANES=1):
+        # exchanged gradients of 1e35, NaN parameters on the second or third replay.  core.function therefore runs
+        # multi-rank steps eagerly (ADVMIX_DP_GRAPH=1 opts back in); this block is the reproducer.
+        runner = AdvMixGraphRunner(args, D, G, T, crit, oD, oG, *data, sync)
+        assert runner.seq.n_graphs == 7
+        for _ in range(2):
+            l, o = runner.step()
+            losses.append(float(l))
+        torch.cuda.synchronize()
+        assert all(same(x) for x in oD.flat_state()) and all(same(x) for x in oG.flat_state())
     rm = D.state_dict()['bn1.running_mean']
     assert not same(rm)                                                     # statistics stay per replica
     la, lb = gathered(torch.tensor(losses, device='cuda'))

@@ -445,3 +445,19 @@ def test_build_refuses_kernels_with_scratch():
     import inspect
     assert 'RESOURCE_FLAG' in inspect.getsource(b.build) and 'refused' in inspect.getsource(b.build)
 
+
+def test_multi_rank_steps_run_eagerly_unless_opted_in(monkeypatch):
+    """core.function._graph_ok: HIP-graph replay for one rank (or no exchange at all); with more than one rank the step
+    runs eagerly until the seven-graph runner's open two-rank bug is fixed; ADVMIX_DP_GRAPH=1
+    opts back in; ADVMIX_EXEC=eager switches the graphs off altogether."""
+    from advmix_amd.core import function as F_
+    sync = lambda world, active=True: types.SimpleNamespace(world=world, active=active)     # noqa: E731
+    monkeypatch.setattr(F_, 'GRAPH_EXEC', True)
+    monkeypatch.setattr(F_, 'DP_GRAPH', False)
+    assert F_._graph_ok(None) and F_._graph_ok(sync(1)) and F_._graph_ok(sync(1, False)) and F_._graph_ok(sync(2, False))
+    assert not F_._graph_ok(sync(2)) and not F_._graph_ok(sync(8))
+    monkeypatch.setattr(F_, 'DP_GRAPH', True)
+    assert F_._graph_ok(sync(8))
+    monkeypatch.setattr(F_, 'GRAPH_EXEC', False)
+    assert not F_._graph_ok(None) and not F_._graph_ok(sync(8))
+

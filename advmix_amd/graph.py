@@ -137,6 +137,13 @@ class AdvMixGraphRunner:
                 self.sync.finish()                         # this segment's optimizer step consumes reduced gradients
             self.seq.replay(g)
             if red is not None and self.sync is not None:
+                # (candidate fix for the open two-rank failure, DESIGN.md section 4 - written after the round's GPU minutes
+                # had run out, NOT yet verified: one ordinary launch on the replay stream between the graph and the event
+                # the side stream waits for, so that the exchange is ordered behind an eagerly submitted kernel instead of
+                # directly behind a graph launch - a one-lane segment is a single chain, which the runtime submits through
+                # its pre-built-packet path, and the failures look like an exchange that started before the graph's data
+                # were there.)
+                self.seq.fence()
                 self.sync.reduce_async(red[0].flat_grads, red[1], red[2])
         return self.loss_D, self.output
 

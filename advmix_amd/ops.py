@@ -994,6 +994,10 @@ class GraphSeq:
     def replay(self, seg):
         self.graphs[seg].replay()
 
+    def fence(self):
+        """One ordinary (non-graph) launch on the current stream: see graph.AdvMixGraphRunner.step."""
+        call('advmix_fill', _p(self._sink), 0.0, self._sink.numel(), _st())
+
     @property
     def n_graphs(self):
         return len(self.graphs)

@@ -76,6 +76,7 @@ SIGNATURES = {
     'advmix_oks_matrix': [_p, _p, _p, _i, _i, _p, _p],
     'advmix_oks_iou': [_p, _p, _i, _p, _p, _i, _p, _i, _i, ctypes.c_double, _p, _p],
     'advmix_oks_greedy': [_p, _p, _i, ctypes.c_double, _p, _p, _p],
+    'advmix_soft_oks_greedy': [_p, _p, _p, _i, ctypes.c_double, _i, _p, _p, _p, _p, _p],
 }
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here == header/library drift

@@ -193,13 +193,11 @@ def advmix_step(args, model, model_G, model_teacher, criterion, optimizer, optim
 # graphs (graph.AdvMixGraphRunner / PlainGraphRunner) and replay it per batch; a batch of another shape (the ragged
 # last batch of an epoch) runs eagerly.  ADVMIX_EXEC=eager disables the capture.
 GRAPH_EXEC = os.environ.get('ADVMIX_EXEC', 'graph') != 'eager'
-# With MORE THAN ONE rank the step runs eagerly unless ADVMIX_DP_GRAPH=1.  Round 3: the seven-graph data-parallel runner kept
-# two ranks' parameters bit-identical for weeks of tests and then, on the last day, stopped doing so in 20-75 % of the
-# two-ranks-on-one-GPU runs (gloo transport) - exchanged gradients came back as garbage (1e35, then NaN) on the second or
-# third replay; ALWAYS with ADVMIX_LANES=1, never in the eager step of the same test, never with one rank (whose exchange
-# moves nothing; 60-step benchmarks of the seven-graph runner are clean).  Not found in the time left;
-# until it is, multi-rank training takes the path that has never failed.
-DP_GRAPH = os.environ.get('ADVMIX_DP_GRAPH', '0') == '1'
+# With more than one rank the step is replayed from seven HIP graphs (graph.AdvMixGraphRunner; ADVMIX_DP_GRAPH=0 falls back to
+# the eager pieces).  Round 3 shipped the eager fallback after the two-ranks-on-one-GPU test began to fail; round 4 found the
+# cause outside the step: replays served from the runtime's captured AQL packets on the NULL stream compute garbage when a
+# second process shares the GPU (tools/dp_graph_repro.py) - the runners now replay on their own stream.
+DP_GRAPH = os.environ.get('ADVMIX_DP_GRAPH', '1') == '1'
 
 
 def _graph_ok(grad_sync):
@@ -332,6 +330,15 @@ def _auto_sync(models, optimizers, grad_sync):
     return hit[0]
 
 
+def _replica_check(grad_sync, optimizers, epoch, i):
+    """Every PRINT_FREQ iterations with more than one rank: the replicas' parameters and optimizer state must still be the
+    same bits and finite on every rank (one 24-byte all-gather).  nn.DataParallel re-broadcast GPU 0's weights before
+    every forward (lib/core/function.py:138,146,160 through tools/train.py:69,106,109), so the reference could not drift;
+    separate processes can, silently, and a log line must not be printed over a job that has."""
+    if grad_sync is not None and grad_sync.active and grad_sync.world > 1:
+        grad_sync.assert_replicas(optimizers, 'epoch %d iteration %d' % (epoch, i))
+
+
 def _net(m):
     """The network inside a DataParallel-shaped wrapper (dp.Replica), or ``m`` itself."""
     from ..dp import unwrap
@@ -376,6 +383,7 @@ def train(config, args, train_loader, model, criterion, optimizer, epoch,
         end = time.time()
         if i % config.PRINT_FREQ == 0:
             meters.flush()
+            _replica_check(grad_sync, [optimizer], epoch, i)
             _log(config, epoch, i, n, batch_time, data_time, losses, acc, input.size(0), writer_dict)
     meters.flush()
 
@@ -415,6 +423,7 @@ def train_advmix(config, args, train_loader, models, criterion, optimizers, epoc
         end = time.time()
         if i % config.PRINT_FREQ == 0:
             meters.flush()
+            _replica_check(grad_sync, [optimizer, optimizer_G], epoch, i)
             _log(config, epoch, i, n, batch_time, data_time, losses, acc, inputs[0].size(0), writer_dict)
     meters.flush()
 
@@ -445,6 +454,12 @@ def validate(config, args, val_loader, val_dataset, model, criterion, output_dir
     GPU - per batch only the loss scalar, [B,J] argmax indices (accuracy) and [B,J,3] predictions do."""
     if cpu:
         raise RuntimeError('advmix_amd: validate() has no CPU path (the reference\'s cpu=True debug mode)')
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_rank() != 0:
+        # One process per GPU: rank 0 evaluates the whole set and writes the results file, as GPU 0 gathered every output
+        # under nn.DataParallel (tools/train.py:300-309: the other ranks' perf_indicator only feeds save_checkpoint's
+        # is_best, and save_checkpoint itself returns on them).  They wait in the next epoch's first gradient exchange.
+        return {}, 0.0
     batch_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter()
     model = _net(model)
     model.eval()

@@ -128,6 +128,53 @@ __global__ __launch_bounds__(256) void oks_greedy_kernel(const double* __restric
     if (threadIdx.x == 0) *count = kept;
 }
 
+// soft_oks_nms's rescoring loop (lib/nms/nms.py:139-177) on the device.  The reference keeps the candidate at the head of
+// the (score-descending) order, multiplies every remaining score by exp(-oks^2 / thresh) (float64) and re-sorts the rest
+// with ``scores.argsort()[::-1]``, at most ``max_dets`` (20) times.  One workgroup: ``order`` / ``score`` ping-pong between
+// two halves of the caller's scratch; the re-sort is a rank computation (position = how many of the others sort before me:
+// strictly greater, or equal and LATER in the current arrangement - a stable ascending sort read backwards).  Without
+// exact ties that IS numpy's argsort()[::-1]; among EQUAL scores numpy's order depends on its build (introsort, or the
+// AVX-512 argsort, which is unstable even for nine elements), so there the reference is defined only up to "a maximum of
+// the scores left is kept next", which is what this does.  NaN scores sort as numpy sorts them (last ascending = first
+// after the reversal).  Only the kept indices leave the GPU.
+__device__ __forceinline__ bool soft_lt(double a, double b) { return a < b || (b != b && a == a); }   // numpy's order, NaN last
+
+__global__ __launch_bounds__(256) void soft_oks_kernel(const double* __restrict__ ious, const int* __restrict__ order0,
+                                                       const double* __restrict__ score0, int n, double thresh, int max_dets,
+                                                       double* __restrict__ sc, int* __restrict__ od, int* __restrict__ keep,
+                                                       int* __restrict__ count) {
+#pragma clang fp contract(off)
+    double* sa = sc;           double* sb = sc + n;        // current / rescored-unsorted (then swapped)
+    int* oa = od;              int* ob = od + n;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) { sa[j] = score0[j]; oa[j] = order0[j]; }
+    __syncthreads();
+    int m = n, kept = 0;
+    while (m > 0 && kept < max_dets) {
+        const int i = oa[0];
+        if (threadIdx.x == 0) keep[kept] = i;
+        ++kept;
+        --m;                                               // the rest: positions 1 .. m of the current arrangement
+        for (int q = threadIdx.x; q < m; q += blockDim.x) {
+            const double o = ious[(int64_t)i * n + oa[q + 1]];
+            sb[q] = sa[q + 1] * exp(-(o * o) / thresh);    // scores[1:] * np.exp(-oks_ovr ** 2 / thresh)
+            ob[q] = oa[q + 1];
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < m; q += blockDim.x) {
+            const double v = sb[q];
+            int pos = 0;
+            for (int r = 0; r < m; ++r) {
+                const double u = sb[r];
+                pos += (soft_lt(v, u) || (!soft_lt(u, v) && r > q)) ? 1 : 0;
+            }
+            sa[pos] = v;
+            oa[pos] = ob[q];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = kept;
+}
+
 }  // namespace
 
 extern "C" int advmix_nms_mask(const float* boxes_dev, int n, float thresh, uint64_t* mask_dev, void* stream) {
@@ -210,6 +257,22 @@ extern "C" int advmix_oks_greedy(const double* ious, const int* order, int n, do
     if (!ious || !order || !keep_out || !count_out || n <= 0 || n > 8192) return ADVMIX_EINVAL;
     hipLaunchKernelGGL(oks_greedy_kernel, dim3(1), dim3(256), n * sizeof(int), (hipStream_t)stream, ious, order, n, thresh,
                        keep_out, count_out);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+// soft_oks_nms's loop on the device (see soft_oks_kernel).  ious: [n][n] fp64; order: int32 [n] candidate indices, best
+// first (the host's argsort, as for advmix_oks_greedy); scores_sorted: fp64 [n] = scores[order]; scratch_scores: fp64 [2n],
+// scratch_order: int32 [2n] (caller-owned, no hidden allocation); keep_out: int32 [max_dets]; count_out: int32 [1].
+extern "C" int advmix_soft_oks_greedy(const double* ious, const int* order, const double* scores_sorted, int n, double thresh,
+                                      int max_dets, double* scratch_scores, int* scratch_order, int* keep_out, int* count_out,
+                                      void* stream) {
+    if (!ious || !order || !scores_sorted || !scratch_scores || !scratch_order || !keep_out || !count_out || n <= 0 ||
+        n > 8192 || max_dets <= 0)
+        return ADVMIX_EINVAL;
+    if (thresh != thresh || thresh == 0.0) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(soft_oks_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ious, order, scores_sorted, n, thresh,
+                       max_dets, scratch_scores, scratch_order, keep_out, count_out);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }

@@ -10,6 +10,8 @@ The loss is a local-batch mean, so averaging gradients over equal shards reprodu
 reference's global-batch mean (lib/core/function.py:151-153)."""
 import torch
 import torch.distributed as dist
+import torch.utils.data
+import torch.utils.data.distributed
 
 
 class GradSync:
@@ -21,6 +23,7 @@ class GradSync:
         self._side = None
         self.pieces = 3             # the backward pass is cut into this many pieces per network (see reduce_async)
         self._cuts = {}
+        self.trace = None           # a list: reduce_async records (flat, lo, hi, copy before, copy after) of every exchange
         # RCCL ("nccl") averages in the collective; any other backend (gloo: the CPU tests, and the two-ranks-on-one-GPU
         # test of the whole path) sums and scales
         self._avg = self.world > 1 and dist.get_backend(group) == 'nccl' or (self.world == 1 and force and
@@ -49,11 +52,17 @@ class GradSync:
             side = self._side_stream(flat.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
+                pre = chunk.clone() if self.trace is not None else None     # what THIS rank handed to the exchange
                 for b in range(0, hi - lo, self.bucket_elems):
                     self._mean_(chunk[b:b + self.bucket_elems])
+                if pre is not None:
+                    self.trace.append((flat, lo, hi, pre, chunk.clone()))
         else:
+            pre = chunk.clone() if self.trace is not None else None
             dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
             chunk.div_(self.world)
+            if pre is not None:
+                self.trace.append((flat, lo, hi, pre, chunk.clone()))
 
     def _mean_(self, t):
         """In-place mean over the ranks of a device tensor, on the current (side) stream."""
@@ -105,6 +114,85 @@ class GradSync:
             for p in g['params']:
                 if p.grad is not None:
                     self.all_reduce_mean(p.grad.view(-1))
+
+    # ---- in-band evidence that an N-rank run was correct ------------------------------------------------------------
+    # nn.DataParallel re-broadcasts GPU 0's weights before every forward (tools/train.py:69,106,109; lib/core/function.py:
+    # 138,146,160), so the reference's replicas CANNOT drift.  Separate processes can - silently, through a bad exchange -
+    # so the N-rank entry points check: what came out of an exchange is the mean of what the ranks put in
+    # (``verify_trace``), and the replicas' parameters / optimizer state are still the same bits (``replicas_state``).
+    def _gather(self, t):
+        if self.world == 1 or not (dist.is_available() and dist.is_initialized()):
+            return [t]
+        got = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(got, t.contiguous(), group=self.group)
+        return got
+
+    def verify_trace(self, rtol=2e-6):
+        """For every exchange recorded in ``self.trace``: all-gather the ranks' inputs and compare their mean with what
+        the exchange left in the buffer.  Returns (ok on EVERY rank, worst |got - mean| / max|mean| over the ranks).  Exact for the sum-and-scale
+        transports at two ranks; RCCL's AVG and larger rings add in another order, hence ``rtol`` (of the range's largest
+        element: a wrong, stale or partial operand is off by O(1) of it)."""
+        ok, worst = True, 0.0
+        for flat, lo, hi, pre, post in (self.trace or ()):
+            parts = self._gather(pre)
+            want = parts[0].double()
+            for q in parts[1:]:
+                want += q.double()
+            want /= len(parts)
+            scale = float(want.abs().max())
+            err = float((post.double() - want).abs().max()) if post.numel() else 0.0
+            fin = bool(torch.isfinite(post).all()) and bool(torch.isfinite(pre).all())
+            rel = err / scale if scale > 0 else (0.0 if err == 0 else float('inf'))
+            worst = max(worst, rel)
+            ok = ok and fin and rel <= rtol
+        dev = self.trace[0][3].device if self.trace else torch.device('cpu')
+        verdict = torch.stack(self._gather(torch.tensor([0.0 if ok else 1.0, min(worst, 3e38)], device=dev,
+                                                        dtype=torch.float32))).cpu()
+        return bool((verdict[:, 0] == 0).all()), float(verdict[:, 1].max())          # the same answer on every rank
+
+    @staticmethod
+    def state_fold(tensors):
+        """Three int64 numbers over the raw bits of ``tensors``: wrapping sum, position-weighted wrapping sum, count of
+        non-finite elements.  Equal bits -> equal folds; one flipped bit changes the first two."""
+        acc = torch.zeros(3, dtype=torch.int64, device=tensors[0].device)
+        for t in tensors:
+            t = t.detach().contiguous().view(-1)
+            if t.is_floating_point():
+                acc[2] += (~torch.isfinite(t)).sum()
+            if t.element_size() % 4:
+                t = t.to(torch.int32)
+            v = t.view(torch.int32).to(torch.int64)
+            w = torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 8191 + 1
+            acc[0] += v.sum()
+            acc[1] += (v * w).sum()
+        return acc
+
+    def replicas_state(self, optimizers):
+        """{'identical': every rank's parameters / optimizer moments / step counters fold to the same numbers,
+        'finite': none of them holds an inf / NaN on any rank}.  One 24-byte all-gather per call."""
+        tensors = []
+        for opt in optimizers:
+            if opt is None:
+                continue
+            if hasattr(opt, 'flat_state'):
+                tensors += opt.flat_state()
+            else:
+                for g in opt.param_groups:
+                    for p in g['params']:
+                        tensors.append(p.data)
+                        st = opt.state.get(p, {})
+                        tensors += [st[k] for k in sorted(st) if torch.is_tensor(st[k])]
+        if not tensors:
+            return {'identical': True, 'finite': True}
+        fold = self.state_fold(tensors)
+        got = torch.stack(self._gather(fold)).cpu()
+        return {'identical': bool((got[:, :2] == got[0, :2]).all()), 'finite': bool((got[:, 2] == 0).all())}
+
+    def assert_replicas(self, optimizers, where=''):
+        st = self.replicas_state(optimizers)
+        if not (st['identical'] and st['finite']):
+            raise RuntimeError('advmix_amd: data-parallel replicas %s%s - the ranks no longer train the same model'
+                               % ('diverged' if not st['identical'] else 'hold non-finite state', where and ' (' + where + ')'))
 
     def broadcast_state(self, models, optimizers, src=0):
         """Make every replica start from rank ``src``'s state.  The reference's single-process nn.DataParallel
@@ -179,3 +267,52 @@ class Replica(torch.nn.Module):
 def unwrap(model):
     """The network inside a Replica / DataParallel-shaped wrapper (or the model itself)."""
     return model.module if isinstance(model, Replica) else model
+
+
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class ShardedDataLoader(torch.utils.data.DataLoader):
+    """``torch.utils.data.DataLoader`` as tools/train.py:165-178 constructs it, for one process per GPU.  The reference's
+    single process loads ``BATCH_SIZE_PER_GPU * len(GPUS)`` shuffled samples per iteration and nn.DataParallel scatters
+    them; with N ranks every rank would load that GLOBAL batch from its own private shuffle - N times the work on
+    overlapping samples.  Under an initialised process group of N > 1 ranks a SHUFFLED loader (the training one) instead
+    draws from a ``DistributedSampler`` (disjoint shards of one common permutation, re-drawn every epoch: ``set_epoch`` is
+    called per ``__iter__``, which the reference loop has no line for) with ``batch_size // N`` samples per iteration -
+    the per-GPU batch when N = len(GPUS).  Unshuffled loaders (validation) are left alone: rank 0 evaluates the whole
+    set (core.function.validate returns at once on the other ranks).  Without a process group this IS DataLoader.
+    Bound by the INTEGRATION.md recipe as ``torch.utils.data.DataLoader``."""
+
+    def __init__(self, dataset, batch_size=1, shuffle=False, sampler=None, batch_sampler=None, **kw):
+        rank, world = _world()
+        self._epoch = 0
+        self._sharded = world > 1 and shuffle and sampler is None and batch_sampler is None
+        if self._sharded:
+            if batch_size % world:
+                raise ValueError('global batch %d does not divide over %d ranks' % (batch_size, world))
+            sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True)
+            shuffle, batch_size = False, batch_size // world
+        super().__init__(dataset, batch_size=batch_size, shuffle=shuffle, sampler=sampler, batch_sampler=batch_sampler, **kw)
+
+    def __iter__(self):
+        if self._sharded:
+            self.sampler.set_epoch(self._epoch)
+            self._epoch += 1
+        return super().__iter__()
+
+
+def rank0_only(fn):
+    """``fn`` on rank 0, a no-op returning None on the other ranks of an initialised process group (for the reference's
+    unguarded writers, e.g. ``torch.save(model.module.state_dict(), final_state.pth)`` at tools/train.py:337, which every
+    rank would otherwise write to the same path)."""
+    import functools
+
+    @functools.wraps(fn)
+    def guarded(*a, **k):
+        if _world()[0] != 0:
+            return None
+        return fn(*a, **k)
+    return guarded

@@ -128,23 +128,25 @@ class AdvMixGraphRunner:
 
     def step(self):
         """Replay one AdvMix step on the current static batch. Returns (loss_D, output) views
-        of graph-owned tensors (valid until the next replay)."""
+        of graph-owned tensors (valid until the next replay).  The replays and the exchanges between them run on the
+        runner's own stream when the caller's current stream is the NULL stream (ops.GraphSeq.replay_stream); the caller's
+        stream waits for the step, so the results can be consumed on it as before."""
         self.opt.sync_hyper()
         self.optG.sync_hyper()
-        for seg in self.segments:
-            g, red = seg[0], seg[1]
-            if len(seg) > 2 and seg[2] and self.sync is not None:
-                self.sync.finish()                         # this segment's optimizer step consumes reduced gradients
-            self.seq.replay(g)
-            if red is not None and self.sync is not None:
-                # (candidate fix for the open two-rank failure, DESIGN.md section 4 - written after the round's GPU minutes
-                # had run out, NOT yet verified: one ordinary launch on the replay stream between the graph and the event
-                # the side stream waits for, so that the exchange is ordered behind an eagerly submitted kernel instead of
-                # directly behind a graph launch - a one-lane segment is a single chain, which the runtime submits through
-                # its pre-built-packet path, and the failures look like an exchange that started before the graph's data
-                # were there.)
-                self.seq.fence()
-                self.sync.reduce_async(red[0].flat_grads, red[1], red[2])
+        cur = torch.cuda.current_stream(self.seq.device)
+        rs, hop = self.seq.replay_stream()
+        if hop:
+            rs.wait_stream(cur)                            # load_batch's copies, the previous step's consumers
+        with torch.cuda.stream(rs):
+            for seg in self.segments:
+                g, red = seg[0], seg[1]
+                if len(seg) > 2 and seg[2] and self.sync is not None:
+                    self.sync.finish()                     # this segment's optimizer step consumes reduced gradients
+                self.seq.replay(g)
+                if red is not None and self.sync is not None:
+                    self.sync.reduce_async(red[0].flat_grads, red[1], red[2])
+        if hop:
+            cur.wait_stream(rs)
         return self.loss_D, self.output
 
 
@@ -185,8 +187,15 @@ class PlainGraphRunner:
 
     def step(self):
         self.opt.sync_hyper()
-        self.seq.replay(self.s1)
-        if self.sync is not None:
-            self.sync.sync(self.opt)
-        self.seq.replay(self.s2)
+        cur = torch.cuda.current_stream(self.seq.device)
+        rs, hop = self.seq.replay_stream()
+        if hop:
+            rs.wait_stream(cur)
+        with torch.cuda.stream(rs):                        # never the NULL stream (ops.GraphSeq)
+            self.seq.replay(self.s1)
+            if self.sync is not None:
+                self.sync.sync(self.opt)
+            self.seq.replay(self.s2)
+        if hop:
+            cur.wait_stream(rs)
         return self.loss, self.output

@@ -8,8 +8,8 @@ argument meaning and return values (lists / arrays of indices into the input).
   ``cpu_nms`` (cpu_nms.pyx:68: suppress ``ovr >= thresh`` compared in double) reuse the same
   device bitmask; ``cpu_nms`` expresses its predicate as a strict fp32 ``>`` against the
   largest fp32 below the threshold, which is exact.
-* OKS variants take the float64 similarity matrix from ``advmix_oks_matrix`` and run the
-  (tiny, inherently sequential) greedy / rescoring loop on the host."""
+* OKS variants take the float64 similarity matrix from ``advmix_oks_iou`` and run the (tiny, inherently
+  sequential) greedy / rescoring loop on the device too: one workgroup, only the kept indices cross PCIe."""
 import ctypes
 
 import numpy as np
@@ -152,24 +152,22 @@ def oks_nms(kpts_db, thresh, sigmas=None, in_vis_thre=None):
 
 
 def soft_oks_nms(kpts_db, thresh, sigmas=None, in_vis_thre=None):
-    """nms.py:139-177: gaussian rescoring, re-sort every round, max_dets = 20."""
+    """nms.py:139-177: gaussian rescoring, re-sort every round, max_dets = 20.  Matrix, rescoring and re-sorting all run
+    on the device (advmix_soft_oks_greedy: one workgroup, <= 20 rounds); only the kept indices come back."""
     if len(kpts_db) == 0:
         return []
     scores, kpts, areas = _unpack(kpts_db)
-    M = _oks_matrix(kpts, areas, sigmas, in_vis_thre=in_vis_thre)
-    order = scores.argsort()[::-1]
-    scores = scores[order]
+    n = len(scores)
     max_dets = 20
-    keep = np.zeros(max_dets, dtype=np.intp)
-    keep_cnt = 0
-    while order.size > 0 and keep_cnt < max_dets:
-        i = order[0]
-        oks_ovr = M[i, order[1:]]
-        order = order[1:]
-        scores = scores[1:] * np.exp(-oks_ovr ** 2 / thresh)
-        tmp = scores.argsort()[::-1]
-        order = order[tmp]
-        scores = scores[tmp]
-        keep[keep_cnt] = i
-        keep_cnt += 1
-    return keep[:keep_cnt]
+    M = _oks_matrix(kpts, areas, sigmas, device=True, in_vis_thre=in_vis_thre)      # [n, n] fp64, stays on the GPU
+    order = scores.argsort()[::-1]                          # numpy's initial order (ties: its own), as in the reference
+    od = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int32)).cuda()
+    sc = _dev64(scores[order])
+    ws_s = torch.empty(2 * n, dtype=torch.float64, device='cuda')
+    ws_o = torch.empty(2 * n, dtype=torch.int32, device='cuda')
+    out = torch.zeros(1 + max_dets, dtype=torch.int32, device='cuda')
+    P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+    call('advmix_soft_oks_greedy', P(M), P(od), P(sc), n, float(thresh), max_dets, P(ws_s), P(ws_o),
+         ctypes.c_void_p(out.data_ptr() + 4), P(out), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    out = out.cpu().numpy()
+    return out[1:1 + int(out[0])].astype(np.intp)

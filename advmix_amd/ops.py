@@ -196,6 +196,7 @@ def _wt(st, w, A, T, B):
 BNB_FUSED = __import__('os').environ.get('ADVMIX_BNB', '1') != '0'
 FUSE_BNB = __import__('os').environ.get('ADVMIX_FUSE_BNB', '1') != '0'    # the fuse layers' BatchNorm-backward sums from FuseSum.bwd
 DETERMINISTIC = False
+REPLAY_ON_NULL = __import__('os').environ.get('ADVMIX_REPLAY_STREAM', 'own') == 'null'
 
 
 def set_deterministic(on=True):
@@ -971,6 +972,22 @@ class GraphSeq:
     def __init__(self, device):
         self.graphs, self.pool = [], None
         self._sink = torch.zeros(64, device=device, dtype=torch.float32)
+        self.device = device
+        # Replays never go onto the NULL stream (round 4): with two processes sharing one GPU, the
+        # SECOND and later launches of an instantiated graph on the null stream - the launches the runtime serves from its
+        # captured AQL packets - computed garbage gradients in 27 of 27 two-rank runs (host fully synchronised, before any
+        # exchange); on a created stream, or with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, 0 of 12.  ADVMIX_REPLAY_STREAM=null
+        # restores the old behaviour for A/B runs.
+        self.stream = None if REPLAY_ON_NULL else torch.cuda.Stream(device=device)
+
+    def replay_stream(self):
+        """(stream, hop): the stream a step's replays (and everything the runner enqueues between them) run on - the
+        caller's current stream unless that is the NULL stream - and whether that is another stream than the current one
+        (the caller then orders the two with wait_stream on both sides)."""
+        cur = torch.cuda.current_stream(self.device)
+        if self.stream is None or cur.cuda_stream != 0:
+            return cur, False
+        return self.stream, True
 
     def capture(self, fn):
         g = torch.cuda.CUDAGraph()
@@ -979,24 +996,21 @@ class GraphSeq:
             kw['pool'] = self.pool
         with torch.cuda.graph(g, **kw):
             r = fn()
-            # ONE sink node on the capture stream, after every lane has been joined into it.  A segment whose last
-            # launches sit on side lanes otherwise ends in several leaf nodes, and work that another stream orders behind
-            # the replay (``side.wait_stream(cur)`` of the data-parallel gradient exchange, dp.GradSync.reduce_async) was
-            # seen to start while such a leaf - the last weight gradients of a backward piece - was still running: with two
-            # ranks the exchanged gradients then differed between the ranks in 20-75 % of the runs (round 3,
-            # test_data_parallel_path_two_ranks_on_one_gpu_over_gloo; never with one rank, whose exchange moves nothing).
-            call('advmix_fill', _p(self._sink), 0.0, self._sink.numel(), _st())
         if self.pool is None:
             self.pool = g.pool()
         self.graphs.append(g)
         return len(self.graphs) - 1, r
 
     def replay(self, seg):
-        self.graphs[seg].replay()
-
-    def fence(self):
-        """One ordinary (non-graph) launch on the current stream: see graph.AdvMixGraphRunner.step."""
-        call('advmix_fill', _p(self._sink), 0.0, self._sink.numel(), _st())
+        rs, hop = self.replay_stream()
+        if not hop:
+            self.graphs[seg].replay()
+            return
+        cur = torch.cuda.current_stream(self.device)       # a lone replay from the NULL stream: hop onto the replay stream
+        rs.wait_stream(cur)
+        with torch.cuda.stream(rs):
+            self.graphs[seg].replay()
+        cur.wait_stream(rs)
 
     @property
     def n_graphs(self):

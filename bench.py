@@ -524,6 +524,85 @@ def rendezvous(a, backend, rank, world, local):
         raise SystemExit(4)
 
 
+
+def verify_data_parallel(make_step, args, nets, crit, opts, data, sync, steps=3, tol=1e-5):
+    """An N-rank run proves itself (the driver is the only one who can run RCCL with N > 1).  nn.DataParallel
+    re-broadcasts GPU 0's weights before every forward (tools/train.py:69,106,109), so the reference cannot drift or train
+    on a bad exchange; this design could, silently.  ``steps`` steps in deterministic mode through the execution under test
+    (``make_step()``: the seven-graph runner or the eager pieces, with the side-stream exchange), each checked three ways:
+      exchange  - what every all-reduce left in the flat gradient buffer == the mean of what the ranks handed to it
+                  (dp.GradSync.verify_trace: all-gather of the operands; exact for sum-and-scale, <= rtol for RCCL's AVG);
+      operands  - what this rank handed to the exchange == the gradients recomputed from the same state WITHOUT pieces,
+                  side stream or graphs (plain backward): an exchange that started before its gradients were complete, or
+                  a graph replay that computed something else, differs by O(1);
+      params    - finishing that local recomputation with the exchanged gradients lands on the same D / G parameters as
+                  the step under test (bit for bit in deterministic mode; ``tol`` of the largest element allowed).
+    With one rank (ADVMIX_FORCE_SYNC=1) the exchange is the identity and the operand / parameter checks still hold the
+    ordering of graphs, pieces and side stream to the plain step.  Leaves the models where the verified steps left them."""
+    from advmix_amd import ops
+    from advmix_amd.graph import _snapshot, _restore
+    from advmix_amd.core.function import advmix_phase_a, advmix_phase_b
+    D, G, T = nets
+    optD, optG = opts
+    views, tgt, tw = data
+    worst = {'exchange': 0.0, 'operands': 0.0, 'params': 0.0}
+    ok = {'exchange': True, 'operands': True, 'params': True, 'coverage': True}
+
+    def rel(a, b):
+        scale = float(b.abs().max())
+        err = float((a.double() - b.double()).abs().max())
+        if not (err == err):
+            return float('inf')
+        return err / scale if scale > 0 else (0.0 if err == 0 else float('inf'))
+
+    ops.set_deterministic(True)
+    try:
+        step = make_step()
+        for _ in range(steps):
+            before = _snapshot([D, G, T], [optD, optG])
+            sync.trace = []
+            step()
+            torch.cuda.synchronize()
+            trace = sync.trace
+            after = _snapshot([D, G, T], [optD, optG])
+            pD, pG = optD.flat_params.clone(), optG.flat_params.clone()
+            e_ok, e_worst = sync.verify_trace()
+            sync.trace = None
+            ok['exchange'] &= e_ok
+            worst['exchange'] = max(worst['exchange'], e_worst)
+            for opt in (optD, optG):                        # the pieces' ranges tile the whole flat buffer exactly once
+                rs = sorted((lo, hi) for f, lo, hi, _a, _b in trace if f is opt.flat_grads)
+                ok['coverage'] &= bool(rs) and rs[0][0] == 0 and rs[-1][1] == opt.flat_grads.numel() and \
+                    all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+            _restore(before)                                # the same state, the plain way
+            _l, tmp = advmix_phase_a(args, D, G, T, crit, optD, views, tgt, tw)
+            for f, lo, hi, pre, post in trace:
+                if f is optD.flat_grads:
+                    worst['operands'] = max(worst['operands'], rel(pre, optD.flat_grads[lo:hi]))
+                    optD.flat_grads[lo:hi].copy_(post)      # adopt the exchanged gradient
+            advmix_phase_b(args, D, crit, optD, optG, tmp, tgt, tw)
+            for f, lo, hi, pre, post in trace:
+                if f is optG.flat_grads:
+                    worst['operands'] = max(worst['operands'], rel(pre, optG.flat_grads[lo:hi]))
+                    optG.flat_grads[lo:hi].copy_(post)
+            optG.step()
+            torch.cuda.synchronize()
+            worst['params'] = max(worst['params'], rel(optD.flat_params, pD), rel(optG.flat_params, pG))
+            del tmp
+            _restore(after)                                 # go on from where the execution under test is
+        ok['operands'] = worst['operands'] <= tol
+        ok['params'] = worst['params'] <= tol
+    finally:
+        sync.trace = None
+        ops.set_deterministic(False)
+    verdict = torch.tensor([0.0 if all(ok.values()) else 1.0], device=views[0].device)
+    if sync.world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(verdict, op=dist.ReduceOp.MAX)      # one answer for the job
+    return float(verdict.item()) == 0.0, {'steps': steps, 'checks': ok,
+                                          'worst_rel': {k: float('%.3g' % v) for k, v in worst.items()}, 'tol': tol}
+
+
 SYNC_METRICS = os.environ.get('ADVMIX_SYNC_METRICS') == '1'
 
 
@@ -546,6 +625,8 @@ def main():
                     help='log kernel template, grid, shape and FLOPs of every MFMA launch of ONE eager step (for '
                          'tools/kernel_shapes.py) and exit')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-verify', action='store_true', help='skip the data-parallel self-verification steps (N > 1 ranks)')
+    ap.add_argument('--no-through-loop', action='store_true', help='skip the extra train_advmix-with-H2D measurement')
     ap.add_argument('--no-roofline', action='store_true')
     a = ap.parse_args()
     if a.dump_shapes:
@@ -621,11 +702,25 @@ def main():
         print('wrote', a.dump_shapes)
         return
     loop_note = None
-    if a.through_loop:
-        # The drop-in entry point itself: train_advmix over a loader of pinned HOST batches (DataLoader(pin_memory=True)
-        # in tools/train.py:295-301), i.e. H2D copies, capture on the first batch, replay, loss.item(), accuracy, meters.
+    from advmix_amd.core import function as F_
+    from advmix_amd.core.evaluate import PendingAccuracy
+    if world > 1 and a.exec_mode == 'graph' and not F_.DP_GRAPH:
+        a.exec_mode = 'eager'                               # core.function.DP_GRAPH (ADVMIX_DP_GRAPH=0): the line says which
+
+    def make_step(holder=None):
+        """The execution the timed region uses: the HIP-graph runner (seven graphs with data parallelism) or the eager step."""
+        if a.exec_mode == 'graph':
+            runner = AdvMixGraphRunner(args, D, G, T, crit, optD, optG, views, tgt, tw, sync)
+            if holder is not None:
+                holder['runner'] = runner
+            return lambda: runner.step() + (runner.target,)
+        return lambda: advmix_step(args, D, G, T, crit, optD, optG, views, tgt, tw, sync) + (tgt,)
+
+    def through_loop(n_warm, n_timed):
+        """The drop-in entry point itself: train_advmix over a loader of pinned HOST batches (DataLoader(pin_memory=True) in
+        tools/train.py:295-301), i.e. H2D copies, capture on the first batch, replay, loss.item(), accuracy, meters -
+        SURVEY 8 d1's full step."""
         import logging
-        from advmix_amd.core import function as F_
         logging.getLogger(F_.__name__).setLevel(logging.WARNING)
         cfg['PRINT_FREQ'] = 10 ** 9
         host = []
@@ -649,34 +744,46 @@ def main():
             wd = {'writer': types.SimpleNamespace(add_scalar=lambda k, v, s: seen.__setitem__(k, float(v))),
                   'train_global_steps': 0}
             F_.train_advmix(cfg, args, Loader(n), [D, G, T], crit, [optD, optG], 0, '', '', wd, sync)
-        run_loop(max(a.warmup, 3))                          # capture + warm-up
+        old_exec = F_.GRAPH_EXEC
+        F_.GRAPH_EXEC = a.exec_mode == 'graph'
+        try:
+            run_loop(max(n_warm, 3))                        # capture + warm-up
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_loop(n_timed)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            return time.perf_counter() - t0, seen.get('train_loss', float('nan')), seen.get('train_acc', 0.0)
+        finally:
+            F_.GRAPH_EXEC = old_exec
+            F_.release_graphs()
+
+    def max_over_ranks(x):
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_loop(a.steps)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        lv, acc = seen.get('train_loss', float('nan')), seen.get('train_acc', 0.0)
+            tmax = torch.tensor([x], device=device, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            return float(tmax.item())
+        return x
+
+    verification = None
+    if sync is not None and not a.no_verify:
+        # before anything is timed: the N-rank execution proves itself (three steps in deterministic mode)
+        verification = verify_data_parallel(make_step, args, (D, G, T), crit, (optD, optG), (views, tgt, tw), sync)
+        torch.cuda.empty_cache()
+    dt_loop = None
+    if a.through_loop:
+        dt, lv, acc = through_loop(a.warmup, a.steps)
         loop_note = 'core.function.train_advmix over pinned host batches (H2D inside the timed region)'
     else:
-        from advmix_amd.core.evaluate import PendingAccuracy
-        if world > 1 and a.exec_mode == 'graph' and os.environ.get('ADVMIX_DP_GRAPH', '0') != '1':
-            # core.function.DP_GRAPH: with more than one rank the step runs eagerly until the seven-graph runner's
-            # two-rank failure is found; the line says which execution it timed
-            a.exec_mode = 'eager'
-        if a.exec_mode == 'graph':
-            runner = AdvMixGraphRunner(args, D, G, T, crit, optD, optG, views, tgt, tw, sync)
+        hold = {}
+        step = make_step(hold)
 
-            def launch():
-                loss_D, out = runner.step()
-                return PendingAccuracy(out, runner.target, loss_D)         # function.py:167-168, device half enqueued
-        else:
-            def launch():
-                loss_D, out = advmix_step(args, D, G, T, crit, optD, optG, views, tgt, tw, sync)
-                return PendingAccuracy(out, tgt, loss_D)
+        def launch():
+            loss_D, out, target = step()
+            return PendingAccuracy(out, target, loss_D)     # function.py:167-168, device half enqueued
 
         def run_steps(n):
             """n steps; loss.item() and accuracy() of every step are read - one step late, while the next one runs (the
@@ -703,10 +810,16 @@ def main():
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        if not a.no_through_loop:
+            # SURVEY 8 d1's step includes the H2D of step 1: the same workload through train_advmix itself, beside the
+            # resident-input figure (never instead of it)
+            hold.clear()
+            del step
+            torch.cuda.empty_cache()
+            dt_loop, _lv2, _acc2 = through_loop(10, 50 if a.steps >= 20 else a.steps)
+            dt_loop = (max_over_ranks(dt_loop), 50 if a.steps >= 20 else a.steps)
+    dt = max_over_ranks(dt)
+    replicas = sync.replicas_state([optD, optG]) if sync is not None else None
     from advmix_amd._lib import lib as _hiplib
     variant = _hiplib.advmix_build_flags()                  # non-zero: a tools/build_variant.sh library (ADVMIX_SO=...)
     if not (lv == lv) and not variant:
@@ -738,6 +851,17 @@ def main():
             'step_frac_of_fp32_mfma_peak': round(value / world * gflop_img / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
             'last_loss_D': round(lv, 6) if lv == lv else None,
         })
+        if dt_loop is not None:
+            line['value_through_loop'] = round(a.batch * world * dt_loop[1] / dt_loop[0], 2)
+            line['through_loop'] = {'entry': 'core.function.train_advmix over pinned host batches: H2D copies, graph replay, '
+                                             'loss.item(), accuracy inside the timed region (SURVEY 8 d1)',
+                                    'steps': dt_loop[1], 'warmup': 10, 'ms_per_step': round(dt_loop[0] / dt_loop[1] * 1e3, 3)}
+        if sync is not None:
+            line['replicas_identical'] = replicas['identical']
+            line['all_finite'] = replicas['finite'] and (lv == lv)
+            line['grad_exchange_verified'] = verification[0] if verification is not None else None
+            line['dp_verification'] = dict(verification[1], exec=line['config']['exec'],
+                                           transport=dist.get_backend()) if verification is not None else 'skipped (--no-verify)'
         if variant:
             line['INVALID_variant_build_flags'] = variant   # measurement build: never a benchmark result
         if not a.no_roofline:
@@ -748,6 +872,8 @@ def main():
             line['cpu_baseline'] = cpu_baseline(a.workload)
 
 
+    failed = sync is not None and (not replicas['identical'] or not replicas['finite']
+                                   or (verification is not None and not verification[0]))
     if world > 1 or force_sync:
         dist.barrier()
         dist.destroy_process_group()
@@ -760,6 +886,8 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
+    if failed:
+        raise SystemExit(5)                                 # the line says which of the three checks failed
 
 
 if __name__ == '__main__':

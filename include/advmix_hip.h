@@ -360,6 +360,15 @@ int advmix_oks_iou(const double* g_kpts, const double* g_areas, int ng, const do
  * kept one has OKS > thresh with it.  keep_out: int32 [n], count_out: int32 [1].  Only the kept indices cross PCIe. */
 int advmix_oks_greedy(const double* ious, const int* order, int n, double thresh, int* keep_out, int* count_out,
                       void* stream);
+/* The rescoring loop of soft_oks_nms (lib/nms/nms.py:139-177) on the device: keep the head of the order, multiply the
+ * remaining scores by exp(-oks^2 / thresh) (float64), re-sort them as ``scores.argsort()[::-1]`` does (among exactly
+ * equal scores, whose numpy order depends on the numpy build: a stable ascending sort read backwards), at most max_dets
+ * (the reference's 20) times.  order / scores_sorted: the host's initial argsort and
+ * scores[order]; scratch_scores fp64 [2n], scratch_order int32 [2n]: caller-owned; keep_out int32 [max_dets], count_out
+ * int32 [1].  ADVMIX_EINVAL for n > 8192, a zero or NaN threshold. */
+int advmix_soft_oks_greedy(const double* ious, const int* order, const double* scores_sorted, int n, double thresh,
+                           int max_dets, double* scratch_scores, int* scratch_order, int* keep_out, int* count_out,
+                           void* stream);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,16 @@ def main():
     from advmix_amd.dp import Replica
     torch.nn.DataParallel = Replica                         # one process per GPU: DataParallel's shape, none of its mechanics
     torch.nn.parallel.DataParallel = Replica
+    from advmix_amd.dp import ShardedDataLoader, rank0_only
+    torch.utils.data.DataLoader = ShardedDataLoader         # per-rank shard + per-GPU batch under a process group; DataLoader otherwise
+    torch.save = rank0_only(torch.save)                     # tools/train.py:337 writes final_state.pth unguarded
+
+    # ---- "the only edit multi-GPU needs" (INTEGRATION.md section 2): the process group, before main() builds anything.
+    # gloo stands in for nccl here (no GPU in this container).
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        import torch.distributed as dist
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%s' % os.environ['MASTER_PORT'],
+                                rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
 
     # ---- the probe: the loops are where the first device call would happen -------------------------------------
     import advmix_amd.core.function as F_
@@ -117,6 +127,8 @@ def main():
         argv += ['--downsamples', '5']                      # the 384x288 generator (tools/_init_parse.py:132-134)
     argv += ['OUTPUT_DIR', os.path.join(tmp, 'output'), 'LOG_DIR', os.path.join(tmp, 'log'), 'WORKERS', '0',
              'DATA_DIR', tmp]               # MODEL.PRETRAINED resolves under DATA_DIR (config/default.py update_config)
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:          # one rank per listed GPU, as the YAMLs' GPUS: (0,...,7) means
+        argv += ['GPUS', '(%s,)' % ','.join(str(i) for i in range(int(os.environ['WORLD_SIZE'])))]
     sys.argv = argv
     os.chdir(REF)                                           # train.py copies 'tools/train.py' relative to the cwd (:81-83)
     try:
@@ -142,6 +154,8 @@ def main():
            'lrs': [o.param_groups[0]['lr'] for o in got['optimizers']],
            'n_params': [sum(len(g['params']) for g in o.param_groups) for o in got['optimizers']],
            'batch_size': got['loader'].batch_size, 'gpus': list(cfg.GPUS),
+           'sampler': type(got['loader'].sampler).__name__, 'loader_len': len(got['loader']),
+           'shard': sorted(int(i) for i in got['loader'].sampler)[:4] + [len(list(got['loader'].sampler))],
            'real_loop_signature_ok': True, 'output_dir_files': sorted(os.listdir(got['output_dir']))}
     if len(models) == 3:
         G, T = models[1], models[2]

@@ -110,3 +110,29 @@ def test_reference_train_py_runs_on_the_mirrors_up_to_the_loop(name, tmp_path):
     assert r['batch_size'] == 32 * len(r['gpus']) and r['real_loop_signature_ok']
     # create_logger, the three shutil.copy2 calls (:72-83): the reference's own side effects happened
     assert 'train.py' in r['output_dir_files'] and os.path.basename(yaml_path) in r['output_dir_files']
+
+
+def test_reference_train_py_on_two_ranks_gets_sharded_loaders(tmp_path):
+    """with one process per GPU the reference's unmodified main() must not load the GLOBAL batch on every rank.
+    Two gloo ranks run tools/train.py (process group created first - the one edit INTEGRATION.md names - and
+    dp.ShardedDataLoader bound as torch.utils.data.DataLoader by the recipe): each arrives at train_advmix with the
+    per-GPU batch (32), a DistributedSampler over its own half of the data set, Replica-wrapped models and the flat
+    optimizers; the log / output directories are shared without a clash."""
+    yaml_path, arch, J, downs = YAMLS['own_coco_w32']
+    _imagenet_checkpoint(tmp_path, yaml_path, arch)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, PYTHONPATH=ROOT, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29651')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dropin_driver.py'), yaml_path, str(tmp_path), '-'],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    res = []
+    for p in procs:
+        so, se = p.communicate(timeout=900)
+        lines = [ln for ln in so.splitlines() if ln.startswith('DROPIN ')]
+        assert p.returncode == 0 and lines, (so[-1500:], se[-3000:])
+        res.append(json.loads(lines[-1][7:]))
+    for r in res:
+        assert r['kind'] == 'train_advmix' and r['gpus'] == [0, 1]
+        assert r['batch_size'] == 32 and r['sampler'] == 'DistributedSampler' and r['loader_len'] == 1   # 64 samples / 2 ranks / 32
+        assert r['shard'][-1] == 32 and r['optimizers'] == ['advmix_amd.utils.utils.FlatAdam'] * 2
+    assert res[0]['shard'] != res[1]['shard']

@@ -963,18 +963,24 @@ def _dp_two_rank_worker():
         losses.append(float(l))
     torch.cuda.synchronize()
     assert all(same(x) for x in oD.flat_state()) and all(same(x) for x in oG.flat_state())
-    if os.environ.get('ADVMIX_TEST_DP_GRAPH') == '1':
-        # KNOWN OPEN ISSUE (round 3): the seven-graph runner with two ranks.  It held this invariant
-        # in every run until the last day of the round and then failed 20-75 % of them (always with ADVMIX_LANES=1):
-        # exchanged gradients of 1e35, NaN parameters on the second or third replay.  core.function therefore runs
-        # multi-rank steps eagerly (ADVMIX_DP_GRAPH=1 opts back in); this block is the reproducer.
-        runner = AdvMixGraphRunner(args, D, G, T, crit, oD, oG, *data, sync)
-        assert runner.seq.n_graphs == 7
-        for _ in range(2):
-            l, o = runner.step()
-            losses.append(float(l))
-        torch.cuda.synchronize()
-        assert all(same(x) for x in oD.flat_state()) and all(same(x) for x in oG.flat_state())
+    # the seven-graph runner (what more than one rank runs by default): 20 replays, replicas identical and finite after each.
+    # Round 3's open bug (replays on the NULL stream with a second process on the GPU: garbage from the second replay on,
+    # 27 of 27 runs on the round-4 box) lived exactly here; the runner replays on its own stream now.
+    runner = AdvMixGraphRunner(args, D, G, T, crit, oD, oG, *data, sync)
+    assert runner.seq.n_graphs == 7
+    for k in range(20):
+        l, o = runner.step()
+        losses.append(float(l))
+        st = sync.replicas_state([oD, oG])
+        assert st == {'identical': True, 'finite': True}, (k, st)
+    torch.cuda.synchronize()
+    assert all(same(x) for x in oD.flat_state()) and all(same(x) for x in oG.flat_state())
+    sync.trace = []                                                         # and one traced step: every exchange == the mean
+    runner.step()
+    torch.cuda.synchronize()
+    v_ok, v_worst = sync.verify_trace()
+    assert v_ok and v_worst == 0.0 and len(sync.trace) == 6, (v_ok, v_worst, len(sync.trace))
+    sync.trace = None
     rm = D.state_dict()['bn1.running_mean']
     assert not same(rm)                                                     # statistics stay per replica
     la, lb = gathered(torch.tensor(losses, device='cuda'))
@@ -1004,16 +1010,19 @@ def _dp_two_rank_worker():
     dist.destroy_process_group()
 
 
-def test_data_parallel_path_two_ranks_on_one_gpu_over_gloo():
+@pytest.mark.parametrize('lanes', ['4', '1'])
+def test_data_parallel_path_two_ranks_on_one_gpu_over_gloo(lanes):
     """SURVEY 8 e / a12 with a world size of TWO ("RCCL has never seen N > 1 ranks" - it still has not: no
-    multi-GPU box; this runs the same path with gloo as the transport, both ranks on cuda:0)."""
+    multi-GPU box; this runs the same path with gloo as the transport, both ranks on cuda:0).  One lane - every captured
+    segment a single chain - was round 3's 10-of-10 failure."""
     import os, subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     code = ('import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_models_gpu as t; '
             't._dp_two_rank_worker(); print("DP_TWO_RANKS_OK")' % (os.path.dirname(here), here))
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29641')
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='2964%s' % lanes,
+                   ADVMIX_LANES=lanes)
         procs.append(subprocess.Popen([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
     for p, (so, se) in zip(procs, outs):

@@ -923,6 +923,65 @@ def test_nms_bit_exact_vs_oracle():
     assert num.value == 0
 
 
+
+def test_soft_oks_nms_device_loop_ties_caps_and_errors():
+    """soft_oks_nms (lib/nms/nms.py:139-177) with matrix, rescoring AND re-sorting on the device (advmix_soft_oks_greedy): the
+    kept indices equal the numpy restatement's on random persons (more than max_dets = 20 candidates: the cap) and for
+    one candidate.  EXACT ties (duplicated persons with equal scores, zero scores): the order numpy's unstable argsort
+    leaves among equal scores depends on its build (here an AVX-512 argsort: nine candidates already come out in neither
+    stable order), so the reference itself is only defined up to that choice - the device must keep the same SET and pick,
+    in every round, a candidate whose rescored score is the maximum of those left (any numpy build does exactly that);
+    bad arguments are refused before anything is launched."""
+    import ctypes
+    from advmix_amd._lib import lib
+    from advmix_amd.nms import nms as pn
+    from oracle import nms as onms
+    rng = np.random.Generator(np.random.Philox(key=23))
+    J = 17
+
+    def person(center, spread):
+        k = np.zeros((J, 3))
+        k[:, :2] = center + rng.standard_normal((J, 2)) * spread
+        k[:, 2] = rng.random(J)
+        return k
+    for n, thresh in ((45, 0.9), (20, 0.5), (7, 0.9), (1, 0.9)):
+        cents = rng.random((6, 1, 2)) * 300 + 50
+        db = [{'score': float(rng.random()), 'keypoints': person(cents[i % 6], 6.0), 'area': float(rng.random() * 20000 + 4000)}
+              for i in range(n)]
+        want = [int(i) for i in onms.soft_oks_nms(db, thresh)]
+        got = [int(i) for i in pn.soft_oks_nms(db, thresh)]
+        assert got == want and len(got) == min(n, 20), (n, got, want)
+    # exact ties: three copies of one person and two of another, all with the same score, plus zero-score candidates
+    a, b = person(np.array([[100.0, 100.0]]), 5.0), person(np.array([[260.0, 140.0]]), 5.0)
+    db = [{'score': 0.5, 'keypoints': a.copy(), 'area': 9000.0} for _ in range(3)] + \
+         [{'score': 0.5, 'keypoints': b.copy(), 'area': 7000.0} for _ in range(2)] + \
+         [{'score': 0.0, 'keypoints': person(np.array([[50.0, 300.0]]), 5.0), 'area': 5000.0} for _ in range(3)] + \
+         [{'score': 0.75, 'keypoints': person(np.array([[180.0, 60.0]]), 5.0), 'area': 6000.0}]
+    sc, kp, ar = onms._unpack(db)
+    M = np.stack([onms.oks_iou(kp[i], kp, ar[i], ar) for i in range(len(db))])
+    for thresh in (0.9, 0.3):
+        want = [int(i) for i in onms.soft_oks_nms(db, thresh)]
+        got = [int(i) for i in pn.soft_oks_nms(db, thresh)]
+        assert sorted(got) == sorted(want) == list(range(len(db)))     # soft NMS drops nobody below max_dets: the ORDER is at stake
+        assert got[0] == want[0] == 8                                  # the one untied candidate leads
+        cur = dict(enumerate(sc))
+        for i in got:                                                  # every pick is a maximum of the scores left
+            assert cur[i] == max(cur.values()), (thresh, got, i)
+            del cur[i]
+            for j in cur:
+                cur[j] = cur[j] * np.exp(-M[i, j] ** 2 / thresh)
+    d = torch.zeros(8, device='cuda', dtype=torch.float64)
+    i32 = torch.zeros(8, device='cuda', dtype=torch.int32)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+    ok = (P(d), P(i32), P(d), 2, 0.9, 20, P(d), P(i32), P(i32), P(i32), None)
+    assert lib.advmix_soft_oks_greedy(*ok) == 0
+    torch.cuda.synchronize()
+    for k, bad in ((0, None), (3, 0), (3, 8193), (4, 0.0), (4, float('nan')), (5, 0), (6, None), (8, None)):
+        argv = list(ok)
+        argv[k] = bad
+        assert lib.advmix_soft_oks_greedy(*argv) == 1, (k, bad)
+
+
 def test_oks_pairs_engineered_onto_the_threshold():
     """``oks_nms`` keeps a pair when ``oks <= thresh`` (nms.py:121).  Persons built so that the OKS is an exactly
     representable k/17 in ANY correct implementation (k joints coincide -> exp(-0) = 1, the other 17 - k are so far

@@ -33,7 +33,7 @@ SIGNATURES = {
     'advmix_deconv4x4s2_narrow': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'advmix_conv_tr_narrow': [_p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_tr_w_add': [_p, _p, _p, _p] + [_i] * 11 + [_p],
-    'advmix_conv_tr_w_bnb': [_p, _p, _p, _p] + [_i] * 11 + [_p, _p, _p, _p, _i, _p, _p, _p],
+    'advmix_conv_tr_w_bnb': [_p, _p, _p, _p] + [_i] * 11 + [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p],
     'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_wgrad_det': [_p, _p, _p] + [_i] * 11 + [_p, _l, _p],
     'advmix_bias_grad_det': [_p, _p, _l, _i, _p, _l, _p],
@@ -41,7 +41,7 @@ SIGNATURES = {
     'advmix_bias_grad': [_p, _p, _l, _i, _p],
     'advmix_norm_stats': [_p, _i, _l, _i, _f, _p, _p, _p, _p, _p, _f, _p, _p],
     'advmix_norm_apply': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _i, _p],
-    'advmix_norm_apply_slots': [_p, _p, _i, _l, _i, _f, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _p],
+    'advmix_norm_apply_slots': [_p, _p, _i, _l, _i, _f, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _f, _p, _p],
     'advmix_norm_bwd_apply_slots': [_p, _p, _p, _p, _p, _p, _i, _l, _i, _p, _p, _p, _p],
     'advmix_stats_fold': [_p, _i, _i, _p, _p],
     'advmix_bn_eval': [_p, _p, _p, _p, _p, _f, _p, _p, _l, _i, _i, _p],
@@ -90,7 +90,8 @@ class ConvProblem(ctypes.Structure):
                [(k, _i) for k in ('N', 'Hx', 'Wx', 'Cx', 'Hy', 'Wy', 'Cy', 'R', 'S', 'stride', 'pad')] + \
                [('bn_gamma', _p), ('bn_beta', _p), ('bn_rm', _p), ('bn_rv', _p), ('bn_eps', _f), ('residual', _p),
                 ('act', _i), ('stats', _p), ('stats_ns', _i),
-                ('bnb_y', _p), ('bnb_c', _p), ('bnb_mean', _p), ('bnb_invstd', _p), ('bnb_act', _i)]
+                ('bnb_mask', _p), ('bnb_c', _p), ('bnb_mean', _p), ('bnb_invstd', _p), ('bnb_gamma', _p), ('bnb_beta', _p),
+                ('bnb_act', _i)]
 
 
 lib.advmix_conv_group.argtypes = [_i, _i, ctypes.POINTER(ConvProblem), _p]

@@ -67,6 +67,7 @@ def build(force=False, verbose=True):
             os.remove(obj)                                  # never link it
             bad += ['%s: %s uses %d bytes of scratch per lane' % (s, n, b) for n, b in users]
     if bad:
+        _record(hipcc, [s for s, obj, _ in procs if os.path.exists(obj)], False)      # what DID compile stays recorded
         raise RuntimeError('kernels with register spills / scratch are refused (see build.py):\n  ' + '\n  '.join(bad))
     linked = False
     if force or procs or _stale(SO, objs):

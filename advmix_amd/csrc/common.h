@@ -49,8 +49,10 @@ struct ConvEpi {
     double* stats;                         // out: [2][Co][ns] fp64 slots.  forward gather: column (sum, sumsq) of the
                                            // RAW conv output; transposed gather: (sum g, sum g * xhat), see bnb_*
     // transposed gather + stats: the output is dL/dy of y = act(BN(c) + residual); the epilogue writes
-    // g = that * act'(y) and the two BatchNorm-backward channel sums
-    const float *bnb_y, *bnb_c, *bnb_mean, *bnb_invstd;
+    // g = that * act'(y) and the two BatchNorm-backward channel sums.  Sign of y: from bnb_mask (a bit per element, see
+    // advmix_norm_apply_slots) or - no residual - recomputed from c with bnb_gamma / bnb_beta
+    const unsigned char* bnb_mask;
+    const float *bnb_c, *bnb_mean, *bnb_invstd, *bnb_gamma, *bnb_beta;
     int bnb_act;
 };
 // conv_direct.hip: second-generation conv; returns -1 when the shape is not eligible, -2 when only the

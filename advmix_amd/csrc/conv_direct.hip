@@ -47,7 +47,11 @@ struct ConvD {
     // The epilogue multiplies by the activation's slope (through y), writes g = g0 * act'(y) and accumulates the two
     // BatchNorm-backward channel sums (sum g, sum g * xhat) into ``stats``: the separate statistics pass over
     // (dy, y, c) and its finalize launch disappear (norm.hip: norm_bwd_apply_slots consumes the slots).
-    const float *bnb_y, *bnb_c, *bnb_mean, *bnb_invstd;
+    // The sign of y comes from ``bnb_mask`` (one bit per element, a byte per 4 channels, written by norm_apply_slots: 1/16
+    // of y's bytes) or, for y = act(BN(c)) WITHOUT a residual, from c itself: fmaf((c - mean) * invstd, gamma, beta) > 0
+    // is exactly the expression norm_apply_slots evaluated (round 4; the fp32 y was read for its sign alone).
+    const unsigned char* bnb_mask;
+    const float *bnb_c, *bnb_mean, *bnb_invstd, *bnb_gamma, *bnb_beta;
     int bnb_act;
     int stats_tiles;        // 1 (deterministic mode): every workgroup STORES its column sums in a slot of its own -
                             // stats[2][Co][stats_nbg] with stats_nbg = row tiles x phases - instead of fp64 atomics
@@ -240,8 +244,8 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
                                                                         0x00020000);
     const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bnb_c ? p.bnb_c : p.y), 0, p.ybytes,
                                                                         0x00020000);
-    const __amdgpu_buffer_rsrc_t yyr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bnb_y ? p.bnb_y : p.y), 0, p.ybytes,
-                                                                         0x00020000);
+    const __amdgpu_buffer_rsrc_t mkr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bnb_mask ? (const void*)p.bnb_mask : (const void*)p.y),
+                                                                         0, p.ybytes >> 4, 0x00020000);
     // element offset of accumulator register r of tile (t, u) in the output (the host checks that y fits 2^31 bytes)
     int e_l31 = l31, e_lh = lh;                            // (made opaque again before the epilogue, see there)
     auto elem_off = [&](int t, int u, int r, bool& valid) -> int {
@@ -282,26 +286,48 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
     // (16 registers per operand).
     constexpr bool PRE = RM * RN == 1 && !SPLIT;
     const bool pre_a_on = PRE && t128 && p.res != nullptr && (MODE == 1 || EPI);
-    const bool pre_c_on = PRE && t128 && EPI && MODE == 1;
-    // The 128-row tile (WM == 4) and the 64x64 four-wave tile (WN == 2) keep three operands x 16 registers through the main
-    // loop; their y operand - needed only for the activation mask - is fetched in the epilogue instead (16-byte loads through
-    // the same transposer), which takes 16 registers off the main loop.
-    constexpr bool LATE_Y = PRE && (WM == 4 || WN == 2);
-    const bool pre_y_on = !LATE_Y && pre_c_on && p.bnb_act != ADVMIX_ACT_NONE;
-    const bool late_y_on = LATE_Y && pre_c_on && p.bnb_act != ADVMIX_ACT_NONE;
-    f32x4 pq_a[TQ], pq_c[TQ], pq_y[TQ];
+    // The 64x64 four-wave tile (WN == 2: two weight staging slots per thread) does not fit both prefetched operands into
+    // 128 registers: its c operand is fetched in the epilogue instead (16-byte loads through the same transposer).
+    constexpr bool LATE_C = PRE && EPI && MODE == 1 && WN == 2;
+    const bool pre_c_on = PRE && t128 && EPI && MODE == 1 && !LATE_C;
+    const bool late_c_on = LATE_C && t128;
+    f32x4 pq_a[TQ], pq_c[TQ];
 #pragma unroll
     for (int q = 0; q < TQ; ++q) {
-        pq_a[q] = f32x4{0.f, 0.f, 0.f, 0.f}; pq_c[q] = pq_a[q]; pq_y[q] = pq_a[q];
+        pq_a[q] = f32x4{0.f, 0.f, 0.f, 0.f}; pq_c[q] = pq_a[q];
         if (PRE) {
             bool valid;
             const int off = chunk_off(0, 0, q, valid);
             const unsigned boff = valid ? (unsigned)off * 4u : OOB;
             if (pre_a_on) pq_a[q] = bload(rr, boff);
             if (pre_c_on) pq_c[q] = bload(cr, boff);
-            if (pre_y_on) pq_y[q] = bload(yyr, boff);
         }
     }
+    // The activation mask of the BatchNorm-backward epilogue: ONE 4-byte load per lane and MFMA tile, requested now.  Lane
+    // (l31, lh) fetches the 16 channels [16 * lh, 16 * lh + 16) of ITS row l31 of the tile (4 mask bytes); in the epilogue
+    // the lane that needs (row, column) gets that word from lane row + 32 * (column / 16) with one ds_bpermute.
+    const bool mask_on = EPI && MODE == 1 && p.bnb_mask != nullptr && p.bnb_act != ADVMIX_ACT_NONE;
+    unsigned mw[RM][RN];
+#pragma unroll
+    for (int t = 0; t < RM; ++t)
+#pragma unroll
+        for (int u = 0; u < RN; ++u) {
+            mw[t][u] = 0u;
+            if (EPI && MODE == 1 && mask_on) {
+                const int col = n0 + wn * TN * 32 + u * MR + 16 * lh;
+                int m = m0 + wm * TM * 32 + t * MR + l31;
+                const bool valid = m < Mp && col < p.Co;
+                if (!valid) m = 0;
+                int pix = m;
+                if (!(MODE == 0 || p.stride == 1)) {
+                    const int n = m / (Hp * Wp);
+                    const int rem = m - n * (Hp * Wp);
+                    const int hi_ = rem / Wp, wi_ = rem - hi_ * Wp;
+                    pix = (n * p.Ho + rh + hi_ * p.stride) * p.Wo + rw + wi_ * p.stride;
+                }
+                mw[t][u] = __builtin_amdgcn_raw_buffer_load_b32(mkr, valid ? (unsigned)(pix * (p.Co >> 2) + (col >> 2)) : OOB, 0, 0);
+            }
+        }
 
     // Two named register sets (statically indexed): one being multiplied, one in flight.  A third
     // set (two chunks of look-ahead) was measured and is NOT faster: 43.4 % vs 43.8 % on the
@@ -466,7 +492,7 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
     float* const Tx = Ts0 + wid * (2 * RSL * TP);
     auto wave_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
-    float pre_a[RSL], pre_c[RSL], pre_y[RSL];
+    float pre_a[RSL], pre_c[RSL];
     auto to_acc_layout = [&](const f32x4 (&q)[TQ], float (&o)[RSL]) {
 #pragma unroll
         for (int i = 0; i < TQ; ++i)
@@ -477,12 +503,12 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
         wave_fence();
     };
 #pragma unroll
-    for (int r = 0; r < RSL; ++r) { pre_a[r] = 0.f; pre_c[r] = 0.f; pre_y[r] = 0.f; }
+    for (int r = 0; r < RSL; ++r) { pre_a[r] = 0.f; pre_c[r] = 0.f; }
     if (PRE) {
         if (pre_a_on) to_acc_layout(pq_a, pre_a);
         if (pre_c_on) to_acc_layout(pq_c, pre_c);
-        if (pre_y_on) to_acc_layout(pq_y, pre_y);
     }
+    const int mshift = ((e_l31 >> 2) & 3) * 8 + (e_l31 & 3);   // this lane's column within its mask word
     // Straight-line stores: out-of-tile lanes get an out-of-range offset and the hardware drops their write
     // (reads return 0), so there is no per-element branch.  The first version branched around every store, and
     // the compiler's s_waitcnt for the bias value at each re-convergence (vmcnt(0) - which on gfx9 also counts
@@ -500,8 +526,10 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
         }
         const bool addend = MODE == 1 && p.res && (!SPLIT || zsl == 0);
         const bool bnb = EPI && MODE == 1;                  // BatchNorm-backward producer (see ConvD)
-        float bb_mu = 0.f, bb_is = 0.f;
+        float bb_mu = 0.f, bb_is = 0.f, bb_g = 0.f, bb_b = 0.f;
         if (bnb && cvalid) { bb_mu = p.bnb_mean[col]; bb_is = p.bnb_invstd[col]; }
+        const bool recompute = bnb && !mask_on && p.bnb_act != ADVMIX_ACT_NONE;     // sign of y = act(BN(c)) from c itself
+        if (recompute && cvalid) { bb_g = p.bnb_gamma[col]; bb_b = p.bnb_beta[col]; }
         const float bb_slope = act_neg_slope(p.bnb_act);
         // element offsets in the accumulator layout are only needed on the scalar path (Co % 4 != 0, K split across
         // the grid): everything else moves in 16-byte chunks through the transposer
@@ -511,35 +539,33 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
 #pragma unroll
         for (int t = 0; t < RM; ++t) {
             // read operands that were not prefetched (multi-tile waves): 16-byte loads now, same transposer
-            float oa[RSL], oc[RSL], oy[RSL];
+            float oa[RSL], oc[RSL];
 #pragma unroll
-            for (int r = 0; r < RSL; ++r) { oa[r] = pre_a[r]; oc[r] = pre_c[r]; oy[r] = pre_y[r]; }
-            if (LATE_Y && late_y_on) {
-                f32x4 qy[TQ];
+            for (int r = 0; r < RSL; ++r) { oa[r] = pre_a[r]; oc[r] = pre_c[r]; }
+            if (LATE_C && late_c_on) {
+                f32x4 qc[TQ];
 #pragma unroll
                 for (int q = 0; q < TQ; ++q) {
                     bool valid;
                     const int off = chunk_off(t, u, q, valid);
-                    qy[q] = bload(yyr, valid ? (unsigned)off * 4u : OOB);
+                    qc[q] = bload(cr, valid ? (unsigned)off * 4u : OOB);
                 }
-                to_acc_layout(qy, oy);
+                to_acc_layout(qc, oc);
             }
             if (t128 && !PRE) {
-                const bool la = op_a, lc = bnb, ly = bnb && p.bnb_act != ADVMIX_ACT_NONE;
-                f32x4 qa[TQ], qc[TQ], qy[TQ];
+                const bool la = op_a, lc = bnb;
+                f32x4 qa[TQ], qc[TQ];
 #pragma unroll
                 for (int q = 0; q < TQ; ++q) {
                     bool valid;
                     const int off = chunk_off(t, u, q, valid);
                     const unsigned boff = valid ? (unsigned)off * 4u : OOB;
-                    qa[q] = qc[q] = qy[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    qa[q] = qc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (la) qa[q] = bload(rr, boff);
                     if (lc) qc[q] = bload(cr, boff);
-                    if (ly) qy[q] = bload(yyr, boff);
                 }
                 if (la) to_acc_layout(qa, oa);
                 if (lc) to_acc_layout(qc, oc);
-                if (ly) to_acc_layout(qy, oy);
             }
             float vo[RSL];
 #pragma unroll
@@ -567,11 +593,15 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
                 }
                 if (bnb) {                                  // out-of-tile lanes load 0 and contribute 0
                     const float cv = t128 ? oc[r] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cr, boff, 0, 0));
-                    if (p.bnb_act != ADVMIX_ACT_NONE) {
-                        const float yv = t128 ? oy[r] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yyr, boff, 0, 0));
-                        v = yv > 0.f ? v : v * bb_slope;
+                    const float xh = (cv - bb_mu) * bb_is;
+                    if (mask_on) {                          // (wave-uniform: every lane takes part in the permute)
+                        const int src = MS::row(r_lo + r, e_lh) + ((e_l31 & 16) << 1);
+                        const unsigned wv = (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)mw[t][u]);
+                        v = ((wv >> mshift) & 1u) ? v : v * bb_slope;
+                    } else if (recompute) {
+                        v = __builtin_fmaf(xh, bb_g, bb_b) > 0.f ? v : v * bb_slope;
                     }
-                    if (valid) { s1 += v; s2 += v * ((cv - bb_mu) * bb_is); }
+                    if (valid) { s1 += v; s2 += v * xh; }
                 }
                 vo[r] = v;
                 if (!t128) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, boff, 0, CD_STORE_AUX);
@@ -629,15 +659,12 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
 }
 
 template <int TM, int TN, int WM, int WN, int KC, int MODE, bool SPLIT, bool BT, bool EPI, int NW = 4>
-// (left free, the register allocator spreads the BatchNorm-backward variants' three prefetched epilogue operands over 254
-// VGPRs = one wave per SIMD.)  Four waves per SIMD (4-wave workgroups: 4 per CU, 8-wave: 2) for every variant EXCEPT the
-// BatchNorm-backward ones, which stay at three (138-152 registers).  Capping those at 128 as well was worth 1.8 % of the
-// step (profiles/r03_ab_launch_bounds.log) and was shipped for a few hours of round 3 - until the two-ranks-on-one-GPU
-// data-parallel test, which had passed a dozen times in a row, began to fail in 2-6 of 8 runs: parameters turned NaN on the
-// third graph replay, with spilling builds (13-20 registers of scratch) and with a spill-free one alike, and in 0 of 10 runs
-// with this line.  No single-process test, benchmark or parity check ever saw it; the cause was not found in the time left
-// (DESIGN.md section 8), so the configuration that is known good ships.
-__global__ __launch_bounds__(64 * NW, NW == 4 ? ((EPI && MODE == 1) ? 3 : 4) : 2) void conv_direct(ConvD p) {
+// (left free, the register allocator spreads the epilogue operands over 254 VGPRs = one wave per SIMD.)  Four waves per SIMD
+// (4-wave workgroups: 4 per CU, 8-wave: 2) for EVERY variant: a kernel's waves share the SIMDs with the other lanes' kernels,
+// and the cap was worth 1.8 % of the step for the BatchNorm-backward variants alone (profiles/r03_ab_launch_bounds.log).
+// Round 3 withdrew it from those variants while hunting the two-rank failure, which turned out to be the NULL-stream graph
+// replay; with the y operand gone (round 4: activation mask) they fit 128 registers without scratch.
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 4 : 2) void conv_direct(ConvD p) {
     using G = Geo<TM, TN, WM, WN, KC, NW>;
     // K split inside the workgroup (WK > 1): the epilogue starts with a workgroup barrier (the partial tiles meet in the
     // FIRST weight buffer), so the wave-private transposer can live in the SECOND weight buffer instead of LDS of its
@@ -812,13 +839,14 @@ static int prepare(int mode, const float* x, const float* w, const float* bias, 
     if (bt && (mode != 1 || Co % 4 != 0)) return -1;
     if (epi && mode != 0 && (epi->gamma || epi->act)) return -2;                 // mode 1: addend and/or BN-backward sums
     if (epi && mode != 0 && epi->stats && !(bt && epi->bnb_c && epi->bnb_mean && epi->bnb_invstd &&
-                                            (epi->bnb_act == ADVMIX_ACT_NONE || epi->bnb_y))) return -2;
+                                            (epi->bnb_act == ADVMIX_ACT_NONE || (epi->bnb_mask && Co % 16 == 0) ||
+                                             (!epi->bnb_mask && epi->bnb_gamma && epi->bnb_beta)))) return -2;
     const int64_t xb = (int64_t)N * Hi * Wi * Ci * 4, wb = (int64_t)Co * R * S * Ci * 4;
     const int64_t yb = (int64_t)N * Ho * Wo * Co * 4;
     if (xb >= 0x7fffffffLL || wb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return -1;
     direct::ConvD p{x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, (int)xb, (int)wb, (int)yb, 1,
                     nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0,
-                    nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     static const int xcd_remap = [] { const char* e = getenv("ADVMIX_XCD_REMAP"); return e ? atoi(e) : 1; }();
     p.xcd_remap = xcd_remap;
     // Slots per channel the workgroup sums are folded onto: many row blocks hammering few addresses serialise the
@@ -841,7 +869,8 @@ static int prepare(int mode, const float* x, const float* w, const float* bias, 
         p.bn_eps = epi->eps; p.act = epi->act; p.stats = epi->stats;
         if (mode != 0 && epi->stats) {
             bnb = true;
-            p.bnb_y = epi->bnb_y; p.bnb_c = epi->bnb_c; p.bnb_mean = epi->bnb_mean; p.bnb_invstd = epi->bnb_invstd;
+            p.bnb_mask = epi->bnb_mask; p.bnb_c = epi->bnb_c; p.bnb_mean = epi->bnb_mean; p.bnb_invstd = epi->bnb_invstd;
+            p.bnb_gamma = epi->bnb_gamma; p.bnb_beta = epi->bnb_beta;
             p.bnb_act = epi->bnb_act;
         }
     }

@@ -567,17 +567,19 @@ extern "C" int advmix_conv_group(int kind, int n, advmix_conv_problem* pr, void*
             if ((a.bn_gamma != nullptr) != (a.bn_beta && a.bn_rm && a.bn_rv)) return ADVMIX_EINVAL;
             const bool has = a.bn_gamma || a.residual || a.act || a.stats;
             e[i] = ConvEpi{a.bn_gamma, a.bn_beta, a.bn_rm, a.bn_rv, a.residual, a.bn_eps, a.act, a.stats,
-                           nullptr, nullptr, nullptr, nullptr, 0};
+                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
             q[i] = ConvProb{a.x, a.w, a.bias, a.y, a.N, a.Hx, a.Wx, a.Cx, a.Hy, a.Wy, a.Cy, a.R, a.S, 1, a.pad,
                             (int64_t)a.N * a.Hy * a.Wy, has ? &e[i] : nullptr, a.stats_ns};
         } else {
             if (a.Hx != a.Hy + 2 * a.pad - a.R + 1 || a.Wx != a.Wy + 2 * a.pad - a.S + 1) return ADVMIX_EINVAL;
             const bool bnb = a.stats != nullptr;
-            if (bnb && (!a.bnb_c || !a.bnb_mean || !a.bnb_invstd || (a.bnb_act != ADVMIX_ACT_NONE && !a.bnb_y)))
+            if (bnb && (!a.bnb_c || !a.bnb_mean || !a.bnb_invstd ||
+                        (a.bnb_act != ADVMIX_ACT_NONE && !a.bnb_mask && !(a.bnb_gamma && a.bnb_beta))))
                 return ADVMIX_EINVAL;
             e[i] = ConvEpi{nullptr, nullptr, nullptr, nullptr, a.residual, 0.f, 0, bnb ? a.stats : nullptr,
-                           bnb ? a.bnb_y : nullptr, bnb ? a.bnb_c : nullptr, bnb ? a.bnb_mean : nullptr,
-                           bnb ? a.bnb_invstd : nullptr, bnb ? a.bnb_act : 0};
+                           bnb ? a.bnb_mask : nullptr, bnb ? a.bnb_c : nullptr, bnb ? a.bnb_mean : nullptr,
+                           bnb ? a.bnb_invstd : nullptr, bnb ? a.bnb_gamma : nullptr, bnb ? a.bnb_beta : nullptr,
+                           bnb ? a.bnb_act : 0};
             q[i] = ConvProb{a.x, a.w, nullptr, a.y, a.N, a.Hx, a.Wx, a.Cx, a.Hy, a.Wy, a.Cy, a.R, a.S, 1, a.pad,
                             (int64_t)a.N * a.Hy * a.Wy, (bnb || a.residual) ? &e[i] : nullptr, a.stats_ns};
         }
@@ -774,7 +776,7 @@ extern "C" int advmix_conv_fwd_ex(const float* x, const float* w, const float* b
     if ((bn_gamma != nullptr) != (bn_beta && bn_rm && bn_rv)) return ADVMIX_EINVAL;
     if (stats && !stats_nbg) return ADVMIX_EINVAL;
     if (!use_direct()) return ADVMIX_EINVAL;
-    ConvEpi e{bn_gamma, bn_beta, bn_rm, bn_rv, residual, bn_eps, act, stats, nullptr, nullptr, nullptr, nullptr, 0};
+    ConvEpi e{bn_gamma, bn_beta, bn_rm, bn_rv, residual, bn_eps, act, stats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     int rc = advmix_conv_direct_dispatch(0, x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad,
                                          (int64_t)N * Ho * Wo, (hipStream_t)stream, 0, &e, stats_nbg);
     return rc < 0 ? ADVMIX_EINVAL : rc;
@@ -788,7 +790,7 @@ extern "C" int advmix_conv_tr_w_add(const float* x, const float* w, const float*
     if (!x || !w || !y || N <= 0 || Ck <= 0 || Cn <= 0 || stride < 1 || stride > 8) return ADVMIX_EINVAL;
     if (Hs != (Hb + 2 * pad - R) / stride + 1 || Ws != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
     if (!use_direct()) return ADVMIX_EINVAL;
-    ConvEpi epi{nullptr, nullptr, nullptr, nullptr, addend, 0.f, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    ConvEpi epi{nullptr, nullptr, nullptr, nullptr, addend, 0.f, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     int64_t Mmax = (int64_t)N * cdiv(Hb, stride) * cdiv(Wb, stride);
     int rc = advmix_conv_direct_dispatch(1, x, w, nullptr, y, N, Hs, Ws, Ck, Hb, Wb, Cn, R, S, stride, pad, Mmax,
                                          (hipStream_t)stream, 1, addend ? &epi : nullptr);
@@ -799,20 +801,24 @@ extern "C" int advmix_conv_tr_w_add(const float* x, const float* w, const float*
 //   g = (conv_transpose(x, w) + addend) * act'(y)        written to ``g_out`` (same layout as y)
 //   stats[0][ch][slot] += sum g,  stats[1][ch][slot] += sum g * (c - mean) * invstd      (fp64 atomics, ns slots)
 // i.e. everything BatchNorm backward needs from a pass over (dy, y, c) is produced here; advmix_norm_bwd_apply_slots
-// finishes it.  ``bn_y`` may be NULL when act == ADVMIX_ACT_NONE.  ``*stats_ns``: in = slots per channel to use
-// (0 = the library default), out = the number used.  Returns 1 (ADVMIX_EINVAL) when the shape is not served (grid
-// K split, tensors >= 2 GiB, Ck % 16 != 0): nothing was launched and the caller runs the separate kernels.
+// finishes it.  The sign of y (act != ADVMIX_ACT_NONE) comes from ``act_mask`` - the bit-per-element mask
+// advmix_norm_apply_slots wrote beside y - or, when act_mask is NULL, is recomputed from c with ``bn_gamma`` / ``bn_beta``
+// (valid for y = act(BN(c)) WITHOUT a residual as advmix_norm_apply_slots computed it: the same fused multiply-add).
+// ``*stats_ns``: in = slots per channel to use (0 = the library default), out = the number used.  Returns 1
+// (ADVMIX_EINVAL) when the shape is not served (grid K split, tensors >= 2 GiB, Ck % 16 != 0, a mask with Cn % 16 != 0):
+// nothing was launched and the caller runs the separate kernels.
 extern "C" int advmix_conv_tr_w_bnb(const float* x, const float* w, const float* addend, float* g_out,
                                     int N, int Hs, int Ws, int Ck, int Hb, int Wb, int Cn,
                                     int R, int S, int stride, int pad,
-                                    const float* bn_y, const float* bn_c, const float* bn_mean, const float* bn_invstd,
+                                    const unsigned char* act_mask, const float* bn_c, const float* bn_mean,
+                                    const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
                                     int act, double* stats, int* stats_ns, void* stream) {
     if (!x || !w || !g_out || !bn_c || !bn_mean || !bn_invstd || !stats || !stats_ns) return ADVMIX_EINVAL;
     if (N <= 0 || Ck <= 0 || Cn <= 0 || stride < 1 || stride > 8) return ADVMIX_EINVAL;
-    if (act != ADVMIX_ACT_NONE && !bn_y) return ADVMIX_EINVAL;
+    if (act != ADVMIX_ACT_NONE && !act_mask && !(bn_gamma && bn_beta)) return ADVMIX_EINVAL;
     if (Hs != (Hb + 2 * pad - R) / stride + 1 || Ws != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
     if (!use_direct()) return ADVMIX_EINVAL;
-    ConvEpi epi{nullptr, nullptr, nullptr, nullptr, addend, 0.f, 0, stats, bn_y, bn_c, bn_mean, bn_invstd, act};
+    ConvEpi epi{nullptr, nullptr, nullptr, nullptr, addend, 0.f, 0, stats, act_mask, bn_c, bn_mean, bn_invstd, bn_gamma, bn_beta, act};
     int64_t Mmax = (int64_t)N * cdiv(Hb, stride) * cdiv(Wb, stride);
     int rc = advmix_conv_direct_dispatch(1, x, w, nullptr, g_out, N, Hs, Ws, Ck, Hb, Wb, Cn, R, S, stride, pad, Mmax,
                                          (hipStream_t)stream, 1, &epi, stats_ns);

@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void norm_apply_slots_kernel(
         const float* __restrict__ c, const double* __restrict__ slots, int ns, int64_t rows, int C, float eps,
         const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res,
         float* __restrict__ y, int act, float* __restrict__ mean_out, float* __restrict__ invstd_out,
-        float* running_mean, float* running_var, int64_t* nbt, float momentum) {
+        float* running_mean, float* running_var, int64_t* nbt, float momentum, unsigned char* __restrict__ mask) {
     __shared__ double sums[2][SLOT_CT];
     __shared__ double red[4 * 2 * SLOT_CT];
     __shared__ float smu[SLOT_CT], sis[SLOT_CT];
@@ -500,8 +500,15 @@ __global__ __launch_bounds__(256) void norm_apply_slots_kernel(
             const int64_t row = r + (int64_t)u * t.rpi;
             if (row >= t.r1) break;
             f32x4 o = (xv[u] - mu) * is;
-            o = o * g + b;
+            // ONE fused multiply-add, spelled out: the BatchNorm-backward epilogue of the consumer's input-gradient conv
+            // (conv_direct.hip) recomputes the sign of y from c with this very expression when there is no residual
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(o[e], g[e], b[e]);
             if (res) o += rv[u];
+            if (mask) {                                     // a bit per element, a byte per 4 channels: 1/16 of y's bytes
+                const unsigned nib = (o[0] > 0.f ? 1u : 0u) | (o[1] > 0.f ? 2u : 0u) | (o[2] > 0.f ? 4u : 0u) | (o[3] > 0.f ? 8u : 0u);
+                mask[(row * C + ch) >> 2] = (unsigned char)nib;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = act_fwd(o[e], act);
             *reinterpret_cast<f32x4*>(y + row * C + ch) = o;
@@ -709,18 +716,20 @@ extern "C" int advmix_norm_bwd(const float* dy, const float* y, int ldy, const f
 
 // Train-mode BatchNorm forward whose statistics were accumulated by the producing conv's epilogue into
 // slots[2][C][ns] (fp64, see conv_direct.hip): reduces them, writes mean / invstd, updates the running statistics and
-// applies y = act(BN(c) + residual) in ONE launch.  Returns ADVMIX_EINVAL (and launches nothing) for shapes it does
+// applies y = act(BN(c) + residual) in ONE launch.  ``act_mask`` (may be NULL): [rows][C / 4] bytes, bit e of byte
+// (row, ch / 4) = "BN(c) + residual > 0 at channel 4 * (ch / 4) + e" - what a ReLU / LeakyReLU backward needs of y, at 1/16
+// of its bytes (advmix_conv_tr_w_bnb reads it).  Returns ADVMIX_EINVAL (and launches nothing) for shapes it does
 // not serve (C % 4 != 0, a channel tile that does not divide the workgroup): the caller falls back to
 // advmix_norm_finalize + advmix_norm_apply.
 extern "C" int advmix_norm_apply_slots(const float* c, const double* slots, int ns, int64_t rows, int C, float eps,
                                        const float* gamma, const float* beta, const float* residual, float* y,
                                        int act, float* mean, float* invstd, float* running_mean, float* running_var,
-                                       int64_t* nbt, float momentum, void* stream) {
+                                       int64_t* nbt, float momentum, unsigned char* act_mask, void* stream) {
     if (!c || !slots || !gamma || !beta || !y || !mean || !invstd || rows <= 0 || C <= 0) return ADVMIX_EINVAL;
     if ((running_mean != nullptr) != (running_var != nullptr)) return ADVMIX_EINVAL;
     if (!slots_ok(ns, C)) return ADVMIX_EINVAL;
     hipLaunchKernelGGL(norm_apply_slots_kernel, slot_grid(rows, C), dim3(256), 0, (hipStream_t)stream, c, slots, ns, rows,
-                       C, eps, gamma, beta, residual, y, act, mean, invstd, running_mean, running_var, nbt, momentum);
+                       C, eps, gamma, beta, residual, y, act, mean, invstd, running_mean, running_var, nbt, momentum, act_mask);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }

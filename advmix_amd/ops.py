@@ -194,7 +194,8 @@ def _wt(st, w, A, T, B):
 #          bwd(st, lane, saved, extra, meta, grads, needs) -> input grads (aligned with tensors)
 # =============================================================================================
 BNB_FUSED = __import__('os').environ.get('ADVMIX_BNB', '1') != '0'
-FUSE_BNB = __import__('os').environ.get('ADVMIX_FUSE_BNB', '1') != '0'    # the fuse layers' BatchNorm-backward sums from FuseSum.bwd
+FUSE_BNB = __import__('os').environ.get('ADVMIX_FUSE_BNB', '1') != '0'
+ACT_MASK = __import__('os').environ.get('ADVMIX_ACT_MASK', '1') != '0'       # 0: residual layers take the unfused BatchNorm backward (A/B)    # the fuse layers' BatchNorm-backward sums from FuseSum.bwd
 DETERMINISTIC = False
 REPLAY_ON_NULL = __import__('os').environ.get('ADVMIX_REPLAY_STREAM', 'own') == 'null'
 
@@ -250,7 +251,8 @@ def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_
 
     ``bnb`` (dict): the conv's input is y = act(BN(c) + res) of a train-mode ConvBN earlier in the same chain and
     this is the LAST contribution to dL/dy.  Where the kernel serves the shape, the epilogue also multiplies by
-    act'(y) and accumulates the two BatchNorm-backward channel sums into the producer's slots; ``bnb['done']`` is
+    act'(y) - the sign of y from the producer's bit mask (``bnb['mask']``) or, without a residual, recomputed from c -
+    and accumulates the two BatchNorm-backward channel sums into the producer's slots; ``bnb['done']`` is
     then set to the slot count and the result is g = dL/dy * act'(y) instead of dL/dy."""
     dx = empty_nhwc(B, Ci, Hi, Wi, x.device)
     if Co % 16 == 0 and Ci % 4 == 0 and _direct_ok():          # weights consumed in their own layout
@@ -265,8 +267,8 @@ def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_
             else:
                 nsv, target = ctypes.c_int(STAT_SLOTS_ASK), bnb['slots']
             rc = lib.advmix_conv_tr_w_bnb(_p(dy), _p(w), _p(add_to), _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride,
-                                          pad, _p(bnb['y']) if bnb['act'] != ACT_NONE else None, _p(bnb['c']),
-                                          _p(bnb['mean']), _p(bnb['invstd']), bnb['act'], target,
+                                          pad, _p(bnb['mask']), _p(bnb['c']), _p(bnb['mean']), _p(bnb['invstd']),
+                                          _p(bnb['gamma']), _p(bnb['beta']), bnb['act'], target,
                                           ctypes.byref(nsv), st)
             if rc == 0:
                 if DETERMINISTIC:
@@ -478,6 +480,7 @@ class ConvBN:
         mean = torch.empty(Co, device=x.device, dtype=torch.float32)
         invstd = torch.empty(Co, device=x.device, dtype=torch.float32)
         rc = 1
+        mask, slot_fwd = None, False       # activation bit mask for the backward epilogue; "y came from norm_apply_slots"
         if fused_ok:
             if arena is not None and arena.t is not None:
                 slots = arena.ptr(fwd_off)
@@ -496,10 +499,17 @@ class ConvBN:
                 call('advmix_stats_fold', target, nbg.value, Co, slots, st)
                 nbg.value = 1
             if rc == 0:
+                if res is not None and act != ACT_NONE and Co % 16 == 0 and any(needs) and BNB_FUSED and ACT_MASK:
+                    # y = act(BN(c) + residual): the consumer's BatchNorm-backward epilogue needs the SIGN of y only - a bit
+                    # per element here (1/16 of y's bytes) instead of reading the fp32 tensor again (without a residual the
+                    # sign is recomputed from c: nothing is written)
+                    mask = torch.empty(rows * Co // 4, device=x.device, dtype=torch.uint8)
                 rc2 = lib.advmix_norm_apply_slots(_p(c), slots, nbg.value, rows, Co, eps, _p(gamma), _p(beta), _p(res),
                                                   _p(y), act, _p(mean), _p(invstd), _p(rmean), _p(rvar), _p(nbt),
-                                                  momentum, st)
+                                                  momentum, _p(mask), st)
+                slot_fwd = rc2 == 0
                 if rc2 == 1:                                # e.g. Co % 4 != 0: separate finalize + apply
+                    mask = None
                     call('advmix_norm_finalize', slots, nbg.value, rows, Co, eps, _p(mean), _p(invstd), _p(rmean),
                          _p(rvar), _p(nbt), momentum, st)
                     call('advmix_norm_apply', _p(c), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), _p(y),
@@ -515,7 +525,7 @@ class ConvBN:
                  _p(nbt), momentum, _p(ws), st)
             call('advmix_norm_apply', _p(c), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), _p(y),
                  Co, 1, rows, Co, act, st)
-        extra = (residual is not None, arena, arena.pass_id if arena is not None else 0, bwd_off)
+        extra = (residual is not None, arena, arena.pass_id if arena is not None else 0, bwd_off, mask, slot_fwd)
         if len(meta) > 9 and meta[9] and arena is not None and arena.t is not None and act == ACT_NONE and any(needs) \
                 and BNB_FUSED and FUSE_BNB and not DETERMINISTIC:
             # the only consumer is a fuse sum in another launch group: its backward can produce this layer's sums
@@ -528,19 +538,24 @@ class ConvBN:
     def bnb_target(saved, extra, meta):
         """What the input-gradient conv of this layer's CONSUMER needs to fold this layer's BatchNorm-backward
         statistics into its epilogue (None if the layer's backward slots cannot be used for this pass)."""
-        has_res, arena, pass_id, bwd_off = extra
+        has_res, arena, pass_id, bwd_off, mask, slot_fwd = extra
         act = meta[2]
-        if arena is None or act not in (ACT_NONE, ACT_RELU) or not arena.claim_bwd(bwd_off, pass_id):
+        if arena is None or act not in (ACT_NONE, ACT_RELU):
+            return None
+        if act != ACT_NONE and (mask is None if has_res else not slot_fwd):
+            return None                                     # no mask was written / y did not come from norm_apply_slots
+        if not arena.claim_bwd(bwd_off, pass_id):
             return None
         x, w, c, y, mean, invstd, gamma, beta = saved
-        return {'y': y, 'c': c, 'mean': mean, 'invstd': invstd, 'act': act, 'slots': arena.ptr(bwd_off)}
+        return {'mask': mask, 'c': c, 'mean': mean, 'invstd': invstd, 'gamma': gamma, 'beta': beta, 'act': act,
+                'slots': arena.ptr(bwd_off)}
 
     @staticmethod
     def bwd(st, lane, saved, extra, meta, grads, needs, add_to=None, pre=0, bnb=None):
         stride, pad, act, training = meta[0], meta[1], meta[2], meta[3]
         if not training:
             raise RuntimeError('advmix_amd: backward through eval-mode BatchNorm is not on the hot path')
-        has_res, arena, _pass, bwd_off = extra
+        has_res, arena, _pass, bwd_off = extra[:4]
         x, w, c, y, mean, invstd, gamma, beta = saved
         dy = nhwc(grads[0])
         B, Ci, Hi, Wi = x.shape

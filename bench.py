@@ -124,8 +124,10 @@ def _event_time(run, iters, reps=5):
 
 CONV_FAMILY = ((32, 64, 48), (64, 32, 24), (128, 16, 12), (256, 8, 6))     # HRNet-W32's 3x3 s1 C->C convs: 1.81 GF each at B = 32
 # launches per AdvMix step of each kind of a given conv: two train-mode student forwards + the eval-mode teacher, two
-# input gradients (D step, G step), one weight gradient (D step)
-KIND_WEIGHT = {'fwd+BN-sums': 2, 'fwd+BN-eval+ReLU': 1, 'dgrad+BN-bwd-sums': 2, 'wgrad': 1}
+# input gradients (D step, G step) - of a BasicBlock's two convs one takes the residual path's gradient as addend and the
+# sign of y from the bit mask, the other recomputes it from c - one weight gradient (D step)
+KIND_WEIGHT = {'fwd+BN-sums': 2, 'fwd+BN-eval+ReLU': 1, 'dgrad+addend+BN-bwd-sums (act mask)': 1,
+               'dgrad+BN-bwd-sums (sign from c)': 1, 'wgrad': 1}
 
 
 def _pmc_file(pattern):
@@ -176,6 +178,7 @@ def time_conv_family(B, device, iters=100, family=None):
         rv = torch.rand(C, device=device) + 0.5
         mean, invstd = torch.zeros(C, device=device), torch.ones(C, device=device)
         slots = torch.zeros(2 * C * 64, device=device, dtype=torch.float64)
+        amask = torch.randint(0, 16, (rows * C // 4,), device=device, dtype=torch.uint8)     # a bit per element of y
         nbg = ctypes.c_int(0)
         geom = (B, H, W, C, H, W, C, 3, 3, 1, 1)
         flops = 2.0 * rows * C * C * 9
@@ -187,8 +190,12 @@ def time_conv_family(B, device, iters=100, family=None):
                                                   None, 0.0, None, 0, P(slots), ctypes.byref(nbg), st)),
             'fwd+BN-eval+ReLU': lambda: call('advmix_conv_fwd_ex', P(x), P(w), None, P(y), *geom, P(g), P(b), P(rm), P(rv),
                                              1e-5, None, 1, None, None, st),
-            'dgrad+BN-bwd-sums': lambda: (reset(), call('advmix_conv_tr_w_bnb', P(dy), P(w), P(c2), P(dx), *geom, P(y),
-                                                        P(c2), P(mean), P(invstd), 1, P(slots), ctypes.byref(nbg), st)),
+            'dgrad+addend+BN-bwd-sums (act mask)': lambda: (reset(), call(
+                'advmix_conv_tr_w_bnb', P(dy), P(w), P(c2), P(dx), *geom, P(amask), P(c2), P(mean), P(invstd), None, None, 1,
+                P(slots), ctypes.byref(nbg), st)),
+            'dgrad+BN-bwd-sums (sign from c)': lambda: (reset(), call(
+                'advmix_conv_tr_w_bnb', P(dy), P(w), None, P(dx), *geom, None, P(c2), P(mean), P(invstd), P(g), P(b), 1,
+                P(slots), ctypes.byref(nbg), st)),
             'wgrad': lambda: call('advmix_conv_wgrad', P(dy), P(x), P(dw), B, H, W, C, H, W, C, 3, 3, 1, 1, st),
         }
         for kind, run in runs.items():
@@ -212,7 +219,7 @@ def time_conv_family(B, device, iters=100, family=None):
             for name, run, passes in (
                     ('norm_apply_slots (BN + residual + ReLU, statistics from %d slots)' % ns,
                      lambda: call('advmix_norm_apply_slots', P(c2), P(slots), ns, rows, C, 1e-5, P(g), P(b), P(res), P(y), 1,
-                                  P(mean), P(invstd), P(rm), P(rv), P(nbt), 0.1, st), 3),
+                                  P(mean), P(invstd), P(rm), P(rv), P(nbt), 0.1, P(amask), st), 3),
                     ('norm_bwd_apply_slots (BN backward from the slot sums)',
                      lambda: call('advmix_norm_bwd_apply_slots', P(dy), P(c2), P(mean), P(invstd), P(g), P(slots), ns, rows,
                                   C, P(dx), None, None, st), 3)):

@@ -93,7 +93,10 @@ int advmix_conv_tr_w_add(const float* x, const float* w, const float* addend, fl
 /* Input gradient of a conv whose INPUT is y = act(BN(c) + residual) of a train-mode BatchNorm
  * (pose_hrnet.py:41-57 backward): g = (conv_transpose(x, w) + addend) * act'(y) is written to g_out and the two
  * BatchNorm-backward channel sums are accumulated with fp64 atomics into stats[2][Cn][ns] (zero on entry):
- * stats[0] += sum g, stats[1] += sum g * (c - mean) * invstd.  bn_y may be NULL when act == ADVMIX_ACT_NONE.
+ * stats[0] += sum g, stats[1] += sum g * (c - mean) * invstd.  The sign of y (act != ADVMIX_ACT_NONE): from act_mask, the
+ * bit-per-element mask advmix_norm_apply_slots wrote ([rows][Cn / 4] bytes; Cn % 16 == 0), or - act_mask NULL - recomputed
+ * from c as fmaf((c - mean) * invstd, gamma, beta) > 0, which is what advmix_norm_apply_slots evaluated when there was no
+ * residual (round 4: the fp32 y was read for its sign alone - 12.6 of 65 MB per launch at 32 x 64 x 48 x 32).
  * *stats_ns: in = slots per channel (0 = library default, a power of two <= 64), out = the number used.
  * Returns ADVMIX_EINVAL without launching when the shape is not served (grid K split, Ck % 16 != 0, >= 2 GiB);
  * the caller then runs advmix_conv_tr_w_add + advmix_norm_bwd.  Replaces torch autograd's cudnn_batch_norm_backward
@@ -101,8 +104,8 @@ int advmix_conv_tr_w_add(const float* x, const float* w, const float* addend, fl
 int advmix_conv_tr_w_bnb(const float* x, const float* w, const float* addend, float* g_out,
                          int N, int Hs, int Ws, int Ck, int Hb, int Wb, int Cn,
                          int R, int S, int stride, int pad,
-                         const float* bn_y, const float* bn_c, const float* bn_mean, const float* bn_invstd,
-                         int act, double* stats, int* stats_ns, void* stream);
+                         const unsigned char* act_mask, const float* bn_c, const float* bn_mean, const float* bn_invstd,
+                         const float* bn_gamma, const float* bn_beta, int act, double* stats, int* stats_ns, void* stream);
 
 /* Transposed gather with <= 4 output channels: the input gradient of a network's FIRST conv (3 image channels; taken
  * when the images come from the generator - lib/core/function.py:146-160 back-propagates loss_G through the frozen
@@ -163,7 +166,8 @@ typedef struct advmix_conv_problem {
     int act;
     double* stats;
     int stats_ns;
-    const float *bnb_y, *bnb_c, *bnb_mean, *bnb_invstd;
+    const unsigned char* bnb_mask;                        /* kind 1 + stats: as advmix_conv_tr_w_bnb's act_mask ... */
+    const float *bnb_c, *bnb_mean, *bnb_invstd, *bnb_gamma, *bnb_beta;
     int bnb_act;
 } advmix_conv_problem;
 int advmix_conv_group(int kind, int n, advmix_conv_problem* problems, void* stream);
@@ -194,11 +198,13 @@ int advmix_norm_finalize(double* partial, int nbg, int64_t rows, int C, float ep
  * advmix_conv_fwd_ex (every workgroup for the channels it streams), writes mean / invstd (saved for backward), updates
  * the running statistics / num_batches_tracked (may be NULL) and applies y = act(BN(c) + residual) in ONE launch.
  * The slots are NOT re-zeroed (the caller zero-fills its per-layer slots once per network pass).
+ * act_mask (may be NULL): out, [rows][C / 4] bytes - bit e of byte (row, ch / 4) says whether BN(c) + residual is positive
+ * at channel 4 * (ch / 4) + e: all a ReLU / LeakyReLU backward needs of y (advmix_conv_tr_w_bnb reads it instead of y).
  * ADVMIX_EINVAL without launching when C % 4 != 0 or ns is not a power of two <= 64. */
 int advmix_norm_apply_slots(const float* c, const double* slots, int ns, int64_t rows, int C, float eps,
                             const float* gamma, const float* beta, const float* residual, float* y, int act,
                             float* mean, float* invstd, float* running_mean, float* running_var,
-                            int64_t* num_batches_tracked, float momentum, void* stream);
+                            int64_t* num_batches_tracked, float momentum, unsigned char* act_mask, void* stream);
 /* BatchNorm backward from the slots advmix_conv_tr_w_bnb filled: dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)),
  * dgamma += sum g*xhat, dbeta += sum g (either may be NULL).  g is already multiplied by the activation's slope. */
 int advmix_norm_bwd_apply_slots(const float* g, const float* c, const float* mean, const float* invstd,

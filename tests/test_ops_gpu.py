@@ -28,6 +28,13 @@ def cl(t):
     return t.float().to(dev()).contiguous(memory_format=torch.channels_last)
 
 
+def pack_act_mask(y_nhwc):
+    """The bit-per-element mask advmix_norm_apply_slots writes beside y (a byte per 4 channels, bit e = channel 4k + e):
+    here from the sign of a dense NHWC tensor."""
+    b = (y_nhwc > 0).reshape(-1, 4).to(torch.uint8)
+    return (b[:, 0] | (b[:, 1] << 1) | (b[:, 2] << 2) | (b[:, 3] << 3)).contiguous()
+
+
 def check(name, got, ref, tol=1e-4):
     got = got.detach().double().cpu()
     ref = ref.detach().double()
@@ -166,10 +173,17 @@ def test_grouped_conv_launch_equals_single_launches(mode):
                     call('advmix_conv_tr_w_add', P(t['x']), P(t['w']), P(t['res']) if i % 2 == 0 else None, P(y), *geom, st)
             else:
                 q.residual, q.stats = A(t['res']), A(slots)
-                q.bnb_y, q.bnb_c, q.bnb_mean, q.bnb_invstd, q.bnb_act = A(t['yy']), A(t['cc']), A(t['mean']), A(t['invstd']), 1
+                if i % 2 == 0:                              # the sign of y from the bit mask / recomputed from c, in one launch
+                    t['mk'] = pack_act_mask(t['yy'])
+                    q.bnb_mask, q.bnb_gamma, q.bnb_beta = A(t['mk']), 0, 0
+                else:
+                    q.bnb_mask, q.bnb_gamma, q.bnb_beta = 0, A(t['g']), A(t['b'])
+                q.bnb_c, q.bnb_mean, q.bnb_invstd, q.bnb_act = A(t['cc']), A(t['mean']), A(t['invstd']), 1
                 if not grouped:
-                    call('advmix_conv_tr_w_bnb', P(t['x']), P(t['w']), P(t['res']), P(y), *geom, P(t['yy']), P(t['cc']),
-                         P(t['mean']), P(t['invstd']), 1, P(slots), ctypes.byref(nbg), st)
+                    call('advmix_conv_tr_w_bnb', P(t['x']), P(t['w']), P(t['res']), P(y), *geom,
+                         P(t['mk']) if i % 2 == 0 else None, P(t['cc']), P(t['mean']), P(t['invstd']),
+                         None if i % 2 == 0 else P(t['g']), None if i % 2 == 0 else P(t['b']), 1, P(slots),
+                         ctypes.byref(nbg), st)
             res.append([y, slots, nbg.value])
         if grouped:
             assert lib.advmix_conv_group(kind, len(T), arr, st) == 0
@@ -438,6 +452,90 @@ def _plan_reference(plan, sd, x):
             raise ValueError(st[0])
     return slots[plan.out]
 
+
+
+BNB_CASES = [
+    # B, C (conv in = out channels), H, W, k, stride: the tile configurations the BatchNorm-backward epilogue runs on
+    (32, 32, 64, 48, 3, 1),      # 128x32 tile, operands prefetched
+    (32, 64, 32, 24, 3, 1),      # 64x32, two wave pairs split K
+    (32, 128, 16, 12, 3, 1),     # 32x32, four waves split K
+    (32, 256, 8, 6, 3, 1),       # eight-wave workgroups
+    (32, 64, 64, 32, 3, 1),      # 128x64: two tiles per wave, operands loaded in the epilogue
+    (16, 64, 32, 32, 3, 1),      # 64x64 four-wave tile (late c)
+    (16, 48, 40, 28, 3, 1),      # C % 32 != 0 (KC = 16), ragged row tiles
+    (32, 64, 33, 25, 3, 2),      # stride 2: phase-decomposed gather, mask addressed through the pixel map
+    (8, 64, 16, 12, 1, 1),       # 1x1
+]
+
+BNB_CFG = dict(zip(BNB_CASES, [1, 6, 5, 7, 2, 3, 6, 3, 3]))      # advmix_conv_direct_config of each
+
+
+@pytest.mark.parametrize('case', BNB_CASES)
+def test_bn_backward_epilogue_sign_from_mask_and_from_c(case):
+    """advmix_conv_tr_w_bnb (round 4): g = (conv_transpose(dy, w) + addend) * relu'(y) and the two BatchNorm-backward channel
+    sums, with the sign of y taken (a) from the bit mask advmix_norm_apply_slots wrote - y = relu(BN(c) + residual) - and
+    (b) recomputed from c - y = relu(BN(c)), no residual, no addend - against a float64 torch evaluation; the mask itself
+    against the sign of the y the same launch wrote (bit for bit), and the recomputed sign against that y too (the gradient
+    must be EXACTLY zero wherever y is - one fused multiply-add on both sides)."""
+    import ctypes
+    from advmix_amd._lib import call, lib
+    _ops()
+    B, C, H, W, k, stride = case
+    pad = k // 2
+    d = dev()
+    cfg = lib.advmix_conv_direct_config(1, B, H, W, C, C, k, k, stride)
+    assert cfg == BNB_CFG[case], (case, cfg)                # the shape really reaches the tile it is here for
+    g_ = torch.Generator().manual_seed(17 + C + H)
+    R = lambda *s_: torch.randn(*s_, generator=g_)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    dy = R(B, Ho, Wo, C)                                   # gradient at the consumer conv's output
+    w = R(C, k, k, C) * (k * k * C) ** -0.5                # [Co][R][S][Ci]
+    c = R(B, H, W, C) * 1.5 + 0.3                          # the producer's raw conv output
+    res, addend = R(B, H, W, C), R(B, H, W, C)
+    gamma, beta = R(C).abs() + 0.5, R(C) * 0.3
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rows = B * H * W
+    D = {n_: v.to(d).contiguous() for n_, v in dict(dy=dy, w=w, c=c, res=res, addend=addend, gamma=gamma, beta=beta).items()}
+    # forward statistics of c -> slots (ns = 1), then advmix_norm_apply_slots twice: with residual + mask, without
+    cd = c.double().reshape(-1, C)
+    slots = torch.stack([cd.sum(0), (cd * cd).sum(0)]).reshape(2, C, 1).contiguous().to(d)
+    outs = {}
+    for tag, r_ in (('res', D['res']), ('plain', None)):
+        y = torch.empty(B, H, W, C, device=d)
+        mean, invstd = torch.empty(C, device=d), torch.empty(C, device=d)
+        mask = torch.zeros(rows * C // 4, device=d, dtype=torch.uint8)
+        call('advmix_norm_apply_slots', P(D['c']), P(slots), 1, rows, C, 1e-5, P(D['gamma']), P(D['beta']), P(r_), P(y), 1,
+             P(mean), P(invstd), None, None, None, 0.1, P(mask), st)
+        torch.cuda.synchronize()
+        assert torch.equal(mask, pack_act_mask(y)), tag                      # the mask IS the sign of the y just written
+        outs[tag] = (y, mean, invstd, mask)
+    # float64 reference of the input gradient
+    dx64 = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), stride=stride, padding=pad,
+                              output_padding=(H + 2 * pad - k - (Ho - 1) * stride, W + 2 * pad - k - (Wo - 1) * stride))
+    dx64 = dx64.permute(0, 2, 3, 1)
+    for tag, add_, use_mask in (('res', D['addend'], True), ('plain', None, False)):
+        y, mean, invstd, mask = outs[tag]
+        gout = torch.full((B, H, W, C), float('nan'), device=d)
+        st_slots = torch.zeros(2 * C * 64, device=d, dtype=torch.float64)
+        ns = ctypes.c_int(0)
+        rc = lib.advmix_conv_tr_w_bnb(P(D['dy']), P(D['w']), P(add_), P(gout), B, Ho, Wo, C, H, W, C, k, k, stride, pad,
+                                      P(mask) if use_mask else None, P(D['c']), P(mean), P(invstd),
+                                      None if use_mask else P(D['gamma']), None if use_mask else P(D['beta']), 1,
+                                      P(st_slots), ctypes.byref(ns), st)
+        assert rc == 0, (tag, rc)
+        torch.cuda.synchronize()
+        pos = (y > 0).cpu()
+        want = (dx64 + (addend.double() if add_ is not None else 0)) * pos
+        check(tag + ' g', gout, want, 2e-5)
+        assert bool((gout.cpu()[~pos] == 0).all()), tag                      # exactly the stored y's sign, not a near miss
+        xh = (c.double() - mean.cpu().double()) * invstd.cpu().double()
+        sums = st_slots[:2 * C * ns.value].view(2, C, ns.value).sum(-1).cpu()
+        check(tag + ' sum g', sums[0], want.reshape(-1, C).sum(0), 2e-5)
+        check(tag + ' sum g xhat', sums[1], (want * xh).reshape(-1, C).sum(0), 2e-5)
+    # an activation with neither a mask nor gamma / beta is refused
+    assert lib.advmix_conv_tr_w_bnb(P(D['dy']), P(D['w']), None, P(gout), B, Ho, Wo, C, H, W, C, k, k, stride, pad, None, P(D['c']),
+                                    P(mean), P(invstd), None, None, 1, P(st_slots), ctypes.byref(ns), st) == 1
 
 @pytest.mark.parametrize('frozen', [False, True])
 def test_chain_bn_backward_fused_into_dgrad_epilogue(frozen):

@@ -11,6 +11,7 @@ x = torch.randn(B, H, W, C, generator=g).to(dev)
 w = (torch.randn(C, 3, 3, C, generator=g) * 0.05).to(dev)
 y = torch.zeros(B, H, W, C, device=dev)
 x2, yy, cc = (torch.randn(B, H, W, C, generator=g).to(dev) for _ in range(3))
+mk = torch.randint(0, 16, (B * H * W * C // 4,), generator=g, dtype=torch.uint8).to(dev)      # the activation bit mask
 mean, invstd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
 slots = torch.zeros(2 * C * 64, device=dev, dtype=torch.float64)
 nbg = ctypes.c_int(0)
@@ -24,7 +25,7 @@ if mode == 'fwd_stats':
 else:
     def run():
         nbg.value = 0
-        call('advmix_conv_tr_w_bnb', P(x), P(w), P(x2), P(y), B, H, W, C, H, W, C, 3, 3, 1, 1, P(yy), P(cc), P(mean), P(invstd), 1,
+        call('advmix_conv_tr_w_bnb', P(x), P(w), P(x2), P(y), B, H, W, C, H, W, C, 3, 3, 1, 1, P(mk), P(cc), P(mean), P(invstd), None, None, 1,
              P(slots), ctypes.byref(nbg), st)
 slots.zero_(); run(); torch.cuda.synchronize()
 ck = (float(y.double().sum()), float(y.double().abs().sum()), float(slots.view(2, C, -1).sum(-1).abs().sum()))

@@ -41,6 +41,7 @@ for (C, H, W) in ((32, 64, 48), (64, 32, 24), (128, 16, 12), (256, 8, 6)):
     c = torch.empty(B, H, W, C, device=dev)
     y = torch.empty_like(c)
     res = torch.randn_like(c)
+    amask = torch.randint(0, 16, (c.numel() // 4,), device=c.device, dtype=torch.uint8)     # the activation bit mask
     dy = torch.randn_like(c)
     dc = torch.empty_like(c)
     dx = torch.empty_like(c)
@@ -62,7 +63,7 @@ for (C, H, W) in ((32, 64, 48), (64, 32, 24), (128, 16, 12), (256, 8, 6)):
             nbg.value = ns
             call('advmix_conv_fwd_ex', P(x), P(w), None, P(c), *geom, None, None, None, None, 0.0, None, 0, P(slots),
                  ctypes.byref(nbg), st)
-            call('advmix_norm_finalize', P(slots), nbg.value, rows, C, 1e-5, P(mean), P(invstd), P(rm), P(rv), P(nbt), 0.1, st)
+            call('advmix_norm_finalize', P(slots), nbg.value, rows, C, 1e-5, P(mean), P(invstd), P(rm), P(rv), P(nbt), 0.1, P(amask), st)
             call('advmix_norm_apply', P(c), P(mean), P(invstd), P(g), P(b), P(res), P(y), C, 1, rows, C, 1, st)
 
         def fwd_new():
@@ -70,7 +71,7 @@ for (C, H, W) in ((32, 64, 48), (64, 32, 24), (128, 16, 12), (256, 8, 6)):
             call('advmix_conv_fwd_ex', P(x), P(w), None, P(c), *geom, None, None, None, None, 0.0, None, 0, P(slots),
                  ctypes.byref(nbg), st)
             call('advmix_norm_apply_slots', P(c), P(slots), nbg.value, rows, C, 1e-5, P(g), P(b), P(res), P(y), 1,
-                 P(mean), P(invstd), P(rm), P(rv), P(nbt), 0.1, st)
+                 P(mean), P(invstd), P(rm), P(rv), P(nbt), 0.1, P(amask), st)
 
         def conv_stats():
             nbg.value = ns
@@ -89,7 +90,7 @@ for (C, H, W) in ((32, 64, 48), (64, 32, 24), (128, 16, 12), (256, 8, 6)):
             nbg.value = ns
             call('advmix_norm_bwd_apply_slots', P(dy), P(c), P(mean), P(invstd), P(g), P(slots), nsu, rows, C, P(dc), P(dg),
                  P(db), st)
-            call('advmix_conv_tr_w_bnb', P(dc), P(w), P(res), P(dx), *geom, P(y), P(c), P(mean), P(invstd), 1, P(slots),
+            call('advmix_conv_tr_w_bnb', P(dc), P(w), P(res), P(dx), *geom, P(amask), P(c), P(mean), P(invstd), None, None, 1, P(slots),
                  ctypes.byref(nbg), st)
         out.append('ns %2d(%2d): conv+sums %.1f | fwd old %.1f new %.1f | bwd old %.1f new %.1f' % (
             ns, nsu, timeit(conv_stats), timeit(fwd_old), timeit(fwd_new), timeit(bwd_old), timeit(bwd_new)))

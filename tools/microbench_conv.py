@@ -37,13 +37,14 @@ elif mode == 'dgrad_bt_add':
     run = lambda: call('advmix_conv_tr_w_add', P(y), P(w), P(x2), P(x), B, Ho, Wo, Co, H, W, Ci, k, k, s, p, st)
 elif mode == 'dgrad_bnb':    # + addend + BatchNorm-backward epilogue of the producer
     x2, yy, cc = torch.randn_like(x), torch.randn_like(x), torch.randn_like(x)
+    mk = torch.randint(0, 16, (x.numel() // 4,), device=x.device, dtype=torch.uint8)       # the activation bit mask
     mean, invstd = torch.zeros(Ci, device=dev), torch.ones(Ci, device=dev)
     slots = torch.zeros(2 * Ci * 64, device=dev, dtype=torch.float64)
     nbg = ctypes.c_int(0)
     def run():
         nbg.value = 0
-        call('advmix_conv_tr_w_bnb', P(y), P(w), P(x2), P(x), B, Ho, Wo, Co, H, W, Ci, k, k, s, p, P(yy), P(cc), P(mean),
-             P(invstd), 1, P(slots), ctypes.byref(nbg), st)
+        call('advmix_conv_tr_w_bnb', P(y), P(w), P(x2), P(x), B, Ho, Wo, Co, H, W, Ci, k, k, s, p, P(mk), P(cc), P(mean),
+             P(invstd), None, None, 1, P(slots), ctypes.byref(nbg), st)
 else:
     run = lambda: call('advmix_conv_wgrad', P(y), P(x), P(dw), B, Ho, Wo, Co, H, W, Ci, k, k, s, p, st)
 for _ in range(5):

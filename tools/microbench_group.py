@@ -18,7 +18,7 @@ T = []
 for (C, H, W) in shapes:
     t = dict(C=C, H=H, W=W, x=torch.randn(B, H, W, C, device=dev), w=torch.randn(C, 3, 3, C, device=dev) * 0.05,
              y=torch.empty(B, H, W, C, device=dev), y2=torch.empty(B, H, W, C, device=dev), res=torch.randn(B, H, W, C, device=dev),
-             yy=torch.randn(B, H, W, C, device=dev), cc=torch.randn(B, H, W, C, device=dev),
+             yy=torch.randn(B, H, W, C, device=dev), mk=torch.randint(0, 16, (B * H * W * C // 4,), device=dev, dtype=torch.uint8), cc=torch.randn(B, H, W, C, device=dev),
              g=torch.rand(C, device=dev) + 0.5, b=torch.randn(C, device=dev), rm=torch.randn(C, device=dev) * 0.1,
              rv=torch.rand(C, device=dev) + 0.5, mean=torch.zeros(C, device=dev), invstd=torch.ones(C, device=dev),
              slots=torch.zeros(2 * C * 64, device=dev, dtype=torch.float64), slots2=torch.zeros(2 * C * 64, device=dev, dtype=torch.float64))
@@ -40,8 +40,8 @@ def single(t, st, out='y', slots='slots'):
     elif mode == 'dgrad_add':
         call('advmix_conv_tr_w_add', P(t['x']), P(t['w']), P(t['res']), P(t[out]), *geom, st)
     else:
-        call('advmix_conv_tr_w_bnb', P(t['x']), P(t['w']), P(t['res']), P(t[out]), *geom, P(t['yy']), P(t['cc']), P(t['mean']),
-             P(t['invstd']), 1, P(t[slots]), ctypes.byref(nbg), st)
+        call('advmix_conv_tr_w_bnb', P(t['x']), P(t['w']), P(t['res']), P(t[out]), *geom, P(t['mk']), P(t['cc']), P(t['mean']),
+             P(t['invstd']), None, None, 1, P(t[slots]), ctypes.byref(nbg), st)
     return nbg.value
 
 
@@ -60,7 +60,7 @@ def problems(out='y', slots='slots'):
             q.residual = A(t['res'])
         else:
             q.residual, q.stats, q.stats_ns = A(t['res']), A(t[slots]), 0
-            q.bnb_y, q.bnb_c, q.bnb_mean, q.bnb_invstd, q.bnb_act = A(t['yy']), A(t['cc']), A(t['mean']), A(t['invstd']), 1
+            q.bnb_mask, q.bnb_c, q.bnb_mean, q.bnb_invstd, q.bnb_act = A(t['mk']), A(t['cc']), A(t['mean']), A(t['invstd']), 1
     return arr
 
 

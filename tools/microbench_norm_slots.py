@@ -19,14 +19,14 @@ def timeit(run, iters=100):
         best = min(best, e0.elapsed_time(e1) / iters * 1e3)
     return best
 for (rows, C) in ((98304, 32), (98304, 64), (98304, 128), (98304, 256), (393216, 64), (24576, 512), (24576, 64), (6144, 128), (1536, 256)):
-    c = torch.randn(rows, C, device=dev); y = torch.empty_like(c); res = torch.randn_like(c); g0 = torch.randn_like(c); dx = torch.empty_like(c)
+    c = torch.randn(rows, C, device=dev); y = torch.empty_like(c); res = torch.randn_like(c); amask = torch.zeros(rows * C // 4, device=dev, dtype=torch.uint8); g0 = torch.randn_like(c); dx = torch.empty_like(c)
     gm, bt = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
     mean, invstd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
     ns = 16
     slots = torch.randn(2 * C * ns, device=dev, dtype=torch.float64).abs() * rows
     dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
-    t1 = timeit(lambda: call('advmix_norm_apply_slots', P(c), P(slots), ns, rows, C, 1e-5, P(gm), P(bt), None, P(y), 1, P(mean), P(invstd), None, None, None, 0.1, st))
-    t2 = timeit(lambda: call('advmix_norm_apply_slots', P(c), P(slots), ns, rows, C, 1e-5, P(gm), P(bt), P(res), P(y), 1, P(mean), P(invstd), None, None, None, 0.1, st))
+    t1 = timeit(lambda: call('advmix_norm_apply_slots', P(c), P(slots), ns, rows, C, 1e-5, P(gm), P(bt), None, P(y), 1, P(mean), P(invstd), None, None, None, 0.1, None, st))
+    t2 = timeit(lambda: call('advmix_norm_apply_slots', P(c), P(slots), ns, rows, C, 1e-5, P(gm), P(bt), P(res), P(y), 1, P(mean), P(invstd), None, None, None, 0.1, P(amask), st))
     t3 = timeit(lambda: call('advmix_norm_bwd_apply_slots', P(g0), P(c), P(mean), P(invstd), P(gm), P(slots), ns, rows, C, P(dx), P(dg), P(db), st))
     mb = rows * C * 4 / 1e6
     print('rows %6d C %4d (%5.1f MB): apply %6.1f us %.2f TB/s | +res %6.1f us %.2f TB/s | bwd %6.1f us %.2f TB/s' % (rows, C, mb, t1, 2 * mb / t1, t2, 3 * mb / t2, t3, 3 * mb / t3))

@@ -309,6 +309,38 @@ def _log(config, epoch, i, n, batch_time, data_time, losses, acc, bs, writer_dic
         writer_dict['train_global_steps'] = global_steps + 1
 
 
+_LOOP_STREAMS = {}
+
+
+class _loop_stream:
+    """The training loops run on a CREATED stream, never on the NULL stream: graph replays, gradient exchanges, the
+    replica checks and the metrics read-back all inherit it as their current stream.  Round 4: a
+    collective issued while the NULL stream was current made later graph replays compute garbage on a GPU shared by two ranks
+    (gloo), and the NULL stream is also the one stream every blocking stream of the process synchronises with implicitly -
+    there is nothing to gain from it.  No-op on the CPU or when the caller already runs on a stream of its own."""
+
+    def __enter__(self):
+        self.ctx = None
+        if torch.cuda.is_available():
+            dev = torch.cuda.current_device()
+            cur = torch.cuda.current_stream(dev)
+            if cur.cuda_stream == 0:
+                st = _LOOP_STREAMS.get(dev)
+                if st is None:
+                    st = _LOOP_STREAMS[dev] = torch.cuda.Stream(device=dev)
+                st.wait_stream(cur)
+                self.cur, self.st = cur, st
+                self.ctx = torch.cuda.stream(st)
+                self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.cur.wait_stream(self.st)
+        return False
+
+
 _AUTO_SYNC = {}
 
 
@@ -364,6 +396,13 @@ def train(config, args, train_loader, model, criterion, optimizer, epoch,
     end = time.time()
     n = len(train_loader) if hasattr(train_loader, '__len__') else -1
     pick = lambda b: [b[0], b[1][0] if isinstance(b[1], (list, tuple)) else b[1], b[2]]     # noqa: E731  (:48-51)
+    with _loop_stream():
+        _train_loop(config, train_loader, pick, model, criterion, optimizer, epoch, grad_sync, meters, batch_time, data_time,
+                    losses, acc, end, n, writer_dict)
+
+
+def _train_loop(config, train_loader, pick, model, criterion, optimizer, epoch, grad_sync, meters, batch_time, data_time,
+                losses, acc, end, n, writer_dict):
     for i, ((input, _t, _w, meta), (x, target, target_weight)) in enumerate(_Prefetch(train_loader, pick)):
         data_time.update(time.time() - end)
         x = x.contiguous()
@@ -400,6 +439,13 @@ def train_advmix(config, args, train_loader, models, criterion, optimizers, epoc
     end = time.time()
     n = len(train_loader) if hasattr(train_loader, '__len__') else -1
     pick = lambda b: [b[0][0], b[0][1], b[0][2], b[1][0], b[2][0]]                        # noqa: E731  (:129-133)
+    with _loop_stream():
+        _advmix_loop(config, args, train_loader, pick, model, model_G, model_teacher, criterion, optimizer, optimizer_G, epoch,
+                     grad_sync, meters, batch_time, data_time, losses, acc, end, n, writer_dict)
+
+
+def _advmix_loop(config, args, train_loader, pick, model, model_G, model_teacher, criterion, optimizer, optimizer_G, epoch,
+                 grad_sync, meters, batch_time, data_time, losses, acc, end, n, writer_dict):
     for i, (_batch, dev) in enumerate(_Prefetch(train_loader, pick)):
         data_time.update(time.time() - end)
         inputs = [v.contiguous() for v in dev[:3]]

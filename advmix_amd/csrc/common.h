@@ -55,6 +55,7 @@ struct ConvEpi {
     const float *bnb_c, *bnb_mean, *bnb_invstd, *bnb_gamma, *bnb_beta;
     int bnb_act;
 };
+int advmix_wgrad_lds_build_flags(void);   // wgrad_lds.hip: its bit of advmix_build_flags() (0 unless a measurement variant)
 // conv_direct.hip: second-generation conv; returns -1 when the shape is not eligible, -2 when only the
 // fused epilogue is unavailable
 int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const float* bias, float* y,

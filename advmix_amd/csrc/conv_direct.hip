@@ -992,9 +992,10 @@ int advmix_conv_direct_group(int mode, int bt, int n, ConvProb* pr, hipStream_t 
     return hipGetLastError() == hipSuccess ? ADVMIX_OK : ADVMIX_ELAUNCH;
 }
 
-// Bit mask of the measurement switches this library was compiled with: 0 for the shipped library (__graft_entry__.build()
-// and advmix_amd/_lib.py assert it).  1 = CD_DBG (parts of the kernel compiled out), 2 = CD_PRELOAD, 4 = CD_CLK, 8 =
-// CD_NO_PRE - all four exist only in tools/variants/conv_direct_dbg.patch - and 16 = a store cache policy other than sc1.
+// Bit mask of the measurement switches this library was compiled with - THE place a measurement build is detected: 0 for the
+// shipped library (__graft_entry__.build(), advmix_amd/_lib.py and bench.py check it).  1 = CD_DBG (parts of the kernel
+// compiled out), 2 = CD_PRELOAD, 4 = CD_CLK, 8 = CD_NO_PRE - all four exist only in tools/variants/conv_direct_dbg.patch -
+// 16 = a store cache policy other than sc1, 32 = WL_DBG (wgrad_lds.hip, tools/variants/wgrad_lds_dbg.patch).
 extern "C" int advmix_build_flags(void) {
     int f = 0;
 #ifdef CD_DBG
@@ -1010,6 +1011,7 @@ extern "C" int advmix_build_flags(void) {
     f |= 8;
 #endif
     if (CD_STORE_AUX != 16) f |= 16;
+    f |= advmix_wgrad_lds_build_flags();
     return f;
 }
 

@@ -13,7 +13,7 @@
 //            32 x 288 partial goes to LDS in dW's layout and all 12 waves add it to dW with fp32 atomics - or, for the
 //            deterministic mode, store it to the slab's slice of ``part`` (summed in slab order by the caller's launch).
 // One workgroup per CU at ROWS = 8 (256 workgroups at B = 32 @64x48): as few partial tiles as CUs, because merging them
-// is what a K split across workgroups costs.  Measured at that shape (tools/build_variant.sh with -DWL_DBG=...):
+// is what a K split across workgroups costs.  Measured at that shape (tools/variants/wgrad_lds_dbg.patch, -DWL_DBG=...):
 // launch 3.8 us + staging 1.6 + MFMA phase 13.5 (11.7 at the matrix peak) + in-workgroup merge 1 + atomics 12 = 32 us
 // (wgrad_direct: 40).  The 2.4 M atomics run at 0.8 TB/s whatever their order (walking the tile from a different
 // offset per workgroup: no change); storing the tiles and summing them with tail workgroups of the same launch (counter
@@ -21,10 +21,6 @@
 // and a device-scope release fence per workgroup 75 us (32 L2 write-backs queue on each XCD), so the simple form stays.
 #include "common.h"
 #include <stdio.h>
-
-#ifndef WL_DBG
-#define WL_DBG 0        // measurement builds (tools/build_variant.sh): 1 no MFMA phase, 2 no output, 4 no staging
-#endif
 
 namespace wgl {
 
@@ -66,7 +62,7 @@ __global__ __launch_bounds__(THREADS) void wgrad3x3_c32(LP p) {
     // ---- phase 1: global -> LDS, 16 bytes per thread and load.  Branch-free: invalid elements (halo outside the image,
     // padding column of an odd width, beyond the tile) get an out-of-range buffer offset and come back as zeros, so a
     // batch of loads is in flight at once; (row, column) advance incrementally (one division per tensor and thread).
-    if (!(WL_DBG & 4)) {
+    {
         const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.bytes, 0x00020000);
         const int q4 = (tid & 7) * 16;                 // byte offset of this thread's 4 channels
@@ -126,7 +122,7 @@ __global__ __launch_bounds__(THREADS) void wgrad3x3_c32(LP p) {
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const int rpg = (WL_DBG & 1) ? 0 : p.rows >> 2;    // rows per row group
+    const int rpg = p.rows >> 2;                       // rows per row group
     for (int rr = 0; rr < rpg; ++rr) {
         const int r = rg * rpg + rr;
         const float* ap = ldy + (r * Wp + lh) * C + l31;
@@ -184,7 +180,7 @@ __global__ __launch_bounds__(THREADS) void wgrad3x3_c32(LP p) {
             }
     }
     __syncthreads();
-    if (!(WL_DBG & 2) || acc[0][0] == 123.f) {
+    {
         if (p.part) {
             const __amdgpu_buffer_rsrc_t ro =
                 __builtin_amdgcn_make_buffer_rsrc((void*)(p.part + (int64_t)slab * TOT), 0, TOT * 4, 0x00020000);
@@ -245,3 +241,7 @@ int advmix_wgrad_lds_dispatch(const float* a, const float* b, float* dw, int N, 
     if (nslices) *nslices = part ? slabs : 0;
     return hipGetLastError() == hipSuccess ? ADVMIX_OK : ADVMIX_ELAUNCH;
 }
+
+// This translation unit's share of advmix_build_flags(): 0 in the shipped library (the measurement switches of this file live
+// in tools/variants/wgrad_lds_dbg.patch, which makes this return 32).
+int advmix_wgrad_lds_build_flags(void) { return 0; }

@@ -8,6 +8,8 @@ re-broadcasts ~110 MiB of weights and scatters/gathers activations through GPU 0
 per step.  BatchNorm statistics stay per replica, as they are per shard under DataParallel.
 The loss is a local-batch mean, so averaging gradients over equal shards reproduces the
 reference's global-batch mean (lib/core/function.py:151-153)."""
+import contextlib
+
 import torch
 import torch.distributed as dist
 import torch.utils.data
@@ -120,11 +122,35 @@ class GradSync:
     # 138,146,160), so the reference's replicas CANNOT drift.  Separate processes can - silently, through a bad exchange -
     # so the N-rank entry points check: what came out of an exchange is the mean of what the ranks put in
     # (``verify_trace``), and the replicas' parameters / optimizer state are still the same bits (``replicas_state``).
+    @contextlib.contextmanager
+    def off_null(self, t):
+        """Issue a collective on a device tensor with a NON-NULL stream current (the side stream, ordered behind the caller's
+        stream and the caller's stream behind it).  Round 4 (tools/dp_graph_repro.py): with two ranks
+        over gloo on one GPU, ANY collective issued while the NULL stream was current - the test's own all_gather checks, the
+        exchange itself in one variant - made later HIP-graph replays (the runtime's captured-packet launches) compute
+        garbage, 34 of 35 runs; with every collective under a created stream, 0 of 15, whichever stream the replays ran on.
+        The exchange proper always ran on the side stream; this keeps every OTHER collective of the product off the NULL
+        stream too."""
+        if not (torch.is_tensor(t) and t.is_cuda):
+            yield
+            return
+        cur = torch.cuda.current_stream(t.device)
+        if cur.cuda_stream != 0:
+            yield
+            return
+        side = self._side_stream(t.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            yield
+        cur.wait_stream(side)
+
     def _gather(self, t):
         if self.world == 1 or not (dist.is_available() and dist.is_initialized()):
             return [t]
-        got = [torch.empty_like(t) for _ in range(self.world)]
-        dist.all_gather(got, t.contiguous(), group=self.group)
+        t = t.contiguous()
+        got = [torch.empty_like(t) for _ in range(self.world)]      # (allocated on the caller's stream)
+        with self.off_null(t):
+            dist.all_gather(got, t, group=self.group)
         return got
 
     def verify_trace(self, rtol=2e-6):
@@ -224,7 +250,8 @@ class GradSync:
             tensors += [p.data for p in m.parameters() if id(p) not in owned]
             tensors += list(m.buffers())
         for t in tensors:
-            dist.broadcast(t, src, group=self.group)
+            with self.off_null(t):
+                dist.broadcast(t, src, group=self.group)
         if tensors and tensors[0].is_cuda:
             torch.cuda.current_stream(tensors[0].device).synchronize()
 

@@ -571,11 +571,17 @@ def test_measurement_variants_patch_still_applies(tmp_path):
     import shutil
     if shutil.which('patch') is None:
         pytest.skip('no patch(1) here')
-    src = tmp_path / 'conv_direct.hip'
-    shutil.copy(os.path.join(ROOT, 'advmix_amd', 'csrc', 'conv_direct.hip'), src)
-    out = subprocess.run(['patch', '--dry-run', '-s', str(src), os.path.join(ROOT, 'tools', 'variants', 'conv_direct_dbg.patch')],
-                         capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout + out.stderr
+    for name in ('conv_direct', 'wgrad_lds'):               # (round 4: the WL_DBG switches of wgrad_lds.hip moved out too)
+        src = tmp_path / (name + '.hip')
+        shutil.copy(os.path.join(ROOT, 'advmix_amd', 'csrc', name + '.hip'), src)
+        out = subprocess.run(['patch', '--dry-run', '-s', str(src), os.path.join(ROOT, 'tools', 'variants', name + '_dbg.patch')],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, name + ': ' + out.stdout + out.stderr
+    # no measurement switch is left in any shipped kernel source: advmix_build_flags() is the one place a variant shows
+    import glob
+    for f in glob.glob(os.path.join(ROOT, 'advmix_amd', 'csrc', '*.hip')):
+        body = open(f).read().split('advmix_build_flags')[0] if f.endswith('conv_direct.hip') else open(f).read()
+        assert not re.search(r'#\s*if.*(_DBG|CD_PRELOAD|CD_CLK|CD_NO_PRE)|\bWL_DBG\s*&', body), f
 
 
 def test_product_never_touches_the_oracle_or_the_reference_tree():

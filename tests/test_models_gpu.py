@@ -908,9 +908,16 @@ def _dp_two_rank_worker():
     dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%s' % os.environ['MASTER_PORT'], rank=rank, world_size=2)
     torch.cuda.set_device(0)
 
+    sync = GradSync(bucket_mb=0.25)
+    assert sync.active and sync.world == 2
+
     def gathered(t):
+        # NOT with the NULL stream current: round 3's "open bug" was exactly this - the test's own all_gathers between the
+        # replays, issued on the NULL stream, made the NEXT graph replays compute garbage (DESIGN.md section 4, 34 of 35 runs;
+        # 0 of 15 with the collectives under a created stream).  The product's collectives all go through off_null.
         got = [torch.zeros_like(t), torch.zeros_like(t)]
-        dist.all_gather(got, t.contiguous())
+        with sync.off_null(t):
+            dist.all_gather(got, t.contiguous())
         return got
 
     def same(t):
@@ -921,8 +928,6 @@ def _dp_two_rank_worker():
     v, t, w = synth_batch('hrnet_tiny.it%d' % rank, B, J, H, W)             # a different shard per rank
     data = ([x.cuda().contiguous() for x in v], t.cuda(), w.cuda())
     cfg, D, G, T, crit, oD, oG, _ = _tiny_setup(salt=10 + 7 * rank, lr=1e-3)  # and different initial weights
-    sync = GradSync(bucket_mb=0.25)
-    assert sync.active and sync.world == 2
     assert not same(oD.flat_params) and not same(oG.flat_params)
     sync.broadcast_state([D, G, T], [oD, oG])
     assert same(oD.flat_params) and same(oG.flat_params) and all(same(b.float()) for b in D.buffers())

@@ -43,6 +43,14 @@ VARIANTS = {
     'r2_l1_product':  ('two', {'ADVMIX_LANES': '1'}, {}),
     'r2_l4_product':  ('two', {'ADVMIX_LANES': '4'}, {}),
     'p1_l4_product':  ('one', {'ADVMIX_LANES': '4'}, {'transport': 'hostrt'}),
+    # --- third pass (r04c): the own-stream product step STILL failed (0/4, 1/4) although the custom loop run wholly under a
+    #     non-null stream had passed (3/3).  What is left of the NULL stream there: the per-step hand-off events and the
+    #     checks between the steps - gloo all_gathers issued with the NULL stream current.
+    'r2_l1_product_chk':  ('two', {'ADVMIX_LANES': '1'}, {'chk_stream': 1}),                 # hand-offs stay, gloo never sees NULL
+    'r2_l1_null_chk':     ('two', dict(NULL, ADVMIX_LANES='1'), {'chk_stream': 1}),          # NULL replays, gloo never sees NULL
+    'r2_l1_loopstream':   ('two', {'ADVMIX_LANES': '1'}, {'ownstream': 1}),                  # everything under one non-null stream
+    'r2_l4_loopstream':   ('two', {'ADVMIX_LANES': '4'}, {'ownstream': 1}),
+    'p1_l1_gloo1_nullchk': ('one', dict(NULL, ADVMIX_LANES='1'), {'custom': 1, 'transport': 'gloo1', 'null_gather': 1}),
 }
 
 
@@ -145,19 +153,24 @@ def worker_two():
     ctx = torch.cuda.stream(torch.cuda.Stream()) if OPT.get('ownstream') else None
     if ctx is not None:
         ctx.__enter__()
+    chk = torch.cuda.Stream() if OPT.get('chk_stream') else None
     for k in range(REPLAYS):
         _replay_loop(runner, sync, None, log, pmaps, k)
         torch.cuda.synchronize()
+        cctx = torch.cuda.stream(chk) if chk is not None else None    # the checks (gloo all_gathers) off the NULL stream
+        if cctx is not None:
+            cctx.__enter__()
         fin = all(bool(torch.isfinite(x.float()).all()) for x in oD.flat_state() + oG.flat_state())
         eq = all(same(x) for x in oD.flat_state()) and all(same(x) for x in oG.flat_state())
+        torch.cuda.synchronize()
+        if cctx is not None:
+            cctx.__exit__(None, None, None)
         if not (fin and eq):
             res['ok'] = False
             res['first_bad_step'] = k
             res['finite'], res['replicas_equal'] = fin, eq
             res['bad_D_grads'] = _bad_report(oD.flat_grads, pmaps[id(oD)])
             res['bad_G_grads'] = _bad_report(oG.flat_grads, pmaps[id(oG)])
-            res['bad_D_params'] = _bad_report(oD.flat_params, pmaps[id(oD)])
-            res['bad_G_params'] = _bad_report(oG.flat_params, pmaps[id(oG)])
             break
     if ctx is not None:
         ctx.__exit__(None, None, None)
@@ -233,6 +246,12 @@ def worker_one():
         _replay_loop(runner, sync, None, log, pmaps, k)
         advmix_step(args, D2, G2, T2, crit2, oD2, oG2, *data, sync2)
         torch.cuda.synchronize()
+        if OPT.get('null_gather'):                          # what the two-rank worker's checks do: gloo all_gathers, NULL stream current
+            import torch.distributed as dist
+            for x in oD.flat_state() + oG.flat_state():
+                got = [torch.zeros_like(x)]
+                dist.all_gather(got, x.contiguous())
+            torch.cuda.synchronize()
         fin = all(bool(torch.isfinite(x.float()).all()) for x in oD.flat_state() + oG.flat_state())
         dD = float((oD.flat_params - oD2.flat_params).abs().max())
         dG = float((oG.flat_params - oG2.flat_params).abs().max())

@@ -129,13 +129,14 @@ class GradSync:
         over gloo on one GPU, ANY collective issued while the NULL stream was current - the test's own all_gather checks, the
         exchange itself in one variant - made later HIP-graph replays (the runtime's captured-packet launches) compute
         garbage, 34 of 35 runs; with every collective under a created stream, 0 of 15, whichever stream the replays ran on.
-        The exchange proper always ran on the side stream; this keeps every OTHER collective of the product off the NULL
-        stream too."""
+        Not the collectives alone: the kernels of ``replicas_state``'s fold on the NULL stream (its all_gather already off
+        it) did the same, 2 of 2, a synchronous loss.item() there did not.  The exchange proper always ran on the side
+        stream; this keeps every OTHER piece of data-parallel bookkeeping off the NULL stream too."""
         if not (torch.is_tensor(t) and t.is_cuda):
             yield
             return
         cur = torch.cuda.current_stream(t.device)
-        if cur.cuda_stream != 0:
+        if cur.cuda_stream != 0:                            # (also the nested case: already on the side stream)
             yield
             return
         side = self._side_stream(t.device)
@@ -210,8 +211,9 @@ class GradSync:
                         tensors += [st[k] for k in sorted(st) if torch.is_tensor(st[k])]
         if not tensors:
             return {'identical': True, 'finite': True}
-        fold = self.state_fold(tensors)
-        got = torch.stack(self._gather(fold)).cpu()
+        with self.off_null(tensors[0]):                     # the fold's kernels too: nothing of this on the NULL stream
+            fold = self.state_fold(tensors)
+            got = torch.stack(self._gather(fold)).cpu()
         return {'identical': bool((got[:, :2] == got[0, :2]).all()), 'finite': bool((got[:, 2] == 0).all())}
 
     def assert_replicas(self, optimizers, where=''):

@@ -112,6 +112,11 @@ def spawn_ranks(argv, n, need_gpus=True, timeout_s=None, env_extra=None):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                        MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
             env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (the only kind this driver has); a user's value wins
+            # Multi-rank jobs replay their HIP graphs WITHOUT the runtime's captured-AQL-packet path: with two ranks on one
+            # GPU, replays served from captured packets computed garbage after NULL-stream traffic between them, and never with
+            # this switch (tools/dp_graph_repro.py: 0 of 5); at four launch lanes it costs nothing
+            # (573.5 vs 573.6 / 575.3 images/s).  The step keeps the NULL stream idle as well - this is the second lock.
+            env.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
             env.update(env_extra or {})
             # ranks > 0: stdout onto the parent's stderr by DESCRIPTOR (sys.stderr may be a capture object with no fileno)
             procs.append(subprocess.Popen(argv, env=env, stdout=None if r == 0 else 2))

@@ -25,6 +25,11 @@ import sys
 import time
 import types
 
+if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+    # (read by the HIP runtime when it comes up, i.e. before ``import torch``: see advmix_amd/launch.py - the driver's
+    #  torch.distributed.run form reaches this file without passing through the launcher)
+    os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

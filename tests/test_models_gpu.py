@@ -907,7 +907,27 @@ def _dp_two_rank_worker():
     rank = int(os.environ['RANK'])
     dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%s' % os.environ['MASTER_PORT'], rank=rank, world_size=2)
     torch.cuda.set_device(0)
+    # Everything below runs as the training loops run it: on a created stream (core.function._loop_stream), never the NULL
+    # stream.  Round 4 (tools/dp_graph_repro.py): on a GPU shared by two ranks, NULL-stream traffic
+    # between two graph replays - this test's own all_gathers and loss.item() reads in round 3 - makes the next replays
+    # compute garbage (the runtime's captured-packet launches; 0 failures with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 or with
+    # the NULL stream left alone).
+    from advmix_amd.core.function import _loop_stream
+    with _loop_stream():
+        assert torch.cuda.current_stream().cuda_stream != 0
+        _dp_two_rank_body(rank)
+    dist.barrier()
+    dist.destroy_process_group()
 
+
+def _dp_two_rank_body(rank):
+    import os
+    import torch.distributed as dist
+    from oracle.synth import synth_batch
+    from advmix_amd import ops as _o
+    from advmix_amd.core.function import advmix_step, advmix_phase_a
+    from advmix_amd.dp import GradSync
+    from advmix_amd.graph import AdvMixGraphRunner
     sync = GradSync(bucket_mb=0.25)
     assert sync.active and sync.world == 2
 
@@ -984,7 +1004,7 @@ def _dp_two_rank_worker():
     runner.step()
     torch.cuda.synchronize()
     v_ok, v_worst = sync.verify_trace()
-    assert v_ok and v_worst == 0.0 and len(sync.trace) == 6, (v_ok, v_worst, len(sync.trace))
+    assert v_ok and v_worst <= 2e-7 and len(sync.trace) == 6, (v_ok, v_worst, len(sync.trace))   # (fp32 sum vs the fp64 mean)
     sync.trace = None
     rm = D.state_dict()['bn1.running_mean']
     assert not same(rm)                                                     # statistics stay per replica
@@ -1011,8 +1031,6 @@ def _dp_two_rank_worker():
     assert all(same(x) for x in oD.flat_state()) and all(same(x) for x in oG.flat_state())
     assert not same(D.state_dict()['bn1.running_mean'])
     F_.release_graphs()
-    dist.barrier()
-    dist.destroy_process_group()
 
 
 @pytest.mark.parametrize('lanes', ['4', '1'])

@@ -51,6 +51,11 @@ VARIANTS = {
     'r2_l1_loopstream':   ('two', {'ADVMIX_LANES': '1'}, {'ownstream': 1}),                  # everything under one non-null stream
     'r2_l4_loopstream':   ('two', {'ADVMIX_LANES': '4'}, {'ownstream': 1}),
     'p1_l1_gloo1_nullchk': ('one', dict(NULL, ADVMIX_LANES='1'), {'custom': 1, 'transport': 'gloo1', 'null_gather': 1}),
+    # --- fourth pass (r04e): the two-rank TEST still failed with every collective off the NULL stream (5 of 5).  What it
+    #     does on the NULL stream between two steps that the passing variant above does not: loss.item(), and the kernels
+    #     of GradSync.replicas_state's fold (its all_gather is off the NULL stream).
+    'r2_l1_product_item': ('two', {'ADVMIX_LANES': '1'}, {'chk_stream': 1, 'item': 1}),
+    'r2_l1_product_fold': ('two', {'ADVMIX_LANES': '1'}, {'chk_stream': 1, 'fold': 1}),
 }
 
 
@@ -156,6 +161,10 @@ def worker_two():
     chk = torch.cuda.Stream() if OPT.get('chk_stream') else None
     for k in range(REPLAYS):
         _replay_loop(runner, sync, None, log, pmaps, k)
+        if OPT.get('item'):
+            float(runner.loss_D)                            # a synchronous read-back with the NULL stream current
+        if OPT.get('fold'):
+            sync.replicas_state([oD, oG])                   # fold kernels on the NULL stream, the all_gather off it
         torch.cuda.synchronize()
         cctx = torch.cuda.stream(chk) if chk is not None else None    # the checks (gloo all_gathers) off the NULL stream
         if cctx is not None:

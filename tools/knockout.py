@@ -1,0 +1,76 @@
+"""Wall-time bounds by knock-out (NOT valid steps: what ANY improvement of an ingredient can buy at most).  Same process,
+interleaved A B A B on the headline workload (HRNet-W32 256x192, B = 32, HIP-graph replay):
+  wgrad_all      every weight-gradient launch dropped
+  wgrad_c64plus  the weight gradients of the 64- / 128- / 256-channel 3x3 convs only (conv_wgrad<2,2,true,1,1>)
+  norm_lowres    norm_apply_slots / norm_bwd_apply_slots launches on the three low-resolution branches (rows <= 32 x 32 x 24:
+                 VERDICT r3 item 5) dropped - an upper bound for grouping them (a grouped launch still does their work)
+usage: python tools/knockout.py [steps]"""
+import os, sys, time, types
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from advmix_amd import ops
+from advmix_amd.graph import AdvMixGraphRunner
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(0)
+real_wgrad, real_call, real_lib = ops._wgrad, ops.call, ops.lib
+MODE = {'v': 'base'}
+
+
+def wgrad(st, lane, a, b, w, geom):
+    if MODE['v'] == 'wgrad_all':
+        return
+    if MODE['v'] == 'wgrad_c64plus' and w.shape[2] == 3 and w.shape[0] >= 64 and w.shape[0] == w.shape[1]:
+        return
+    return real_wgrad(st, lane, a, b, w, geom)
+
+
+def call(name, *a):
+    if MODE['v'] == 'norm_lowres' and name == 'advmix_norm_bwd_apply_slots' and a[7] <= 32 * 32 * 24:
+        return 0
+    return real_call(name, *a)
+
+
+class Lib:
+    def __getattr__(self, k):
+        f = getattr(real_lib, k)
+        if k == 'advmix_norm_apply_slots':
+            def g(*a):
+                if MODE['v'] == 'norm_lowres' and a[3] <= 32 * 32 * 24:
+                    return 0
+                return f(*a)
+            return g
+        return f
+
+
+ops._wgrad, ops.call, ops.lib = wgrad, call, Lib()
+
+
+def measure(mode):
+    MODE['v'] = mode
+    cfg, D, G, T, crit, optD, optG = bench.build_models('hrnet_w32', dev)
+    net, extra, J, H, W, downs, _ = bench.WORKLOADS['hrnet_w32']
+    views, tgt, tw = bench.synth(32, J, H, W, dev, 1234)
+    args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        runner = AdvMixGraphRunner(args, D, G, T, crit, optD, optG, views, tgt, tw)
+        for _ in range(5):
+            runner.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            runner.step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    del runner
+    torch.cuda.empty_cache()
+    return ms
+
+
+for rep in range(2):
+    for mode in ('base', 'wgrad_all', 'wgrad_c64plus', 'norm_lowres'):
+        print('%-14s %.2f ms/step' % (mode, measure(mode)), flush=True)

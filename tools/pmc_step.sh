@@ -2,7 +2,7 @@
 # MFMA utilisation of the WHOLE step from hardware counters (north_star: "rocprof reports ... MFMA utilisation against gfx950
 # peak"): one rocprofv3 --pmc pass (kernel trace only, as the pool requires) over a few eager steps; the counters are per
 # kernel dispatch, so serialisation under the profiler does not change them.   usage: tools/pmc_step.sh <tag> [steps=3]
-R=$PWD; TAG=$1; STEPS=${2:-3}; OUT=$R/gpurun_out/pmc_step_$TAG
+R=$PWD; TAG=$1; STEPS=${2:-3}; OUT=$R/gpurun_out/pmc_step_$TAG; mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT -- python3 $R/bench.py --exec eager --steps $STEPS --warmup 1 --no-cpu-baseline --no-roofline > $OUT.log 2>&1
 # memory-side traffic of the step: FETCH_SIZE and WRITE_SIZE need a pass each (TCC counter slots)

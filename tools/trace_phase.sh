@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/trace_phase.sh <tag> <phase> [workload]: kernel trace of one phase's graph replays -> gpurun_out/<tag>_<phase>_trace.txt
 R=$PWD; TAG=$1; PH=$2; shift 2; OUT=$R/gpurun_out; mkdir -p $OUT
+EXC=${EXC:-}        # optional: first row of the excerpt (tools/trace_excerpt.py's own default when unset; was read without ever being set)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/raw_ph
 rocprofv3 --kernel-trace --output-format csv -d /tmp/raw_ph -o p -- python3 $R/tools/trace_phase.py $PH "$@" > $OUT/${TAG}_${PH}.log 2>&1

@@ -128,7 +128,7 @@ class GradSync:
         stream and the caller's stream behind it).  Round 4 (tools/dp_graph_repro.py): with two ranks
         over gloo on one GPU, ANY collective issued while the NULL stream was current - the test's own all_gather checks, the
         exchange itself in one variant - made later HIP-graph replays (the runtime's captured-packet launches) compute
-        garbage, 34 of 35 runs; with every collective under a created stream, 0 of 15, whichever stream the replays ran on.
+        garbage, 28 of 29 runs; with everything between the replays under a created stream, 0 of 11, whichever stream the replays ran on.
         Not the collectives alone: the kernels of ``replicas_state``'s fold on the NULL stream (its all_gather already off
         it) did the same, 2 of 2, a synchronous loss.item() there did not.  The exchange proper always ran on the side
         stream; this keeps every OTHER piece of data-parallel bookkeeping off the NULL stream too."""

@@ -990,8 +990,8 @@ class GraphSeq:
         self.device = device
         # Replays never go onto the NULL stream (round 4): with two processes sharing one GPU, the
         # SECOND and later launches of an instantiated graph on the null stream - the launches the runtime serves from its
-        # captured AQL packets - computed garbage gradients in 27 of 27 two-rank runs (host fully synchronised, before any
-        # exchange); on a created stream, or with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, 0 of 12.  ADVMIX_REPLAY_STREAM=null
+        # captured AQL packets - computed garbage gradients in 21 of 21 two-rank runs (host fully synchronised, before any
+        # exchange); on a created stream, or with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, 0 of 16.  ADVMIX_REPLAY_STREAM=null
         # restores the old behaviour for A/B runs.
         self.stream = None if REPLAY_ON_NULL else torch.cuda.Stream(device=device)
 

@@ -933,8 +933,8 @@ def _dp_two_rank_body(rank):
 
     def gathered(t):
         # NOT with the NULL stream current: round 3's "open bug" was exactly this - the test's own all_gathers between the
-        # replays, issued on the NULL stream, made the NEXT graph replays compute garbage (DESIGN.md section 4, 34 of 35 runs;
-        # 0 of 15 with the collectives under a created stream).  The product's collectives all go through off_null.
+        # replays, issued on the NULL stream, made the NEXT graph replays compute garbage (DESIGN.md section 4, 28 of 29 runs;
+        # 0 of 11 with the NULL stream left alone).  The product's collectives all go through off_null.
         got = [torch.zeros_like(t), torch.zeros_like(t)]
         with sync.off_null(t):
             dist.all_gather(got, t.contiguous())
@@ -990,7 +990,7 @@ def _dp_two_rank_body(rank):
     assert all(same(x) for x in oD.flat_state()) and all(same(x) for x in oG.flat_state())
     # the seven-graph runner (what more than one rank runs by default): 20 replays, replicas identical and finite after each.
     # Round 3's open bug (replays on the NULL stream with a second process on the GPU: garbage from the second replay on,
-    # 27 of 27 runs on the round-4 box) lived exactly here; the runner replays on its own stream now.
+    # 21 of 21 runs on the round-4 box with this test's old NULL-stream checks) lived exactly here; the worker now runs as the loops do.
     runner = AdvMixGraphRunner(args, D, G, T, crit, oD, oG, *data, sync)
     assert runner.seq.n_graphs == 7
     for k in range(20):

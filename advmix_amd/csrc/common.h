@@ -110,6 +110,8 @@ int advmix_wgrad_direct_dispatch(const float* a, const float* b, float* dw, int 
 
 // wgrad_lds.hip: 3x3 s1 32->32 with both operands staged once in LDS; -1 = not eligible.  With ``part`` the workgroups
 // store their partial tiles ([*nslices][32*9*32], slab order, summed by the caller) instead of adding them to dw atomically.
+int advmix_wgrad_lds_group_dispatch(int n, const float* const* a, const float* const* b, float* const* dw, int N, int Ha,
+                                    int Wa, int Ca, int Hb, int Wb, int Cb, int R, int S, int stride, int pad, hipStream_t st);
 int advmix_wgrad_lds_dispatch(const float* a, const float* b, float* dw, int N, int Ha, int Wa, int Ca, int Hb, int Wb,
                               int Cb, int R, int S, int stride, int pad, float* part, int64_t part_floats, int* nslices,
                               hipStream_t st);

@@ -300,14 +300,26 @@ static void launch_reduce_slices(const float* part, int nslices, int64_t total, 
 
 // TM x TN 32x32 tiles per wave (default 1 x 1): the U-Net's weight gradients (hundreds of output channels x thousands of
 // tap-channels) take 128 x 128 per workgroup - one LDS read per MFMA instead of two, half the staging per FLOP.
+// Several weight gradients of ONE geometry in one launch (round 4): weight gradients have no consumer before the optimizer
+// step, so the eight 3x3 C -> C convs of an HRNet branch (four residual blocks, one launch chain) hand their (dY, X, dW)
+// triples to a single launch at the end of the chain's backward - eight times the work per launch means an eighth of the
+// pixel slices per problem (fewer partial tiles to merge with atomics, longer main loops per workgroup) and room for the
+// 128 x 128 tile (one LDS read per MFMA instead of two).  blockIdx.z = problem * slices + slice.
+struct WgGroup {
+    int n, slices;
+    const float* a[8];
+    const float* b[8];
+    float* dw[8];
+};
+
 template <int WM, int WN, bool VEC, int TM = 1, int TN = 1>
-__global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
+__device__ __forceinline__ void wgrad_body(const WgP p, const int zslice, float* const As0, float* const Bs0) {
     constexpr int BMw = 32 * WM * TM, BNw = 32 * WN * TN;
     constexpr int KS = 32;                             // pixels per step (16 MFMAs per wave between barriers)
     constexpr int ASL = (KS * BMw / 4 + 255) / 256;    // float4 slots per thread
     constexpr int BSL = (KS * BNw / 4 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float As[2][KS * BMw];       // double-buffered: one barrier per step
-    __shared__ __attribute__((aligned(16))) float Bs[2][KS * BNw];
+    float (*const As)[KS * BMw] = reinterpret_cast<float (*)[KS * BMw]>(As0);   // double-buffered: one barrier per step
+    float (*const Bs)[KS * BNw] = reinterpret_cast<float (*)[KS * BNw]>(Bs0);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -316,7 +328,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
     const int co0 = blockIdx.x * BMw, j0 = blockIdx.y * BNw;
     const int P = p.N * p.Ha * p.Wa;
     const int Ntot = p.R * p.S * p.Cb;
-    const int p_lo = blockIdx.z * p.chunk;
+    const int p_lo = zslice * p.chunk;
     const int p_hi = min(P, p_lo + p.chunk);
     if (p_lo >= P) return;
 
@@ -465,10 +477,28 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
             for (int r = 0; r < 16; ++r) {
                 int co = co0 + (wm * TM + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (co >= p.Ca) continue;
-                if (p.part) p.part[((int64_t)blockIdx.z * p.Ca + co) * Ntot + j] = acc[t][u][r];
+                if (p.part) p.part[((int64_t)zslice * p.Ca + co) * Ntot + j] = acc[t][u][r];
                 else atomicAdd(p.dw + (int64_t)co * Ntot + j, acc[t][u][r]);
             }
         }
+}
+
+template <int WM, int WN, bool VEC, int TM = 1, int TN = 1>
+__global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
+    __shared__ __attribute__((aligned(16))) float As[2 * 32 * 32 * WM * TM];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * 32 * 32 * WN * TN];
+    wgrad_body<WM, WN, VEC, TM, TN>(p, blockIdx.z, As, Bs);
+}
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_wgrad_group(WgP p, WgGroup g) {
+    __shared__ __attribute__((aligned(16))) float As[2 * 32 * 32 * WM * TM];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * 32 * 32 * WN * TN];
+    const int prob = blockIdx.z / g.slices;
+    p.a = g.a[prob];
+    p.b = g.b[prob];
+    p.dw = g.dw[prob];
+    wgrad_body<WM, WN, true, TM, TN>(p, blockIdx.z - prob * g.slices, As, Bs);
 }
 
 __global__ void transpose_w_kernel(const float* __restrict__ in, float* __restrict__ out, int A, int T, int B) {
@@ -697,6 +727,63 @@ extern "C" int advmix_conv_wgrad(const float* a, const float* b, float* dw,
                                  int N, int Ha, int Wa, int Ca, int Hb, int Wb, int Cb,
                                  int R, int S, int stride, int pad, void* stream) {
     return wgrad_impl(a, b, dw, N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad, nullptr, 0, stream);
+}
+
+// 2-8 weight gradients of one geometry as ONE launch (see WgGroup).  a / b / dw: host arrays of n device pointers.  Served:
+// Ca a multiple of 64 with Cb a multiple of 4 (the 3x3 C -> C convs of the pose nets' branches, C >= 64; the 1x1 and 3x3
+// convs of the bottlenecks), and 3x3 32 -> 32 (wgrad_lds.hip: every workgroup walks several
+// slabs of its problem before it merges); ADVMIX_EINVAL (nothing launched) otherwise - the caller launches the problems one by one.
+static int wgrad_group_blocks() {
+    static int v = [] { const char* e = getenv("ADVMIX_WGRAD_GROUP_BLOCKS"); int t = e ? atoi(e) : 768; return t > 0 ? t : 768; }();
+    return v;
+}
+
+extern "C" int advmix_conv_wgrad_group(int n, const float* const* a, const float* const* b, float* const* dw,
+                                       int N, int Ha, int Wa, int Ca, int Hb, int Wb, int Cb,
+                                       int R, int S, int stride, int pad, void* stream) {
+    if (n < 2 || n > 8 || !a || !b || !dw || N <= 0 || Ca <= 0 || Cb <= 0 || stride < 1) return ADVMIX_EINVAL;
+    if (Ha != (Hb + 2 * pad - R) / stride + 1 || Wa != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
+    const int Ntot = R * S * Cb;
+    if (advmix_opts().deterministic) return ADVMIX_EINVAL;
+    for (int i = 0; i < n; ++i)
+        if (!a[i] || !b[i] || !dw[i]) return ADVMIX_EINVAL;
+    {                                                      // 3x3 32 -> 32: the LDS-patch kernel, several slabs per workgroup
+        int rc = advmix_wgrad_lds_group_dispatch(n, a, b, dw, N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
+    if (Ca % 64 != 0 || Cb % 4 != 0) return ADVMIX_EINVAL;      // (ragged column tiles are bounds-checked: 3x3 64 -> 64 has 576)
+    WgGroup g;
+    g.n = n;
+    for (int i = 0; i < 8; ++i) {
+        g.a[i] = i < n ? a[i] : nullptr;
+        g.b[i] = i < n ? b[i] : nullptr;
+        g.dw[i] = i < n ? dw[i] : nullptr;
+        if (i < n && (!a[i] || !b[i] || !dw[i])) return ADVMIX_EINVAL;
+    }
+    WgP p{nullptr, nullptr, nullptr, N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad, 0, nullptr};
+    const int64_t P = (int64_t)N * Ha * Wa;
+    hipStream_t st = (hipStream_t)stream;
+    const bool big = Ca % 128 == 0;                        // 128 x 128 per workgroup (2 x 2 tiles per wave), else 64 x 128
+    const int tiles = big ? cdiv(Ca, 128) * cdiv(Ntot, 128) : cdiv(Ca, 64) * cdiv(Ntot, 128);
+    int64_t ns = wgrad_group_blocks() / ((int64_t)tiles * n);
+    if (ns < 1) ns = 1;
+    const int64_t maxs = (P + 63) / 64;
+    if (ns > maxs) ns = maxs;
+    const int64_t chunk = ((P + ns - 1) / ns + 31) / 32 * 32;
+    p.chunk = (int)chunk;
+    g.slices = (int)cdiv(P, chunk);
+    if ((int64_t)g.slices * n > 65535) return ADVMIX_EINVAL;
+    const dim3 grid(big ? cdiv(Ca, 128) : cdiv(Ca, 64), cdiv(Ntot, 128), g.slices * n);
+    if (big) hipLaunchKernelGGL((conv_wgrad_group<2, 2, 2, 2>), grid, dim3(256), 0, st, p, g);
+    else hipLaunchKernelGGL((conv_wgrad_group<1, 4, 2, 1>), grid, dim3(256), 0, st, p, g);
+    if (advmix_opts().trace_shapes) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "conv_wgrad_group<%s> x%d", big ? "2, 2, 2, 2" : "1, 4, 2, 1", n);
+        advmix_trace_launch(nm, grid, "wgrad group", N, Hb, Wb, Cb, Ha, Wa, Ca, R, S, stride,
+                            2.0 * n * N * (double)Ha * Wa * Ca * Cb * R * S);
+    }
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
 }
 
 // Deterministic weight gradient: every pixel slice STORES its partial tile into ``ws`` (ws_bytes; the call needs

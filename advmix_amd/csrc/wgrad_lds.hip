@@ -30,8 +30,16 @@ struct LP {
     float* dw;         // [32][9][32]
     float* part;       // [slabs][32*9*32] or null
     int N, H, W, Wp;   // Wp = W rounded up to even
-    int rows;          // image rows per workgroup (multiple of 4)
+    int rows;          // image rows per slab (multiple of 4)
     int bytes;         // of dy and of x (same shape)
+    // round 4: a workgroup walks ``nslab`` consecutive slabs (stage, multiply, stage, multiply ... one accumulator set) before
+    // it merges - 1 / nslab of the partial tiles - and one launch serves up to 8 problems of one geometry (the eight 3x3
+    // 32 -> 32 convs of an HRNet branch: weight gradients have no consumer before the optimizer step).  Workgroup b belongs
+    // to problem b / wgs and walks slabs (b % wgs) * nslab ... of it.  Single problems: nslab = 1, n = 1, pointers in [0].
+    int nslab, wgs, n;
+    const float* dyv[8];
+    const float* xv[8];
+    float* dwv[8];
 };
 
 constexpr int C = 32;
@@ -51,20 +59,33 @@ __global__ __launch_bounds__(THREADS) void wgrad3x3_c32(LP p) {
     const int rg = wid / 3, kh = wid - rg * 3;
     constexpr int TOT = C * 9 * C;                     // 9216 outputs = 12 x 768
     const int slabs_per_img = p.H / p.rows;
-    const int slab = blockIdx.x;
-    const int n = slab / slabs_per_img;
-    const int h0 = (slab - n * slabs_per_img) * p.rows;
+    const int prob = blockIdx.x / p.wgs;
+    const int wg = blockIdx.x - prob * p.wgs;
+    const float* const pdy = p.dyv[prob];
+    const float* const px = p.xv[prob];
+    float* const pdw = p.dwv[prob];
     const int Wp = p.Wp, Wx = p.Wp + 2;
 
     float* ldy = lds;                                  // [rows][Wp][32]
     float* lx = lds + p.rows * Wp * C;                 // [rows+2][Wp+2][32]
 
+    f32x16 acc[3];                                     // kw = 0, 1, 2 of this wave's kernel row, over ALL the slabs it walks
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    int slab = wg * p.nslab;
+  for (int it = 0; it < p.nslab; ++it, ++slab) {
+    const int n = slab / slabs_per_img;
+    const int h0 = (slab - n * slabs_per_img) * p.rows;
+    if (it > 0) __syncthreads();                       // the previous slab's multiplies are done with the LDS image
+
     // ---- phase 1: global -> LDS, 16 bytes per thread and load.  Branch-free: invalid elements (halo outside the image,
     // padding column of an odd width, beyond the tile) get an out-of-range buffer offset and come back as zeros, so a
     // batch of loads is in flight at once; (row, column) advance incrementally (one division per tensor and thread).
     {
-        const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)pdy, 0, p.bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)px, 0, p.bytes, 0x00020000);
         const int q4 = (tid & 7) * 16;                 // byte offset of this thread's 4 channels
         constexpr int PSTEP = THREADS / 8;             // pixels between a thread's consecutive loads
         {
@@ -117,11 +138,6 @@ __global__ __launch_bounds__(THREADS) void wgrad3x3_c32(LP p) {
     __syncthreads();
 
     // ---- phase 2: 3 accumulators (kw = 0, 1, 2) per wave, operands from LDS -----------------------------------------
-    f32x16 acc[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const int rpg = p.rows >> 2;                       // rows per row group
     for (int rr = 0; rr < rpg; ++rr) {
         const int r = rg * rpg + rr;
@@ -147,6 +163,7 @@ __global__ __launch_bounds__(THREADS) void wgrad3x3_c32(LP p) {
             for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bp[(w + t) * C], acc[t], 0, 0, 0);
         }
     }
+  }                                                    // next slab of this workgroup
 
     // ---- phase 3: row groups 1..3 are added to row group 0 in that order, then one partial per workgroup ------------
     float* red = lds;                                  // 3 waves x 3 tiles
@@ -183,7 +200,7 @@ __global__ __launch_bounds__(THREADS) void wgrad3x3_c32(LP p) {
     {
         if (p.part) {
             const __amdgpu_buffer_rsrc_t ro =
-                __builtin_amdgcn_make_buffer_rsrc((void*)(p.part + (int64_t)slab * TOT), 0, TOT * 4, 0x00020000);
+                __builtin_amdgcn_make_buffer_rsrc((void*)(p.part + (int64_t)blockIdx.x * TOT), 0, TOT * 4, 0x00020000);
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int j = 0; j < TOT / 4 / THREADS; ++j) {
@@ -191,11 +208,11 @@ __global__ __launch_bounds__(THREADS) void wgrad3x3_c32(LP p) {
                 __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(red + i4), ro, i4 * 4, 0, 0);
             }
         } else {
-            int idx = tid + (slab * 37 % (TOT / 64)) * 64;
+            int idx = tid + ((int)blockIdx.x * 37 % (TOT / 64)) * 64;
 #pragma unroll
             for (int j = 0; j < TOT / THREADS; ++j) {
                 if (idx >= TOT) idx -= TOT;
-                atomicAdd(p.dw + idx, red[idx]);
+                atomicAdd(pdw + idx, red[idx]);
                 idx += THREADS;
             }
         }
@@ -232,13 +249,65 @@ int advmix_wgrad_lds_dispatch(const float* a, const float* b, float* dw, int N, 
             return -1;
         attr_lds = lds;
     }
-    wgl::LP p{a, b, dw, part, N, Ha, Wa, Wp, rows, (int)bytes};
+    wgl::LP p{a, b, dw, part, N, Ha, Wa, Wp, rows, (int)bytes, 1, slabs, 1, {a}, {b}, {dw}};
     dim3 g(slabs);
     hipLaunchKernelGGL(wgl::wgrad3x3_c32, g, dim3(wgl::THREADS), lds, st, p);
     if (advmix_opts().trace_shapes)
         advmix_trace_launch("wgrad3x3_c32", g, "wgrad", N, Hb, Wb, Cb, Ha, Wa, Ca, R, S, stride,
                             2.0 * N * (double)Ha * Wa * Ca * Cb * R * S);
     if (nslices) *nslices = part ? slabs : 0;
+    return hipGetLastError() == hipSuccess ? ADVMIX_OK : ADVMIX_ELAUNCH;
+}
+
+// n problems of one geometry in one launch, each workgroup walking ``nslab`` slabs before it merges (see wgl::LP).  -1 = not
+// eligible (nothing launched).
+int advmix_wgrad_lds_group_dispatch(int n, const float* const* a, const float* const* b, float* const* dw, int N, int Ha, int Wa,
+                                    int Ca, int Hb, int Wb, int Cb, int R, int S, int stride, int pad, hipStream_t st) {
+    const int mode = advmix_opts().wgrad_lds;
+    if (!mode || n < 2 || n > 8 || Ca != 32 || Cb != 32 || R != 3 || S != 3 || stride != 1 || pad != 1 || Ha != Hb || Wa != Wb)
+        return -1;
+    const int64_t bytes = (int64_t)N * Ha * Wa * 32 * 4;
+    if (bytes >= 0x7fffffffLL) return -1;
+    const int Wp = (Wa + 1) & ~1;
+    int rows = 0;
+    for (int r : {8, 4}) {
+        if (Ha % r) continue;
+        const int64_t lds = ((int64_t)r * Wp + (int64_t)(r + 2) * (Wp + 2)) * 32 * 4;
+        if (lds > 150 * 1024) continue;
+        rows = r;
+        break;
+    }
+    if (!rows) return -1;
+    const int slabs = N * (Ha / rows);
+    // as many workgroups as CUs over ALL the problems: the smallest divisor of the slab count that leaves <= 256 / n
+    // workgroups per problem (B = 32 @64x48, eight problems: 8 slabs per workgroup, 32 workgroups each)
+    static const int target = [] { const char* e = getenv("ADVMIX_WGRAD_GROUP_WGS"); int t = e ? atoi(e) : 256; return t > 0 ? t : 256; }();
+    int nslab = 0;
+    for (int d = 1; d <= slabs; ++d)
+        if (slabs % d == 0 && (int64_t)n * (slabs / d) <= target) { nslab = d; break; }
+    if (!nslab) return -1;
+    int lds = (rows * Wp + (rows + 2) * (Wp + 2)) * 32 * 4;
+    if (lds < 9 * wgl::TILE * 4) lds = 9 * wgl::TILE * 4;
+    static int attr_lds = 0;
+    if (lds > attr_lds) {
+        if (hipFuncSetAttribute((const void*)wgl::wgrad3x3_c32, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return -1;
+        attr_lds = lds;
+    }
+    wgl::LP p{nullptr, nullptr, nullptr, nullptr, N, Ha, Wa, Wp, rows, (int)bytes, nslab, slabs / nslab, n, {}, {}, {}};
+    for (int i = 0; i < 8; ++i) {
+        p.dyv[i] = i < n ? a[i] : nullptr;
+        p.xv[i] = i < n ? b[i] : nullptr;
+        p.dwv[i] = i < n ? dw[i] : nullptr;
+    }
+    dim3 g(n * (slabs / nslab));
+    hipLaunchKernelGGL(wgl::wgrad3x3_c32, g, dim3(wgl::THREADS), lds, st, p);
+    if (advmix_opts().trace_shapes) {
+        char nm[48];
+        snprintf(nm, sizeof nm, "wgrad3x3_c32 x%d", n);
+        advmix_trace_launch(nm, g, "wgrad group", N, Hb, Wb, Cb, Ha, Wa, Ca, R, S, stride,
+                            2.0 * n * N * (double)Ha * Wa * Ca * Cb * R * S);
+    }
     return hipGetLastError() == hipSuccess ? ADVMIX_OK : ADVMIX_ELAUNCH;
 }
 

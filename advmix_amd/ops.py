@@ -89,6 +89,7 @@ STAT_SLOTS_ASK = int(__import__('os').environ.get('ADVMIX_STAT_SLOTS', '0'))   #
 #  _BNB_PRE: (gradient tensor data_ptr, arena id, slot offset) -> slot count: "this gradient's two channel sums are
 #            already in your backward slots" (FuseSum.bwd -> ConvBN.bwd).
 _BNB_FWD, _BNB_PRE = {}, {}
+_WARNED = {}
 
 
 class StatArena:
@@ -118,8 +119,17 @@ class StatArena:
         self.pass_id += 1
         self.dirty.clear()
         for reg in (_BNB_FWD, _BNB_PRE):                   # hand-offs of an earlier pass that nobody picked up
-            for k in [k for k, v in reg.items() if v[0] is self]:
+            stale = [k for k, v in reg.items() if v[0] is self]
+            for k in stale:
                 del reg[k]
+            if stale and reg is _BNB_PRE and not _WARNED.get('bnb_pre'):
+                # FuseSum.bwd left a layer's BatchNorm-backward sums in its slots and claimed them, but that layer's backward
+                # never saw the gradient tensor it was keyed by (autograd copied or summed it on the way): the layer took the
+                # unfused path - correct, but fusion was lost silently
+                _WARNED['bnb_pre'] = True
+                import warnings
+                warnings.warn('advmix_amd: %d fuse-layer BatchNorm-backward hand-off(s) were not consumed in the last pass; '
+                              'those layers ran the unfused backward' % len(stale))
 
     def ptr(self, off):
         return ctypes.c_void_p(self.t.data_ptr() + 8 * off)
@@ -218,14 +228,48 @@ if __import__('os').environ.get('ADVMIX_DETERMINISTIC', '0') == '1':
     set_deterministic(True)
 
 
+# Weight gradients have no consumer before the optimizer step (lib/core/function.py:154-155): inside a launch chain they are
+# not launched where autograd reaches them but collected, and at the end of the chain's backward the ones of ONE geometry - the
+# eight 3x3 C -> C convs of an HRNet branch's four residual blocks - go out as a single launch (advmix_conv_wgrad_group: an
+# eighth of the pixel slices per problem to merge with atomics, longer main loops, the 128 x 128 tile).  Round 4: a knock-out
+# had shown the weight gradients cost the step 9.4 of 55.5 ms, i.e. they are NOT hidden behind the other lanes.
+WGRAD_GROUP = __import__('os').environ.get('ADVMIX_WGRAD_GROUP', '1') != '0'
+_WG_DEFER = []          # a stack of pending lists: [(a, b, grad, geom)] of the Chain.bwd calls in progress
+
+
 def _wgrad(st, lane, a, b, w, geom):
     """Weight gradient accumulated into w.grad (atomics, or ordered partials in deterministic mode)."""
     g = _grad_buf(w, st)
     if DETERMINISTIC:
         ws = _workspace(a.device, 0, lane)
         call('advmix_conv_wgrad_det', _p(a), _p(b), _p(g), *geom, _p(ws), WS_BYTES, st)
+    elif _WG_DEFER and WGRAD_GROUP and ((geom[3] % 64 == 0 and geom[6] % 4 == 0)
+                                        or (geom[3] == 32 and geom[6] == 32 and geom[7:] == (3, 3, 1, 1))):
+        _WG_DEFER[-1].append((a, b, g, geom))               # (a - a kept temporary - and b stay alive in the pending list)
     else:
         call('advmix_conv_wgrad', _p(a), _p(b), _p(g), *geom, st)
+
+
+def _flush_wgrads(st, pending):
+    """Launch the collected weight gradients: groups of 2-8 of one geometry as one launch, the rest one by one."""
+    by = {}
+    for a, b, g, geom in pending:
+        by.setdefault(geom, []).append((a, b, g))
+    for geom, items in by.items():
+        for i in range(0, len(items), 8):
+            grp = items[i:i + 8]
+            n = len(grp)
+            if n >= 2:
+                arr = ctypes.c_void_p * n
+                rc = lib.advmix_conv_wgrad_group(n, arr(*[x[0].data_ptr() for x in grp]), arr(*[x[1].data_ptr() for x in grp]),
+                                                 arr(*[x[2].data_ptr() for x in grp]), *geom, st)
+                if rc == 0:
+                    COUNTERS['wgrad_group'] = COUNTERS.get('wgrad_group', 0) + 1
+                    continue
+                if rc != 1:
+                    raise RuntimeError('advmix_conv_wgrad_group failed: %d' % rc)
+            for a, b, g in grp:
+                call('advmix_conv_wgrad', _p(a), _p(b), _p(g), *geom, st)
 
 
 def _bias_grad(st, lane, dy, bias, rows, C):
@@ -927,6 +971,14 @@ class Chain:
     def bwd(st, lane, saved, rec, meta, grads, needs):
         subs, ext_slots, out_slots = meta[:3]
         plan = (meta[3] if len(meta) > 3 else Chain.bnb_plan(subs)) if BNB_FUSED else {}
+        _WG_DEFER.append([])                                # this chain's weight gradients are collected ...
+        try:
+            return Chain._bwd(st, lane, saved, rec, subs, ext_slots, out_slots, plan, grads, needs)
+        finally:
+            _flush_wgrads(st, _WG_DEFER.pop())              # ... and go out grouped, on this chain's lane
+
+    @staticmethod
+    def _bwd(st, lane, saved, rec, subs, ext_slots, out_slots, plan, grads, needs):
         grad, pre = {}, {}
         for s_, g in zip(out_slots, grads):
             if g is not None:

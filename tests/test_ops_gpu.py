@@ -537,6 +537,88 @@ def test_bn_backward_epilogue_sign_from_mask_and_from_c(case):
     assert lib.advmix_conv_tr_w_bnb(P(D['dy']), P(D['w']), None, P(gout), B, Ho, Wo, C, H, W, C, k, k, stride, pad, None, P(D['c']),
                                     P(mean), P(invstd), None, None, 1, P(st_slots), ctypes.byref(ns), st) == 1
 
+
+@pytest.mark.parametrize('case', [(8, 32, 64, 32, 24, 3), (3, 32, 128, 16, 12, 3), (8, 32, 256, 8, 6, 3), (2, 4, 64, 20, 14, 3),
+                                  (5, 8, 128, 12, 9, 1), (8, 32, 32, 64, 48, 3), (3, 4, 32, 16, 11, 3), (2, 2, 32, 8, 8, 3)])
+def test_grouped_weight_gradients_equal_single_launches(case):
+    """advmix_conv_wgrad_group (round 4): n weight gradients of one geometry in one launch accumulate the same sums into their
+    dW buffers as n advmix_conv_wgrad calls (other slices, other order: agreement to fp32 rounding) and equal a float64 torch
+    evaluation; they ADD to what the buffers hold; geometries it does not serve are refused with nothing launched."""
+    import ctypes
+    from advmix_amd._lib import call, lib
+    _ops()
+    n, B, C, H, W, k = case
+    pad = k // 2
+    d = dev()
+    g_ = torch.Generator().manual_seed(3 + C + n)
+    R = lambda *s_: torch.randn(*s_, generator=g_)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dys = [R(B, H, W, C) for _ in range(n)]
+    xs = [R(B, H, W, C) for _ in range(n)]
+    base = [R(C, k, k, C) for _ in range(n)]               # what the gradient buffers hold before
+    dev_ = lambda ts: [t.to(d).contiguous() for t in ts]
+    dyd, xd = dev_(dys), dev_(xs)
+    geom = (B, H, W, C, H, W, C, k, k, 1, pad)
+    single, group = dev_(base), dev_(base)
+    for i in range(n):
+        call('advmix_conv_wgrad', P(dyd[i]), P(xd[i]), P(single[i]), *geom, st)
+    arr = ctypes.c_void_p * n
+    rc = lib.advmix_conv_wgrad_group(n, arr(*[t.data_ptr() for t in dyd]), arr(*[t.data_ptr() for t in xd]),
+                                     arr(*[t.data_ptr() for t in group]), *geom, st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    for i in range(n):
+        ref = torch.nn.grad.conv2d_weight(xs[i].double().permute(0, 3, 1, 2), (C, C, k, k), dys[i].double().permute(0, 3, 1, 2),
+                                          padding=pad).permute(0, 2, 3, 1) + base[i].double()
+        check('group %d vs fp64' % i, group[i], ref, 2e-5)
+        check('group %d vs single' % i, group[i], single[i].cpu().double(), 2e-5)
+    # not served: Ca % 64 (and not 32), one problem, a null pointer -> refused, buffers untouched
+    before = [t.clone() for t in group]
+    bad_geom = (B, H, W, 48, H, W, 48, k, k, 1, pad)
+    assert lib.advmix_conv_wgrad_group(n, arr(*[t.data_ptr() for t in dyd]), arr(*[t.data_ptr() for t in xd]),
+                                       arr(*[t.data_ptr() for t in group]), *bad_geom, st) == 1
+    one = ctypes.c_void_p * 1
+    assert lib.advmix_conv_wgrad_group(1, one(dyd[0].data_ptr()), one(xd[0].data_ptr()), one(group[0].data_ptr()), *geom, st) == 1
+    nul = arr(*([None] + [t.data_ptr() for t in dyd[1:]]))
+    assert lib.advmix_conv_wgrad_group(n, nul, arr(*[t.data_ptr() for t in xd]), arr(*[t.data_ptr() for t in group]), *geom, st) == 1
+    torch.cuda.synchronize()
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(before, group))
+
+
+def test_launch_chain_groups_its_weight_gradients():
+    """ops.Chain.bwd collects the weight gradients of its sub-members and launches those of one geometry together: an HRNet-like
+    branch of four BasicBlocks (eight 3x3 64 -> 64 convs) takes ONE grouped launch; gradients equal the ungrouped run to rounding."""
+    import advmix_amd.ops as ops
+    from advmix_amd.plan import Plan, PlanNet
+    P = Plan(64)
+    P.tag = 'all'
+    x = 0
+    for i in range(4):
+        x = P.block('BASIC', x, 'b%d' % i, 64)
+    P.out = x
+    torch.manual_seed(11)
+    net = PlanNet(P).to(dev()).train()
+    xin, dy = rnd(8, 64, 16, 12, seed=5), rnd(8, 64, 16, 12, seed=6)
+    got = {}
+    for grouped in (True, False):
+        ops.WGRAD_GROUP = grouped
+        ops.COUNTERS['wgrad_group'] = 0
+        try:
+            for p_ in net.parameters():
+                p_.grad = None
+            xg = cl(xin).requires_grad_(True)
+            net(xg).backward(cl(dy))
+            torch.cuda.synchronize()
+        finally:
+            ops.WGRAD_GROUP = True
+        assert ops.COUNTERS['wgrad_group'] == (1 if grouped else 0), ops.COUNTERS
+        got[grouped] = {k_: p_.grad.detach().cpu().double() for k_, p_ in net.named_parameters()}
+    for k_ in got[True]:
+        scale = max(float(got[False][k_].abs().max()), 1e-9)
+        # (two separate forward / backward runs, other pixel slices: fp32 sums with cancellation - a lost or doubled problem is O(1))
+        assert float((got[True][k_] - got[False][k_]).abs().max()) <= 2e-3 * scale, k_
+
 @pytest.mark.parametrize('frozen', [False, True])
 def test_chain_bn_backward_fused_into_dgrad_epilogue(frozen):
     """Residual blocks as ONE launch chain: the input-gradient conv of each consumer carries the BatchNorm-backward

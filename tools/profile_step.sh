@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for L in 4 1; do
   export ADVMIX_LANES=$L
   rm -rf $OUT/raw
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -o p -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline "$@" > $OUT/bench_${L}lane.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -o p -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-through-loop "$@" > $OUT/bench_${L}lane.log 2>&1
   T=$(ls $OUT/raw/*/*kernel_trace.csv $OUT/raw/*kernel_trace.csv 2>/dev/null | head -1)
   S=$(ls $OUT/raw/*/*kernel_stats.csv $OUT/raw/*kernel_stats.csv 2>/dev/null | head -1)
   cp $S $OUT/stats_${L}lane.csv

@@ -733,9 +733,29 @@ extern "C" int advmix_conv_wgrad(const float* a, const float* b, float* dw,
 // Ca a multiple of 64 with Cb a multiple of 4 (the 3x3 C -> C convs of the pose nets' branches, C >= 64; the 1x1 and 3x3
 // convs of the bottlenecks), and 3x3 32 -> 32 (wgrad_lds.hip: every workgroup walks several
 // slabs of its problem before it merges); ADVMIX_EINVAL (nothing launched) otherwise - the caller launches the problems one by one.
-static int wgrad_group_blocks() {
-    static int v = [] { const char* e = getenv("ADVMIX_WGRAD_GROUP_BLOCKS"); int t = e ? atoi(e) : 768; return t > 0 ? t : 768; }();
-    return v;
+// Pixel slices per problem of a grouped launch.  A launch runs in rounds of 256 CUs x (workgroups that fit a CU's LDS): what
+// matters is how full its LAST round is, and how many partial tiles are merged with atomics (microbenchmark, eight 3x3 C -> C
+// problems at B = 32, us per problem: 64 -> 64 with 480 / 760 / 1000 / 1520 workgroups 21.7 / 19.8 / 24.0 / 20.8 at 768 slots per
+// round; 128 -> 128 with 504 / 720 / 1008 / 1512: 18.8 / 23.5 / 20.2 / 22.5 at 512; 256 -> 256 with 288 / 576 / 864 / 1440: 30.2 /
+// 24.0 / 21.9 / 20.6 - profiles/r04_microbench_wgrad_group.log).  The slice count with the fullest rounds, fewer rounds first.
+// ADVMIX_WGRAD_GROUP_BLOCKS=<n> forces a workgroup target instead (sweeps).
+static int wgrad_group_slices(int tiles_all, int wg_per_cu, int64_t maxs) {
+    static const int force = [] { const char* e = getenv("ADVMIX_WGRAD_GROUP_BLOCKS"); return e ? atoi(e) : 0; }();
+    if (force > 0) {
+        int64_t ns = force / tiles_all;
+        return (int)(ns < 1 ? 1 : (ns > maxs ? maxs : ns));
+    }
+    const int slots = 256 * wg_per_cu;
+    int best = 1;
+    double best_score = -1.0;
+    for (int ns = 1; ns <= 64 && ns <= maxs; ++ns) {
+        const int64_t w = (int64_t)tiles_all * ns;
+        const int64_t rounds = (w + slots - 1) / slots;
+        if (rounds > 3 && best_score >= 0) break;
+        const double score = (double)w / (double)(rounds * slots) - 0.02 * (double)(rounds - 1);
+        if (score > best_score + 1e-9) { best_score = score; best = ns; }
+    }
+    return best;
 }
 
 extern "C" int advmix_conv_wgrad_group(int n, const float* const* a, const float* const* b, float* const* dw,
@@ -765,10 +785,8 @@ extern "C" int advmix_conv_wgrad_group(int n, const float* const* a, const float
     hipStream_t st = (hipStream_t)stream;
     const bool big = Ca % 128 == 0;                        // 128 x 128 per workgroup (2 x 2 tiles per wave), else 64 x 128
     const int tiles = big ? cdiv(Ca, 128) * cdiv(Ntot, 128) : cdiv(Ca, 64) * cdiv(Ntot, 128);
-    int64_t ns = wgrad_group_blocks() / ((int64_t)tiles * n);
-    if (ns < 1) ns = 1;
     const int64_t maxs = (P + 63) / 64;
-    if (ns > maxs) ns = maxs;
+    const int64_t ns = wgrad_group_slices(tiles * n, big ? 2 : 3, maxs);    // (LDS: 64 KB / 48 KB per workgroup)
     const int64_t chunk = ((P + ns - 1) / ns + 31) / 32 * 32;
     p.chunk = (int)chunk;
     g.slices = (int)cdiv(P, chunk);

@@ -601,14 +601,15 @@ def test_launch_chain_groups_its_weight_gradients():
     net = PlanNet(P).to(dev()).train()
     xin, dy = rnd(8, 64, 16, 12, seed=5), rnd(8, 64, 16, 12, seed=6)
     got = {}
-    for grouped in (True, False):
+    xg = cl(xin).requires_grad_(True)
+    out = net(xg)                                          # ONE forward: two forwards of a train-mode BatchNorm net differ by
+    for grouped in (True, False):                          # flipped ReLU masks, which move isolated gradients by O(1e-3)
         ops.WGRAD_GROUP = grouped
         ops.COUNTERS['wgrad_group'] = 0
         try:
             for p_ in net.parameters():
                 p_.grad = None
-            xg = cl(xin).requires_grad_(True)
-            net(xg).backward(cl(dy))
+            out.backward(cl(dy), retain_graph=True)
             torch.cuda.synchronize()
         finally:
             ops.WGRAD_GROUP = True
@@ -616,8 +617,10 @@ def test_launch_chain_groups_its_weight_gradients():
         got[grouped] = {k_: p_.grad.detach().cpu().double() for k_, p_ in net.named_parameters()}
     for k_ in got[True]:
         scale = max(float(got[False][k_].abs().max()), 1e-9)
-        # (two separate forward / backward runs, other pixel slices: fp32 sums with cancellation - a lost or doubled problem is O(1))
-        assert float((got[True][k_] - got[False][k_]).abs().max()) <= 2e-3 * scale, k_
+        # (the second backward through the same forward takes the unfused BatchNorm backward - its slots are used - and the
+        #  grouped launch cuts the pixels into other slices: fp32 rounding; a lost or doubled problem is O(1))
+        assert float((got[True][k_] - got[False][k_]).abs().max()) <= 5e-4 * scale, k_
+
 
 @pytest.mark.parametrize('frozen', [False, True])
 def test_chain_bn_backward_fused_into_dgrad_epilogue(frozen):

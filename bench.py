@@ -201,14 +201,30 @@ def time_conv_family(B, device, iters=100, family=None):
             'dgrad+BN-bwd-sums (sign from c)': lambda: (reset(), call(
                 'advmix_conv_tr_w_bnb', P(dy), P(w), None, P(dx), *geom, None, P(c2), P(mean), P(invstd), P(g), P(b), 1,
                 P(slots), ctypes.byref(nbg), st)),
-            'wgrad': lambda: call('advmix_conv_wgrad', P(dy), P(x), P(dw), B, H, W, C, H, W, C, 3, 3, 1, 1, st),
         }
+        # the weight gradients of a branch's eight 3x3 convs go out as ONE launch (ops.Chain.bwd, advmix_conv_wgrad_group): timed
+        # as that launch, reported per problem
+        NG = 8
+        gdy = [dy] + [torch.randn_like(x) for _ in range(NG - 1)]
+        gx = [x] + [torch.randn_like(x) for _ in range(NG - 1)]
+        gdw = [dw] + [torch.zeros_like(w) for _ in range(NG - 1)]
+        arr = ctypes.c_void_p * NG
+        ga, gb, gd = arr(*[t.data_ptr() for t in gdy]), arr(*[t.data_ptr() for t in gx]), arr(*[t.data_ptr() for t in gdw])
+        from advmix_amd._lib import lib as _lib
+        grouped = _lib.advmix_conv_wgrad_group(NG, ga, gb, gd, B, H, W, C, H, W, C, 3, 3, 1, 1, st) == 0   # (not every width is served)
+        if grouped:
+            runs['wgrad'] = lambda: call('advmix_conv_wgrad_group', NG, ga, gb, gd, B, H, W, C, H, W, C, 3, 3, 1, 1, st)
+        else:
+            runs['wgrad'] = lambda: call('advmix_conv_wgrad', P(dy), P(x), P(dw), B, H, W, C, H, W, C, 3, 3, 1, 1, st)
         for kind, run in runs.items():
-            ms, rr = _event_time(run, iters)
+            ms, rr = _event_time(run, iters if not (kind == 'wgrad' and grouped) else max(iters // 4, 10))
+            if kind == 'wgrad' and grouped:
+                ms, rr = ms / NG, [v / NG for v in rr]      # per problem of the eight-problem launch
             wgt = KIND_WEIGHT[kind]
             tot_f += wgt * flops
             tot_t += wgt * ms * 1e-3
-            m = {'kernel': '3x3 s1 %d->%d @%dx%d %s' % (C, C, H, W, kind), 'us_per_launch': round(ms * 1e3, 2),
+            m = {'kernel': '3x3 s1 %d->%d @%dx%d %s' % (C, C, H, W, kind if not (kind == 'wgrad' and grouped) else 'wgrad (1 of 8 problems of one launch)'),
+                 'us_per_launch': round(ms * 1e3, 2),
                  'tflops': round(flops / (ms * 1e-3) / 1e12, 2), 'frac': round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                  'launches_per_step_weight': wgt}
             members.append(m)

@@ -795,9 +795,10 @@ extern "C" int advmix_conv_wgrad_group(int n, const float* const* a, const float
     if (big) hipLaunchKernelGGL((conv_wgrad_group<2, 2, 2, 2>), grid, dim3(256), 0, st, p, g);
     else hipLaunchKernelGGL((conv_wgrad_group<1, 4, 2, 1>), grid, dim3(256), 0, st, p, g);
     if (advmix_opts().trace_shapes) {
-        char nm[64];
-        snprintf(nm, sizeof nm, "conv_wgrad_group<%s> x%d", big ? "2, 2, 2, 2" : "1, 4, 2, 1", n);
-        advmix_trace_launch(nm, grid, "wgrad group", N, Hb, Wb, Cb, Ha, Wa, Ca, R, S, stride,
+        char nm[64], kd[24];
+        snprintf(nm, sizeof nm, "conv_wgrad_group<%s>", big ? "2, 2, 2, 2" : "1, 4, 2, 1");
+        snprintf(kd, sizeof kd, "wgrad x%d", n);
+        advmix_trace_launch(nm, grid, kd, N, Hb, Wb, Cb, Ha, Wa, Ca, R, S, stride,
                             2.0 * n * N * (double)Ha * Wa * Ca * Cb * R * S);
     }
     ADVMIX_CHECK_LAUNCH();

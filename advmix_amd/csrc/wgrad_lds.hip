@@ -303,9 +303,9 @@ int advmix_wgrad_lds_group_dispatch(int n, const float* const* a, const float* c
     dim3 g(n * (slabs / nslab));
     hipLaunchKernelGGL(wgl::wgrad3x3_c32, g, dim3(wgl::THREADS), lds, st, p);
     if (advmix_opts().trace_shapes) {
-        char nm[48];
-        snprintf(nm, sizeof nm, "wgrad3x3_c32 x%d", n);
-        advmix_trace_launch(nm, g, "wgrad group", N, Hb, Wb, Cb, Ha, Wa, Ca, R, S, stride,
+        char kd[24];
+        snprintf(kd, sizeof kd, "wgrad x%d", n);
+        advmix_trace_launch("wgrad3x3_c32", g, kd, N, Hb, Wb, Cb, Ha, Wa, Ca, R, S, stride,
                             2.0 * n * N * (double)Ha * Wa * Ca * Cb * R * S);
     }
     return hipGetLastError() == hipSuccess ? ADVMIX_OK : ADVMIX_ELAUNCH;

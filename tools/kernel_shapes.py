@@ -20,8 +20,8 @@ shape_of, seq_of, ambiguous = {}, collections.defaultdict(list), set()
 for r in csv.DictReader(open(shapes)):
     key = (r['kernel'], int(r['grid_x']), int(r['grid_y']), int(r['grid_z']))
     desc = '%s %sx%s s%s %s->%s @%sx%s (B %s)' % (r['kind'], r['R'], r['S'], r['stride'], r['Ci'], r['Co'],
-                                                  r['Ho'] if r['kind'].startswith('fwd') or r['kind'] == 'wgrad' else r['Hi'],
-                                                  r['Wo'] if r['kind'].startswith('fwd') or r['kind'] == 'wgrad' else r['Wi'], r['N'])
+                                                  r['Ho'] if r['kind'].startswith('fwd') or r['kind'].startswith('wgrad') else r['Hi'],
+                                                  r['Wo'] if r['kind'].startswith('fwd') or r['kind'].startswith('wgrad') else r['Wi'], r['N'])
     if key in shape_of and shape_of[key] != (desc, float(r['flops'])):
         ambiguous.add(key)                                 # two shapes share template AND grid
     shape_of.setdefault(key, (desc, float(r['flops'])))

@@ -772,6 +772,7 @@ extern "C" int advmix_conv_wgrad_group(int n, const float* const* a, const float
         if (rc >= 0) return rc;
     }
     if (Ca % 64 != 0 || Cb % 4 != 0) return ADVMIX_EINVAL;      // (ragged column tiles are bounds-checked: 3x3 64 -> 64 has 576)
+    if (cdiv(Ntot, 128) * 128 > Ntot + Ntot / 6) return ADVMIX_EINVAL;   // a 128-column tile mostly empty (1x1 64 -> 256: 64 columns)
     WgGroup g;
     g.n = n;
     for (int i = 0; i < 8; ++i) {

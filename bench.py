@@ -552,6 +552,67 @@ def rendezvous(a, backend, rank, world, local):
         raise SystemExit(4)
 
 
+def dp_verdict(line, sync, optimizers, verification, lv):
+    """The three fields every N-rank line carries, from the SAME calls the train path makes, and the job's exit verdict."""
+    replicas = sync.replicas_state(optimizers)
+    line['replicas_identical'] = replicas['identical']
+    line['all_finite'] = replicas['finite'] and (lv == lv)
+    line['grad_exchange_verified'] = verification[0] if verification is not None else None
+    return not line['replicas_identical'] or not line['all_finite'] or (verification is not None and not verification[0])
+
+
+def replicas_selftest(a, backend, rank, world, local):
+    """--path replicas: the N-rank verdict's self-test (ADVMIX_BENCH_BACKEND=gloo: on CPU, tests/test_host_cpu.py).  Every rank
+    trains a small network for a few synced steps through dp.GradSync with its exchanges traced; ADVMIX_BENCH_CORRUPT=
+    weight | nan | exchange makes rank 1 move one weight by a few ulps / put a NaN into its Adam moments / hand back a wrong
+    exchange result - the line must say so and the job must exit 5."""
+    import torch.distributed as dist
+    import torch.nn as nn
+    from advmix_amd.dp import GradSync
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29555')
+    if backend != 'gloo':
+        raise SystemExit('--path replicas is a CPU self-test: ADVMIX_BENCH_BACKEND=gloo')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 2, 1))
+    opt = torch.optim.Adam(net.parameters(), 1e-2)
+    sync = GradSync(bucket_mb=0.001)
+    sync.broadcast_state([net], [opt])
+    sync.trace = []
+    corrupt = os.environ.get('ADVMIX_BENCH_CORRUPT', '')
+    lv = 0.0
+    for step in range(3):
+        opt.zero_grad()
+        loss = net(torch.randn(4, 3, 8, 8)).square().mean()
+        loss.backward()
+        flat = torch.cat([p.grad.view(-1) for p in net.parameters()])
+        sync.reduce_async(flat, 0, flat.numel())
+        if corrupt == 'exchange' and rank == 1 and step == 1:
+            sync.trace[-1][4][3] += 1.0
+        off = 0
+        for p in net.parameters():
+            p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        opt.step()
+        lv = float(loss)
+    with torch.no_grad():
+        if corrupt == 'weight' and rank == 1:
+            next(net.parameters()).view(-1)[5] += 1e-7
+        if corrupt == 'nan' and rank == 1:
+            opt.state[next(net.parameters())]['exp_avg'].view(-1)[0] = float('nan')
+    verification = sync.verify_trace()
+    line = {'metric': 'replicas self-test', 'n_gpus': a.gpus, 'rccl_ranks': dist.get_world_size(), 'backend': backend,
+            'corrupt': corrupt or None}
+    failed = dp_verdict(line, sync, [opt], (verification[0], {}), lv)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if failed:
+        raise SystemExit(5)
+
+
 
 def verify_data_parallel(step, args, nets, crit, opts, data, sync, steps=3):
     """An N-rank run proves itself (the driver is the only one who can run RCCL with N > 1).  nn.DataParallel
@@ -640,7 +701,7 @@ def main():
     ap.add_argument('--workload', default='hrnet_w32', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=32, help='images per GPU (TRAIN.BATCH_SIZE_PER_GPU)')
     ap.add_argument('--exec', dest='exec_mode', default='graph', choices=['graph', 'eager'])
-    ap.add_argument('--path', default='train', choices=['train', 'validate', 'inputs', 'nms', 'rendezvous'],
+    ap.add_argument('--path', default='train', choices=['train', 'validate', 'inputs', 'nms', 'rendezvous', 'replicas'],
                     help='train = the headline AdvMix step; validate = the validate() batch body (SURVEY 8 f1); '
                          'inputs = the device input pipeline (SURVEY 8 f2); rendezvous = start the ranks, one all-reduce, '
                          'report (launcher self-test; ADVMIX_BENCH_BACKEND=gloo runs it without GPUs)')
@@ -668,7 +729,7 @@ def main():
         # nn.DataParallel, tools/train.py:69,106,109).  This parent has NOT touched the GPU; it starts one fresh
         # process per GPU, relays rank 0's JSON line and fails loudly rather than run fewer ranks than asked for.
         from advmix_amd.launch import spawn_ranks
-        need = not (a.path == 'rendezvous' and backend == 'gloo') and not share_gpu
+        need = not (a.path in ('rendezvous', 'replicas') and backend == 'gloo') and not share_gpu
         raise SystemExit(spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], a.gpus, need_gpus=need))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -677,6 +738,8 @@ def main():
         raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, a.gpus))
     if a.path == 'rendezvous':
         return rendezvous(a, backend, rank, world, local)
+    if a.path == 'replicas':
+        return replicas_selftest(a, backend, rank, world, local)
     if backend != 'nccl':
         raise SystemExit('ADVMIX_BENCH_BACKEND=%s is only for --path rendezvous' % backend)
     if share_gpu:
@@ -890,8 +953,7 @@ def main():
                                              'loss.item(), accuracy inside the timed region (SURVEY 8 d1)',
                                     'steps': dt_loop[1], 'warmup': 10, 'ms_per_step': round(dt_loop[0] / dt_loop[1] * 1e3, 3)}
         if sync is not None:
-            line['replicas_identical'] = replicas['identical']
-            line['all_finite'] = replicas['finite'] and (lv == lv)
+            line['replicas_identical'], line['all_finite'] = replicas['identical'], replicas['finite'] and (lv == lv)
             line['grad_exchange_verified'] = verification[0] if verification is not None else None
             line['dp_verification'] = dict(verification[1], exec=line['config']['exec'],
                                            transport=dist.get_backend()) if verification is not None else 'skipped (--no-verify)'

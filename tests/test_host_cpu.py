@@ -377,6 +377,18 @@ def test_bench_launches_its_own_ranks_over_gloo():
     assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['allreduce_ok'] is True
 
 
+@pytest.mark.parametrize('corrupt', ['', 'weight', 'nan', 'exchange'])
+def test_bench_n_rank_line_proves_itself_or_exits_non_zero(corrupt):
+    """`bench.py --gpus 2` (its own launcher, gloo on CPU, `--path replicas`): the JSON line carries
+    replicas_identical / all_finite / grad_exchange_verified; one rank's weight moved by a few ulps, a NaN in one rank's Adam
+    moments or a wrong exchange result flips the field AND the job's exit code (5)."""
+    out = _run_bench(['--gpus', '2', '--path', 'replicas'], {'ADVMIX_BENCH_BACKEND': 'gloo', 'ADVMIX_BENCH_CORRUPT': corrupt})
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    want = {'': (True, True, True), 'weight': (False, True, True), 'nan': (False, False, True), 'exchange': (True, True, False)}[corrupt]
+    assert (line['replicas_identical'], line['all_finite'], line['grad_exchange_verified']) == want, line
+    assert out.returncode == (0 if not corrupt else 5), (out.returncode, out.stderr[-1500:])
+
+
 def test_bench_refuses_to_run_fewer_ranks_than_asked():
     """Fewer GPUs than --gpus (none here; one on the 1-GPU box): non-zero exit and no JSON line, never a silent single
     rank.  A WORLD_SIZE that disagrees with --gpus is refused too."""

@@ -86,8 +86,12 @@ STAT_SLOTS_ASK = int(__import__('os').environ.get('ADVMIX_STAT_SLOTS', '0'))   #
 # Side channels between members of DIFFERENT launch groups (the autograd graph only carries tensors):
 #  _BNB_FWD: output tensor (data_ptr) of a train-mode ConvBN whose only consumer is a fuse sum -> what that sum's backward
 #            needs to leave the BatchNorm-backward channel sums in the layer's slots (ConvBN.fwd -> FuseSum.fwd);
-#  _BNB_PRE: (gradient tensor data_ptr, arena id, slot offset) -> slot count: "this gradient's two channel sums are
-#            already in your backward slots" (FuseSum.bwd -> ConvBN.bwd).
+#  _BNB_PRE: (arena id, slot offset) -> (arena, pass id, slot count): "the gradient of THIS layer's output already carries
+#            act' and its two channel sums are in your backward slots" (FuseSum.bwd -> ConvBN.bwd).  Keyed by the LAYER, not
+#            by the gradient tensor's address (round 4): a layer registered here has the fuse sum as its ONLY consumer
+#            (plan.PlanNet._fuse_only), so what reaches its backward is that one gradient - stolen, or copied by autograd on the
+#            way (across a data-parallel cut it is: four hand-offs per pass used to be lost to the address check), never summed
+#            with another; the pass id keeps a second backward through the same forward out.
 _BNB_FWD, _BNB_PRE = {}, {}
 _WARNED = {}
 
@@ -608,7 +612,7 @@ class ConvBN:
         rows = B * Ho * Wo
         need_res = has_res and needs[7]
         if not pre and arena is not None:                   # sums left by the backward of a fuse sum in another group
-            hit = _BNB_PRE.pop((dy.data_ptr(), id(arena), bwd_off), None)
+            hit = _BNB_PRE.pop((id(arena), bwd_off), None)
             if hit is not None and hit[0] is arena and hit[1] == _pass:
                 pre = hit[2]
         dc = keep(empty_nhwc(B, Co, Ho, Wo, x.device))
@@ -780,7 +784,7 @@ class FuseSum:
             if rc == 0:
                 for j, tg in enumerate(tgs):
                     if tg is not None:
-                        _BNB_PRE[(outs[j].data_ptr(), id(tg[0]), tg[2])] = (tg[0], tg[1], NS)
+                        _BNB_PRE[(id(tg[0]), tg[2])] = (tg[0], tg[1], NS)
                         COUNTERS['fuse_bnb'] = COUNTERS.get('fuse_bnb', 0) + 1
                 return tuple(outs)
             for tg in tgs:                                  # not served (rc 1): release the slot claims, separate kernels

@@ -858,8 +858,7 @@ static int prepare(int mode, const float* x, const float* w, const float* bias, 
     if (ns <= 0) {                                         // (longer kernels spread their atomics over more time:
         int ph_, nch_;                                     //  HRNet-W48 384x288 is faster with fewer slots to re-read)
         direct::problem_shape(mode, Ci, R, S, stride, Ci % 32 == 0 ? 32 : 16, &ph_, &nch_);
-        static const int low = [] { const char* e = getenv("ADVMIX_STAT_SLOTS_LOW"); int v = e ? atoi(e) : 16; return v > 0 ? v : 16; }();
-        ns = cdiv(Mmax, 128) >= 256 ? (nch_ <= 12 ? 64 : 32) : low;
+        ns = cdiv(Mmax, 128) >= 256 ? (nch_ <= 12 ? 64 : 32) : 16;     // (8 / 4 for the small grids: 587 / 586-590 vs 594 images/s, round 4)
     }
     if (ns > 64 || (ns & (ns - 1))) ns = 16;
     p.stats_nbg = ns;

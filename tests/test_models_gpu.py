@@ -1065,6 +1065,70 @@ def test_data_parallel_path_on_one_rank_real_rccl():
     assert out.returncode == 0 and 'DP_ONE_RANK_OK' in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
 
 
+@pytest.mark.parametrize('transport', ['device', 'host round trip'])
+def test_seven_graph_runner_equals_the_eager_pieces_bit_for_bit_when_the_exchange_changes_the_data(transport):
+    """VERDICT r3 item 1's separating experiment, kept as a test: ONE process, the gradient exchange replaced by a transport
+    that CHANGES the data on the side stream (x 0.5 on the device; or gloo's path restated - an internal stream waits for an
+    event of the side stream, copies to pinned memory, the HOST waits and halves, copies back, the side stream waits for that
+    copy's event), seven-graph runner against the eager pieces from the same state in deterministic mode: parameters, Adam
+    moments and gradients bit-identical after every one of four steps.  With one real rank an all-reduce is the identity and
+    hides every ordering mistake between graphs, pieces and side stream; this does not."""
+    from oracle.synth import synth_batch
+    from advmix_amd import ops
+    from advmix_amd.core.function import advmix_step
+    from advmix_amd.dp import GradSync
+    from advmix_amd.graph import AdvMixGraphRunner
+    pool = [torch.cuda.Stream() for _ in range(3)]
+    count = [0]
+
+    class ChangingSync(GradSync):
+        def __init__(self):
+            super().__init__(bucket_mb=0.25, force=True)
+
+        def _mean_(self, t):
+            if transport == 'device':
+                t.mul_(0.5)
+                return
+            cur = torch.cuda.current_stream()
+            s = pool[count[0] % len(pool)]
+            count[0] += 1
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            s.wait_event(ev)
+            with torch.cuda.stream(s):
+                tmp = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                tmp.copy_(t, non_blocking=True)
+            s.synchronize()
+            tmp.mul_(0.5)
+            with torch.cuda.stream(s):
+                t.copy_(tmp, non_blocking=True)
+                ev2 = torch.cuda.Event()
+                ev2.record(s)
+            cur.wait_event(ev2)
+
+    args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
+    B, J, H, W = 2, 5, 64, 64
+    v, t, w = synth_batch('hrnet_tiny.it0', B, J, H, W)
+    data = ([x.cuda().contiguous() for x in v], t.cuda(), w.cuda())
+    ops.set_deterministic(True)
+    try:
+        cfg, D, G, T, crit, oD, oG, _ = _tiny_setup(salt=10)
+        cfg, D2, G2, T2, crit2, oD2, oG2, _ = _tiny_setup(salt=10)
+        runner = AdvMixGraphRunner(args, D, G, T, crit, oD, oG, *data, ChangingSync())
+        assert runner.seq.n_graphs == 7
+        sync2 = ChangingSync()
+        for k in range(4):
+            runner.step()
+            advmix_step(args, D2, G2, T2, crit2, oD2, oG2, *data, sync2)
+            torch.cuda.synchronize()
+            for a_, b_ in zip(oD.flat_state() + oG.flat_state() + [oD.flat_grads, oG.flat_grads],
+                              oD2.flat_state() + oG2.flat_state() + [oD2.flat_grads, oG2.flat_grads]):
+                assert torch.equal(a_, b_), k
+        assert float(oD.flat_grads.abs().max()) > 0 and bool(torch.isfinite(oG.flat_params).all())
+    finally:
+        ops.set_deterministic(False)
+
+
 def test_deterministic_mode_is_bit_reproducible():
     """ops.set_deterministic(True): ordered partial sums instead of fp32 / fp64 atomics everywhere (weight and bias
     gradients, the loss sum, BatchNorm statistics, no K split across the grid).  Two AdvMix steps run twice from the

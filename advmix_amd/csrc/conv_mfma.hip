@@ -234,7 +234,25 @@ struct WgP {
     int R, S, stride, pad;
     int chunk;               // pixels per z-slice (multiple of 32)
     float* part;             // deterministic mode: slice z STORES its partial tile at part[z * Ca * Ntot + ...] instead of
-};                           // adding it to dw with fp32 atomics; reduce_slices_kernel sums the slices in order
+                             // adding it to dw with fp32 atomics; reduce_slices_kernel sums the slices in order
+    int excl;                // one slice per tile (a large group): the workgroup owns its outputs, dw += with plain accesses
+    int xcd;                 // 1: workgroup order remapped so that the tiles of one pixel slice run on ONE XCD (xcd_order)
+};
+
+// Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest), so the column / row tiles of one pixel slice -
+// which all read the SAME dy and x pixels - land on 8 different L2s and each fetches them from the fabric again (3x3
+// 128 -> 128: 9 column tiles = 9 reads of every operand byte; 3.2 TB/s at the rate the kernel runs).  Remapped, XCD k works
+// through the contiguous range [k T / 8, (k + 1) T / 8) of (slice, row tile, column tile) in order: the tiles of a slice are
+// neighbours in time on one L2.  Bijective for any grid (the first T % 8 XCDs hold one workgroup more).
+__device__ __forceinline__ void xcd_order(int& bx, int& by, int& bz) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, T = gx * gy * gridDim.z;
+    const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned q = T >> 3, rem = T & 7, xcd = L & 7, k = L >> 3;
+    const unsigned v = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;
+    bx = (int)(v % gx);
+    by = (int)((v / gx) % gy);
+    bz = (int)(v / (gx * gy));
+}
 
 // dw[i] += the slices' partials in a FIXED order: the deterministic tail of the weight / bias gradients.  Scalar form (any
 // total): one thread per output walks the slices in order.
@@ -305,15 +323,23 @@ static void launch_reduce_slices(const float* part, int nslices, int64_t total, 
 // triples to a single launch at the end of the chain's backward - eight times the work per launch means an eighth of the
 // pixel slices per problem (fewer partial tiles to merge with atomics, longer main loops per workgroup) and room for the
 // 128 x 128 tile (one LDS read per MFMA instead of two).  blockIdx.z = problem * slices + slice.
+constexpr int WG_MAXG = 64;
+#ifndef WG_PIPE
+#define WG_PIPE 1
+#endif
+#ifndef WG_VALU
+#define WG_VALU 0           // > 0: also pin that many VALU instructions per k-pair (the solver then gives up on the whole pattern)
+#endif
 struct WgGroup {
     int n, slices;
-    const float* a[8];
-    const float* b[8];
-    float* dw[8];
+    const float* a[WG_MAXG];
+    const float* b[WG_MAXG];
+    float* dw[WG_MAXG];
 };
 
 template <int WM, int WN, bool VEC, int TM = 1, int TN = 1>
-__device__ __forceinline__ void wgrad_body(const WgP p, const int zslice, float* const As0, float* const Bs0) {
+__device__ __forceinline__ void wgrad_body(const WgP p, const int bx, const int by, const int zslice, float* const As0,
+                                           float* const Bs0) {
     constexpr int BMw = 32 * WM * TM, BNw = 32 * WN * TN;
     constexpr int KS = 32;                             // pixels per step (16 MFMAs per wave between barriers)
     constexpr int ASL = (KS * BMw / 4 + 255) / 256;    // float4 slots per thread
@@ -325,7 +351,7 @@ __device__ __forceinline__ void wgrad_body(const WgP p, const int zslice, float*
     const int lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wid / WN, wn = wid % WN;
-    const int co0 = blockIdx.x * BMw, j0 = blockIdx.y * BNw;
+    const int co0 = bx * BMw, j0 = by * BNw;
     const int P = p.N * p.Ha * p.Wa;
     const int Ntot = p.R * p.S * p.Cb;
     const int p_lo = zslice * p.chunk;
@@ -379,7 +405,76 @@ __device__ __forceinline__ void wgrad_body(const WgP p, const int zslice, float*
         b_wa[i] = rem - b_ha[i] * p.Wa;
     }
     f32x4 ra[ASL], rb[BSL];
-    auto load_tile = [&](int pt) {
+    // VEC (every channel count a multiple of 4): branch-free buffer loads.  The pointer form below costs ~1,100 cycles of
+    // address arithmetic per step and wave (64-bit multiply-adds, eight exec-masked branches) in basic blocks of its own, which
+    // the scheduler cannot move under the step's 4,096 cycles of MFMA - and two workgroups per CU fall into lockstep, so
+    // the matrix pipe idles through both address sections.  Here a slot carries a 32-bit byte offset (relative to the slice's first
+    // pixel / first image) from step to step - three adds and two selects - and an out-of-range slot loads from offset 2^31,
+    // past the resource's end, which returns zeros.
+    constexpr unsigned WOOB = 0x80000000u;
+    __amdgpu_buffer_rsrc_t a_rs, b_rs;
+    unsigned a_off[ASL], b_off[BSL];
+    int b_tap[BSL], b_dh0[BSL], b_dw0[BSL];
+    bool a_cv[ASL], b_ok[BSL];
+    int bD0 = 0, bDW = 0, bDH = 0;
+    if constexpr (VEC) {
+        const int n0 = p_lo / HWa;
+        const int64_t a_left = ((int64_t)P - p_lo) * p.Ca * 4;
+        const int64_t b_left = ((int64_t)p.N - n0) * p.Hb * p.Wb * p.Cb * 4;
+        a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + (int64_t)p_lo * p.Ca), 0,
+                                                 (int)(a_left < 0x7fffffffLL ? a_left : 0x7fffffffLL), 0x00020000);
+        b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.b + (int64_t)n0 * p.Hb * p.Wb * p.Cb), 0,
+                                                 (int)(b_left < 0x7fffffffLL ? b_left : 0x7fffffffLL), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < ASL; ++i) {
+            a_off[i] = (unsigned)((a_k[i] * p.Ca + co0 + a_c[i]) * 4);
+            a_cv[i] = a_in[i] && co0 + a_c[i] < p.Ca;
+        }
+#pragma unroll
+        for (int i = 0; i < BSL; ++i) {
+            b_off[i] = (unsigned)((((b_n[i] - n0) * p.Hb + b_ha[i] * p.stride) * p.Wb + b_wa[i] * p.stride) * p.Cb * 4);
+            b_tap[i] = ((b_dh[i][0] * p.Wb + b_dw[i][0]) * p.Cb + b_cb[i][0]) * 4;
+            b_dh0[i] = b_dh[i][0];
+            b_dw0[i] = b_dw[i][0];
+            b_ok[i] = b_in[i] && b_jv[i][0];
+        }
+        bD0 = ((step_n * p.Hb + step_h * p.stride) * p.Wb + step_w * p.stride) * p.Cb * 4;
+        bDW = (p.stride * p.Wb - p.Wa * p.stride) * p.Cb * 4;        // the column wrapped: wa -= Wa, ha += 1
+        bDH = (p.Hb * p.Wb - p.Ha * p.stride * p.Wb) * p.Cb * 4;     // the row wrapped: ha -= Ha, n += 1
+    }
+    // The offsets of the tile after the one being loaded are formed under the MFMAs of the current step (advance_v after the
+    // loads have been issued): the top of a step is eight buffer loads and nothing else.
+    unsigned a_vo[ASL], b_vo[BSL];
+    auto advance_v = [&](int pt, bool first) {            // -> a_vo / b_vo of tile pt (first: the state IS tile pt's)
+#pragma unroll
+        for (int i = 0; i < ASL; ++i) {
+            if (!first) a_off[i] += (unsigned)(KS * p.Ca * 4);
+            const bool ok = a_cv[i] & (pt + a_k[i] < p_hi);
+            a_vo[i] = ok ? a_off[i] : WOOB;
+        }
+#pragma unroll
+        for (int i = 0; i < BSL; ++i) {
+            if (!first) {
+                const int w2 = b_wa[i] + step_w, cw = w2 >= p.Wa;
+                const int h2 = b_ha[i] + step_h + cw, ch = h2 >= p.Ha;
+                b_wa[i] = w2 - (cw ? p.Wa : 0);
+                b_ha[i] = h2 - (ch ? p.Ha : 0);
+                b_off[i] += (unsigned)(bD0 + (cw ? bDW : 0) + (ch ? bDH : 0));
+            }
+            const int hb = __mul24(b_ha[i], p.stride) + b_dh0[i], wb = __mul24(b_wa[i], p.stride) + b_dw0[i];
+            const bool v = b_ok[i] & (pt + b_k[i] < p_hi) & ((unsigned)hb < (unsigned)p.Hb) & ((unsigned)wb < (unsigned)p.Wb);   // (no short circuit: no branch)
+            b_vo[i] = v ? b_off[i] + (unsigned)b_tap[i] : WOOB;
+        }
+    };
+    auto load_tile_v = [&]() {
+#pragma unroll
+        for (int i = 0; i < ASL; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo[i], 0, 0));
+#pragma unroll
+        for (int i = 0; i < BSL; ++i)
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_vo[i], 0, 0));
+    };
+    auto load_tile_p = [&](int pt) {
 #pragma unroll
         for (int i = 0; i < ASL; ++i) {
             int pix = pt + a_k[i];
@@ -420,13 +515,14 @@ __device__ __forceinline__ void wgrad_body(const WgP p, const int zslice, float*
             }
         }
     };
+    constexpr bool A_FULL = (KS * BMw / 4) % 256 == 0, B_FULL = (KS * BNw / 4) % 256 == 0;    // every thread owns ASL / BSL slots
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < ASL; ++i)
-            if (a_in[i]) *reinterpret_cast<f32x4*>(&As[buf][a_k[i] * BMw + a_c[i]]) = ra[i];
+            if (A_FULL || a_in[i]) *reinterpret_cast<f32x4*>(&As[buf][a_k[i] * BMw + a_c[i]]) = ra[i];
 #pragma unroll
         for (int i = 0; i < BSL; ++i)
-            if (b_in[i]) *reinterpret_cast<f32x4*>(&Bs[buf][b_k[i] * BNw + b_c[i]]) = rb[i];
+            if (B_FULL || b_in[i]) *reinterpret_cast<f32x4*>(&Bs[buf][b_k[i] * BNw + b_c[i]]) = rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -440,13 +536,21 @@ __device__ __forceinline__ void wgrad_body(const WgP p, const int zslice, float*
     // Branch-free steady state (a tile past the slice loads zeros, so the prefetch is unconditional): the first
     // version's "if (more) load" made the compiler shuttle the accumulator AGPR -> VGPR -> AGPR around the branch
     // on every 8-MFMA step, and it paid two barriers per 16 pixels.
-    load_tile(p_lo);
+    if constexpr (VEC) {
+        advance_v(p_lo, true);
+        load_tile_v();
+        advance_v(p_lo + KS, false);
+    } else {
+        load_tile_p(p_lo);
+    }
     store_tile(0);
     __syncthreads();
     int buf = 0;
     for (int pt = p_lo; pt < p_hi; pt += KS) {
-        load_tile(pt + KS);
+        if constexpr (VEC) load_tile_v();
+        else load_tile_p(pt + KS);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (VEC) advance_v(pt + 2 * KS, false);
         float av[KS / 2][TM], bv[KS / 2][TN];
 #pragma unroll
         for (int kk = 0; kk < KS / 2; ++kk) {
@@ -462,6 +566,20 @@ __device__ __forceinline__ void wgrad_body(const WgP p, const int zslice, float*
 #pragma unroll
                 for (int u = 0; u < TN; ++u)
                     acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][t], bv[kk][u], acc[t][u], 0, 0, 0);
+        // The operand reads run TWO k-pairs ahead of the MFMAs that use them.  Left alone the compiler reuses one register set:
+        // read, wait, 4 MFMAs, read, wait ... - every k-pair's LDS latency (~100 cycles per 256 of MFMA) in the open.
+        if (WG_PIPE) {
+            constexpr int DSK = (TM == 2 ? 1 : TM) + (TN == 2 ? 1 : TN);     // LDS instructions per k-pair (pairs fuse to read2)
+            constexpr int AHEAD = 2;
+            __builtin_amdgcn_sched_group_barrier(0x100, DSK * AHEAD, 0);
+#pragma unroll
+            for (int kk = 0; kk < KS / 2 - AHEAD; ++kk) {
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, DSK, 0);
+                if (VEC && WG_VALU > 0) __builtin_amdgcn_sched_group_barrier(0x002, WG_VALU, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * AHEAD, 0);
+        }
         store_tile(buf ^ 1);
         __syncthreads();
         buf ^= 1;
@@ -478,6 +596,7 @@ __device__ __forceinline__ void wgrad_body(const WgP p, const int zslice, float*
                 int co = co0 + (wm * TM + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (co >= p.Ca) continue;
                 if (p.part) p.part[((int64_t)zslice * p.Ca + co) * Ntot + j] = acc[t][u][r];
+                else if (p.excl) p.dw[(int64_t)co * Ntot + j] += acc[t][u][r];
                 else atomicAdd(p.dw + (int64_t)co * Ntot + j, acc[t][u][r]);
             }
         }
@@ -487,18 +606,22 @@ template <int WM, int WN, bool VEC, int TM = 1, int TN = 1>
 __global__ __launch_bounds__(256) void conv_wgrad(WgP p) {
     __shared__ __attribute__((aligned(16))) float As[2 * 32 * 32 * WM * TM];
     __shared__ __attribute__((aligned(16))) float Bs[2 * 32 * 32 * WN * TN];
-    wgrad_body<WM, WN, VEC, TM, TN>(p, blockIdx.z, As, Bs);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd) xcd_order(bx, by, bz);
+    wgrad_body<WM, WN, VEC, TM, TN>(p, bx, by, bz, As, Bs);
 }
 
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_wgrad_group(WgP p, WgGroup g) {
     __shared__ __attribute__((aligned(16))) float As[2 * 32 * 32 * WM * TM];
     __shared__ __attribute__((aligned(16))) float Bs[2 * 32 * 32 * WN * TN];
-    const int prob = blockIdx.z / g.slices;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd) xcd_order(bx, by, bz);
+    const int prob = bz / g.slices;
     p.a = g.a[prob];
     p.b = g.b[prob];
     p.dw = g.dw[prob];
-    wgrad_body<WM, WN, true, TM, TN>(p, blockIdx.z - prob * g.slices, As, Bs);
+    wgrad_body<WM, WN, true, TM, TN>(p, bx, by, bz - prob * g.slices, As, Bs);
 }
 
 __global__ void transpose_w_kernel(const float* __restrict__ in, float* __restrict__ out, int A, int T, int B) {
@@ -644,6 +767,19 @@ extern "C" int advmix_conv_tr(const float* x, const float* wt, const float* bias
 
 // workgroups a wgrad launch aims for (output tiles x pixel slices); every slice adds its partial tile with
 // fp32 atomics, so this trades parallelism against atomic traffic (ADVMIX_WGRAD_BLOCKS to experiment)
+static int wgrad_xcd_order() {          // ADVMIX_WGRAD_XCD=0: launch order as dealt (A/B of xcd_order)
+    static const int v = [] { const char* e = getenv("ADVMIX_WGRAD_XCD"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
+// The vector form of wgrad_body addresses a workgroup's pixel slice with 32-bit byte offsets from the slice's first pixel (a)
+// and first image (b); a slice whose span does not fit (a > 2 GB image pair) takes the pointer form.
+static bool wgrad_spans_ok(int64_t chunk, int Ha, int Wa, int Ca, int Hb, int Wb, int Cb) {
+    const int64_t span_a = (chunk + 64) * Ca * 4;
+    const int64_t span_b = (chunk / ((int64_t)Ha * Wa) + 3) * Hb * Wb * Cb * 4;
+    return span_a < 0x7fff0000LL && span_b < 0x7fff0000LL;
+}
+
 static int wgrad_target_blocks() {
     static int v = [] { const char* e = getenv("ADVMIX_WGRAD_BLOCKS"); int t = e ? atoi(e) : 1024; return t > 0 ? t : 1024; }();
     return v;
@@ -676,6 +812,7 @@ static int wgrad_impl(const float* a, const float* b, float* dw, int N, int Ha, 
         if (rc >= 0) return rc;
     }
     WgP p{a, b, dw, N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad, 0, part};
+    p.xcd = wgrad_xcd_order();
     const int64_t P = (int64_t)N * Ha * Wa;
     const int Ntot = R * S * Cb;
     const bool vec = (Ca % 4 == 0) && (Cb % 4 == 0);
@@ -696,10 +833,12 @@ static int wgrad_impl(const float* a, const float* b, float* dw, int N, int Ha, 
         if (part) {                                                                       \
             if ((int64_t)nslices * Ca * Ntot > part_floats) return ADVMIX_EINVAL;         \
         }                                                                                 \
-        hipLaunchKernelGGL((conv_wgrad<WM_, WN_, V_, TM_, TN_>), g, dim3(256), 0, st, p); \
+        const bool v_ = V_ && wgrad_spans_ok(chunk, Ha, Wa, Ca, Hb, Wb, Cb);              \
+        if (v_) hipLaunchKernelGGL((conv_wgrad<WM_, WN_, V_, TM_, TN_>), g, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((conv_wgrad<WM_, WN_, false, TM_, TN_>), g, dim3(256), 0, st, p); \
         if (advmix_opts().trace_shapes) {                                                 \
             char nm[64];                                                                  \
-            snprintf(nm, sizeof nm, "conv_wgrad<%d, %d, %s, %d, %d>", WM_, WN_, V_ ? "true" : "false", TM_, TN_); \
+            snprintf(nm, sizeof nm, "conv_wgrad<%d, %d, %s, %d, %d>", WM_, WN_, v_ ? "true" : "false", TM_, TN_); \
             advmix_trace_launch(nm, g, "wgrad", N, Hb, Wb, Cb, Ha, Wa, Ca, R, S, stride,  \
                                 2.0 * N * (double)Ha * Wa * Ca * Cb * R * S);             \
         }                                                                                 \
@@ -761,7 +900,7 @@ static int wgrad_group_slices(int tiles_all, int wg_per_cu, int64_t maxs) {
 extern "C" int advmix_conv_wgrad_group(int n, const float* const* a, const float* const* b, float* const* dw,
                                        int N, int Ha, int Wa, int Ca, int Hb, int Wb, int Cb,
                                        int R, int S, int stride, int pad, void* stream) {
-    if (n < 2 || n > 8 || !a || !b || !dw || N <= 0 || Ca <= 0 || Cb <= 0 || stride < 1) return ADVMIX_EINVAL;
+    if (n < 2 || n > WG_MAXG || !a || !b || !dw || N <= 0 || Ca <= 0 || Cb <= 0 || stride < 1) return ADVMIX_EINVAL;
     if (Ha != (Hb + 2 * pad - R) / stride + 1 || Wa != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
     const int Ntot = R * S * Cb;
     if (advmix_opts().deterministic) return ADVMIX_EINVAL;
@@ -775,13 +914,14 @@ extern "C" int advmix_conv_wgrad_group(int n, const float* const* a, const float
     if (cdiv(Ntot, 128) * 128 > Ntot + Ntot / 6) return ADVMIX_EINVAL;   // a 128-column tile mostly empty (1x1 64 -> 256: 64 columns)
     WgGroup g;
     g.n = n;
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < WG_MAXG; ++i) {
         g.a[i] = i < n ? a[i] : nullptr;
         g.b[i] = i < n ? b[i] : nullptr;
         g.dw[i] = i < n ? dw[i] : nullptr;
         if (i < n && (!a[i] || !b[i] || !dw[i])) return ADVMIX_EINVAL;
     }
     WgP p{nullptr, nullptr, nullptr, N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad, 0, nullptr};
+    p.xcd = wgrad_xcd_order();
     const int64_t P = (int64_t)N * Ha * Wa;
     hipStream_t st = (hipStream_t)stream;
     const bool big = Ca % 128 == 0;                        // 128 x 128 per workgroup (2 x 2 tiles per wave), else 64 x 128
@@ -791,6 +931,8 @@ extern "C" int advmix_conv_wgrad_group(int n, const float* const* a, const float
     const int64_t chunk = ((P + ns - 1) / ns + 31) / 32 * 32;
     p.chunk = (int)chunk;
     g.slices = (int)cdiv(P, chunk);
+    p.excl = g.slices == 1;
+    if (!wgrad_spans_ok(chunk, Ha, Wa, Ca, Hb, Wb, Cb)) return ADVMIX_EINVAL;
     if ((int64_t)g.slices * n > 65535) return ADVMIX_EINVAL;
     const dim3 grid(big ? cdiv(Ca, 128) : cdiv(Ca, 64), cdiv(Ntot, 128), g.slices * n);
     if (big) hipLaunchKernelGGL((conv_wgrad_group<2, 2, 2, 2>), grid, dim3(256), 0, st, p, g);

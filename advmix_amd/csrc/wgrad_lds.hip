@@ -37,9 +37,9 @@ struct LP {
     // 32 -> 32 convs of an HRNet branch: weight gradients have no consumer before the optimizer step).  Workgroup b belongs
     // to problem b / wgs and walks slabs (b % wgs) * nslab ... of it.  Single problems: nslab = 1, n = 1, pointers in [0].
     int nslab, wgs, n;
-    const float* dyv[8];
-    const float* xv[8];
-    float* dwv[8];
+    const float* dyv[64];
+    const float* xv[64];
+    float* dwv[64];
 };
 
 constexpr int C = 32;
@@ -264,7 +264,7 @@ int advmix_wgrad_lds_dispatch(const float* a, const float* b, float* dw, int N, 
 int advmix_wgrad_lds_group_dispatch(int n, const float* const* a, const float* const* b, float* const* dw, int N, int Ha, int Wa,
                                     int Ca, int Hb, int Wb, int Cb, int R, int S, int stride, int pad, hipStream_t st) {
     const int mode = advmix_opts().wgrad_lds;
-    if (!mode || n < 2 || n > 8 || Ca != 32 || Cb != 32 || R != 3 || S != 3 || stride != 1 || pad != 1 || Ha != Hb || Wa != Wb)
+    if (!mode || n < 2 || n > 64 || Ca != 32 || Cb != 32 || R != 3 || S != 3 || stride != 1 || pad != 1 || Ha != Hb || Wa != Wb)
         return -1;
     const int64_t bytes = (int64_t)N * Ha * Wa * 32 * 4;
     if (bytes >= 0x7fffffffLL) return -1;
@@ -295,7 +295,7 @@ int advmix_wgrad_lds_group_dispatch(int n, const float* const* a, const float* c
         attr_lds = lds;
     }
     wgl::LP p{nullptr, nullptr, nullptr, nullptr, N, Ha, Wa, Wp, rows, (int)bytes, nslab, slabs / nslab, n, {}, {}, {}};
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 64; ++i) {
         p.dyv[i] = i < n ? a[i] : nullptr;
         p.xv[i] = i < n ? b[i] : nullptr;
         p.dwv[i] = i < n ? dw[i] : nullptr;

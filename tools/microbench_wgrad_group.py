@@ -9,6 +9,7 @@ dev = torch.device('cuda:0')
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 B, n = 32, int(sys.argv[1]) if len(sys.argv) > 1 else 8
+check = len(sys.argv) > 2 and sys.argv[2] == 'check'     # also compare the grouped launch's result with the singles'
 
 
 def timeit(fn, iters=50):
@@ -38,6 +39,15 @@ for C, H, W in ((32, 64, 48), (64, 32, 24), (128, 16, 12), (256, 8, 6), (64, 64,
 
     def grouped():
         assert lib.advmix_conv_wgrad_group(n, A, Bp, D, *geom, st) == 0
+    if check:
+        for d in dws: d.zero_()
+        singles()
+        ref = [d.clone() for d in dws]
+        for d in dws: d.zero_()
+        grouped()
+        torch.cuda.synchronize()
+        worst = max(float((d - r).abs().max() / r.abs().max()) for d, r in zip(dws, ref))
+        assert worst < 2e-5, worst
     t1, t2 = timeit(singles), timeit(grouped)
     fl = 2.0 * B * H * W * C * C * 9 * n
     print('3x3 %3d->%-3d @%dx%d x%d: singles %.1f us (%.1f us each, %.2f of peak) | grouped %.1f us (%.1f us each, %.2f of peak)' % (

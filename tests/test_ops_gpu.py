@@ -539,7 +539,9 @@ def test_bn_backward_epilogue_sign_from_mask_and_from_c(case):
 
 
 @pytest.mark.parametrize('case', [(8, 32, 64, 32, 24, 3), (3, 32, 128, 16, 12, 3), (8, 32, 256, 8, 6, 3), (2, 4, 64, 20, 14, 3),
-                                  (5, 8, 128, 12, 9, 1), (8, 32, 32, 64, 48, 3), (3, 4, 32, 16, 11, 3), (2, 2, 32, 8, 8, 3)])
+                                  (5, 8, 128, 12, 9, 1), (8, 32, 32, 64, 48, 3), (3, 4, 32, 16, 11, 3), (2, 2, 32, 8, 8, 3),
+                                  # more than eight problems: one pixel slice per tile -> the workgroup owns its outputs (plain +=)
+                                  (56, 8, 128, 16, 12, 3), (40, 4, 64, 16, 12, 3), (64, 2, 32, 16, 16, 3), (24, 8, 256, 8, 6, 3)])
 def test_grouped_weight_gradients_equal_single_launches(case):
     """advmix_conv_wgrad_group (round 4): n weight gradients of one geometry in one launch accumulate the same sums into their
     dW buffers as n advmix_conv_wgrad calls (other slices, other order: agreement to fp32 rounding) and equal a float64 torch
@@ -578,6 +580,9 @@ def test_grouped_weight_gradients_equal_single_launches(case):
     bad_geom = (B, H, W, 48, H, W, 48, k, k, 1, pad)
     assert lib.advmix_conv_wgrad_group(n, arr(*[t.data_ptr() for t in dyd]), arr(*[t.data_ptr() for t in xd]),
                                        arr(*[t.data_ptr() for t in group]), *bad_geom, st) == 1
+    many = ctypes.c_void_p * 65                           # more than 64 problems
+    rep = lambda ts: many(*[ts[i % n].data_ptr() for i in range(65)])
+    assert lib.advmix_conv_wgrad_group(65, rep(dyd), rep(xd), rep(group), *geom, st) == 1
     one = ctypes.c_void_p * 1
     assert lib.advmix_conv_wgrad_group(1, one(dyd[0].data_ptr()), one(xd[0].data_ptr()), one(group[0].data_ptr()), *geom, st) == 1
     nul = arr(*([None] + [t.data_ptr() for t in dyd[1:]]))

@@ -932,6 +932,9 @@ extern "C" int advmix_conv_wgrad_group(int n, const float* const* a, const float
     p.chunk = (int)chunk;
     g.slices = (int)cdiv(P, chunk);
     p.excl = g.slices == 1;
+    for (int i = 1; i < n && p.excl; ++i)                  // (the same buffer twice - shared weights - keeps the atomics)
+        for (int j = 0; j < i; ++j)
+            if (dw[i] == dw[j]) { p.excl = 0; break; }
     if (!wgrad_spans_ok(chunk, Ha, Wa, Ca, Hb, Wb, Cb)) return ADVMIX_EINVAL;
     if ((int64_t)g.slices * n > 65535) return ADVMIX_EINVAL;
     const dim3 grid(big ? cdiv(Ca, 128) : cdiv(Ca, 64), cdiv(Ntot, 128), g.slices * n);

@@ -139,7 +139,7 @@ int advmix_conv_wgrad(const float* a, const float* b, float* dw,
  * C -> C convs of an HRNet branch (pose_hrnet.py:28-57, four BasicBlocks) are differentiated together at the end of the
  * branch's backward: an eighth of the pixel slices per problem to merge, the 128 x 128 tile.  Same sums as n single calls, in
  * another order (with enough problems that every tile is one pixel slice, the owning workgroup adds its tile with plain
- * accesses: no atomics, run-to-run reproducible; the dw buffers must then be distinct, as they must be anyway).  Served:
+ * accesses: no atomics, run-to-run reproducible - unless two problems share a dw buffer).  Served:
  * Ca % 64 == 0 with Cb % 4 == 0, and 3x3 / stride 1 / 32 -> 32.  ADVMIX_EINVAL without launching otherwise (and in
  * deterministic mode): call advmix_conv_wgrad per problem. */
 int advmix_conv_wgrad_group(int n, const float* const* a, const float* const* b, float* const* dw,

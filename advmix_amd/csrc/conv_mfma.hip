@@ -536,6 +536,11 @@ __device__ __forceinline__ void wgrad_body(const WgP p, const int bx, const int 
     // Branch-free steady state (a tile past the slice loads zeros, so the prefetch is unconditional): the first
     // version's "if (more) load" made the compiler shuttle the accumulator AGPR -> VGPR -> AGPR around the branch
     // on every 8-MFMA step, and it paid two barriers per 16 pixels.
+    // Register staging with the LDS write AFTER the barrier: tile t + 1 (loaded during step t - 1) is written into the other
+    // buffer at the START of step t - its last readers left it before the barrier - and the same registers take the loads of
+    // tile t + 2.  A load has a whole step to land before anything waits for it, and the write has one before the barrier that
+    // publishes it; written at the END of the step (until round 4) both latencies sat in front of the barrier: 10 % of the
+    // kernel (profiles/r04_wgrad_knockouts_x56.log).
     if constexpr (VEC) {
         advance_v(p_lo, true);
         load_tile_v();
@@ -544,13 +549,20 @@ __device__ __forceinline__ void wgrad_body(const WgP p, const int bx, const int 
         load_tile_p(p_lo);
     }
     store_tile(0);
+    if constexpr (VEC) {
+        load_tile_v();
+        advance_v(p_lo + 2 * KS, false);
+    } else {
+        load_tile_p(p_lo + KS);
+    }
     __syncthreads();
     int buf = 0;
     for (int pt = p_lo; pt < p_hi; pt += KS) {
-        if constexpr (VEC) load_tile_v();
-        else load_tile_p(pt + KS);
+        store_tile(buf ^ 1);                               // tile pt + KS
+        if constexpr (VEC) load_tile_v();                  // tile pt + 2 KS
+        else load_tile_p(pt + 2 * KS);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (VEC) advance_v(pt + 2 * KS, false);
+        if constexpr (VEC) advance_v(pt + 3 * KS, false);
         float av[KS / 2][TM], bv[KS / 2][TN];
 #pragma unroll
         for (int kk = 0; kk < KS / 2; ++kk) {
@@ -580,7 +592,6 @@ __device__ __forceinline__ void wgrad_body(const WgP p, const int bx, const int 
             }
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * AHEAD, 0);
         }
-        store_tile(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }

@@ -31,6 +31,7 @@ SIGNATURES = {
     'advmix_conv_tr_w': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_direct_config': [_i] * 9,
     'advmix_deconv4x4s2_narrow': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    'advmix_deconv4x4s2_narrow_gemm': [_p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p],
     'advmix_conv_tr_narrow': [_p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_tr_w_add': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_tr_w_bnb': [_p, _p, _p, _p] + [_i] * 11 + [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p],
@@ -101,6 +102,8 @@ lib.advmix_norm_ws_bytes.argtypes = [_i, _i]
 lib.advmix_norm_ws_bytes.restype = ctypes.c_int64
 lib.advmix_wgrad_det_ws_bytes.argtypes = [_i, _i, _i, _i]
 lib.advmix_wgrad_det_ws_bytes.restype = ctypes.c_int64
+lib.advmix_deconv4x4s2_narrow_ws_bytes.argtypes = [_i, _i, _i, _i]
+lib.advmix_deconv4x4s2_narrow_ws_bytes.restype = ctypes.c_int64
 
 
 class AdvmixHipError(RuntimeError):

@@ -541,6 +541,75 @@ extern "C" int advmix_deconv4x4s2_narrow(const float* x, const float* w, const f
     return ADVMIX_OK;
 }
 
+// The same layer as a GEMM and a gather (round 4).  deconv4x4s2_narrow_kernel reads every input element 16 times - four
+// parity classes x four taps - from L2 / L1: 3.2 GB for the U-Net's 128 -> 3 tail, 395 us, 0.06 of the matrix peak and L2-bound.
+// Here every input pixel's 16 x Cout products p[pixel][kh][kw][co] = sum_ci x[pixel][ci] w[ci][kh][kw][co] are ONE 1 x 1
+// transposed-weight convolution on the matrix pipe (w[Cin][4][4][Cout] IS its k-major weight, Cn = 16 Cout: no padding, no
+// re-layout; the input is read once), and an output pixel is the sum of the four products that land on it:
+// (oh, ow) <- kh = (oh + 1) % 2 (+ 2), a = (oh + 1 - kh) / 2, likewise kw, b.
+template <int CO>
+__global__ __launch_bounds__(256) void deconv4x4s2_gather_kernel(const float* __restrict__ p, const float* __restrict__ bias,
+                                                                 float* __restrict__ y, int N, int Hi, int Wi) {
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    const int64_t total = (int64_t)N * Ho * Wo;
+    float bv[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) bv[o] = bias ? bias[o] : 0.f;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
+        const int ow = (int)(i % Wo);
+        const int64_t t = i / Wo;
+        const int oh = (int)(t % Ho), n = (int)(t / Ho);
+        const int kh0 = (oh + 1) & 1, kw0 = (ow + 1) & 1;
+        float s[CO];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) s[o] = bv[o];
+#pragma unroll
+        for (int dh = 0; dh < 4; dh += 2) {
+            const int kh = kh0 + dh, a = (oh + 1 - kh) / 2;               // (oh + 1 - kh is even; -2 -> row -1: outside)
+            if ((unsigned)a >= (unsigned)Hi) continue;
+#pragma unroll
+            for (int dw = 0; dw < 4; dw += 2) {
+                const int kw = kw0 + dw, b = (ow + 1 - kw) / 2;
+                if ((unsigned)b >= (unsigned)Wi) continue;
+                const float* src = p + (((int64_t)n * Hi + a) * Wi + b) * (16 * CO) + (kh * 4 + kw) * CO;
+#pragma unroll
+                for (int o = 0; o < CO; ++o) s[o] += src[o];
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < CO; ++o) y[i * CO + o] = s[o];
+    }
+}
+
+extern "C" int64_t advmix_deconv4x4s2_narrow_ws_bytes(int N, int Hi, int Wi, int Co) {
+    return (int64_t)N * Hi * Wi * 16 * Co * 4;
+}
+
+// ConvTranspose2d(Cin, Cout <= 4, 4, 2, 1) forward through ``ws`` (advmix_deconv4x4s2_narrow_ws_bytes; the products of every
+// input pixel).  ADVMIX_EINVAL (nothing launched) where the 1 x 1 kernel does not serve the shape (Cin % 16) or ws is too small:
+// call advmix_deconv4x4s2_narrow.
+extern "C" int advmix_deconv4x4s2_narrow_gemm(const float* x, const float* w, const float* bias, float* y, float* ws,
+                                              int64_t ws_bytes, int N, int Hi, int Wi, int Ci, int Co, void* stream) {
+    if (!x || !w || !y || !ws || N <= 0 || Hi <= 0 || Wi <= 0) return ADVMIX_EINVAL;
+    if (Co < 1 || Co > 4 || Ci % 16 != 0) return ADVMIX_EINVAL;
+    if (ws_bytes < advmix_deconv4x4s2_narrow_ws_bytes(N, Hi, Wi, Co)) return ADVMIX_EINVAL;
+    const int rc = advmix_conv_tr_w_add(x, w, nullptr, ws, N, Hi, Wi, Ci, Hi, Wi, 16 * Co, 1, 1, 1, 0, stream);
+    if (rc != ADVMIX_OK) return rc;
+    const int64_t total = (int64_t)N * 4 * Hi * Wi;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    dim3 g((unsigned)blocks);
+    hipStream_t st = (hipStream_t)stream;
+    switch (Co) {
+        case 1: hipLaunchKernelGGL((deconv4x4s2_gather_kernel<1>), g, dim3(256), 0, st, ws, bias, y, N, Hi, Wi); break;
+        case 2: hipLaunchKernelGGL((deconv4x4s2_gather_kernel<2>), g, dim3(256), 0, st, ws, bias, y, N, Hi, Wi); break;
+        case 3: hipLaunchKernelGGL((deconv4x4s2_gather_kernel<3>), g, dim3(256), 0, st, ws, bias, y, N, Hi, Wi); break;
+        default: hipLaunchKernelGGL((deconv4x4s2_gather_kernel<4>), g, dim3(256), 0, st, ws, bias, y, N, Hi, Wi); break;
+    }
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
 // One SGD step over a flat parameter buffer (lib/utils/utils.py:80-88: optim.SGD(lr, momentum, weight_decay, nesterov)).
 extern "C" int advmix_sgd(float* p, const float* g, float* buf, int64_t n, const float* hyper, void* stream) {
     if (!p || !g || !buf || !hyper || n <= 0) return ADVMIX_EINVAL;

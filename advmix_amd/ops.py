@@ -237,6 +237,7 @@ if __import__('os').environ.get('ADVMIX_DETERMINISTIC', '0') == '1':
 # eight 3x3 C -> C convs of an HRNet branch's four residual blocks - go out as a single launch (advmix_conv_wgrad_group: an
 # eighth of the pixel slices per problem to merge with atomics, longer main loops, the 128 x 128 tile).  Round 4: a knock-out
 # had shown the weight gradients cost the step 9.4 of 55.5 ms, i.e. they are NOT hidden behind the other lanes.
+DECONV_GEMM = __import__('os').environ.get('ADVMIX_DECONV_GEMM', '1') != '0'   # narrow ConvTranspose2d forward: GEMM + gather (A/B switch)
 WGRAD_GROUP = __import__('os').environ.get('ADVMIX_WGRAD_GROUP', '1') != '0'
 _WG_DEFER = []          # a stack of pending lists: [(a, b, grad, geom)] of the Chain.bwd calls in progress
 
@@ -398,8 +399,15 @@ class Deconv:
         Ho = (Hi - 1) * stride - 2 * pad + R
         Wo = (Wi - 1) * stride - 2 * pad + S
         y = empty_nhwc(B, Co, Ho, Wo, x.device)
-        if Co <= 4 and R == 4 and S == 4 and stride == 2 and pad == 1 and Ci % 8 == 0 and _direct_ok():
-            call('advmix_deconv4x4s2_narrow', _p(x), _p(w), _p(bias), _p(y), B, Hi, Wi, Ci, Co, st)   # the U-Net's tail
+        if Co <= 4 and R == 4 and S == 4 and stride == 2 and pad == 1 and Ci % 8 == 0 and _direct_ok():   # the U-Net's tail
+            if DECONV_GEMM and Ci % 16 == 0:               # products of every input pixel on the matrix pipe + a gather
+                ws = keep(torch.empty(B * Hi * Wi * 16 * Co, device=x.device, dtype=torch.float32))
+                rc = lib.advmix_deconv4x4s2_narrow_gemm(_p(x), _p(w), _p(bias), _p(y), _p(ws), ws.numel() * 4, B, Hi, Wi, Ci, Co, st)
+                if rc == 0:
+                    return (y,), (x, w, bias), None
+                if rc != 1:
+                    raise RuntimeError('advmix_deconv4x4s2_narrow_gemm failed: %d' % rc)
+            call('advmix_deconv4x4s2_narrow', _p(x), _p(w), _p(bias), _p(y), B, Hi, Wi, Ci, Co, st)
             return (y,), (x, w, bias), None
         if Ci % 16 == 0 and Co % 4 == 0 and _direct_ok():
             rc = lib.advmix_conv_tr_w(_p(x), _p(w), _p(bias), _p(y), B, Hi, Wi, Ci, Ho, Wo, Co, R, S,

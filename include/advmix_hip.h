@@ -120,6 +120,14 @@ int advmix_conv_tr_narrow(const float* x, const float* w, float* y, int N, int H
 int advmix_deconv4x4s2_narrow(const float* x, const float* w, const float* bias, float* y, int N, int Hi, int Wi,
                               int Ci, int Co, void* stream);
 
+/* The same layer as ONE 1 x 1 transposed-weight convolution on the matrix pipe - every input pixel's 16 x Cout products into
+ * ws (advmix_deconv4x4s2_narrow_ws_bytes bytes, caller-owned) - and a gather that sums the four products reaching an output
+ * pixel (+ bias): x is read once instead of 16 times (395 -> ~125 us for the U-Net's 128 -> 3 tail at 256x192, B = 32).
+ * ADVMIX_EINVAL (nothing launched): Cout > 4, Cin % 16, ws too small - call advmix_deconv4x4s2_narrow. */
+int64_t advmix_deconv4x4s2_narrow_ws_bytes(int N, int Hi, int Wi, int Co);
+int advmix_deconv4x4s2_narrow_gemm(const float* x, const float* w, const float* bias, float* y, float* ws, int64_t ws_bytes,
+                                   int N, int Hi, int Wi, int Ci, int Co, void* stream);
+
 /* Which tile configuration the second-generation conv kernel picks (introspection for tests / tuning):
  * 1 = 128x32, 2 = 128x64, 3 = 64x64, 4 = 64x64 + K split across the grid (atomics), 5 = 32x32 + K split between
  * the four waves of a workgroup, 6 = 64x32 + K split between two wave pairs, 7 = 64x32 with eight waves (two row tiles

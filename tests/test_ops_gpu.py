@@ -264,6 +264,8 @@ def test_conv2d_fwd_dgrad_wgrad(case, conv_path):
 DECONV_CASES = [
     (2, 64, 4, 3, 32, True), (2, 512, 4, 3, 512, True), (2, 128, 8, 6, 3, True),
     (1, 16, 5, 7, 24, False), (2, 256, 16, 12, 256, False), (2, 2048, 4, 3, 256, False),
+    # narrow outputs (the U-Net's tail): one 1 x 1 GEMM + a gather where Cin % 16 == 0, the VALU kernel otherwise
+    (2, 128, 9, 7, 1, True), (3, 64, 7, 5, 2, False), (2, 128, 9, 6, 4, True), (2, 24, 6, 5, 3, True), (4, 128, 32, 24, 3, True),
 ]
 
 
@@ -289,6 +291,35 @@ def test_conv_transpose2d(case, conv_path):
     check('dw', wg.grad, wr.grad, 2e-4)
     if hb:
         check('db', bg.grad, br.grad, 2e-4)
+
+
+def test_narrow_deconv_gemm_form_equals_the_valu_kernel_and_refuses_what_it_does_not_serve():
+    """advmix_deconv4x4s2_narrow_gemm (round 4) against advmix_deconv4x4s2_narrow on the same tensors (other summation order:
+    fp32 rounding) and against torch; too small a workspace, Cin % 16 != 0 and Cout > 4 are refused with nothing written."""
+    import ctypes
+    from advmix_amd._lib import call, lib
+    _ops()
+    B, Ci, H, W, Co = 3, 128, 10, 7, 3
+    x, w, b = (t.float().to(dev()) for t in (rnd(B, H, W, Ci, seed=21), rnd(Ci, 4, 4, Co, seed=22, scale=0.05), rnd(Co, seed=23)))
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    need = lib.advmix_deconv4x4s2_narrow_ws_bytes(B, H, W, Co)
+    assert need == B * H * W * 16 * Co * 4
+    ws = torch.empty(need // 4, device=dev())
+    y1 = torch.full((B, 2 * H, 2 * W, Co), 7.0, device=dev())
+    y2 = torch.full_like(y1, 7.0)
+    call('advmix_deconv4x4s2_narrow', P(x), P(w), P(b), P(y1), B, H, W, Ci, Co, st)
+    assert lib.advmix_deconv4x4s2_narrow_gemm(P(x), P(w), P(b), P(y2), P(ws), need, B, H, W, Ci, Co, st) == 0
+    ref = F.conv_transpose2d(x.permute(0, 3, 1, 2).double().cpu(), w.permute(0, 3, 1, 2).double().cpu(), b.double().cpu(), 2, 1)
+    check('gemm form vs torch', y2.permute(0, 3, 1, 2), ref, 2e-5)
+    check('gemm form vs valu kernel', y2, y1.cpu().double(), 2e-5)
+    y3 = torch.full_like(y1, 7.0)
+    assert lib.advmix_deconv4x4s2_narrow_gemm(P(x), P(w), P(b), P(y3), P(ws), need - 4, B, H, W, Ci, Co, st) == 1
+    assert lib.advmix_deconv4x4s2_narrow_gemm(P(x), P(w), P(b), P(y3), P(ws), need, B, H, W, 24, Co, st) == 1
+    assert lib.advmix_deconv4x4s2_narrow_gemm(P(x), P(w), P(b), P(y3), P(ws), need, B, H, W, Ci, 5, st) == 1
+    assert lib.advmix_deconv4x4s2_narrow_gemm(P(x), P(w), P(b), P(y3), None, need, B, H, W, Ci, Co, st) == 1
+    torch.cuda.synchronize()
+    assert bool((y3 == 7.0).all())
 
 
 @pytest.mark.parametrize('case', [(4, 32, 16, 12, 1, True), (2, 64, 9, 7, 1, False), (2, 256, 8, 6, 0, True),

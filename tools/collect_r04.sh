@@ -21,7 +21,8 @@ MODE=fwd_stats bash tools/pmc_conv.sh ${TAG}_conv32_epi > $O/pmc_epi.log 2>&1
 MODE=dgrad_bnb bash tools/pmc_conv.sh ${TAG}_conv32_dgrad_bnb > $O/pmc_bnb.log 2>&1
 python tools/summarize_pmc.py gpurun_out/pmc_${TAG}_conv32_epi $O/pmc_conv32_epi.json > /dev/null 2>&1
 python tools/summarize_pmc.py gpurun_out/pmc_${TAG}_conv32_dgrad_bnb $O/pmc_conv32_dgrad_bnb.json $((32*64*48*32*4*4 + 32*64*48*32/4 + 32*9*32*4)) > /dev/null 2>&1
-bash tools/pmc_step.sh $TAG 3 > $O/pmc_step.log 2>&1; cp gpurun_out/pmc_step_$TAG.json $O/ 2>/dev/null
+bash tools/pmc_step.sh $TAG 3 $(python -c "import json; print(json.load(open('$O/bench_line.json'))['ms_per_step'])") > $O/pmc_step.log 2>&1;   # (utilisation against THIS call's step time)
+ cp gpurun_out/pmc_step_$TAG.json $O/ 2>/dev/null
 rm -rf gpurun_out/pmc_${TAG}_conv32_epi gpurun_out/pmc_${TAG}_conv32_dgrad_bnb gpurun_out/pmc_step_${TAG} gpurun_out/pmc_step_${TAG}_fetch gpurun_out/pmc_step_${TAG}_write
 for f in $O/*_bench_line.json $O/bench_line.json; do python -c "import json,sys; d=json.load(open('$f')); print('$f', d.get('value'), d.get('ms_per_step'), (d.get('roofline') or {}).get('frac'), d.get('grad_exchange_verified'), d.get('replicas_identical'))"; done
 python -c "import json; d=json.load(open('$O/pmc_conv32_dgrad_bnb.json')); print('bnb traffic', d['hbm_bytes_per_launch'], d['traffic_ratio'])"

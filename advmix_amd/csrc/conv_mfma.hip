@@ -324,12 +324,6 @@ static void launch_reduce_slices(const float* part, int nslices, int64_t total, 
 // pixel slices per problem (fewer partial tiles to merge with atomics, longer main loops per workgroup) and room for the
 // 128 x 128 tile (one LDS read per MFMA instead of two).  blockIdx.z = problem * slices + slice.
 constexpr int WG_MAXG = 64;
-#ifndef WG_PIPE
-#define WG_PIPE 1
-#endif
-#ifndef WG_VALU
-#define WG_VALU 0           // > 0: also pin that many VALU instructions per k-pair (the solver then gives up on the whole pattern)
-#endif
 struct WgGroup {
     int n, slices;
     const float* a[WG_MAXG];
@@ -580,7 +574,9 @@ __device__ __forceinline__ void wgrad_body(const WgP p, const int bx, const int 
                     acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][t], bv[kk][u], acc[t][u], 0, 0, 0);
         // The operand reads run TWO k-pairs ahead of the MFMAs that use them.  Left alone the compiler reuses one register set:
         // read, wait, 4 MFMAs, read, wait ... - every k-pair's LDS latency (~100 cycles per 256 of MFMA) in the open.
-        if (WG_PIPE) {
+        // (Asking for the address VALU work to be placed as well - a VALU group per k-pair - makes the solver give up on the whole
+        // pattern and fall back to the serial schedule; left alone, the default heuristics interleave it with the MFMAs.)
+        {
             constexpr int DSK = (TM == 2 ? 1 : TM) + (TN == 2 ? 1 : TN);     // LDS instructions per k-pair (pairs fuse to read2)
             constexpr int AHEAD = 2;
             __builtin_amdgcn_sched_group_barrier(0x100, DSK * AHEAD, 0);
@@ -588,7 +584,6 @@ __device__ __forceinline__ void wgrad_body(const WgP p, const int bx, const int 
             for (int kk = 0; kk < KS / 2 - AHEAD; ++kk) {
                 __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, DSK, 0);
-                if (VEC && WG_VALU > 0) __builtin_amdgcn_sched_group_barrier(0x002, WG_VALU, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * AHEAD, 0);
         }

@@ -41,7 +41,7 @@ struct ConvD {
     const float *bn_gamma, *bn_beta, *bn_rm, *bn_rv, *res;
     float bn_eps;
     int act;
-    double* stats;          // [2][Co][stats_nbg]: (sum, sum of squares), wave slabs folded onto
+    double* stats;          // [2][stats_nbg][Co] (stats_tiles: [2][Co][stats_nbg]): (sum, sum of squares), wave slabs folded onto
     int stats_nbg;          // stats_nbg slots with fp64 atomics; must be zero on entry
     // MODE 1 + EPI: this launch is the input gradient g0 = dL/dy of a tensor y = act(BN(c) + residual) (train mode).
     // The epilogue multiplies by the activation's slope (through y), writes g = g0 * act'(y) and accumulates the two
@@ -650,9 +650,12 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
                 p.stats[(int64_t)(n0 + tid) * p.stats_nbg + pb] = d1;
                 p.stats[((int64_t)p.Co + n0 + tid) * p.stats_nbg + pb] = d2;
             } else {
+                // slot-major, [2][slots][Co]: the BN threads' atomics are consecutive doubles - a few cache-line requests per
+                // workgroup where the channel-major layout of rounds 2-3 ([2][Co][slots]: one line per thread, and every
+                // channel's slots in ONE run of lines) made 2 BN of them (round 4: -0.5 ... -1.5 us per launch, -5 at 1x1 64->256)
                 const int pb = bx % p.stats_nbg;
-                atomicAdd(p.stats + (int64_t)(n0 + tid) * p.stats_nbg + pb, d1);
-                atomicAdd(p.stats + ((int64_t)p.Co + n0 + tid) * p.stats_nbg + pb, d2);
+                atomicAdd(p.stats + (int64_t)pb * p.Co + n0 + tid, d1);
+                atomicAdd(p.stats + ((int64_t)p.stats_nbg + pb) * p.Co + n0 + tid, d2);
             }
         }
     }

@@ -209,14 +209,16 @@ __global__ void norm_partial_scalar(const float* __restrict__ x, const float* __
 // (Measured and rejected: letting the last-arriving partial block do this in the same launch -
 // sc1 partial stores + ticket + acquire, placement-independent and correct, but the serial tail on
 // one CU costs more than the launch it saves: 108.6 vs 87.7 ms per AdvMix step.)
+// ``sm`` (slot-major): the conv epilogues' slots[2][nbg][C] (groups == 1) instead of norm_partial's [g][2][C][nbg].
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partial, int nbg, int g, int c, int C,
-                                                int lane, double& s, double& ss) {
+                                                int lane, double& s, double& ss, bool sm = false) {
     s = 0.0; ss = 0.0;
-    const double* p0 = partial + ((int64_t)g * 2 * C + c) * nbg;
-    const double* p1 = partial + ((int64_t)g * 2 * C + C + c) * nbg;
+    const double* p0 = sm ? partial + c : partial + ((int64_t)g * 2 * C + c) * nbg;
+    const double* p1 = sm ? partial + (int64_t)nbg * C + c : partial + ((int64_t)g * 2 * C + C + c) * nbg;
+    const int64_t str = sm ? C : 1;
     for (int b = lane; b < nbg; b += 64) {
-        s += p0[b];
-        ss += p1[b];
+        s += p0[b * str];
+        ss += p1[b * str];
     }
     s = wave_sum_d(s);
     ss = wave_sum_d(ss);
@@ -233,11 +235,11 @@ __global__ __launch_bounds__(256) void norm_finalize_fwd(const double* __restric
     if (i >= groups * C) return;
     const int g = i / C, c = i - g * C;
     double s, ss;
-    reduce_partials(partial, nbg, g, c, C, lane, s, ss);
-    if (zero_after) {                                    // atomically accumulated slots: leave them clean
+    reduce_partials(partial, nbg, g, c, C, lane, s, ss, zero_after != nullptr);
+    if (zero_after) {                                    // atomically accumulated slots ([2][nbg][C]): leave them clean
         for (int b = lane; b < nbg; b += 64) {
-            zero_after[((int64_t)g * 2 * C + c) * nbg + b] = 0.0;
-            zero_after[((int64_t)g * 2 * C + C + c) * nbg + b] = 0.0;
+            zero_after[(int64_t)b * C + c] = 0.0;
+            zero_after[((int64_t)nbg + b) * C + c] = 0.0;
         }
     }
     if (lane != 0) return;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(const float* __restrict__ 
 
 // ---- statistics folded into their consumer ------------------------------------------------------------------------
 // The conv epilogues (conv_direct: forward column sums; transposed gather: BatchNorm-backward sums) add their
-// per-workgroup fp64 partial sums into ``ns`` slots per channel, slots[2][C][ns].  The kernels below reduce the slots
+// per-workgroup fp64 partial sums into ``ns`` slots per channel, slots[2][ns][C].  The kernels below reduce the slots
 // THEMSELVES (every workgroup, for the <= 64 channels it streams) instead of waiting for a one-wave-per-channel
 // finalize launch in between: 2 x 593 launches of ~4.9 us per AdvMix step were 6.9 % of the kernel time and sat on the
 // critical path of every conv -> BN -> conv chain.  The slots are per layer and zero-filled once per network pass
@@ -394,9 +396,10 @@ __global__ __launch_bounds__(256) void norm_bwd_apply(const float* __restrict__ 
 constexpr int SLOT_CT = 64;                              // channels per workgroup (channel tile)
 
 // sums[k][ch] = sum over the ns slots of statistic k of channel ct0 + ch (ch < ctn <= 64); ns a power of two <= 64.
-// Every (statistic, channel) pair is summed by 256 / pairs threads ("parts"), each loading ITS contiguous run of
-// slots with independent 16-byte loads before the first add (a load -> shuffle loop waited one L2 round trip per
-// iteration: 18.7 instead of 6.3 us for the whole apply launch at 64 slots), then the parts meet in LDS.
+// Slot-major layout (round 4), slots[2][ns][C]: every (statistic, channel) pair is summed by 256 / pairs threads ("parts"),
+// each taking ITS run of slots - one 8-byte load per slot, a wave's loads of one slot contiguous over the channels - all
+// issued before the first add (a load -> shuffle loop waited one L2 round trip per iteration: 18.7 instead of 6.3 us for
+// the whole apply launch at 64 slots), then the parts meet in LDS.
 __device__ __forceinline__ void reduce_slots(const double* __restrict__ slots, int ns, int C, int ct0, int ctn,
                                              double (*sums)[SLOT_CT], double* red /* [4][2 * SLOT_CT] */) {
     const int tid = threadIdx.x;
@@ -404,24 +407,19 @@ __device__ __forceinline__ void reduce_slots(const double* __restrict__ slots, i
     int parts = 256 / pairs;                             // >= 2
     if (parts > 4) parts = 4;
     if (parts > ns) parts = ns;
-    const int per = ns / parts;                          // slots per part (ns and parts are powers of two)
+    const int per = ns / parts;                          // slots per part (ns and parts are powers of two): <= 32
     const int pr = tid % pairs, part = tid / pairs;
     if (part < parts) {
         const int k = pr / ctn, ch = pr - k * ctn;
-        const double* src = slots + ((int64_t)k * C + ct0 + ch) * ns + part * per;
+        const double* src = slots + ((int64_t)k * ns + part * per) * C + ct0 + ch;
+        double v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            if (i < per) v[i] = src[(int64_t)i * C];
         double acc = 0.0;
-        if (per >= 2) {
-            typedef double d2 __attribute__((ext_vector_type(2)));
-            d2 v[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (2 * i < per) v[i] = *reinterpret_cast<const d2*>(src + 2 * i);
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (2 * i < per) acc += v[i][0] + v[i][1];
-        } else {
-            acc = src[0];
-        }
+        for (int i = 0; i < 32; ++i)
+            if (i < per) acc += v[i];
         red[part * (2 * SLOT_CT) + pr] = acc;
     }
     __syncthreads();
@@ -569,7 +567,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_slots_kernel(
 
 // Deterministic mode: the conv epilogues STORE one partial per row tile (stats[2][C][cnt], conv_direct.hip
 // ConvD::stats_tiles); one wave per (statistic, channel) adds them in a fixed order - lane l takes l, l + 64, ... in
-// sequence, then a fixed butterfly - and writes the total as slot 0 of the ns = 1 layout [2][C][1] the consumers read.
+// sequence, then a fixed butterfly - and writes the total as slot 0 of the ns = 1 layout [2][1][C] the consumers read.
 __global__ __launch_bounds__(256) void stats_fold_kernel(const double* __restrict__ part, int cnt, int pairs,
                                                          double* __restrict__ out) {
     const int pair = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -715,7 +713,7 @@ extern "C" int advmix_norm_bwd(const float* dy, const float* y, int ldy, const f
 }
 
 // Train-mode BatchNorm forward whose statistics were accumulated by the producing conv's epilogue into
-// slots[2][C][ns] (fp64, see conv_direct.hip): reduces them, writes mean / invstd, updates the running statistics and
+// slots[2][ns][C] (fp64, see conv_direct.hip): reduces them, writes mean / invstd, updates the running statistics and
 // applies y = act(BN(c) + residual) in ONE launch.  ``act_mask`` (may be NULL): [rows][C / 4] bytes, bit e of byte
 // (row, ch / 4) = "BN(c) + residual > 0 at channel 4 * (ch / 4) + e" - what a ReLU / LeakyReLU backward needs of y, at 1/16
 // of its bytes (advmix_conv_tr_w_bnb reads it).  Returns ADVMIX_EINVAL (and launches nothing) for shapes it does
@@ -734,7 +732,7 @@ extern "C" int advmix_norm_apply_slots(const float* c, const double* slots, int 
     return ADVMIX_OK;
 }
 
-// BatchNorm backward (groups = 1) whose two channel sums were left in slots[2][C][ns] by the input-gradient conv
+// BatchNorm backward (groups = 1) whose two channel sums were left in slots[2][ns][C] by the input-gradient conv
 // that produced ``g`` (= dy * act'(y), see advmix_conv_tr_w_bnb): dx, and dgamma += / dbeta += when given.
 extern "C" int advmix_norm_bwd_apply_slots(const float* g, const float* c, const float* mean, const float* invstd,
                                            const float* gamma, const double* slots, int ns, int64_t rows, int C,
@@ -748,7 +746,7 @@ extern "C" int advmix_norm_bwd_apply_slots(const float* g, const float* c, const
 }
 
 // Deterministic mode: fold the per-tile partial sums a conv epilogue stored (partials[2][C][count], see
-// advmix_conv_fwd_ex / advmix_conv_tr_w_bnb with *stats_nbg = -capacity) into slots_out[2][C][1] in a fixed order.
+// advmix_conv_fwd_ex / advmix_conv_tr_w_bnb with *stats_nbg = -capacity) into slots_out[2][1][C] in a fixed order.
 extern "C" int advmix_stats_fold(const double* partials, int count, int C, double* slots_out, void* stream) {
     if (!partials || !slots_out || count <= 0 || C <= 0) return ADVMIX_EINVAL;
     hipLaunchKernelGGL(stats_fold_kernel, dim3(cdiv(2 * C, 4)), dim3(256), 0, (hipStream_t)stream, partials, count, 2 * C,

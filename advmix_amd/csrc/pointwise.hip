@@ -236,9 +236,9 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(FuseBwdArgs a, const floa
                 if (qn == 0) {
 #pragma unroll
                     for (int t = 0; t < 3; ++t)
-                        if (t < nt) atomicAdd(tsl[t] + (int64_t)ch * a.ns + pb, acc.v[e]);
+                        if (t < nt) atomicAdd(tsl[t] + (int64_t)pb * C + ch, acc.v[e]);       // slot-major: [2][ns][C]
                 } else {
-                    atomicAdd(tsl[qn == 0 ? 0 : qn - 1] + ((int64_t)C + ch) * a.ns + pb, acc.v[e]);
+                    atomicAdd(tsl[qn == 0 ? 0 : qn - 1] + ((int64_t)a.ns + pb) * C + ch, acc.v[e]);
                 }
             }
         }
@@ -406,7 +406,7 @@ extern "C" int advmix_fuse_sum_bwd(const float* dy, const float* y, float* g_out
 
 // advmix_fuse_sum_bwd in one launch + the BatchNorm-backward channel sums of the sources that are conv + BN outputs.
 // bnb_c[j] != null: source j is the output (no activation) of a train-mode conv + BN whose raw conv output is bnb_c[j],
-// saved statistics bnb_mean[j] / bnb_invstd[j]; its sums are ADDED to bnb_slots[j] ([2][C][ns] fp64, pre-zeroed).
+// saved statistics bnb_mean[j] / bnb_invstd[j]; its sums are ADDED to bnb_slots[j] ([2][ns][C] fp64, pre-zeroed).
 // g_out may be null when no same-resolution source needs a gradient.  ADVMIX_EINVAL: shape not served (C / 4 must
 // divide 256, at most three same-resolution targets) - nothing launched, use advmix_fuse_sum_bwd.
 extern "C" int advmix_fuse_sum_bwd_bnb(const float* dy, const float* y, float* g_out, float* const* dins,

@@ -99,7 +99,7 @@ _WARNED = {}
 class StatArena:
     """The fp64 statistics slots of ONE network: for every conv -> train-mode BatchNorm pair a forward set
     (column sum / sum of squares of the conv output, written by the conv's epilogue) and a backward set (sum g,
-    sum g * xhat, written by the epilogue of the input-gradient conv that produces g), each [2][C][STAT_SLOTS].
+    sum g * xhat, written by the epilogue of the input-gradient conv that produces g), each [2][STAT_SLOTS][C] (slot-major since round 4).
     The consumers (norm_apply_slots / norm_bwd_apply_slots) reduce the slots themselves - no finalize launch - and
     nobody re-zeroes them in a kernel: the whole arena is zero-filled ONCE at the start of every training forward
     (``begin_pass``, on the caller's stream before any lane forks; ~10 MB for HRNet-W32).  ``pass_id`` / ``dirty``

@@ -57,7 +57,7 @@ int advmix_conv_fwd(const float* x, const float* w, const float* bias, float* y,
 
 /* Conv2d forward with a fused epilogue.  Eval-mode BatchNorm (bn_* all non-NULL or all NULL): y =
  * act((conv + bias - rm) / sqrt(rv + eps) * gamma + beta + residual).  stats != NULL: additionally writes
- * column sums of the RAW conv output, ACCUMULATED with fp64 atomics into stats[2][Co][*stats_nbg] (the buffer
+ * column sums of the RAW conv output, ACCUMULATED with fp64 atomics into stats[2][*stats_nbg][Co] (slot-major; the buffer
  * must be zero on entry; advmix_norm_finalize consumes it and leaves it zero), so a following train-mode
  * BatchNorm needs no statistics pass.  Returns
  * ADVMIX_EINVAL when the shape is served by a kernel without the fused epilogue (Cin % 16 != 0, K-split
@@ -210,11 +210,11 @@ int64_t advmix_norm_ws_bytes(int groups, int C);
 int advmix_norm_stats(const float* x, int groups, int64_t rows_per_group, int C, float eps,
                       float* mean, float* invstd, float* running_mean, float* running_var,
                       int64_t* num_batches_tracked, float momentum, void* ws, void* stream);
-/* groups == 1 statistics from the sums accumulated by advmix_conv_fwd_ex: partial[2][C][nbg]; zeroes them. */
+/* groups == 1 statistics from the sums accumulated by advmix_conv_fwd_ex: partial[2][nbg][C] (slot-major); zeroes them. */
 int advmix_norm_finalize(double* partial, int nbg, int64_t rows, int C, float eps, float* mean,
                          float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                          float momentum, void* stream);
-/* Train-mode BatchNorm forward with the finalize folded in: reduces the slots[2][C][ns] sums left by
+/* Train-mode BatchNorm forward with the finalize folded in: reduces the slots[2][ns][C] sums left by
  * advmix_conv_fwd_ex (every workgroup for the channels it streams), writes mean / invstd (saved for backward), updates
  * the running statistics / num_batches_tracked (may be NULL) and applies y = act(BN(c) + residual) in ONE launch.
  * The slots are NOT re-zeroed (the caller zero-fills its per-layer slots once per network pass).
@@ -234,7 +234,7 @@ int advmix_norm_bwd_apply_slots(const float* g, const float* c, const float* mea
 /* Deterministic statistics (bit-reproducible runs, ops.set_deterministic): call advmix_conv_fwd_ex / advmix_conv_tr_w_bnb
  * with *stats_nbg = -capacity; the epilogue then STORES one partial per row tile, stats[2][C][count] (no atomics), and
  * returns count in *stats_nbg (ADVMIX_EINVAL, nothing launched, if count > capacity).  advmix_stats_fold adds the partials
- * in a fixed order into slots_out[2][C][1], which advmix_norm_apply_slots / advmix_norm_bwd_apply_slots read with ns = 1. */
+ * in a fixed order into slots_out[2][1][C], which advmix_norm_apply_slots / advmix_norm_bwd_apply_slots read with ns = 1. */
 int advmix_stats_fold(const double* partials, int count, int C, double* slots_out, void* stream);
 /* y = act((x - mean)*invstd*gamma + beta + residual); gamma/beta/residual may be NULL.
  * y rows have stride ldy floats (>= C) so the result can land in a channel slice. */
@@ -271,7 +271,7 @@ int advmix_fuse_sum_bwd(const float* dy, const float* y, float* g_out, float* co
                         void* stream);
 /* The same in ONE launch, leaving the BatchNorm-backward channel sums (sum g_j, sum g_j * xhat_j) of the sources that
  * are outputs of a train-mode conv + BN (pose_hrnet.py:196-232: the fuse layers end in BN without activation) in
- * their fp64 slots [2][C][ns] (pre-zeroed, added to): advmix_norm_bwd_apply_slots then finishes that BatchNorm's
+ * their fp64 slots [2][ns][C] (pre-zeroed, added to): advmix_norm_bwd_apply_slots then finishes that BatchNorm's
  * backward in one launch.  bnb_c[j] == NULL: source j has no such target.  ADVMIX_EINVAL = shape not served, nothing
  * launched (use advmix_fuse_sum_bwd). */
 int advmix_fuse_sum_bwd_bnb(const float* dy, const float* y, float* g_out, float* const* dins_host,

@@ -201,8 +201,8 @@ def test_grouped_conv_launch_equals_single_launches(mode):
         assert not torch.isnan(y1).any()
         assert torch.equal(y0, y1), 'problem %d' % i
         if mode in ('fwd_stats', 'dgrad_bnb'):
-            a = s0[:2 * t['C'] * n0].view(2, t['C'], n0).sum(-1)
-            b = s1[:2 * t['C'] * n1].view(2, t['C'], n1).sum(-1)
+            a = s0[:2 * t['C'] * n0].view(2, n0, t['C']).sum(1)
+            b = s1[:2 * t['C'] * n1].view(2, n1, t['C']).sum(1)
             # (fp32 per-workgroup partial sums: a group keeps four-wave workgroups where the single launch takes the
             #  eight-wave form - one row tile per workgroup instead of two - so the fp64 totals differ by fp32 rounding)
             assert n0 > 0 and n1 > 0 and torch.allclose(a, b, rtol=2e-6, atol=1e-5)
@@ -561,7 +561,7 @@ def test_bn_backward_epilogue_sign_from_mask_and_from_c(case):
         check(tag + ' g', gout, want, 2e-5)
         assert bool((gout.cpu()[~pos] == 0).all()), tag                      # exactly the stored y's sign, not a near miss
         xh = (c.double() - mean.cpu().double()) * invstd.cpu().double()
-        sums = st_slots[:2 * C * ns.value].view(2, C, ns.value).sum(-1).cpu()
+        sums = st_slots[:2 * C * ns.value].view(2, ns.value, C).sum(1).cpu()
         check(tag + ' sum g', sums[0], want.reshape(-1, C).sum(0), 2e-5)
         check(tag + ' sum g xhat', sums[1], (want * xh).reshape(-1, C).sum(0), 2e-5)
     # an activation with neither a mask nor gamma / beta is refused
@@ -829,7 +829,7 @@ def test_fuse_sum_backward_one_launch_with_bn_backward_sums(shape):
     for a, b in zip(outs0, outs1):
         assert (a is None and b is None) or torch.equal(a, b)
     for j, s in enumerate(shifts):
-        sl = slots[j].view(2, C, NS).sum(-1).cpu()
+        sl = slots[j].view(2, NS, C).sum(1).cpu()
         if not tgt[j]:
             assert float(sl.abs().max()) == 0.0
             continue

@@ -28,7 +28,7 @@ else:
         call('advmix_conv_tr_w_bnb', P(x), P(w), P(x2), P(y), B, H, W, C, H, W, C, 3, 3, 1, 1, P(mk), P(cc), P(mean), P(invstd), None, None, 1,
              P(slots), ctypes.byref(nbg), st)
 slots.zero_(); run(); torch.cuda.synchronize()
-ck = (float(y.double().sum()), float(y.double().abs().sum()), float(slots.view(2, C, -1).sum(-1).abs().sum()))
+ck = (float(y.double().sum()), float(y.double().abs().sum()), float(slots.view(2, -1, C).sum(1).abs().sum()))
 for _ in range(20):
     run()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -79,8 +79,8 @@ for i, t in enumerate(T):
     assert torch.equal(t['y'], t['y2']), 'branch %d differs' % i
     if mode in ('fwd_stats', 'dgrad_bnb'):
         ns = arr[i].stats_ns
-        a = t['slots'][:2 * t['C'] * ns].view(2, t['C'], ns).sum(-1)
-        b = t['slots2'][:2 * t['C'] * ns].view(2, t['C'], ns).sum(-1)
+        a = t['slots'][:2 * t['C'] * ns].view(2, ns, t['C']).sum(1)
+        b = t['slots2'][:2 * t['C'] * ns].view(2, ns, t['C']).sum(1)
         assert torch.allclose(a, b, rtol=1e-9, atol=1e-6), 'branch %d sums differ' % i
 print('grouped launch == single launches (outputs bit-identical)')
 

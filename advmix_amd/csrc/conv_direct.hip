@@ -853,16 +853,14 @@ static int prepare(int mode, const float* x, const float* w, const float* bias, 
     static const int xcd_remap = [] { const char* e = getenv("ADVMIX_XCD_REMAP"); return e ? atoi(e) : 1; }();
     p.xcd_remap = xcd_remap;
     // Slots per channel the workgroup sums are folded onto: many row blocks hammering few addresses serialise the
-    // fp64 atomics at the memory side (3x3 32->32 @64x48, 768 workgroups: 30.8 us with 16 slots, 23.1 with 64), while
-    // every consumer workgroup has to reduce all of them again - 64 only where the contention is real.
+    // fp64 atomics at the memory side, while every consumer workgroup has to reduce all of them again.  (Channel-major
+    // slots, rounds 2-3: 3x3 32->32 @64x48, 768 workgroups, 30.8 us with 16 slots, 23.1 with 64.  Slot-major - a workgroup's
+    // atomics are a few whole cache lines - the count stopped mattering below 32.)
     // *stats_nbg < 0 (deterministic mode): -capacity - one slot per row tile, plain stores (see ConvD::stats_tiles)
     const bool tiles = epi && epi->stats && stats_nbg && *stats_nbg < 0;
     int ns = stats_nbg && *stats_nbg > 0 ? *stats_nbg : advmix_opts().stat_slots;
-    if (ns <= 0) {                                         // (longer kernels spread their atomics over more time:
-        int ph_, nch_;                                     //  HRNet-W48 384x288 is faster with fewer slots to re-read)
-        direct::problem_shape(mode, Ci, R, S, stride, Ci % 32 == 0 ? 32 : 16, &ph_, &nch_);
-        ns = cdiv(Mmax, 128) >= 256 ? (nch_ <= 12 ? 64 : 32) : 16;     // (8 / 4 for the small grids: 587 / 586-590 vs 594 images/s, round 4)
-    }
+    if (ns <= 0) ns = 16;      // (slot-major layout, round 4: 16 everywhere 606.9 / 606.6 images/s, 8: 606.8 / 607.1, 4: 605.7 / 606.4, the
+                               //  channel-major rule - 64 / 32 for the large grids, 16 for the small - 604.9 / 605.3, 64: 598.0 / 599.8)
     if (ns > 64 || (ns & (ns - 1))) ns = 16;
     p.stats_nbg = ns;
     p.stats_tiles = tiles ? 1 : 0;

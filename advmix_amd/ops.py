@@ -79,7 +79,7 @@ def _grad_buf(p, st):
 
 _ws_cache = {}
 WS_BYTES = 48 << 20      # fixed per-lane scratch: norm partials need <= 512*2*C*8 B (C = 2048: 16.8 MB)
-STAT_SLOTS = 64          # capacity reserved per channel and statistic; a launch uses 16 or 64 of them (conv_direct.hip)
+STAT_SLOTS = 64          # capacity reserved per channel and statistic; a launch uses 16 of them (conv_direct.hip; ADVMIX_STAT_SLOTS)
 STAT_SLOTS_ASK = int(__import__('os').environ.get('ADVMIX_STAT_SLOTS', '0'))   # 0 = the kernel's choice
 
 

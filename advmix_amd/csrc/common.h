@@ -93,6 +93,13 @@ inline int advmix_env_int(const char* name, int dflt) {
     const int v = e ? atoi(e) : dflt;
     return v > 0 ? v : dflt;
 }
+
+// Fewest pixels a weight-gradient workgroup reduces over (the pixel axis is split over workgroups to fill the chip; every slice
+// merges its tile into dW with atomics that serialise per cache line).  ADVMIX_WGRAD_MINPIX.
+inline int advmix_wgrad_min_pix() {
+    static const int v = [] { int x = advmix_env_int("ADVMIX_WGRAD_MINPIX", 64); return x < 32 ? 32 : x; }();
+    return v;
+}
 inline int advmix_stream_cap() {
     static const int v = advmix_env_int("ADVMIX_STREAM_WGS", 2048);
     return v;

@@ -874,7 +874,7 @@ static int wgrad_impl(const float* a, const float* b, float* dw, int N, int Ha, 
         int tiles = cdiv(Ca, 32 * WM_ * TM_) * cdiv(Ntot, 32 * WN_ * TN_);                \
         int64_t ns = wgrad_target_blocks() / tiles;                                       \
         if (ns < 1) ns = 1;                                                               \
-        int64_t maxs = (P + 63) / 64;                                                     \
+        int64_t maxs = (P + advmix_wgrad_min_pix() - 1) / advmix_wgrad_min_pix();         \
         if (ns > maxs) ns = maxs;                                                         \
         int64_t chunk = ((P + ns - 1) / ns + 31) / 32 * 32;                               \
         p.chunk = (int)chunk;                                                             \

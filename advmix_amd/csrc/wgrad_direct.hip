@@ -155,7 +155,7 @@ int launch(WP& p, hipStream_t st) {
     const int tiles = cdiv(p.Ca, 32 * TM) * ((p.R * p.S * p.Cb) / (32 * TN));
     int64_t ns = 768 / tiles;                               // ~3 workgroups per CU
     if (ns < 1) ns = 1;
-    int64_t maxs = (P + 63) / 64;                           // at least 16 pixels (2 load batches) per wave
+    int64_t maxs = (P + advmix_wgrad_min_pix() - 1) / advmix_wgrad_min_pix();   // (>= 16 pixels = 2 load batches per wave)
     if (ns > maxs) ns = maxs;
     int64_t chunk = ((P + ns - 1) / ns + 31) / 32 * 32;     // multiple of 32: a multiple of 8 per wave
     p.chunk = (int)chunk;

@@ -404,6 +404,8 @@ def test_norm_statistics_survive_large_mean(ratio):
     (32, 256, 8, 6, 256, 3, 1, 1, 1, True),     # wave K-split: fused epilogue (ksplit_wg = 1) vs grid split (0)
     (2, 3, 32, 24, 64, 3, 2, 1, 1, False),      # Cin = 3: first-generation conv + separate norm
     (3, 48, 20, 12, 96, 3, 2, 1, 1, False),
+    (3, 32, 12, 10, 6, 3, 1, 1, 1, False),      # Cout % 4 != 0: the sums come from the epilogue's slots, finalize + apply are separate
+    (4, 16, 9, 7, 10, 1, 1, 0, 0, True),
 ])
 @pytest.mark.parametrize('ksplit_wg', [0, 1])
 def test_conv_bn_fused_member(case, ksplit_wg):
@@ -457,6 +459,34 @@ def _conv_bn_fused_member(case):
             check('dbeta', bg.grad, br.grad, 5e-4)
             if has_res:
                 check('dres', rg.grad, rr.grad)
+
+
+@pytest.mark.parametrize('C,ns', [(6, 16), (32, 16), (10, 4), (64, 64), (7, 1)])
+def test_norm_finalize_reads_and_clears_slot_major_slots(C, ns):
+    """advmix_norm_finalize on the conv epilogues' slots, slot-major [2][ns][C] since round 4 (the path ConvBN takes when
+    norm_apply_slots refuses a channel count): mean / invstd / running statistics from the slots' sums, slots zero afterwards."""
+    from advmix_amd._lib import call
+    _ops()
+    d = dev()
+    rows = 4096
+    g_ = torch.Generator().manual_seed(11 + C + ns)
+    x = torch.randn(rows, C, generator=g_, dtype=torch.float64) * 1.7 + 0.3
+    parts = x.view(ns, rows // ns, C)                       # slot s holds the sums of its share of the rows
+    slots = torch.stack([parts.sum(1), (parts * parts).sum(1)]).contiguous().to(d)      # [2][ns][C]
+    mean, invstd = torch.empty(C, device=d), torch.empty(C, device=d)
+    rm, rv = torch.zeros(C, device=d), torch.ones(C, device=d)
+    nbt = torch.zeros((), dtype=torch.int64, device=d)
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: t.data_ptr()
+    call('advmix_norm_finalize', p(slots), ns, rows, C, 1e-5, p(mean), p(invstd), p(rm), p(rv), p(nbt), 0.1, st)
+    torch.cuda.synchronize()
+    var = x.var(0, unbiased=False)
+    check('mean', mean, x.mean(0), 1e-6)
+    check('invstd', invstd, (var + 1e-5).rsqrt(), 1e-6)
+    check('running_mean', rm, 0.1 * x.mean(0), 1e-6)
+    check('running_var', rv, 0.9 + 0.1 * x.var(0, unbiased=True), 1e-6)
+    assert int(nbt) == 1
+    assert bool((slots == 0).all())
 
 
 def _plan_reference(plan, sd, x):

@@ -2,6 +2,7 @@
 interleaved A B A B on the headline workload (HRNet-W32 256x192, B = 32, HIP-graph replay):
   wgrad_all      every weight-gradient launch dropped
   wgrad_c64plus  the weight gradients of the 64- / 128- / 256-channel 3x3 convs only (conv_wgrad<2,2,true,1,1>)
+  wgrad_small    the weight gradients below 0.5 GFLOP only (the fuse layers' strided 3x3 and 1x1 convs: ~57 launches of 8-23 us)
   norm_lowres    norm_apply_slots / norm_bwd_apply_slots launches on the three low-resolution branches (rows <= 32 x 32 x 24:
                  VERDICT r3 item 5) dropped - an upper bound for grouping them (a grouped launch still does their work)
 usage: python tools/knockout.py [steps]"""
@@ -25,6 +26,9 @@ def wgrad(st, lane, a, b, w, geom):
         return
     if MODE['v'] == 'wgrad_c64plus' and w.shape[2] == 3 and w.shape[0] >= 64 and w.shape[0] == w.shape[1]:
         return
+    if MODE['v'] == 'wgrad_small':                          # B, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad
+        if 2.0 * geom[0] * geom[1] * geom[2] * geom[3] * geom[6] * geom[7] * geom[8] < 0.5e9:
+            return
     return real_wgrad(st, lane, a, b, w, geom)
 
 
@@ -72,5 +76,5 @@ def measure(mode):
 
 
 for rep in range(2):
-    for mode in ('base', 'wgrad_all', 'wgrad_c64plus', 'norm_lowres'):
+    for mode in ('base', 'wgrad_all', 'wgrad_c64plus', 'wgrad_small', 'norm_lowres'):
         print('%-14s %.2f ms/step' % (mode, measure(mode)), flush=True)

@@ -35,6 +35,10 @@ SIGNATURES = {
     'advmix_conv_tr_narrow': [_p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_tr_w_add': [_p, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_tr_w_bnb': [_p, _p, _p, _p] + [_i] * 11 + [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p],
+    'advmix_conv_wino_config': [_i] * 5,
+    'advmix_wino_weights': [_p, _p, _i, _p],
+    'advmix_conv3x3_wino_fwd': [_p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _f, _p, _i, _p, _p, _p],
+    'advmix_conv3x3_wino_dgrad': [_p, _p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p],
     'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_wgrad_group': [_i, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_wgrad_det': [_p, _p, _p] + [_i] * 11 + [_p, _l, _p],
@@ -100,6 +104,8 @@ lib.advmix_conv_group.argtypes = [_i, _i, ctypes.POINTER(ConvProblem), _p]
 lib.advmix_conv_group.restype = ctypes.c_int
 lib.advmix_norm_ws_bytes.argtypes = [_i, _i]
 lib.advmix_norm_ws_bytes.restype = ctypes.c_int64
+lib.advmix_wino_u_floats.argtypes = [_i, _i]
+lib.advmix_wino_u_floats.restype = ctypes.c_int64
 lib.advmix_wgrad_det_ws_bytes.argtypes = [_i, _i, _i, _i]
 lib.advmix_wgrad_det_ws_bytes.restype = ctypes.c_int64
 lib.advmix_deconv4x4s2_narrow_ws_bytes.argtypes = [_i, _i, _i, _i]

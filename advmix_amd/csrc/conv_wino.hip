@@ -1,0 +1,466 @@
+// Winograd F(2x2, 3x3) convolution for gfx950 (fp32 MFMA 32x32x2) - round 5.
+//
+// For the 3x3 / stride 1 / pad 1 C -> C convolutions of HRNet's high-resolution branches (pose_hrnet.py:22-57: 32 -> 32
+// @64x48 and 64 -> 64 @32x24 at 256x192 are 47 % of the forward FLOPs) the direct kernel (conv_direct.hip) sits at 0.41-0.51
+// of the fp32 matrix peak with its main loop 77 % MFMA-busy: the remaining lever is the multiply count itself.
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A          (Lavin & Gray; 16 multiplies per 2x2 outputs and channel pair, not 36)
+// turns the conv into 16 independent [tiles x Ci] . [Ci x Co] products, one per position xi of the 4x4 transformed patch:
+// 2.25x fewer MFMAs, pure fp32 (the transforms are additions and two multiplications by 1/2).
+//
+//   * Weights: U = G g G^T is computed ONCE per forward pass for every eligible conv of a network by ONE launch
+//     (wino_weights; advmix_wino_weights) into a side buffer laid out in MFMA B-fragment order,
+//     U[n tile][xi][k group q][lane][4] - a wave's B operand of (xi, q) is one contiguous 1 KB load, never staged in LDS
+//     (the four waves of a workgroup multiply DIFFERENT xi, so there is nothing to share).  Two images per conv: the
+//     forward one (n = Cout, k = Cin) and the input-gradient one (n = Cin, k = Cout, taps rotated by 180 degrees): a
+//     stride-1 input gradient is the same convolution with the rotated, transposed filter.
+//   * A workgroup = 32 tiles (128 output pixels) x 32 output channels, four waves.  Wave i owns row i of the transformed
+//     patch, xi = (i, 0..3): row i of B^T d needs two of the patch's four pixel rows (8 of its 16 pixels), loaded
+//     straight into the MFMA A-fragment layout (lane = tile, 16 bytes = 4 channels) with bounds-checked buffer loads -
+//     an out-of-image pixel returns 0.0f.  Per 8-channel group: 8 + 4 sixteen-byte loads, 32 additions, 16 MFMAs.
+//   * Inverse transform: the column half (A applied from the right) stays inside the wave's accumulators; the row half
+//     (A^T from the left) adds across the four waves through LDS - one exchange per workgroup.  Wave w then holds output
+//     position (w / 2, w % 2) of the 32 tiles in the accumulator layout and runs the SAME fused epilogues as conv_direct:
+//     BatchNorm column sums (fp64 slots), eval-mode BatchNorm + residual + activation, or - input-gradient role - addend,
+//     activation slope from the bit mask / from c, BatchNorm-backward sums; 16-byte stores through a wave-private
+//     transposer.
+#include "common.h"
+#include <stdio.h>
+
+namespace wino {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;      // >= any buffer size accepted -> loads return 0, stores are dropped
+constexpr int STORE_AUX = 16;              // sc1 (write-through), as conv_direct's epilogue
+constexpr int TP = 36;                     // pitch of the wave-private transposer (floats)
+
+struct WinoP {
+    const float* x;
+    const float* u;           // transformed weights, fragment order (see wino_weights)
+    float* y;
+    int N, H, W, Ci, Co;      // 3x3, stride 1, pad 1: input and output are both H x W
+    int Ht, Wt, HtWt, Mt;     // tiles per column / row / image, tiles in all
+    unsigned mg_hw, mg_w;     // floor(2^32 / d) + 1 for d = HtWt, Wt (exact quotients for the tile counts the host admits)
+    int xbytes, ybytes, ubytes;
+    // role 0 (forward): column sums of the raw output and / or eval-mode BatchNorm, residual, activation
+    const float *bn_gamma, *bn_beta, *bn_rm, *bn_rv, *res;
+    float bn_eps;
+    int act;
+    double* stats;            // [2][stats_nbg][Co] fp64 slots (slot-major), zero on entry
+    int stats_nbg;
+    // role 1 (input gradient): ``res`` is the addend; with bnb_c the epilogue is the BatchNorm-backward one (ConvD in
+    // conv_direct.hip: same fields, same arithmetic)
+    const unsigned char* bnb_mask;
+    const float *bnb_c, *bnb_mean, *bnb_invstd, *bnb_gamma, *bnb_beta;
+    int bnb_act;
+    int xcd_remap;
+};
+
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+__device__ __forceinline__ int acc_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }   // v_mfma_f32_32x32x2 D layout
+
+// NQ = Ci / 8 (k groups of 8 channels: two k-lanes x 4 channels per 16-byte load).  ROLE 0: forward epilogues, 1: input gradient.
+template <int NQ, int ROLE>
+__global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
+    __shared__ __attribute__((aligned(16))) float X[4 * 2 * 4 * 64 * 4];   // [wave][b][r / 4][lane][4]: the row half of the inverse transform
+    __shared__ __attribute__((aligned(16))) float Ts[4 * 32 * TP];         // wave-private transposers
+    __shared__ float sred[2 * 4 * 32];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    int bx = blockIdx.x;
+    if (p.xcd_remap && (gridDim.x & 7) == 0 && gridDim.x >= 16)            // each XCD (and its L2) works through a contiguous
+        bx = (bx & 7) * ((int)gridDim.x >> 3) + (bx >> 3);                  // range of tile rows: halos are L2 hits
+    const int m0 = bx * 32, n0 = blockIdx.y * 32;
+
+    // ---- this lane's tile ------------------------------------------------------------------------------------------
+    const int t = m0 + l31;
+    const bool tok = t < p.Mt;
+    const unsigned tt = tok ? (unsigned)t : 0u;
+    const unsigned img = __umulhi(tt, p.mg_hw);
+    const unsigned rem = tt - img * (unsigned)p.HtWt;
+    const unsigned ty = __umulhi(rem, p.mg_w);
+    const unsigned tx = rem - ty * (unsigned)p.Wt;
+    const int h0 = 2 * (int)ty, w0 = 2 * (int)tx;
+    const int pb = tok ? ((int)img * p.H + h0) * p.W + w0 : -1;            // pixel of the tile's output (0, 0)
+
+    // wave i multiplies row i of B^T d B:   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]  ->  d[ra] + sg * d[rb]
+    const int ra = wid == 0 ? 0 : (wid == 2 ? 2 : 1);
+    const int rb = wid == 3 ? 3 : (wid == 2 ? 1 : 2);
+    const float sg = wid == 1 ? 1.f : -1.f;
+    unsigned ao[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int h = h0 - 1 + (k ? rb : ra);
+        const bool okh = tok && (unsigned)h < (unsigned)p.H;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int w = w0 - 1 + c;
+            const bool ok = okh && (unsigned)w < (unsigned)p.W;
+            ao[k][c] = ok ? (unsigned)(((((int)img * p.H + h) * p.W + w) * p.Ci + lh * 4) * 4) : OOB;
+        }
+    }
+    const unsigned bo = (unsigned)((((blockIdx.y * 16 + wid * 4) * NQ) * 64 + lane) * 16);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, p.ubytes, 0x00020000);
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    f32x4 dn[2][4], bn[4];
+    auto issue = [&](int q) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dn[k][c] = bload(xr, ao[k][c] + (unsigned)(q * 32));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bn[j] = bload(ur, bo + (unsigned)((j * NQ + q) * 1024));
+    };
+    issue(0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        f32x4 rc[4], v[4], bc[4];
+        __builtin_amdgcn_sched_barrier(0);                  // (nothing of group q + 1 is hoisted above group q's MFMAs: its
+                                                            //  transform would wait for loads that were only just issued)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rc[c][e] = __builtin_fmaf(sg, dn[1][c][e], dn[0][c][e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                       // (B^T d) B:  columns [1 0 0 0; 0 1 -1 1; -1 1 1 0; 0 0 0 -1]
+            v[0][e] = rc[0][e] - rc[2][e];
+            v[1][e] = rc[1][e] + rc[2][e];
+            v[2][e] = rc[2][e] - rc[1][e];
+            v[3][e] = rc[1][e] - rc[3][e];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bc[j] = bn[j];
+        if (q + 1 < NQ) issue(q + 1);                       // the next group's loads fly under this group's 16 MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bc[j][e], acc[j], 0, 0, 0);
+    }
+
+    // ---- inverse transform, column half (inside the wave):  M A,  A^T = [1 1 1 0; 0 1 -1 -1] ---------------------------
+    const int oa_ = wid >> 1, ob_ = wid & 1;                // the output position this wave finishes
+    // epilogue read operands (residual / addend, the producer's c, its activation mask): requested now, they arrive under the
+    // exchange.  Chunk qq of the 16-byte view = tile rows 8 qq .. 8 qq + 7 x 32 columns, lane -> (row 8 qq + lane / 8, 4 columns).
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.y), 0, p.ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bnb_c ? p.bnb_c : p.y), 0, p.ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mkr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.bnb_mask ? (const void*)p.bnb_mask : (const void*)p.y), 0, p.ybytes >> 4, 0x00020000);
+    const int pos = oa_ * p.W + ob_;
+    unsigned co4[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        const int pq = __shfl(pb, 8 * qq + (lane >> 3), 64);
+        co4[qq] = pq >= 0 ? (unsigned)(((pq + pos) * p.Co + n0 + ((lane & 7) << 2)) * 4) : OOB;
+    }
+    const bool bnb = ROLE == 1 && p.bnb_c != nullptr;
+    const bool op_a = p.res != nullptr;
+    const bool mask_on = bnb && p.bnb_mask != nullptr && p.bnb_act != ADVMIX_ACT_NONE;
+    f32x4 pq_a[4], pq_c[4];
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        pq_a[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+        pq_c[qq] = pq_a[qq];
+        if (op_a) pq_a[qq] = bload(rr, co4[qq]);
+        if (ROLE == 1 && bnb) pq_c[qq] = bload(cr, co4[qq]);
+    }
+    unsigned mw = 0u;
+    if (ROLE == 1 && mask_on)       // lane (l31, lh): the 16 channels [16 lh, 16 lh + 16) of ITS tile's pixel = 4 mask bytes
+        mw = __builtin_amdgcn_raw_buffer_load_b32(mkr, pb >= 0 ? (unsigned)((pb + pos) * (p.Co >> 2) + ((n0 + 16 * lh) >> 2)) : OOB, 0, 0);
+
+    {
+        f32x16 t0, t1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            t0[r] = (acc[0][r] + acc[1][r]) + acc[2][r];
+            t1[r] = (acc[1][r] - acc[2][r]) - acc[3][r];
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            *reinterpret_cast<f32x4*>(&X[(((wid * 2 + 0) * 4 + r4) * 64 + lane) * 4]) = f32x4{t0[4 * r4], t0[4 * r4 + 1], t0[4 * r4 + 2], t0[4 * r4 + 3]};
+            *reinterpret_cast<f32x4*>(&X[(((wid * 2 + 1) * 4 + r4) * 64 + lane) * 4]) = f32x4{t1[4 * r4], t1[4 * r4 + 1], t1[4 * r4 + 2], t1[4 * r4 + 3]};
+        }
+    }
+    __syncthreads();
+    // ---- row half (across the waves):  Y[0][b] = T0 + T1 + T2,  Y[1][b] = T1 - T2 - T3 -----------------------------------
+    float yv[16];
+    {
+        const float s = oa_ ? -1.f : 1.f;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(&X[((((oa_ + 0) * 2 + ob_) * 4 + r4) * 64 + lane) * 4]);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(&X[((((oa_ + 1) * 2 + ob_) * 4 + r4) * 64 + lane) * 4]);
+            const f32x4 x2 = *reinterpret_cast<const f32x4*>(&X[((((oa_ + 2) * 2 + ob_) * 4 + r4) * 64 + lane) * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yv[4 * r4 + e] = __builtin_fmaf(s, x1[e] + x2[e], x0[e]);
+        }
+    }
+
+    // ---- fused epilogue (conv_direct.hip's, for one tile per wave) -----------------------------------------------------
+    float* const Tx = Ts + wid * (32 * TP);
+    auto wave_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    auto to_acc_layout = [&](const f32x4 (&q)[4], float (&o)[16]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4*>(&Tx[(8 * i + (lane >> 3)) * TP + ((lane & 7) << 2)]) = q[i];
+        wave_fence();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = Tx[acc_row(r, lh) * TP + l31];
+        wave_fence();
+    };
+    float oa[16], oc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oa[r] = 0.f; oc[r] = 0.f; }
+    if (op_a) to_acc_layout(pq_a, oa);
+    if (ROLE == 1 && bnb) to_acc_layout(pq_c, oc);
+
+    const int col = n0 + l31;                               // (Co % 32 == 0: every column is valid)
+    const bool stats = p.stats != nullptr;
+    float bn_is = 1.f, bn_g = 1.f, bn_b = 0.f, bn_m = 0.f;
+    const bool bnf = ROLE == 0 && p.bn_gamma != nullptr;
+    if (bnf) {
+        bn_is = 1.0f / sqrtf(p.bn_rv[col] + p.bn_eps);
+        bn_g = p.bn_gamma[col]; bn_b = p.bn_beta[col]; bn_m = p.bn_rm[col];
+    }
+    float bb_mu = 0.f, bb_is = 0.f, bb_g = 0.f, bb_b = 0.f;
+    if (ROLE == 1 && bnb) { bb_mu = p.bnb_mean[col]; bb_is = p.bnb_invstd[col]; }
+    const bool recompute = ROLE == 1 && bnb && !mask_on && p.bnb_act != ADVMIX_ACT_NONE;
+    if (recompute) { bb_g = p.bnb_gamma[col]; bb_b = p.bnb_beta[col]; }
+    const float bb_slope = act_neg_slope(p.bnb_act);
+    const int mshift = ((l31 >> 2) & 3) * 8 + (l31 & 3);    // this lane's column within its mask word
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, lh);
+        const bool valid = (m0 + row) < p.Mt;
+        float v = yv[r];
+        if (ROLE == 0) {
+            if (valid) { s1 += v; s2 += v * v; }
+            if (bnf) v = (v - bn_m) * bn_is * bn_g + bn_b;
+            if (op_a) v += oa[r];
+            v = act_fwd(v, p.act);
+        } else {
+            if (op_a) v += oa[r];
+            if (bnb) {
+                const float xh = (oc[r] - bb_mu) * bb_is;
+                if (mask_on) {                              // (wave-uniform: every lane takes part in the permute)
+                    const int src = row + ((l31 & 16) << 1);
+                    const unsigned wv = (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)mw);
+                    v = ((wv >> mshift) & 1u) ? v : v * bb_slope;
+                } else if (recompute) {
+                    v = __builtin_fmaf(xh, bb_g, bb_b) > 0.f ? v : v * bb_slope;
+                }
+                if (valid) { s1 += v; s2 += v * xh; }
+            }
+        }
+        yv[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Tx[acc_row(r, lh) * TP + l31] = yv[r];
+    wave_fence();
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(&Tx[(8 * qq + (lane >> 3)) * TP + ((lane & 7) << 2)]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w4), yr, co4[qq], 0, STORE_AUX);
+    }
+    if (stats) {                                            // uniform over the grid
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (lh == 0) {
+            sred[wid * 32 + l31] = s1;
+            sred[(4 + wid) * 32 + l31] = s2;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                d1 += (double)sred[k * 32 + tid];
+                d2 += (double)sred[(4 + k) * 32 + tid];
+            }
+            const int sl = (int)blockIdx.x % p.stats_nbg;  // slot-major [2][slots][Co]: consecutive doubles per workgroup
+            atomicAdd(p.stats + (int64_t)sl * p.Co + n0 + tid, d1);
+            atomicAdd(p.stats + ((int64_t)p.stats_nbg + sl) * p.Co + n0 + tid, d2);
+        }
+    }
+}
+
+// ---- weight transform -------------------------------------------------------------------------------------------------
+// One block of 256 threads = one (n tile of 32, k group of 8) of one image: thread t = 4 * (32 * lh + n) + e holds
+// (n, k = 8 q + 4 lh + e) and writes its 16 values U[xi] at ((ntile * 16 + xi) * NQ + q) * 256 + t - the order in which
+// the conv's lanes read them.  role 0: g[r][s] = w[n][r][s][k] (forward; n = Cout, k = Cin); role 1: g[r][s] = w[k][2 - r][2 - s][n]
+// (input gradient; n = Cin, k = Cout).  G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1].
+struct WinoEnt {
+    const float* w;
+    float* u;
+    int Cn, Ck, role, blk0;
+};
+
+__global__ __launch_bounds__(256) void wino_weights(const WinoEnt* __restrict__ ents, const int* __restrict__ blk_ent) {
+    const WinoEnt e = ents[blk_ent[blockIdx.x]];
+    const int lb = (int)blockIdx.x - e.blk0;
+    const int NQ = e.Ck >> 3;
+    const int nt = lb / NQ, q = lb - nt * NQ;
+    const int t = threadIdx.x;
+    const int cn = nt * 32 + ((t >> 2) & 31), ck = q * 8 + (t >> 7) * 4 + (t & 3);
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            g[r][s] = e.role == 0 ? e.w[((int64_t)(cn * 3 + r) * 3 + s) * e.Ck + ck]
+                                  : e.w[((int64_t)(ck * 3 + (2 - r)) * 3 + (2 - s)) * e.Cn + cn];
+    float a[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        a[0][s] = g[0][s];
+        a[1][s] = 0.5f * ((g[0][s] + g[2][s]) + g[1][s]);
+        a[2][s] = 0.5f * ((g[0][s] + g[2][s]) - g[1][s]);
+        a[3][s] = g[2][s];
+    }
+    float* const out = e.u + ((int64_t)nt * 16 * NQ + q) * 256 + t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float u0 = a[i][0];
+        const float u1 = 0.5f * ((a[i][0] + a[i][2]) + a[i][1]);
+        const float u2 = 0.5f * ((a[i][0] + a[i][2]) - a[i][1]);
+        const float u3 = a[i][2];
+        out[(int64_t)(i * 4 + 0) * NQ * 256] = u0;
+        out[(int64_t)(i * 4 + 1) * NQ * 256] = u1;
+        out[(int64_t)(i * 4 + 2) * NQ * 256] = u2;
+        out[(int64_t)(i * 4 + 3) * NQ * 256] = u3;
+    }
+}
+
+static unsigned magic(unsigned d) { return (unsigned)((1ull << 32) / d) + 1u; }
+
+}  // namespace wino
+
+// Which problems the Winograd kernel serves at all (3x3 / stride 1 / pad 1 is implied by the entry points).
+static bool wino_shape_ok(int N, int H, int W, int Ci, int Co) {
+    if (N <= 0 || H < 4 || W < 4 || (H & 1) || (W & 1)) return false;
+    if (!(Ci == 32 || Ci == 64) || Co % 32 != 0 || Co > 4096) return false;
+    const int64_t Mt = (int64_t)N * (H / 2) * (W / 2);
+    if (Mt * (H / 2) * (W / 2) >= (1ll << 32)) return false;              // the magic-number quotients are exact below this
+    if ((int64_t)N * H * W * (Ci > Co ? Ci : Co) * 4 >= 0x7fffffffLL) return false;
+    return true;
+}
+
+extern "C" int advmix_conv_wino_config(int N, int H, int W, int Ci, int Co) { return wino_shape_ok(N, H, W, Ci, Co) ? 1 : 0; }
+
+// floats of one transformed image (forward or input gradient) of a 3x3 Cn x Ck filter bank
+extern "C" int64_t advmix_wino_u_floats(int Co, int Ci) { return (int64_t)16 * Co * Ci; }
+
+// Transform the filters of n convs in one launch.  ``ents`` (device): n records {w, u, Cn, Ck, role, first block}, ``blk_ent``
+// (device): the record index of each of the ``blocks`` workgroups (a record owns (Cn / 32) * (Ck / 8) consecutive ones).
+// The caller builds both once (ops.py: WinoBank).  Replaces nothing in the reference - cuDNN picks and prepares its own
+// algorithm behind nn.Conv2d (lib/models/pose_hrnet.py:22-25).
+extern "C" int advmix_wino_weights(const void* ents, const int* blk_ent, int blocks, void* stream) {
+    if (!ents || !blk_ent || blocks <= 0) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(wino::wino_weights, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const wino::WinoEnt*)ents, blk_ent);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+static int wino_launch(int role, wino::WinoP& p, hipStream_t st) {
+    dim3 g(cdiv(p.Mt, 32), p.Co / 32);
+    const int NQ = p.Ci / 8;
+#define WL(NQ_, ROLE_) hipLaunchKernelGGL((wino::conv_wino<NQ_, ROLE_>), g, dim3(256), 0, st, p)
+    if (NQ == 4) { if (role) WL(4, 1); else WL(4, 0); }
+    else if (NQ == 8) { if (role) WL(8, 1); else WL(8, 0); }
+    else return ADVMIX_EINVAL;
+#undef WL
+    if (advmix_opts().trace_shapes) {
+        char nm[48];
+        snprintf(nm, sizeof nm, "conv_wino<%d, %d>", NQ, role);
+        advmix_trace_launch(nm, g, role == 0 ? (p.stats ? "fwd+sums" : (p.bn_gamma ? "fwd+bn_eval" : "fwd")) : (p.bnb_c ? "dgrad+bnb" : "dgrad"),
+                            p.N, p.H, p.W, p.Ci, p.H, p.W, p.Co, 3, 3, 1, 2.0 * p.N * (double)p.H * p.W * p.Co * p.Ci * 9);
+    }
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+static int wino_fill(wino::WinoP& p, const float* x, const float* u, float* y, int N, int H, int W, int Ci, int Co) {
+    if (!x || !u || !y || !wino_shape_ok(N, H, W, Ci, Co)) return ADVMIX_EINVAL;
+    p = wino::WinoP{};
+    p.x = x; p.u = u; p.y = y;
+    p.N = N; p.H = H; p.W = W; p.Ci = Ci; p.Co = Co;
+    p.Ht = H / 2; p.Wt = W / 2; p.HtWt = p.Ht * p.Wt; p.Mt = N * p.HtWt;
+    p.mg_hw = wino::magic((unsigned)p.HtWt); p.mg_w = wino::magic((unsigned)p.Wt);
+    p.xbytes = (int)((int64_t)N * H * W * Ci * 4);
+    p.ybytes = (int)((int64_t)N * H * W * Co * 4);
+    p.ubytes = (int)((int64_t)16 * Co * Ci * 4);
+    static const int xcd_remap = [] { const char* e = getenv("ADVMIX_XCD_REMAP"); return e ? atoi(e) : 1; }();
+    p.xcd_remap = xcd_remap;
+    return ADVMIX_OK;
+}
+
+static int wino_slots(const int* stats_ns) {
+    int ns = stats_ns && *stats_ns > 0 ? *stats_ns : advmix_opts().stat_slots;
+    if (ns <= 0 || ns > ADVMIX_STAT_SLOTS_MAX || (ns & (ns - 1))) ns = 16;
+    return ns;
+}
+
+// advmix_conv_fwd_ex for a 3x3 / stride 1 / pad 1 conv whose filters were transformed by advmix_wino_weights (role 0 image
+// ``u``): y = act(BN_eval(conv(x)) + residual) and / or the column (sum, sum of squares) of the raw output into ``stats``
+// ([2][*stats_ns][Co], zero on entry; *stats_ns: in = slots to use or 0, out = slots used).  Returns ADVMIX_EINVAL (nothing
+// launched) for shapes the kernel does not serve: the caller runs advmix_conv_fwd_ex on the untransformed filters.
+// Semantics: lib/models/pose_hrnet.py:22-57 (conv3x3 + BatchNorm2d (+ residual) + ReLU of a BasicBlock).
+extern "C" int advmix_conv3x3_wino_fwd(const float* x, const float* u, float* y, int N, int H, int W, int Ci, int Co,
+                                       const float* bn_gamma, const float* bn_beta, const float* bn_rm, const float* bn_rv,
+                                       float bn_eps, const float* residual, int act, double* stats, int* stats_ns, void* stream) {
+    if ((bn_gamma != nullptr) != (bn_beta && bn_rm && bn_rv)) return ADVMIX_EINVAL;
+    if (stats && !stats_ns) return ADVMIX_EINVAL;
+    if (advmix_opts().deterministic && stats) return ADVMIX_EINVAL;        // fp64 atomics: the ordered form is conv_direct's
+    wino::WinoP p;
+    int rc = wino_fill(p, x, u, y, N, H, W, Ci, Co);
+    if (rc) return rc;
+    p.bn_gamma = bn_gamma; p.bn_beta = bn_beta; p.bn_rm = bn_rm; p.bn_rv = bn_rv; p.bn_eps = bn_eps;
+    p.res = residual; p.act = act; p.stats = stats;
+    p.stats_nbg = wino_slots(stats_ns);
+    rc = wino_launch(0, p, (hipStream_t)stream);
+    if (rc == ADVMIX_OK && stats_ns) *stats_ns = p.stats_nbg;
+    return rc;
+}
+
+// advmix_conv_tr_w_add / advmix_conv_tr_w_bnb for the same convs: dx = conv(dy, rotated transposed filters) + addend from the
+// role 1 image ``u`` (n = Cin, k = Cout); with ``bn_c`` the BatchNorm-backward epilogue of advmix_conv_tr_w_bnb (same
+// arguments, same arithmetic).  dy: [N,H,W,Co], dx / addend / bn_c / mask: [N,H,W,Ci].
+extern "C" int advmix_conv3x3_wino_dgrad(const float* dy, const float* u, const float* addend, float* dx, int N, int H, int W,
+                                         int Co, int Ci, const unsigned char* act_mask, const float* bn_c, const float* bn_mean,
+                                         const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int act,
+                                         double* stats, int* stats_ns, void* stream) {
+    if (bn_c) {
+        if (!bn_mean || !bn_invstd || !stats || !stats_ns) return ADVMIX_EINVAL;
+        if (act != ADVMIX_ACT_NONE && !act_mask && !(bn_gamma && bn_beta)) return ADVMIX_EINVAL;
+        if (advmix_opts().deterministic) return ADVMIX_EINVAL;
+    } else if (stats) {
+        return ADVMIX_EINVAL;
+    }
+    wino::WinoP p;
+    int rc = wino_fill(p, dy, u, dx, N, H, W, Co, Ci);      // the gradient conv reads Co channels and writes Ci
+    if (rc) return rc;
+    p.res = addend;
+    if (bn_c) {
+        p.stats = stats; p.stats_nbg = wino_slots(stats_ns);
+        p.bnb_mask = act_mask; p.bnb_c = bn_c; p.bnb_mean = bn_mean; p.bnb_invstd = bn_invstd;
+        p.bnb_gamma = bn_gamma; p.bnb_beta = bn_beta; p.bnb_act = act;
+    }
+    rc = wino_launch(1, p, (hipStream_t)stream);
+    if (rc == ADVMIX_OK && bn_c) *stats_ns = p.stats_nbg;
+    return rc;
+}

@@ -294,6 +294,68 @@ def _det_stats(C, device, lane):
     return ws, WS_BYTES // 8 // (2 * C)
 
 
+# ---- Winograd F(2x2,3x3) path (csrc/conv_wino.hip) ---------------------------------------------------------------------
+WINO = __import__('os').environ.get('ADVMIX_WINO', '1') != '0'       # A/B switch: 0 = every conv on the direct kernels
+WINO_MIN_TILES = int(__import__('os').environ.get('ADVMIX_WINO_MIN_TILES', '4096'))   # 2x2 output tiles below which the direct kernel stays
+_WINO = {}          # weight data_ptr -> (forward image ptr, input-gradient image ptr), filled by WinoBank
+
+
+class WinoBank:
+    """The transformed-filter images (U = G g G^T, MFMA fragment order) of a set of 3x3 / stride 1 / pad 1 conv weights: one
+    side buffer, one launch to refresh all of it (``refresh``: at the start of every forward pass of the owning network, on
+    the caller's stream before any lane forks - the filters change once per optimizer step and the launch is ~10 us, so
+    nothing tracks versions).  Registers each weight's two images in ``_WINO`` under the weight's device address."""
+
+    def __init__(self, weights):
+        import numpy as np
+        dev = weights[0].device
+        self.key = tuple(w.data_ptr() for w in weights)
+        sizes = [16 * w.shape[0] * w.shape[1] for w in weights]
+        self.buf = torch.empty(2 * sum(sizes), device=dev, dtype=torch.float32)
+        ent = np.zeros(2 * len(weights), dtype=np.dtype([('w', '<u8'), ('u', '<u8'), ('Cn', '<i4'), ('Ck', '<i4'),
+                                                         ('role', '<i4'), ('blk0', '<i4')]))
+        blk, off, owner = 0, 0, []
+        for i, w in enumerate(weights):
+            Co, Ci, R, S = w.shape
+            if (R, S) != (3, 3) or Co % 32 or Ci % 32 or not w.is_contiguous(memory_format=_CL):
+                raise ValueError('WinoBank: 3x3 channels_last weights with Cout, Cin multiples of 32')
+            ptrs = []
+            for role, (Cn, Ck) in enumerate(((Co, Ci), (Ci, Co))):
+                u = self.buf.data_ptr() + 4 * off
+                ent[2 * i + role] = (w.data_ptr(), u, Cn, Ck, role, blk)
+                nb = (Cn // 32) * (Ck // 8)
+                owner += [2 * i + role] * nb
+                blk += nb
+                off += sizes[i]
+                ptrs.append(ctypes.c_void_p(u))
+            _WINO[w.data_ptr()] = tuple(ptrs)
+        self.blocks = blk
+        self.ents = torch.from_numpy(ent.view(np.uint8).copy()).to(dev)
+        self.blk_ent = torch.tensor(owner, dtype=torch.int32).to(dev)
+
+    def matches(self, weights):
+        return self.key == tuple(w.data_ptr() for w in weights)
+
+    def refresh(self, st=None):
+        call('advmix_wino_weights', _p(self.ents), _p(self.blk_ent), self.blocks, st if st is not None else _st())
+
+    def release(self):
+        for k in self.key:
+            _WINO.pop(k, None)
+
+
+def _wino_images(w, B, H, W, Ci, Co, R, S, stride, pad):
+    """(forward image, input-gradient image) of ``w`` when this problem goes to the Winograd kernel, else None."""
+    if not (WINO and R == 3 and S == 3 and stride == 1 and pad == 1) or DETERMINISTIC or not _direct_ok():
+        return None
+    if B * (H // 2) * (W // 2) < WINO_MIN_TILES:
+        return None
+    u = _WINO.get(w.data_ptr())
+    if u is None or not lib.advmix_conv_wino_config(B, H, W, Ci, Co):
+        return None
+    return u
+
+
 def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to=None, bnb=None, lane=0):
     """Input gradient of a conv (+ ``add_to``, another gradient of the same input: summed in the kernel's
     epilogue on the conv_direct path, by advmix_add otherwise).
@@ -307,9 +369,22 @@ def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_
     if Co % 16 == 0 and Ci % 4 == 0 and _direct_ok():          # weights consumed in their own layout
         if add_to is not None and (add_to.shape != dx.shape or add_to.stride() != dx.stride()):
             raise RuntimeError('advmix_amd: gradient fan-in of differently laid out tensors')
+        wu = _wino_images(w, B, Hi, Wi, Co, Ci, R, S, stride, pad)      # (the gradient conv reads Co channels, writes Ci)
         if bnb is not None and BNB_FUSED:
             if tuple(bnb['c'].shape) != tuple(dx.shape) or bnb['c'].stride() != dx.stride():
                 raise RuntimeError('advmix_amd: BatchNorm-backward epilogue on a differently laid out tensor')
+            if wu is not None:
+                nsv = ctypes.c_int(STAT_SLOTS_ASK)
+                rc = lib.advmix_conv3x3_wino_dgrad(_p(dy), wu[1], _p(add_to), _p(dx), B, Hi, Wi, Co, Ci, _p(bnb['mask']),
+                                                   _p(bnb['c']), _p(bnb['mean']), _p(bnb['invstd']), _p(bnb['gamma']),
+                                                   _p(bnb['beta']), bnb['act'], bnb['slots'], ctypes.byref(nsv), st)
+                if rc == 0:
+                    bnb['done'] = nsv.value
+                    COUNTERS['bnb'] += 1
+                    COUNTERS['wino'] = COUNTERS.get('wino', 0) + 1
+                    return dx
+                if rc != 1:
+                    raise RuntimeError('advmix_conv3x3_wino_dgrad failed: %d' % rc)
             if DETERMINISTIC:                               # per-tile partials (plain stores) + an ordered fold: no atomics
                 ws, cap = _det_stats(Ci, x.device, lane)
                 nsv, target = ctypes.c_int(-cap), _p(ws)
@@ -328,6 +403,14 @@ def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_
                 return dx
             if rc != 1:
                 raise RuntimeError('advmix_conv_tr_w_bnb failed: %d' % rc)
+        if wu is not None:
+            rc = lib.advmix_conv3x3_wino_dgrad(_p(dy), wu[1], _p(add_to), _p(dx), B, Hi, Wi, Co, Ci, None, None, None, None,
+                                               None, None, 0, None, None, st)
+            if rc == 0:
+                COUNTERS['wino'] = COUNTERS.get('wino', 0) + 1
+                return dx
+            if rc != 1:
+                raise RuntimeError('advmix_conv3x3_wino_dgrad failed: %d' % rc)
         rc = lib.advmix_conv_tr_w_add(_p(dy), _p(w), _p(add_to), _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
                                       stride, pad, st)
         if rc == 0:
@@ -521,9 +604,17 @@ class ConvBN:
         geom = (B, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad)
         y = empty_nhwc(B, Co, Ho, Wo, x.device)
         fused_ok = _direct_ok() and Ci % 16 == 0
+        wu = _wino_images(w, B, Hi, Wi, Ci, Co, R, S, stride, pad) if fused_ok else None
         if not training:
-            rc = lib.advmix_conv_fwd_ex(_p(x), _p(w), None, _p(y), *geom, _p(gamma), _p(beta), _p(rmean),
-                                        _p(rvar), eps, _p(res), act, None, None, st) if fused_ok else 1
+            rc = 1
+            if wu is not None:                              # Winograd F(2x2,3x3): same fused epilogue, 2.25x fewer MFMAs
+                rc = lib.advmix_conv3x3_wino_fwd(_p(x), wu[0], _p(y), B, Hi, Wi, Ci, Co, _p(gamma), _p(beta), _p(rmean),
+                                                 _p(rvar), eps, _p(res), act, None, None, st)
+                if rc == 0:
+                    COUNTERS['wino'] = COUNTERS.get('wino', 0) + 1
+            if rc == 1:
+                rc = lib.advmix_conv_fwd_ex(_p(x), _p(w), None, _p(y), *geom, _p(gamma), _p(beta), _p(rmean),
+                                            _p(rvar), eps, _p(res), act, None, None, st) if fused_ok else 1
             if rc == 1:                                     # not served by the fused epilogue
                 c = keep(empty_nhwc(B, Co, Ho, Wo, x.device))
                 call('advmix_conv_fwd', _p(x), _p(w), None, _p(c), *geom, st)
@@ -549,8 +640,14 @@ class ConvBN:
                 nbg, target = ctypes.c_int(-cap), _p(ws)    # the layer's slots (ns = 1) - no extra pass over c
             else:
                 nbg, target = ctypes.c_int(STAT_SLOTS_ASK), slots
-            rc = lib.advmix_conv_fwd_ex(_p(x), _p(w), None, _p(c), *geom, None, None, None, None, 0.0, None, 0,
-                                        target, ctypes.byref(nbg), st)
+            if wu is not None and not DETERMINISTIC:
+                rc = lib.advmix_conv3x3_wino_fwd(_p(x), wu[0], _p(c), B, Hi, Wi, Ci, Co, None, None, None, None, 0.0, None, 0,
+                                                 target, ctypes.byref(nbg), st)
+                if rc == 0:
+                    COUNTERS['wino'] = COUNTERS.get('wino', 0) + 1
+            if rc == 1:
+                rc = lib.advmix_conv_fwd_ex(_p(x), _p(w), None, _p(c), *geom, None, None, None, None, 0.0, None, 0,
+                                            target, ctypes.byref(nbg), st)
             if rc == 0 and DETERMINISTIC:
                 call('advmix_stats_fold', target, nbg.value, Co, slots, st)
                 nbg.value = 1

@@ -603,6 +603,38 @@ class PlanNet(nn.Module):
             return (ops.MaxPool, (slots[st[1]],), None)
         raise ValueError(k)
 
+    def _wino_refresh(self, device):
+        """Winograd path (ops.WinoBank, csrc/conv_wino.hip): the 3x3 / stride 1 / pad 1 conv + BatchNorm steps with 32 or 64
+        input channels keep transformed images of their filters in a side buffer; ONE launch re-computes all of them at the
+        start of every forward pass (the filters change once per optimizer step; ~10 us per launch), on the caller's stream
+        before any lane forks.  The bank is rebuilt when the parameters have moved (``.to(device)``, FlatAdam's flat
+        buffer, ``load_state_dict`` of differently placed tensors)."""
+        if not ops.WINO:
+            return
+        names = getattr(self, '_wino_names', None)
+        if names is None:
+            names = []
+            for sts in self._levels:
+                for st in sts:
+                    for sub in (st[1] if st[0] == 'chain' else (st,)):
+                        if sub[0] == 'convbn' and sub[5] == 1 and sub[6] == 1:
+                            names.append(sub[1] + '.weight')
+            self._wino_names = names
+        T = self._tensors()
+        ws = [T[n] for n in names]
+        ws = [w for w in ws if w.is_cuda and tuple(w.shape[2:]) == (3, 3) and w.shape[1] in (32, 64) and w.shape[0] % 32 == 0]
+        if not ws:
+            return
+        bank = getattr(self, '_wino_bank', None)
+        if bank is None or not bank.matches(ws):
+            if bank is not None:
+                bank.release()
+                self._wino_bank = None
+            if torch.cuda.is_current_stream_capturing():   # (building allocates and copies tables: not inside a capture -
+                return                                     #  without images these convs take the direct kernels)
+            bank = self._wino_bank = ops.WinoBank(ws)
+        bank.refresh()
+
     def begin(self, x):
         """Start a level-by-level execution (see PlanRun)."""
         return PlanRun(self, x)
@@ -626,6 +658,8 @@ class PlanRun:
         net.last_cuts = []
         if self.train and torch.is_tensor(x) and x.is_cuda:
             net._arena.begin_pass(x.device)                # zero the statistics slots once, before any lane forks
+        if torch.is_tensor(x) and x.is_cuda:
+            net._wino_refresh(x.device)                    # transformed filters of the Winograd convs, one launch
 
     @property
     def done(self):

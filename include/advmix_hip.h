@@ -107,6 +107,34 @@ int advmix_conv_tr_w_bnb(const float* x, const float* w, const float* addend, fl
                          const unsigned char* act_mask, const float* bn_c, const float* bn_mean, const float* bn_invstd,
                          const float* bn_gamma, const float* bn_beta, int act, double* stats, int* stats_ns, void* stream);
 
+/* ---- Winograd F(2x2,3x3) path for the 3x3 / stride 1 / pad 1 C -> C convs of HRNet's high-resolution branches
+ * (lib/models/pose_hrnet.py:22-57: BasicBlock conv3x3 + BatchNorm2d (+ residual) + ReLU; 32 -> 32 @64x48 and
+ * 64 -> 64 @32x24 are 47 % of the forward FLOPs at 256x192).  16 multiplies per 2x2 outputs and channel pair instead of 36;
+ * fp32 throughout.  The filters are transformed ONCE per forward pass into a side buffer (advmix_wino_weights), never
+ * inside the conv; the conv entry points keep the fused epilogues of advmix_conv_fwd_ex / advmix_conv_tr_w_bnb. */
+
+/* 1 when advmix_conv3x3_wino_fwd / _dgrad serve [N,H,W,Ci] -> [N,H,W,Co] (H, W even, Ci in {32, 64}, Co % 32 == 0), else 0. */
+int advmix_conv_wino_config(int N, int H, int W, int Ci, int Co);
+/* floats of ONE transformed image (forward or input gradient) of a [Co][3][3][Ci] filter bank: 16 * Co * Ci. */
+int64_t advmix_wino_u_floats(int Co, int Ci);
+/* Transform the filters of several convs in one launch.  ents (device): records {const float* w; float* u; int Cn, Ck, role,
+ * blk0;} - role 0: the forward image of w[Cn][3][3][Ck] (n = Cout, k = Cin), role 1: the input-gradient image of
+ * w[Ck][3][3][Cn] (n = Cin, k = Cout, taps rotated by 180 degrees); a record owns the (Cn / 32) * (Ck / 8) workgroups from
+ * blk0 on.  blk_ent (device): record index of each of the `blocks` workgroups.  u is written in the order the conv's lanes
+ * read it: u[n / 32][xi][k / 8][32 * ((k % 8) / 4) + n % 32][k % 4], xi = 4 * row + column of G g G^T. */
+int advmix_wino_weights(const void* ents, const int* blk_ent, int blocks, void* stream);
+/* advmix_conv_fwd_ex (no bias) from the role 0 image u: same epilogue arguments, same results to rounding.  ADVMIX_EINVAL
+ * (nothing launched) when advmix_conv_wino_config is 0, or in deterministic mode with stats. */
+int advmix_conv3x3_wino_fwd(const float* x, const float* u, float* y, int N, int H, int W, int Ci, int Co,
+                            const float* bn_gamma, const float* bn_beta, const float* bn_rm, const float* bn_rv,
+                            float bn_eps, const float* residual, int act, double* stats, int* stats_ns, void* stream);
+/* advmix_conv_tr_w_add (bn_c NULL) / advmix_conv_tr_w_bnb (bn_c given) from the role 1 image u: dx[N,H,W,Ci] from
+ * dy[N,H,W,Co]; addend, bn_c and act_mask are laid out like dx. */
+int advmix_conv3x3_wino_dgrad(const float* dy, const float* u, const float* addend, float* dx, int N, int H, int W,
+                              int Co, int Ci, const unsigned char* act_mask, const float* bn_c, const float* bn_mean,
+                              const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int act,
+                              double* stats, int* stats_ns, void* stream);
+
 /* Transposed gather with <= 4 output channels: the input gradient of a network's FIRST conv (3 image channels; taken
  * when the images come from the generator - lib/core/function.py:146-160 back-propagates loss_G through the frozen
  * student into G).  Arguments as advmix_conv_tr_w without the bias; one thread per output pixel instead of 32 MFMA

@@ -599,6 +599,134 @@ def test_bn_backward_epilogue_sign_from_mask_and_from_c(case):
                                     P(mean), P(invstd), None, None, 1, P(st_slots), ctypes.byref(ns), st) == 1
 
 
+WINO_CASES = [
+    # B, Ci, Co, H, W
+    (32, 32, 32, 64, 48),        # HRNet-W32's first branch at the bench batch: 768 workgroups
+    (32, 64, 64, 32, 24),        # second branch: two column tiles per row tile
+    (3, 32, 32, 10, 14),         # 105 tiles: a ragged last workgroup, odd tile counts per row / image
+    (2, 64, 32, 8, 6),           # Ci != Co
+    (2, 32, 64, 6, 4),
+    (1, 32, 32, 4, 4),           # every tile touches the border
+]
+
+
+def _wino_images(w_dev):
+    """(bank, forward image, input-gradient image) of one [Co][3][3][Ci] filter bank through advmix_wino_weights."""
+    ops = _ops()
+    bank = ops.WinoBank([w_dev])
+    bank.refresh()
+    uf, ud = ops._WINO[w_dev.data_ptr()]
+    return bank, uf, ud
+
+
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_winograd_conv_all_roles(case):
+    """csrc/conv_wino.hip (round 5): the Winograd F(2x2,3x3) kernel in every role the step uses - forward + BatchNorm column
+    sums, forward + eval-mode BatchNorm + residual + ReLU, input gradient + addend, input gradient + addend + BatchNorm-
+    backward sums with the sign of y from the bit mask and recomputed from c - against a float64 torch evaluation (1e-4 of
+    scale like every other kernel; the transforms add ~3 bits of rounding to the direct kernel's) and against the direct
+    kernel's own result for the same arguments."""
+    import ctypes
+    from advmix_amd._lib import call, lib
+    _ops()
+    B, Ci, Co, H, W = case
+    d = dev()
+    assert lib.advmix_conv_wino_config(B, H, W, Ci, Co) == 1 and lib.advmix_conv_wino_config(B, H, W, Co, Ci) == 1
+    g_ = torch.Generator().manual_seed(23 + Ci + H)
+    R = lambda *s_: torch.randn(*s_, generator=g_)
+    x, dy = R(B, H, W, Ci), R(B, H, W, Co)
+    w = R(Co, 3, 3, Ci) * (9 * Ci) ** -0.5                 # [Co][R][S][Ci]
+    res = R(B, H, W, Co)
+    gamma, beta, rm, rv = R(Co).abs() + 0.5, R(Co) * 0.3, R(Co) * 0.2, R(Co).abs() + 0.4
+    c_in, addend = R(B, H, W, Ci) * 1.5 + 0.3, R(B, H, W, Ci)      # the producer's raw output / the other gradient of its y
+    gi, bi = R(Ci).abs() + 0.5, R(Ci) * 0.3
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    D = {n_: v.to(d).contiguous() for n_, v in dict(x=x, dy=dy, res=res, gamma=gamma, beta=beta, rm=rm, rv=rv, c=c_in,
+                                                    addend=addend, gi=gi, bi=bi).items()}
+    wd = w.to(d).permute(0, 3, 1, 2)                        # logical [Co,Ci,3,3], channels_last memory = [Co][3][3][Ci]
+    assert wd.is_contiguous(memory_format=torch.channels_last)
+    bank, uf, ud = _wino_images(wd)
+    y64 = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    dx64 = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    rows = B * H * W
+    geom = (B, H, W, Ci, H, W, Co, 3, 3, 1, 1)
+
+    # (1) forward + column sums of the raw output
+    for entry in ('wino', 'direct'):
+        y = torch.full((B, H, W, Co), float('nan'), device=d)
+        slots = torch.zeros(2 * Co * 64, device=d, dtype=torch.float64)
+        ns = ctypes.c_int(0)
+        if entry == 'wino':
+            rc = lib.advmix_conv3x3_wino_fwd(P(D['x']), uf, P(y), B, H, W, Ci, Co, None, None, None, None, 0.0, None, 0,
+                                             P(slots), ctypes.byref(ns), st)
+        else:
+            rc = lib.advmix_conv_fwd_ex(P(D['x']), P(wd), None, P(y), *geom, None, None, None, None, 0.0, None, 0, P(slots),
+                                        ctypes.byref(ns), st)
+            if rc == 1:
+                continue
+        assert rc == 0, (entry, rc)
+        torch.cuda.synchronize()
+        check(entry + ' fwd', y, y64, 2e-5)
+        sums = slots[:2 * Co * ns.value].view(2, ns.value, Co).sum(1).cpu()
+        check(entry + ' sum', sums[0], y64.reshape(-1, Co).sum(0), 2e-5 * rows ** 0.5)
+        check(entry + ' sumsq', sums[1], (y64 * y64).reshape(-1, Co).sum(0), 2e-5)
+    # (2) forward + eval-mode BatchNorm + residual + ReLU (the teacher)
+    want = F.relu((y64 - rm.double()) / torch.sqrt(rv.double() + 1e-5) * gamma.double() + beta.double() + res.double())
+    y = torch.full((B, H, W, Co), float('nan'), device=d)
+    assert lib.advmix_conv3x3_wino_fwd(P(D['x']), uf, P(y), B, H, W, Ci, Co, P(D['gamma']), P(D['beta']), P(D['rm']), P(D['rv']),
+                                       1e-5, P(D['res']), 1, None, None, st) == 0
+    torch.cuda.synchronize()
+    check('fwd eval', y, want, 2e-5)
+    # (3) input gradient, with and without the addend
+    for add_ in (None, D['addend']):
+        gout = torch.full((B, H, W, Ci), float('nan'), device=d)
+        assert lib.advmix_conv3x3_wino_dgrad(P(D['dy']), ud, P(add_), P(gout), B, H, W, Co, Ci, None, None, None, None, None, None,
+                                             0, None, None, st) == 0
+        torch.cuda.synchronize()
+        check('dgrad', gout, dx64 + (addend.double() if add_ is not None else 0), 2e-5)
+    # (4) input gradient + BatchNorm-backward epilogue: y = relu(BN(c) + residual) through the mask, y = relu(BN(c)) from c
+    cd = c_in.double().reshape(-1, Ci)
+    fslots = torch.stack([cd.sum(0), (cd * cd).sum(0)]).reshape(2, 1, Ci).contiguous().to(d)
+    res_in = R(B, H, W, Ci).to(d)
+    for tag, r_, add_, use_mask in (('mask', res_in, D['addend'], True), ('from c', None, None, False)):
+        yy = torch.empty(B, H, W, Ci, device=d)
+        mean, invstd = torch.empty(Ci, device=d), torch.empty(Ci, device=d)
+        mask = torch.zeros(rows * Ci // 4, device=d, dtype=torch.uint8)
+        call('advmix_norm_apply_slots', P(D['c']), P(fslots), 1, rows, Ci, 1e-5, P(D['gi']), P(D['bi']), P(r_), P(yy), 1,
+             P(mean), P(invstd), None, None, None, 0.1, P(mask), st)
+        results = {}
+        for entry in ('wino', 'direct'):
+            gout = torch.full((B, H, W, Ci), float('nan'), device=d)
+            bslots = torch.zeros(2 * Ci * 64, device=d, dtype=torch.float64)
+            ns = ctypes.c_int(0)
+            tail = (P(mask) if use_mask else None, P(D['c']), P(mean), P(invstd), None if use_mask else P(D['gi']),
+                    None if use_mask else P(D['bi']), 1, P(bslots), ctypes.byref(ns), st)
+            if entry == 'wino':
+                rc = lib.advmix_conv3x3_wino_dgrad(P(D['dy']), ud, P(add_), P(gout), B, H, W, Co, Ci, *tail)
+            else:
+                rc = lib.advmix_conv_tr_w_bnb(P(D['dy']), P(wd), P(add_), P(gout), B, H, W, Co, H, W, Ci, 3, 3, 1, 1, *tail)
+            if entry == 'direct' and rc == 1:               # (small shapes: the direct kernel would split K across the grid -
+                continue                                    #  no fused epilogue there; the float64 reference stands alone)
+            assert rc == 0, (tag, entry, rc)
+            torch.cuda.synchronize()
+            pos = (yy > 0).cpu()
+            want = (dx64 + (addend.double() if add_ is not None else 0)) * pos
+            check(tag + ' g ' + entry, gout, want, 2e-5)
+            assert bool((gout.cpu()[~pos] == 0).all()), (tag, entry)       # exactly the stored y's sign
+            xh = (c_in.double() - mean.cpu().double()) * invstd.cpu().double()
+            sums = bslots[:2 * Ci * ns.value].view(2, ns.value, Ci).sum(1).cpu()
+            check(tag + ' sum g ' + entry, sums[0], want.reshape(-1, Ci).sum(0), 2e-5 * rows ** 0.5)
+            check(tag + ' sum g xhat ' + entry, sums[1], (want * xh).reshape(-1, Ci).sum(0), 2e-5 * rows ** 0.5)
+            results[entry] = gout
+        if 'direct' in results:
+            check(tag + ' wino vs direct', results['wino'], results['direct'].double().cpu(), 1e-5)
+    # refused without launching: odd sizes, channel counts the kernel has no instance for, a missing image
+    assert lib.advmix_conv_wino_config(B, H + 1, W, Ci, Co) == 0 and lib.advmix_conv_wino_config(B, H, W, 48, 48) == 0
+    assert lib.advmix_conv3x3_wino_fwd(P(D['x']), None, P(y), B, H, W, Ci, Co, None, None, None, None, 0.0, None, 0, None, None, st) == 1
+    bank.release()
+
+
 @pytest.mark.parametrize('case', [(8, 32, 64, 32, 24, 3), (3, 32, 128, 16, 12, 3), (8, 32, 256, 8, 6, 3), (2, 4, 64, 20, 14, 3),
                                   (5, 8, 128, 12, 9, 1), (8, 32, 32, 64, 48, 3), (3, 4, 32, 16, 11, 3), (2, 2, 32, 8, 8, 3),
                                   # more than eight problems: one pixel slice per tile -> the workgroup owns its outputs (plain +=)

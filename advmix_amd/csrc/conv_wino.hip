@@ -38,8 +38,8 @@ struct WinoP {
     const float* u;           // transformed weights, fragment order (see wino_weights)
     float* y;
     int N, H, W, Ci, Co;      // 3x3, stride 1, pad 1: input and output are both H x W
-    int Ht, Wt, HtWt, Mt;     // tiles per column / row / image, tiles in all
-    unsigned mg_hw, mg_w;     // floor(2^32 / d) + 1 for d = HtWt, Wt (exact quotients for the tile counts the host admits)
+    int Ht, Wt;               // 2x2 output tiles per column / row
+    int nbw, nblk;            // blocks of BW x BH tiles per row / per image
     int xbytes, ybytes, ubytes;
     // role 0 (forward): column sums of the raw output and / or eval-mode BatchNorm, residual, activation
     const float *bn_gamma, *bn_beta, *bn_rm, *bn_rv, *res;
@@ -61,51 +61,94 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
 }
 __device__ __forceinline__ int acc_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }   // v_mfma_f32_32x32x2 D layout
 
+// Geometry of a workgroup's block of BW x BH = 32 tiles and of its input patch in LDS.  Pixel (pr, pc) of the
+// (2 BH + 2) x (2 BW + 2) patch lives at position pr * PWL + (pc & 1) * HALF + (pc >> 1), PP = C + 4 floats per position:
+// a lane's 16-byte read of column c of ITS tile touches position ... + bx' + (c >> 1) - even and odd pixel columns are
+// stored apart, so the 32 tiles of a wave read CONSECUTIVE positions (not every second one), and with HALF chosen so that
+// a tile row (two pixel rows = 4 HALF positions) advances the 16-byte slot by BW, the 16 lanes the hardware serves per
+// cycle of a ds_read_b128 fall on 16 different slots: no bank conflicts.
+template <int LBW, int C>
+struct Geo {
+    static constexpr int BW = 1 << LBW, BH = 32 >> LBW;
+    static constexpr int PH = 2 * BH + 2, PW = 2 * BW + 2;
+    static constexpr int HALF = LBW == 3 ? 10 : (LBW == 2 ? 5 : (LBW == 4 ? 20 : PW / 2));
+    static constexpr int PWL = 2 * HALF, PP = C + 4;
+    static constexpr int PATCH = PH * PWL * PP;             // floats
+    static constexpr int XCH = 4 * 2 * 4 * 64 * 4;          // floats of the inverse transform's exchange
+    static constexpr int LDS = PATCH > XCH ? PATCH : XCH;
+};
+
 // NQ = Ci / 8 (k groups of 8 channels: two k-lanes x 4 channels per 16-byte load).  ROLE 0: forward epilogues, 1: input gradient.
-template <int NQ, int ROLE>
+template <int NQ, int ROLE, int LBW>
 __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
-    __shared__ __attribute__((aligned(16))) float X[4 * 2 * 4 * 64 * 4];   // [wave][b][r / 4][lane][4]: the row half of the inverse transform
-    __shared__ __attribute__((aligned(16))) float Ts[4 * 32 * TP];         // wave-private transposers
+    using G = Geo<LBW, NQ * 8>;
+    constexpr int C = NQ * 8, BW = G::BW, BH = G::BH, PW = G::PW, PH = G::PH, HALF = G::HALF, PWL = G::PWL, PP = G::PP;
+    // one region, four lives (separated by workgroup barriers): the input patch, the exchange of the inverse transform's
+    // row half ([wave][b][r / 4][lane][4]), then the wave-private transposers of the epilogue
+    __shared__ __attribute__((aligned(16))) float L[G::LDS];
     __shared__ float sred[2 * 4 * 32];
+    float* const X = L;
+    float* const Ts = L;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    int bx = blockIdx.x;
+    int bm = blockIdx.x;
     if (p.xcd_remap && (gridDim.x & 7) == 0 && gridDim.x >= 16)            // each XCD (and its L2) works through a contiguous
-        bx = (bx & 7) * ((int)gridDim.x >> 3) + (bx >> 3);                  // range of tile rows: halos are L2 hits
-    const int m0 = bx * 32, n0 = blockIdx.y * 32;
+        bm = (bm & 7) * ((int)gridDim.x >> 3) + (bm >> 3);                  // range of blocks: halos are L2 hits
+    const int n0 = blockIdx.y * 32;
+    const int img = bm / p.nblk;                                            // (uniform: scalar arithmetic)
+    const int rblk = bm - img * p.nblk;
+    const int bby = rblk / p.nbw, bbx = rblk - bby * p.nbw;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, p.ubytes, 0x00020000);
+    const unsigned bo = (unsigned)((((blockIdx.y * 16 + wid * 4) * NQ) * 64 + lane) * 16);
+    f32x4 bn[4];
+    auto issue_b = [&](int q) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bn[j] = bload(ur, bo + (unsigned)((j * NQ + q) * 1024));
+    };
+    issue_b(0);
+
+    // ---- the block's input patch -> LDS: every input byte is requested ONCE per workgroup (the first version loaded each
+    // lane's 8 patch pixels straight into registers: 4x the bytes - neighbouring tiles and the four waves overlap - at a
+    // quarter of a cache line per request; the loads, not the MFMAs, set its time: profiles/r05a_knockout_wino_v1.log) ----
+    {
+        constexpr int NS = PH * PW * (C / 4), NIT = (NS + 255) / 256;
+        const int hb = 2 * BH * bby - 1, wb = 2 * BW * bbx - 1;
+        f32x4 stg[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int s = tid + 256 * it;
+            const int px = s / (C / 4), cs = s % (C / 4);
+            const int pr = px / PW, pc = px % PW;
+            const int h = hb + pr, w = wb + pc;
+            const bool ok = s < NS && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+            stg[it] = bload(xr, ok ? (unsigned)((((img * p.H + h) * p.W + w) * C + cs * 4) * 4) : OOB);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int s = tid + 256 * it;
+            const int px = s / (C / 4), cs = s % (C / 4);
+            const int pr = px / PW, pc = px % PW;
+            if (s < NS) *reinterpret_cast<f32x4*>(&L[(pr * PWL + (pc & 1) * HALF + (pc >> 1)) * PP + cs * 4]) = stg[it];
+        }
+    }
 
     // ---- this lane's tile ------------------------------------------------------------------------------------------
-    const int t = m0 + l31;
-    const bool tok = t < p.Mt;
-    const unsigned tt = tok ? (unsigned)t : 0u;
-    const unsigned img = __umulhi(tt, p.mg_hw);
-    const unsigned rem = tt - img * (unsigned)p.HtWt;
-    const unsigned ty = __umulhi(rem, p.mg_w);
-    const unsigned tx = rem - ty * (unsigned)p.Wt;
-    const int h0 = 2 * (int)ty, w0 = 2 * (int)tx;
-    const int pb = tok ? ((int)img * p.H + h0) * p.W + w0 : -1;            // pixel of the tile's output (0, 0)
+    const int bxl = l31 & (BW - 1), byl = l31 >> LBW;
+    const int ty = bby * BH + byl, tx = bbx * BW + bxl;
+    const bool tok = ty < p.Ht && tx < p.Wt;
+    const int pb = tok ? (img * p.H + 2 * ty) * p.W + 2 * tx : -1;         // pixel of the tile's output (0, 0)
+    const unsigned vmask = (unsigned)__ballot(tok);                         // bit t: tile t of the block exists
 
     // wave i multiplies row i of B^T d B:   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]  ->  d[ra] + sg * d[rb]
     const int ra = wid == 0 ? 0 : (wid == 2 ? 2 : 1);
     const int rb = wid == 3 ? 3 : (wid == 2 ? 1 : 2);
     const float sg = wid == 1 ? 1.f : -1.f;
-    unsigned ao[2][4];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int h = h0 - 1 + (k ? rb : ra);
-        const bool okh = tok && (unsigned)h < (unsigned)p.H;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int w = w0 - 1 + c;
-            const bool ok = okh && (unsigned)w < (unsigned)p.W;
-            ao[k][c] = ok ? (unsigned)(((((int)img * p.H + h) * p.W + w) * p.Ci + lh * 4) * 4) : OOB;
-        }
-    }
-    const unsigned bo = (unsigned)((((blockIdx.y * 16 + wid * 4) * NQ) * 64 + lane) * 16);
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, p.ubytes, 0x00020000);
+    const float* const la = L + ((2 * byl + ra) * PWL + bxl) * PP + 4 * lh;
+    const float* const lb = L + ((2 * byl + rb) * PWL + bxl) * PP + 4 * lh;
 
     f32x16 acc[4];
 #pragma unroll
@@ -113,25 +156,22 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    f32x4 dn[2][4], bn[4];
-    auto issue = [&](int q) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) dn[k][c] = bload(xr, ao[k][c] + (unsigned)(q * 32));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bn[j] = bload(ur, bo + (unsigned)((j * NQ + q) * 1024));
-    };
-    issue(0);
+    __syncthreads();                                        // the patch is complete
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         f32x4 rc[4], v[4], bc[4];
-        __builtin_amdgcn_sched_barrier(0);                  // (nothing of group q + 1 is hoisted above group q's MFMAs: its
-                                                            //  transform would wait for loads that were only just issued)
+        __builtin_amdgcn_sched_barrier(0);                  // (nothing of group q + 1 is hoisted above group q's MFMAs)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int j = 0; j < 4; ++j) bc[j] = bn[j];
+        if (q + 1 < NQ) issue_b(q + 1);                     // the next group's filters fly under this group's 16 MFMAs
 #pragma unroll
-            for (int e = 0; e < 4; ++e) rc[c][e] = __builtin_fmaf(sg, dn[1][c][e], dn[0][c][e]);
+        for (int c = 0; c < 4; ++c) {
+            const int o = ((c & 1) * HALF + (c >> 1)) * PP + 8 * q;
+            const f32x4 da = *reinterpret_cast<const f32x4*>(la + o);
+            const f32x4 db = *reinterpret_cast<const f32x4*>(lb + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rc[c][e] = __builtin_fmaf(sg, db[e], da[e]);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {                       // (B^T d) B:  columns [1 0 0 0; 0 1 -1 1; -1 1 1 0; 0 0 0 -1]
             v[0][e] = rc[0][e] - rc[2][e];
@@ -139,9 +179,6 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
             v[2][e] = rc[2][e] - rc[1][e];
             v[3][e] = rc[1][e] - rc[3][e];
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bc[j] = bn[j];
-        if (q + 1 < NQ) issue(q + 1);                       // the next group's loads fly under this group's 16 MFMAs
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -181,6 +218,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
     if (ROLE == 1 && mask_on)       // lane (l31, lh): the 16 channels [16 lh, 16 lh + 16) of ITS tile's pixel = 4 mask bytes
         mw = __builtin_amdgcn_raw_buffer_load_b32(mkr, pb >= 0 ? (unsigned)((pb + pos) * (p.Co >> 2) + ((n0 + 16 * lh) >> 2)) : OOB, 0, 0);
 
+    __syncthreads();                                        // every wave is done with the patch: the region becomes the exchange
     {
         f32x16 t0, t1;
 #pragma unroll
@@ -209,6 +247,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
         }
     }
 
+    __syncthreads();                                        // the exchange has been read: the region becomes the transposers
     // ---- fused epilogue (conv_direct.hip's, for one tile per wave) -----------------------------------------------------
     float* const Tx = Ts + wid * (32 * TP);
     auto wave_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
@@ -246,7 +285,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = acc_row(r, lh);
-        const bool valid = (m0 + row) < p.Mt;
+        const bool valid = (vmask >> row) & 1u;
         float v = yv[r];
         if (ROLE == 0) {
             if (valid) { s1 += v; s2 += v * v; }
@@ -346,18 +385,22 @@ __global__ __launch_bounds__(256) void wino_weights(const WinoEnt* __restrict__ 
     }
 }
 
-static unsigned magic(unsigned d) { return (unsigned)((1ull << 32) / d) + 1u; }
-
 }  // namespace wino
 
 // Which problems the Winograd kernel serves at all (3x3 / stride 1 / pad 1 is implied by the entry points).
 static bool wino_shape_ok(int N, int H, int W, int Ci, int Co) {
     if (N <= 0 || H < 4 || W < 4 || (H & 1) || (W & 1)) return false;
     if (!(Ci == 32 || Ci == 64) || Co % 32 != 0 || Co > 4096) return false;
-    const int64_t Mt = (int64_t)N * (H / 2) * (W / 2);
-    if (Mt * (H / 2) * (W / 2) >= (1ll << 32)) return false;              // the magic-number quotients are exact below this
     if ((int64_t)N * H * W * (Ci > Co ? Ci : Co) * 4 >= 0x7fffffffLL) return false;
     return true;
+}
+
+// Block shape: 8 x 4 or 4 x 8 tiles, whichever wastes fewer tiles at the borders; on a tie 8 x 4 for 32 channels (longer
+// contiguous pixel runs), 4 x 8 for 64 (its patch is 49 KB of LDS against 54: three workgroups per CU).
+static int wino_lbw(int Ht, int Wt, int Ci) {
+    const int64_t w3 = (int64_t)cdiv(Wt, 8) * cdiv(Ht, 4), w2 = (int64_t)cdiv(Wt, 4) * cdiv(Ht, 8);
+    if (w3 != w2) return w3 < w2 ? 3 : 2;
+    return Ci == 32 ? 3 : 2;
 }
 
 extern "C" int advmix_conv_wino_config(int N, int H, int W, int Ci, int Co) { return wino_shape_ok(N, H, W, Ci, Co) ? 1 : 0; }
@@ -377,16 +420,23 @@ extern "C" int advmix_wino_weights(const void* ents, const int* blk_ent, int blo
 }
 
 static int wino_launch(int role, wino::WinoP& p, hipStream_t st) {
-    dim3 g(cdiv(p.Mt, 32), p.Co / 32);
+    const int lbw = wino_lbw(p.Ht, p.Wt, p.Ci);
+    p.nbw = cdiv(p.Wt, 1 << lbw);
+    p.nblk = p.nbw * cdiv(p.Ht, 32 >> lbw);
+    dim3 g(p.N * p.nblk, p.Co / 32);
     const int NQ = p.Ci / 8;
-#define WL(NQ_, ROLE_) hipLaunchKernelGGL((wino::conv_wino<NQ_, ROLE_>), g, dim3(256), 0, st, p)
-    if (NQ == 4) { if (role) WL(4, 1); else WL(4, 0); }
-    else if (NQ == 8) { if (role) WL(8, 1); else WL(8, 0); }
+#define WL(NQ_, ROLE_, LBW_) hipLaunchKernelGGL((wino::conv_wino<NQ_, ROLE_, LBW_>), g, dim3(256), 0, st, p)
+#define WR(NQ_, LBW_) do { if (role) WL(NQ_, 1, LBW_); else WL(NQ_, 0, LBW_); } while (0)
+    if (NQ == 4 && lbw == 3) WR(4, 3);
+    else if (NQ == 4) WR(4, 2);
+    else if (NQ == 8 && lbw == 3) WR(8, 3);
+    else if (NQ == 8) WR(8, 2);
     else return ADVMIX_EINVAL;
+#undef WR
 #undef WL
     if (advmix_opts().trace_shapes) {
         char nm[48];
-        snprintf(nm, sizeof nm, "conv_wino<%d, %d>", NQ, role);
+        snprintf(nm, sizeof nm, "conv_wino<%d, %d, %d>", NQ, role, lbw);
         advmix_trace_launch(nm, g, role == 0 ? (p.stats ? "fwd+sums" : (p.bn_gamma ? "fwd+bn_eval" : "fwd")) : (p.bnb_c ? "dgrad+bnb" : "dgrad"),
                             p.N, p.H, p.W, p.Ci, p.H, p.W, p.Co, 3, 3, 1, 2.0 * p.N * (double)p.H * p.W * p.Co * p.Ci * 9);
     }
@@ -399,8 +449,7 @@ static int wino_fill(wino::WinoP& p, const float* x, const float* u, float* y, i
     p = wino::WinoP{};
     p.x = x; p.u = u; p.y = y;
     p.N = N; p.H = H; p.W = W; p.Ci = Ci; p.Co = Co;
-    p.Ht = H / 2; p.Wt = W / 2; p.HtWt = p.Ht * p.Wt; p.Mt = N * p.HtWt;
-    p.mg_hw = wino::magic((unsigned)p.HtWt); p.mg_w = wino::magic((unsigned)p.Wt);
+    p.Ht = H / 2; p.Wt = W / 2;
     p.xbytes = (int)((int64_t)N * H * W * Ci * 4);
     p.ybytes = (int)((int64_t)N * H * W * Co * 4);
     p.ubytes = (int)((int64_t)16 * Co * Ci * 4);

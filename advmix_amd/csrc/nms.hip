@@ -9,6 +9,7 @@
 // Bit-exactness: devIoU is evaluated in fp32 with one IEEE operation per statement; the build
 // uses -ffp-contract=off for this file's arithmetic (no FMA contraction) and IEEE division.
 #include "common.h"
+#include <stdio.h>
 #include <vector>
 #include <string.h>
 
@@ -220,6 +221,20 @@ extern "C" int advmix_nms_host(int* keep_out, int* num_out, const float* boxes_h
     }
     *num_out = k;
     return ADVMIX_OK;
+}
+
+// The reference's own native symbol (lib/nms/gpu_nms.hpp:1-2; C++ linkage - `_Z4_nmsPiS_PKfiifi` - bound by the Cython
+// wrapper gpu_nms.pyx:10-11,31): same arguments, same contract - returns nothing, an error is PRINTED and execution
+// continues (CUDA_CHECK, nms_kernel.cu:11-18), here with *num_out = 0 so that the caller's `keep[:num_out]` is empty rather
+// than uninitialised.  With this symbol the reference's gpu_nms.pyx links against -ladvmix_hip in place of nms_kernel.cu
+// (INTEGRATION.md section 3); include/gpu_nms.hpp carries the declaration.
+void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim, float nms_overlap_thresh,
+          int device_id) {
+    const int rc = advmix_nms_host(keep_out, num_out, boxes_host, boxes_num, boxes_dim, nms_overlap_thresh, device_id);
+    if (rc != ADVMIX_OK) {
+        printf("_nms: %s\n", rc == ADVMIX_EINVAL ? "invalid argument" : hipGetErrorString(hipGetLastError()));
+        if (num_out) *num_out = 0;
+    }
 }
 
 extern "C" int advmix_oks_matrix(const double* kpts, const double* areas, const double* sigmas, int n, int K,

@@ -297,17 +297,20 @@ def _det_stats(C, device, lane):
 # ---- Winograd F(2x2,3x3) path (csrc/conv_wino.hip) ---------------------------------------------------------------------
 WINO = __import__('os').environ.get('ADVMIX_WINO', '1') != '0'       # A/B switch: 0 = every conv on the direct kernels
 WINO_MIN_TILES = int(__import__('os').environ.get('ADVMIX_WINO_MIN_TILES', '4096'))   # 2x2 output tiles below which the direct kernel stays
-_WINO = {}          # weight data_ptr -> (forward image ptr, input-gradient image ptr), filled by WinoBank
 
 
 class WinoBank:
     """The transformed-filter images (U = G g G^T, MFMA fragment order) of a set of 3x3 / stride 1 / pad 1 conv weights: one
     side buffer, one launch to refresh all of it (``refresh``: at the start of every forward pass of the owning network, on
-    the caller's stream before any lane forks - the filters change once per optimizer step and the launch is ~10 us, so
-    nothing tracks versions).  Registers each weight's two images in ``_WINO`` under the weight's device address."""
+    the caller's stream before any lane forks - the filters change once per optimizer step and the launch is ~4 us, so
+    nothing tracks versions).  Each weight TENSOR OBJECT is tagged with its two images and the device address they were
+    made for (``w._wino``): a conv finds them on the tensor it was handed, and a tensor whose storage has moved since
+    (``.to()``, FlatAdam's flat buffer) - or any other tensor that merely lives at a recycled address - has no valid tag and
+    takes the direct kernel.  (A registry keyed by address alone served stale images to a later test's weights.)"""
 
     def __init__(self, weights):
         import numpy as np
+        import weakref
         dev = weights[0].device
         self.key = tuple(w.data_ptr() for w in weights)
         sizes = [16 * w.shape[0] * w.shape[1] for w in weights]
@@ -315,6 +318,7 @@ class WinoBank:
         ent = np.zeros(2 * len(weights), dtype=np.dtype([('w', '<u8'), ('u', '<u8'), ('Cn', '<i4'), ('Ck', '<i4'),
                                                          ('role', '<i4'), ('blk0', '<i4')]))
         blk, off, owner = 0, 0, []
+        self._tagged = []
         for i, w in enumerate(weights):
             Co, Ci, R, S = w.shape
             if (R, S) != (3, 3) or Co % 32 or Ci % 32 or not w.is_contiguous(memory_format=_CL):
@@ -328,20 +332,36 @@ class WinoBank:
                 blk += nb
                 off += sizes[i]
                 ptrs.append(ctypes.c_void_p(u))
-            _WINO[w.data_ptr()] = tuple(ptrs)
+            w._wino = (self.buf, ptrs[0], ptrs[1], w.data_ptr())           # (the tag keeps the side buffer alive)
+            self._tagged.append(weakref.ref(w))
         self.blocks = blk
         self.ents = torch.from_numpy(ent.view(np.uint8).copy()).to(dev)
         self.blk_ent = torch.tensor(owner, dtype=torch.int32).to(dev)
 
     def matches(self, weights):
-        return self.key == tuple(w.data_ptr() for w in weights)
+        return self.key == tuple(w.data_ptr() for w in weights) and all(_wino_tag(w) is not None for w in weights)
 
     def refresh(self, st=None):
         call('advmix_wino_weights', _p(self.ents), _p(self.blk_ent), self.blocks, st if st is not None else _st())
 
+    def images(self, w):
+        """(forward image, input-gradient image) pointers of one of the bank's weights."""
+        tag = _wino_tag(w)
+        if tag is None or tag[0] is not self.buf:
+            raise KeyError('not a weight of this bank (or its storage has moved)')
+        return tag[1], tag[2]
+
     def release(self):
-        for k in self.key:
-            _WINO.pop(k, None)
+        for r in self._tagged:
+            w = r()
+            if w is not None and getattr(w, '_wino', (None,))[0] is self.buf:
+                del w._wino
+        self._tagged = []
+
+
+def _wino_tag(w):
+    tag = getattr(w, '_wino', None)
+    return tag if tag is not None and tag[3] == w.data_ptr() else None
 
 
 def _wino_images(w, B, H, W, Ci, Co, R, S, stride, pad):
@@ -350,10 +370,10 @@ def _wino_images(w, B, H, W, Ci, Co, R, S, stride, pad):
         return None
     if B * (H // 2) * (W // 2) < WINO_MIN_TILES:
         return None
-    u = _WINO.get(w.data_ptr())
-    if u is None or not lib.advmix_conv_wino_config(B, H, W, Ci, Co):
+    tag = _wino_tag(w)
+    if tag is None or not lib.advmix_conv_wino_config(B, H, W, Ci, Co):
         return None
-    return u
+    return tag[1], tag[2]
 
 
 def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to=None, bnb=None, lane=0):

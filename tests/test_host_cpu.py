@@ -26,6 +26,7 @@ def test_library_exports_every_header_symbol():
     sizes = {'advmix_norm_ws_bytes', 'advmix_wgrad_det_ws_bytes', 'advmix_deconv4x4s2_narrow_ws_bytes', 'advmix_wino_u_floats',   # int64 results, bound separately
              'advmix_conv_group'}                                          # struct argument, bound separately
     assert names - sizes == set(L.SIGNATURES), (names ^ set(L.SIGNATURES))
+    assert hasattr(L.lib, '_Z4_nmsPiS_PKfiifi')            # the reference's own C++-linkage `_nms` (include/gpu_nms.hpp; lib/nms/gpu_nms.hpp:1-2)
     assert L.lib.advmix_version() == 1
     assert L.lib.advmix_build_flags() == 0                 # the shipped library carries no measurement switches
     src = open(os.path.join(ROOT, 'advmix_amd', 'csrc', 'conv_direct.hip')).read()

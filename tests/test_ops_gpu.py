@@ -615,7 +615,7 @@ def _wino_images(w_dev):
     ops = _ops()
     bank = ops.WinoBank([w_dev])
     bank.refresh()
-    uf, ud = ops._WINO[w_dev.data_ptr()]
+    uf, ud = bank.images(w_dev)
     return bank, uf, ud
 
 
@@ -1297,6 +1297,23 @@ def test_nms_bit_exact_vs_oracle():
     assert list(keep[:num.value]) == [0, 1]
     call('advmix_nms_host', keep.ctypes.data_as(ctypes.c_void_p), ctypes.byref(num),
          d2.ctypes.data_as(ctypes.c_void_p), 0, 5, ctypes.c_float(th), 0)
+    assert num.value == 0
+    # the reference's own symbol (lib/nms/gpu_nms.hpp:1-2), through its C++-mangled name: void, same arguments
+    from advmix_amd._lib import lib
+    ref_nms = getattr(lib, '_Z4_nmsPiS_PKfiifi')
+    ref_nms.restype = None
+    ref_nms.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]
+    rng = np.random.Generator(np.random.Philox(key=6))
+    for N in (1, 65, 300):
+        c = rng.random((N, 2)) * 200
+        dets = np.concatenate([c, c + rng.random((N, 2)) * 80 + 4, (rng.permutation(N).astype(np.float32) / N + 0.001)[:, None]], 1).astype(np.float32)
+        order = dets[:, 4].argsort()[::-1].astype(np.int32)
+        sd = np.ascontiguousarray(dets[order])
+        keep, num = np.zeros(N, np.int32), ctypes.c_int(-1)
+        ref_nms(keep.ctypes.data_as(ctypes.c_void_p), ctypes.byref(num), sd.ctypes.data_as(ctypes.c_void_p), N, 5, 0.5, 0)
+        assert [int(i) for i in order[keep[:num.value]]] == onms.gpu_nms(dets, 0.5), N
+    num = ctypes.c_int(-1)                                  # an error is printed, nothing is kept, nothing is raised (CUDA_CHECK)
+    ref_nms(keep.ctypes.data_as(ctypes.c_void_p), ctypes.byref(num), sd.ctypes.data_as(ctypes.c_void_p), N, 4, 0.5, 0)
     assert num.value == 0
 
 

@@ -41,7 +41,7 @@ for C, H, W in ((32, 64, 48), (64, 32, 24), (64, 64, 48)):
     slots = torch.zeros(2 * C * 64, device=dev, dtype=torch.float64)
     bank = ops.WinoBank([w])
     bank.refresh()
-    uf, ud = ops._WINO[w.data_ptr()]
+    uf, ud = bank.images(w)
     geom = (B, H, W, C, H, W, C, 3, 3, 1, 1)
     ns = ctypes.c_int(0)
 

@@ -501,11 +501,15 @@ def validate(config, args, val_loader, val_dataset, model, criterion, output_dir
     if cpu:
         raise RuntimeError('advmix_amd: validate() has no CPU path (the reference\'s cpu=True debug mode)')
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_rank() != 0:
-        # One process per GPU: rank 0 evaluates the whole set and writes the results file, as GPU 0 gathered every output
-        # under nn.DataParallel (tools/train.py:300-309: the other ranks' perf_indicator only feeds save_checkpoint's
-        # is_best, and save_checkpoint itself returns on them).  They wait in the next epoch's first gradient exchange.
-        return {}, 0.0
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    # One process per GPU (round 5): nn.DataParallel scattered every validation batch over all GPUs
+    # (tools/train.py:106,300); here rank r evaluates batches r, r + world, ... of the SAME loader order, the ranks' rows
+    # meet on rank 0 (gather_object: [B,J,3] predictions, boxes, paths - never heat-maps), rank 0 alone runs
+    # ``val_dataset.evaluate`` and writes the results, and the others wait for it on the HOST (a key in the process group's
+    # store, hours of timeout) - not inside the next epoch's first all-reduce, where NCCL's watchdog would abort the job
+    # when COCOeval on one rank takes longer than its default ten minutes.
+    loader, mine = _val_shard(val_loader, rank, world)
     batch_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter()
     model = _net(model)
     model.eval()
@@ -513,11 +517,19 @@ def validate(config, args, val_loader, val_dataset, model, criterion, output_dir
     all_preds = np.zeros((num_samples, config.MODEL.NUM_JOINTS, 3), dtype=np.float32)
     all_boxes = np.zeros((num_samples, 6))
     image_path, filenames, imgnums = [], [], []
+    rows = []                                               # [(first row, image paths)] of the batches this rank evaluated
     idx = 0
     end = time.time()
     time_gpu = 0.
     n_batches = 0
-    for i, (input, target, target_weight, meta) in enumerate(val_loader):
+    for i, (input, target, target_weight, meta) in enumerate(loader):
+        num_images = input.size(0)
+        if mine is None:                                    # the loader could not be re-sharded: every rank walks all of it
+            if i % world != rank:                           # and computes its own batches only
+                idx += num_images
+                continue
+        else:
+            idx = mine[i]
         if isinstance(target, (list, tuple)):
             target = target[0]                                                           # :264
         target = _cuda(target)
@@ -528,7 +540,6 @@ def validate(config, args, val_loader, val_dataset, model, criterion, output_dir
                                       val_dataset.flip_pairs)
         torch.cuda.synchronize()
         time_gpu += time.time() - infer_start
-        num_images = input.size(0)
         losses.update(loss.item(), num_images)
         _, avg_acc, cnt, pred = accuracy(output, target, args=None, cfg=config)          # :274
         acc.update(avg_acc, cnt)
@@ -547,7 +558,7 @@ def validate(config, args, val_loader, val_dataset, model, criterion, output_dir
         all_boxes[idx:idx + num_images, 2:4] = s[:, 0:2]
         all_boxes[idx:idx + num_images, 4] = np.prod(s * 200, 1)
         all_boxes[idx:idx + num_images, 5] = score
-        image_path.extend(meta['image'])
+        rows.append((idx, list(meta['image'])))
         idx += num_images
         n_batches += 1
         if i % config.PRINT_FREQ == 0:
@@ -555,25 +566,83 @@ def validate(config, args, val_loader, val_dataset, model, criterion, output_dir
                         'Time {batch_time.val:.3f} ({batch_time.avg:.3f})\t'
                         'Loss {loss.val:.4f} ({loss.avg:.4f})\t'
                         'Accuracy {acc.val:.3f} ({acc.avg:.3f})'.format(
-                            i, len(val_loader) if hasattr(val_loader, '__len__') else -1,
+                            i, len(loader) if hasattr(loader, '__len__') else -1,
                             batch_time=batch_time, loss=losses, acc=acc))
     logger.info('=> The average inference time is : %s', time_gpu / max(n_batches, 1))
 
-    name_values, perf_indicator = val_dataset.evaluate(
-        config, all_preds, output_dir, all_boxes, image_path, filenames, imgnums)
-    model_name = config.MODEL.NAME
-    for name_value in (name_values if isinstance(name_values, list) else [name_values]):
-        _print_name_value(name_value, model_name)
-    if writer_dict:
-        writer = writer_dict['writer']
-        global_steps = writer_dict['valid_global_steps']
-        writer.add_scalar('valid_loss', losses.avg, global_steps)
-        writer.add_scalar('valid_acc', acc.avg, global_steps)
+    if world > 1:
+        part = {'rows': [(r0, all_preds[r0:r0 + len(pths)], all_boxes[r0:r0 + len(pths)], pths) for r0, pths in rows],
+                'loss': (losses.sum, losses.count), 'acc': (acc.sum, acc.count)}
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object(part, parts, dst=0)
+        validate.calls = getattr(validate, 'calls', 0) + 1
+        key = 'advmix_validate_done_%d' % validate.calls
+        store = dist.distributed_c10d._get_default_store()
+        if rank != 0:
+            import datetime
+            store.wait([key], datetime.timedelta(hours=int(os.environ.get('ADVMIX_VALIDATE_WAIT_HOURS', '12'))))
+            perf = float(store.get(key).decode())
+            validate.last = {'loss': losses.avg, 'acc': acc.avg}
+            return {}, perf
+        losses, acc = AverageMeter(), AverageMeter()
+        for prt in parts:
+            for r0, pr, bx, pths in prt['rows']:
+                all_preds[r0:r0 + len(pths)] = pr
+                all_boxes[r0:r0 + len(pths)] = bx
+            for m, k in ((losses, 'loss'), (acc, 'acc')):
+                m.sum += prt[k][0]
+                m.count += prt[k][1]
+                m.avg = m.sum / m.count if m.count else 0
+        rows = sorted((r for prt in parts for r in ((r0, pths) for r0, _p, _b, pths in prt['rows'])), key=lambda r: r[0])
+    for _r0, pths in rows:
+        image_path.extend(pths)
+
+    try:
+        name_values, perf_indicator = val_dataset.evaluate(
+            config, all_preds, output_dir, all_boxes, image_path, filenames, imgnums)
+        model_name = config.MODEL.NAME
         for name_value in (name_values if isinstance(name_values, list) else [name_values]):
-            writer.add_scalars('valid', dict(name_value), global_steps)
-        writer_dict['valid_global_steps'] = global_steps + 1
+            _print_name_value(name_value, model_name)
+        if writer_dict:
+            writer = writer_dict['writer']
+            global_steps = writer_dict['valid_global_steps']
+            writer.add_scalar('valid_loss', losses.avg, global_steps)
+            writer.add_scalar('valid_acc', acc.avg, global_steps)
+            for name_value in (name_values if isinstance(name_values, list) else [name_values]):
+                writer.add_scalars('valid', dict(name_value), global_steps)
+            writer_dict['valid_global_steps'] = global_steps + 1
+    except BaseException:
+        if world > 1:                                       # never leave the other ranks waiting for a rank that has failed
+            store.set(key, 'nan')
+        raise
+    if world > 1:
+        store.set(key, repr(float(perf_indicator)))
     validate.last = {'loss': losses.avg, 'acc': acc.avg}        # for callers that want the meters
     return name_values, perf_indicator
+
+
+def _val_shard(val_loader, rank, world):
+    """(loader, first rows): this rank's share of a validation loader - batches rank, rank + world, ... in the loader's own
+    order, with the row of ``all_preds`` each starts at - as a DataLoader over the same dataset / collate function /
+    workers.  (val_loader, None) when there is one rank, or when the loader cannot be re-sharded (no batch sampler to
+    enumerate): validate() then walks the whole loader on every rank and computes every world-th batch."""
+    if world <= 1:
+        return val_loader, None
+    bs, ds = getattr(val_loader, 'batch_sampler', None), getattr(val_loader, 'dataset', None)
+    if bs is None or ds is None:
+        return val_loader, None
+    try:
+        batches = [list(b) for b in bs]
+    except TypeError:
+        return val_loader, None
+    first, r0 = [], 0
+    for b in batches:
+        first.append(r0)
+        r0 += len(b)
+    pick = range(rank, len(batches), world)
+    kw = {k: getattr(val_loader, k) for k in ('num_workers', 'collate_fn', 'pin_memory') if hasattr(val_loader, k)}
+    loader = torch.utils.data.DataLoader(ds, batch_sampler=[batches[i] for i in pick], **kw)
+    return loader, [first[i] for i in pick]
 
 
 def _print_name_value(name_value, full_arch_name):

@@ -92,31 +92,56 @@ def visible_gpus():
         return 0
 
 
-def spawn_ranks(argv, n, need_gpus=True, timeout_s=None, env_extra=None):
+def ranks_share_a_device(n, visible, share_gpu=False):
+    """True when the ranks of this job cannot each have a GPU of their own: the caller says so (``share_gpu``: a functional
+    run of the N-rank path on a smaller box) or fewer than ``n`` devices are visible while ranks are still started
+    (``need_gpus=False``).  LOCAL_RANK r binds device r (bench.py, tools/train.py recipe), so with ``visible >= n`` every
+    rank has its own."""
+    return bool(share_gpu) or (visible is not None and 0 < visible < n)
+
+
+def rank_env(r, n, port, shared_device, base=None, cores=None):
+    """Environment of rank ``r`` of ``n``.
+      * rendezvous variables, dmabuf IPC (the only kind this driver has; a user's value wins);
+      * a bounded CPU budget (round 5): OMP / MKL threads = cores / n, at least 1 - N ranks each capturing ~3,500 launches
+        into HIP graphs and each owning a torch intra-op pool of ALL cores oversubscribe the host N times over
+        (``cores``: os.cpu_count() unless given; a user's OMP_NUM_THREADS wins);
+      * DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 ONLY when ranks share a device (``shared_device``): with two processes on ONE GPU,
+        replays served from the runtime's captured AQL packets computed garbage after NULL-stream traffic between them
+        (tools/dp_graph_repro.py; 0 failures with the switch).  Every ingredient of that failure needs
+        the second process on the SAME device, so a one-process-per-GPU job does not carry an undocumented runtime debug
+        switch; ADVMIX_GRAPH_PACKET_CAPTURE_OFF=1 forces it on for A/B runs."""
+    env = dict(os.environ if base is None else base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    threads = str(max(1, (cores or os.cpu_count() or 1) // n))
+    env.setdefault('OMP_NUM_THREADS', threads)
+    env.setdefault('MKL_NUM_THREADS', threads)
+    if shared_device or env.get('ADVMIX_GRAPH_PACKET_CAPTURE_OFF') == '1':
+        env.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+    return env
+
+
+def spawn_ranks(argv, n, need_gpus=True, timeout_s=None, env_extra=None, share_gpu=False):
     """Run ``argv`` (a full command line) as ranks 0..n-1 of one node.  Rank 0 inherits stdout (its JSON line is the
     job's output); the other ranks' stdout goes to stderr.  Returns the job's exit code: 0 only if EVERY rank exited 0.
     Raises SystemExit with a non-zero code if fewer than ``n`` GPUs are visible (``need_gpus``) - never runs fewer
-    ranks than asked for."""
+    ranks than asked for.  Children are FRESH processes (nothing that has touched the GPU is ever re-exec'ed)."""
     if n < 2:
         raise ValueError('spawn_ranks is for n >= 2 ranks')
-    if need_gpus:
+    have = None
+    if need_gpus or share_gpu:
         have = visible_gpus()
-        if have < n:
-            sys.stderr.write('launch: --gpus %d asked for but only %d GPU(s) visible - refusing to run fewer ranks\n'
-                             % (n, have))
-            raise SystemExit(2)
+    if need_gpus and have < n:
+        sys.stderr.write('launch: --gpus %d asked for but only %d GPU(s) visible - refusing to run fewer ranks\n'
+                         % (n, have))
+        raise SystemExit(2)
+    shared = ranks_share_a_device(n, have, share_gpu)
     port = os.environ.get('MASTER_PORT') or str(free_port())
     procs = []
     try:
         for r in range(n):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                       MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
-            env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC (the only kind this driver has); a user's value wins
-            # Multi-rank jobs replay their HIP graphs WITHOUT the runtime's captured-AQL-packet path: with two ranks on one
-            # GPU, replays served from captured packets computed garbage after NULL-stream traffic between them, and never with
-            # this switch (tools/dp_graph_repro.py: 0 of 5; DESIGN.md section 4); at four launch lanes it costs nothing
-            # (573.5 vs 573.6 / 575.3 images/s).  The step keeps the NULL stream idle as well - this is the second lock.
-            env.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+            env = rank_env(r, n, port, shared)
             env.update(env_extra or {})
             # ranks > 0: stdout onto the parent's stderr by DESCRIPTOR (sys.stderr may be a capture object with no fileno)
             procs.append(subprocess.Popen(argv, env=env, stdout=None if r == 0 else 2))

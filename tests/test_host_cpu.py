@@ -679,3 +679,25 @@ def test_multi_rank_steps_replay_graphs_by_default(monkeypatch):
     monkeypatch.setattr(F_, 'GRAPH_EXEC', False)
     assert not F_._graph_ok(None) and not F_._graph_ok(sync(8))
 
+
+
+def test_launcher_rank_environment_shared_device_detection_and_cpu_budget():
+    """VERDICT r4 item 4 a / c: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (an undocumented runtime debug switch, adopted in round 4 for
+    a failure that needs two processes on ONE GPU) goes only to ranks that share a device - said by the caller
+    (ADVMIX_BENCH_SHARE_GPU) or visible from the device count - never to a one-process-per-GPU job, unless
+    ADVMIX_GRAPH_PACKET_CAPTURE_OFF=1 asks for it; every rank gets cores / N OpenMP / MKL threads, and a user's own values win."""
+    from advmix_amd.launch import ranks_share_a_device, rank_env
+    assert not ranks_share_a_device(8, 8) and not ranks_share_a_device(2, 8) and not ranks_share_a_device(2, None)
+    assert ranks_share_a_device(2, 1) and ranks_share_a_device(8, 4) and ranks_share_a_device(2, 8, share_gpu=True)
+    base = {'PATH': '/bin'}
+    e = rank_env(3, 8, 29500, False, base=base, cores=64)
+    assert (e['RANK'], e['LOCAL_RANK'], e['WORLD_SIZE'], e['MASTER_ADDR'], e['MASTER_PORT']) == ('3', '3', '8', '127.0.0.1', '29500')
+    assert 'DEBUG_CLR_GRAPH_PACKET_CAPTURE' not in e and e['OMP_NUM_THREADS'] == '8' and e['MKL_NUM_THREADS'] == '8'
+    assert e['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and 'RANK' not in base            # (the base mapping is not modified)
+    assert rank_env(0, 2, 1, True, base=base, cores=3)['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] == '0'
+    assert rank_env(0, 2, 1, True, base=base, cores=3)['OMP_NUM_THREADS'] == '1'
+    assert rank_env(0, 2, 1, False, base=dict(base, ADVMIX_GRAPH_PACKET_CAPTURE_OFF='1'))['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] == '0'
+    keep = rank_env(0, 2, 1, True, base=dict(base, OMP_NUM_THREADS='5', DEBUG_CLR_GRAPH_PACKET_CAPTURE='1'), cores=64)
+    assert keep['OMP_NUM_THREADS'] == '5' and keep['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] == '1'
+    src = open(os.path.join(ROOT, 'bench.py')).read()      # the driver's torch.distributed.run form: same rule in bench.py
+    assert "os.environ.get('ADVMIX_BENCH_SHARE_GPU') == '1'" in src.split('\nimport torch\n')[0]

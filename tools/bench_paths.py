@@ -1,0 +1,443 @@
+"""The other measurements behind bench.py's CLI (``--path validate | inputs | nms | rendezvous | replicas``, ``--through-loop``,
+``--dump-shapes``) and the data-parallel self-verification the headline run performs before it times anything."""
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+from bench_common import ROOT, WORKLOADS, synth, build_models, _event_time, cpu_baseline, FP32_MFMA_PEAK_TFLOPS
+from bench_roofline import time_eval_conv
+
+def bench_validate(a, device, rank, world):
+    """--path validate: images/sec of the validate() batch body (function.py:223-300) with the COCO test
+    settings of the experiment YAMLs (FLIP_TEST, SHIFT_HEATMAP, POST_PROCESS): two eval forwards, the
+    fused flip-back/shift/average kernel, loss.item(), PCK accuracy, device get_final_preds + its D2H."""
+    import numpy as np
+    from advmix_amd.core.function import validate_batch
+    from advmix_amd.core.evaluate import accuracy
+    from advmix_amd.core.inference import get_final_preds
+    from advmix_amd.dataset.coco import COCO_FLIP_PAIRS
+    from advmix_amd.config import CfgNode
+    net, extra, J, H, W, downs, _ = WORKLOADS[a.workload]
+    cfg, D, G, T, crit, optD, optG = build_models(a.workload, device)
+    cfg['TEST'] = CfgNode({'FLIP_TEST': True, 'SHIFT_HEATMAP': True, 'POST_PROCESS': True})
+    D.eval()
+    views, tgt, tw = synth(a.batch, J, H, W, device, 1234 + rank)
+    rng = np.random.default_rng(7 + rank)
+    center = (rng.random((a.batch, 2)) * [600, 440] + 20).astype(np.float32)
+    sw = (rng.random(a.batch) * 2.5 + 0.4).astype(np.float32)
+    scale = np.stack([sw, sw / np.float32(0.75)], 1)
+    graph = None
+    if a.exec_mode == 'graph':
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                validate_batch(cfg, D, crit, views[0], tgt, tw, COCO_FLIP_PAIRS)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        from advmix_amd import ops as _ops
+        graph = _ops.GraphSeq(device)
+        gseg, (g_out, g_loss) = graph.capture(lambda: validate_batch(cfg, D, crit, views[0], tgt, tw, COCO_FLIP_PAIRS))
+
+    def one_batch():
+        if graph is not None:
+            graph.replay(gseg)
+            out, loss = g_out, g_loss
+        else:
+            out, loss = validate_batch(cfg, D, crit, views[0], tgt, tw, COCO_FLIP_PAIRS)
+        lv = loss.item()
+        accuracy(out, tgt)
+        preds, maxvals = get_final_preds(cfg, None, out, center, scale)
+        return lv, preds
+
+    import torch.distributed as dist
+    for _ in range(a.warmup):
+        one_batch()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        lv, preds = one_batch()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank != 0:
+        return None
+    fwd_gflop = {'hrnet_w32': 15.290, 'hrnet_w48': 70.613, 'resnet50': 10.853, 'hrnet_w32_512': 81.55}[a.workload]
+    value = a.batch * world * a.steps / dt
+    line = {'metric': 'images/sec validate batch, flip test (%s)' % a.workload, 'value': round(value, 2),
+            'unit': 'images/sec', 'n_gpus': world, 'rccl_ranks': _ranks(), 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic (N(0,1) images, Gaussian targets, random boxes), random-init weights',
+            'config': {'workload': '%s_%dx%d_validate_flip' % (a.workload, H, W), 'batch_per_gpu': a.batch,
+                       'global_batch': a.batch * world, 'parallelism': 'dp%d' % world,
+                       'exec': 'hipgraph' if graph is not None else 'eager',
+                       'batch_gflop_per_image': 2 * fwd_gflop},
+            'step_tflops_per_gpu': round(value / world * 2 * fwd_gflop / 1e3, 2),
+            'step_frac_of_fp32_mfma_peak': round(value / world * 2 * fwd_gflop / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4),
+            'last_loss': round(lv, 6)}
+    if not a.no_roofline:
+        line['roofline'] = time_eval_conv(a.batch, device)
+    if world == 1 and not a.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(a.workload, path='validate')
+    return line
+
+
+def bench_inputs(a, device, rank, world):
+    """--path inputs: images/sec of the device input pipeline: from ONE uint8 crop per sample and the
+    workers' draws to the AutoAugment view (device, round 3), the three normalised float views (GridMask on the third)
+    and the gaussian targets / target weights.  HBM-bound: 6 B read + 36 B written per pixel by the view kernel."""
+    import numpy as np
+    import random as pyrandom
+    from advmix_amd.dataset.advaug import make_views, pack_grid, grid_params, auto_augment, pack_autoaug, autoaug_params
+    from advmix_amd.dataset.JointsDataset import TargetRenderer
+    net, extra, J, H, W, downs, _ = WORKLOADS[a.workload]
+    rng = np.random.RandomState(99 + rank)
+    base = torch.from_numpy(rng.randint(0, 256, (a.batch, H, W, 3), dtype=np.uint8)).to(device)
+    grid = pack_grid([grid_params(H, W, rng=rng) for _ in range(a.batch)], device)
+    prng = pyrandom.Random(7 + rank)
+    aa = pack_autoaug([autoaug_params(prng) for _ in range(a.batch)], device)      # the workers' draws (advaug.py:38-40,102-105)
+    joints = np.zeros((a.batch, J, 3)); joints[:, :, 0] = rng.rand(a.batch, J) * W; joints[:, :, 1] = rng.rand(a.batch, J) * H
+    vis = np.zeros((a.batch, J, 3)); vis[:, :, :2] = (rng.rand(a.batch, J, 1) < 0.8)
+    jd, vd = torch.from_numpy(joints).to(device), torch.from_numpy(vis).to(device)
+    rend = TargetRenderer((W, H), (W // 4, H // 4), 2, device=device)
+
+    def one_batch():
+        aug = auto_augment(base, aa)                        # the AutoAugment view on the device (round 3)
+        views = make_views(base, aug, grid)
+        tgt, tw = rend.render(jd, vd)
+        return views, tgt, tw
+    aug = auto_augment(base, aa)
+
+    for _ in range(a.warmup):
+        one_batch()
+    torch.cuda.synchronize()
+    steps = max(a.steps, 200)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_batch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank != 0:
+        return None
+    import ctypes
+    from advmix_amd._lib import call
+    v = [torch.empty((a.batch, 3, H, W), device=device) for _ in range(3)]
+    P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+    m = (ctypes.c_float * 3)(0.485, 0.456, 0.406); sd = (ctypes.c_float * 3)(0.229, 0.224, 0.225)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ms, runs = _event_time(lambda: call('advmix_make_views', P(base), P(aug), P(grid), ctypes.cast(m, ctypes.c_void_p),
+                                        ctypes.cast(sd, ctypes.c_void_p), P(v[0]), P(v[1]), P(v[2]), a.batch, H, W, st), 100)
+    nbytes = a.batch * H * W * (6 + 36)
+    value = a.batch * world * steps / dt
+    ms_aa, _ = _event_time(lambda: auto_augment(base, aa), 100)
+    line = {'metric': 'images/sec device input pipeline: AutoAugment + 3 views + targets (%dx%d)' % (H, W), 'value': round(value, 1),
+            'unit': 'images/sec', 'n_gpus': world, 'steps': steps, 'warmup': a.warmup,
+            'ms_per_step': round(dt / steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'u8->f32', 'data': 'synthetic uint8 crops resident in HBM, random joints',
+            'config': {'workload': 'inputs_%dx%d_3views_targets' % (H, W), 'batch_per_gpu': a.batch, 'joints': J},
+            'roofline': {'bound': 'hbm', 'kernel': 'make_views_kernel', 'achieved': round(nbytes / (ms * 1e-3) / 1e9, 1),
+                         'peak': 8000.0, 'unit': 'GB/s', 'frac': round(nbytes / (ms * 1e-3) / 1e9 / 8000.0, 4),
+                         'traffic': None, 'us_per_launch': round(ms * 1e3, 2),
+                         'algorithmic_bytes_per_launch': nbytes},
+            'autoaug_us_per_batch': round(ms_aa * 1e3, 2)}
+    if world == 1 and not a.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(a.workload, path='inputs')
+    return line
+
+
+def bench_nms(a, device, rank, world):
+    """--path nms: the lib/nms row.  A step = the post-process of one image: box NMS over
+    N = 1000 scored boxes through the reproduced ``_nms`` ABI (H2D, 64-wide bitmask kernel, D2H, host greedy
+    pass - per-call malloc/free like the reference) plus OKS-NMS over 30 person candidates (fp64 OKS matrix on
+    the device, greedy pass on the host).  Latency-bound by design: the reference's interface is host to host."""
+    import numpy as np
+    from advmix_amd.nms.nms import gpu_nms, oks_nms
+    rng = np.random.RandomState(11 + rank)
+    N = 1000
+    xy = rng.rand(N, 2) * 400
+    wh = rng.rand(N, 2) * 120 + 10
+    dets = np.concatenate([xy, xy + wh, rng.rand(N, 1)], 1).astype(np.float32)
+    people = []
+    base = rng.rand(6, 17, 2) * 300 + 50
+    for n in range(30):
+        k = np.zeros((17, 3)); k[:, :2] = base[n % 6] + rng.randn(17, 2) * 4; k[:, 2] = rng.rand(17)
+        people.append({'keypoints': k.reshape(-1), 'area': float(rng.rand() * 20000 + 5000), 'score': float(rng.rand())})
+
+    def one():
+        return len(gpu_nms(dets, 0.5)), len(oks_nms(people, 0.9))
+    for _ in range(a.warmup):
+        one()
+    torch.cuda.synchronize()
+    steps = max(a.steps, 100)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        kept = one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        gpu_nms(dets, 0.5)
+    torch.cuda.synchronize()
+    dt_box = time.perf_counter() - t1
+    if rank != 0:
+        return None
+    line = {'metric': 'images/sec NMS post-process (box NMS N=1000 + OKS-NMS 30 persons)', 'value': round(world * steps / dt, 1),
+            'unit': 'images/sec', 'n_gpus': world, 'steps': steps, 'warmup': a.warmup, 'ms_per_step': round(dt / steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 IoU / f64 OKS -> int indices',
+            'data': 'synthetic boxes / keypoints (host arrays, as the reference interface takes them)',
+            'config': {'workload': 'nms_box1000_oks30', 'kept': list(kept)},
+            'box_nms_us_per_call': round(dt_box / steps * 1e6, 1),
+            'roofline': {'bound': 'latency', 'kernel': 'nms_mask (16 x 16 tiles of 64 x 64 IoUs, one ballot per row)',
+                         'achieved': None, 'peak': None, 'unit': None, 'frac': None, 'traffic': None,
+                         'note': '1 M IoUs = a few microseconds of device work; the call is bound by hipMalloc/free + '
+                                 'two PCIe copies + the host greedy pass, all of which the reference ABI prescribes'}}
+    if world == 1 and not a.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(a.workload, path='nms')
+    return line
+
+
+def rendezvous(a, backend, rank, world, local):
+    """--path rendezvous: the launcher's self-test.  Every rank joins the process group, one all-reduce checks that
+    all ``world`` ranks are really there, rank 0 prints a JSON line.  With the default backend (nccl = RCCL) each rank
+    binds its own GPU; ADVMIX_BENCH_BACKEND=gloo runs the same path on CPU (tests/test_host_cpu.py)."""
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29555')
+    if backend == 'nccl':
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+        torch.cuda.set_device(local)
+        device = torch.device('cuda', local)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    else:
+        device = torch.device('cpu')
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], device=device)
+    dist.all_reduce(t)
+    ok = float(t.item()) == world * (world + 1) / 2
+    ranks = dist.get_world_size()
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'metric': 'rendezvous', 'n_gpus': a.gpus, 'rccl_ranks': ranks, 'backend': backend,
+                          'allreduce_ok': ok}), flush=True)
+    if not ok:
+        raise SystemExit(4)
+
+
+def dp_verdict(line, sync, optimizers, verification, lv):
+    """The three fields every N-rank line carries, from the SAME calls the train path makes, and the job's exit verdict."""
+    replicas = sync.replicas_state(optimizers)
+    line['replicas_identical'] = replicas['identical']
+    line['all_finite'] = replicas['finite'] and (lv == lv)
+    line['grad_exchange_verified'] = verification[0] if verification is not None else None
+    return not line['replicas_identical'] or not line['all_finite'] or (verification is not None and not verification[0])
+
+
+def replicas_selftest(a, backend, rank, world, local):
+    """--path replicas: the N-rank verdict's self-test (ADVMIX_BENCH_BACKEND=gloo: on CPU, tests/test_host_cpu.py).  Every rank
+    trains a small network for a few synced steps through dp.GradSync with its exchanges traced; ADVMIX_BENCH_CORRUPT=
+    weight | nan | exchange makes rank 1 move one weight by a few ulps / put a NaN into its Adam moments / hand back a wrong
+    exchange result - the line must say so and the job must exit 5."""
+    import torch.distributed as dist
+    import torch.nn as nn
+    from advmix_amd.dp import GradSync
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29555')
+    if backend != 'gloo':
+        raise SystemExit('--path replicas is a CPU self-test: ADVMIX_BENCH_BACKEND=gloo')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 2, 1))
+    opt = torch.optim.Adam(net.parameters(), 1e-2)
+    sync = GradSync(bucket_mb=0.001)
+    sync.broadcast_state([net], [opt])
+    sync.trace = []
+    corrupt = os.environ.get('ADVMIX_BENCH_CORRUPT', '')
+    lv = 0.0
+    for step in range(3):
+        opt.zero_grad()
+        loss = net(torch.randn(4, 3, 8, 8)).square().mean()
+        loss.backward()
+        flat = torch.cat([p.grad.view(-1) for p in net.parameters()])
+        sync.reduce_async(flat, 0, flat.numel())
+        if corrupt == 'exchange' and rank == 1 and step == 1:
+            sync.trace[-1][4][3] += 1.0
+        off = 0
+        for p in net.parameters():
+            p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        opt.step()
+        lv = float(loss)
+    with torch.no_grad():
+        if corrupt == 'weight' and rank == 1:
+            next(net.parameters()).view(-1)[5] += 1e-7
+        if corrupt == 'nan' and rank == 1:
+            opt.state[next(net.parameters())]['exp_avg'].view(-1)[0] = float('nan')
+    verification = sync.verify_trace()
+    line = {'metric': 'replicas self-test', 'n_gpus': a.gpus, 'rccl_ranks': dist.get_world_size(), 'backend': backend,
+            'corrupt': corrupt or None}
+    failed = dp_verdict(line, sync, [opt], (verification[0], {}), lv)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if failed:
+        raise SystemExit(5)
+
+
+
+def verify_data_parallel(step, args, nets, crit, opts, data, sync, steps=3):
+    """An N-rank run proves itself (the driver is the only one who can run RCCL with N > 1).  nn.DataParallel
+    re-broadcasts GPU 0's weights before every forward (tools/train.py:69,106,109), so the reference cannot drift or train
+    on a bad exchange; this design could, silently.  ``steps`` steps through the execution under test itself (``step``: the
+    seven-graph runner or the eager pieces the timed region uses - the SAME object, no second capture), each checked:
+      exchange  - what every all-reduce left in the flat gradient buffer == the mean of what the ranks handed to it
+                  (dp.GradSync.verify_trace: all-gather of the operands; exact for sum-and-scale, <= 1e-4 of the range's largest element for RCCL's AVG);
+      coverage  - the exchanged ranges tile each flat gradient buffer exactly once;
+      operands  - what this rank handed to the exchange is finite and is the gradient: recomputed from the same state WITHOUT
+                  pieces, side stream or graphs (plain backward).  The two evaluations differ by the order of their fp32 / fp64
+                  atomics and by the ReLU masks those flip (the timed region is not the deterministic mode: observed 0.018 at
+                  init_weights()), so D's operands are held to a relative L2 distance of 0.2 - a missing (1.0), partial or
+                  garbage operand is caught, one that is merely a step old on this constant batch is not: that is what the
+                  exact exchange check and the replica fold after the timed steps are for; G's gradient at init_weights() is
+                  rounding noise through the frozen D, so it is held to finiteness and to the NORM of the
+                  recomputed one within a factor of ten.
+    With one rank (ADVMIX_FORCE_SYNC=1) the exchange is the identity and the operand checks still hold the ordering of
+    graphs, pieces and side stream to the plain step.  Leaves the models where the verified steps left them."""
+    from advmix_amd.graph import _snapshot, _restore
+    from advmix_amd.core.function import advmix_phase_a, advmix_phase_b
+    D, G, T = nets
+    optD, optG = opts
+    views, tgt, tw = data
+    worst = {'exchange': 0.0, 'operands_D_rel_l2': 0.0, 'operands_G_norm_ratio': 1.0}
+    ok = {'exchange': True, 'coverage': True, 'operands_finite': True}
+
+    def l2(a, b):
+        nb = float(b.double().norm())
+        d = float((a.double() - b.double()).norm())
+        return d / nb if nb > 0 else (0.0 if d == 0 else float('inf'))
+
+    try:
+        for _ in range(steps):
+            before = _snapshot([D, G, T], [optD, optG])
+            sync.trace = []
+            step()
+            torch.cuda.synchronize()
+            trace = sync.trace
+            after = _snapshot([D, G, T], [optD, optG])
+            e_ok, e_worst = sync.verify_trace()
+            sync.trace = None
+            ok['exchange'] &= e_ok
+            worst['exchange'] = max(worst['exchange'], e_worst)
+            for opt in (optD, optG):
+                rs = sorted((lo, hi) for f, lo, hi, _a, _b in trace if f is opt.flat_grads)
+                ok['coverage'] &= bool(rs) and rs[0][0] == 0 and rs[-1][1] == opt.flat_grads.numel() and \
+                    all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+            ok['operands_finite'] &= all(bool(torch.isfinite(pre).all()) for _f, _lo, _hi, pre, _post in trace)
+            _restore(before)                                # the same state, the plain way
+            _l, tmp = advmix_phase_a(args, D, G, T, crit, optD, views, tgt, tw)
+            mine = torch.cat([pre for f, lo, hi, pre, post in sorted(trace, key=lambda e: e[1]) if f is optD.flat_grads])
+            worst['operands_D_rel_l2'] = max(worst['operands_D_rel_l2'], l2(mine, optD.flat_grads))
+            for f, lo, hi, pre, post in trace:
+                if f is optD.flat_grads:
+                    optD.flat_grads[lo:hi].copy_(post)      # adopt the exchanged gradient
+            advmix_phase_b(args, D, crit, optD, optG, tmp, tgt, tw)
+            mine = torch.cat([pre for f, lo, hi, pre, post in sorted(trace, key=lambda e: e[1]) if f is optG.flat_grads])
+            n_mine, n_ref = float(mine.double().norm()), float(optG.flat_grads.double().norm())
+            ratio = n_mine / n_ref if n_ref > 0 else (1.0 if n_mine == 0 else float('inf'))
+            if not (ratio == ratio):
+                ratio = float('inf')
+            worst['operands_G_norm_ratio'] = max(worst['operands_G_norm_ratio'], ratio, 1.0 / ratio if ratio > 0 else float('inf'))
+            torch.cuda.synchronize()
+            del tmp, mine
+            _restore(after)                                 # go on from where the execution under test is
+        ok['operands_D'] = worst['operands_D_rel_l2'] <= 0.2     # (observed 0.018: atomics order + flipped ReLU masks at init_weights())
+        ok['operands_G'] = worst['operands_G_norm_ratio'] <= 10.0
+    finally:
+        sync.trace = None
+    verdict = torch.tensor([0.0 if all(ok.values()) else 1.0], device=views[0].device)
+    if sync.world > 1:
+        import torch.distributed as dist
+        with sync.off_null(verdict):
+            dist.all_reduce(verdict, op=dist.ReduceOp.MAX)  # one answer for the job
+    return float(verdict.item()) == 0.0, {'steps': steps, 'checks': ok,
+                                          'worst': {k: float('%.3g' % v) for k, v in worst.items()}}
+
+
+
+
+def dump_shapes(path, step):
+    """--dump-shapes: log kernel template, grid, shape and FLOPs of every MFMA launch of ONE eager step (``step``: a callable
+    running it) for tools/kernel_shapes.py."""
+    from advmix_amd import ops as _ops
+    step()                                                  # lazy buffers first
+    torch.cuda.synchronize()
+    _ops.set_option('trace_shapes', 1)
+    step()
+    torch.cuda.synchronize()
+    _ops.set_option('trace_shapes', 0)
+    print('wrote', path)
+
+
+def through_loop(a, cfg, args, nets, crit, opts, sync, rank, world, n_warm, n_timed):
+    """The drop-in entry point itself: train_advmix over a loader of pinned HOST batches (DataLoader(pin_memory=True) in
+    tools/train.py:295-301), i.e. H2D copies, capture on the first batch, replay, loss.item(), accuracy, meters -
+    SURVEY 8 d1's full step.  Returns (seconds for n_timed steps, last loss, last accuracy)."""
+    import logging
+    import torch.distributed as dist
+    from advmix_amd.core import function as F_
+    D, G, T = nets
+    optD, optG = opts
+    net, extra, J, H, W, downs, _ = WORKLOADS[a.workload]
+    logging.getLogger(F_.__name__).setLevel(logging.WARNING)
+    cfg['PRINT_FREQ'] = 10 ** 9
+    host = []
+    for k in range(4):                                  # four distinct pinned batches, cycled
+        v, t, w = synth(a.batch, J, H, W, torch.device('cpu'), 1234 + rank + 100 * k)
+        host.append(([x.pin_memory() for x in v], [t.pin_memory()] * 3, [w.pin_memory()] * 3, [{}, {}, {}]))
+
+    class Loader:
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def __iter__(self):
+            return (host[i % len(host)] for i in range(self.n))
+
+    seen = {}
+
+    def run_loop(n):
+        wd = {'writer': types.SimpleNamespace(add_scalar=lambda k, v, s: seen.__setitem__(k, float(v))),
+              'train_global_steps': 0}
+        F_.train_advmix(cfg, args, Loader(n), [D, G, T], crit, [optD, optG], 0, '', '', wd, sync)
+    old_exec = F_.GRAPH_EXEC
+    F_.GRAPH_EXEC = a.exec_mode == 'graph'
+    try:
+        run_loop(max(n_warm, 3))                        # capture + warm-up
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_loop(n_timed)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return time.perf_counter() - t0, seen.get('train_loss', float('nan')), seen.get('train_acc', 0.0)
+    finally:
+        F_.GRAPH_EXEC = old_exec
+        F_.release_graphs()

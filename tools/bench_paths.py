@@ -8,7 +8,7 @@ import types
 
 import torch
 
-from bench_common import ROOT, WORKLOADS, synth, build_models, _event_time, cpu_baseline, FP32_MFMA_PEAK_TFLOPS
+from bench_common import ROOT, WORKLOADS, synth, build_models, _event_time, _ranks, cpu_baseline, FP32_MFMA_PEAK_TFLOPS
 from bench_roofline import time_eval_conv
 
 def bench_validate(a, device, rank, world):

@@ -294,6 +294,35 @@ def gen_benchtiles(M):
     gen_forward(M, BENCH_TILE_CASES, 'benchtiles_forward.npz')
 
 
+# C4 at ITS benchmarked batch (VERDICT r4 item 6 a): HRNet-W48 384x288, B = 32 - forward only (eval forward, train forward,
+# loss, running statistics under no_grad: the backward of gen_forward would need ~40 GB here)
+C4_B32_CASE = ('hrnet_w48_b32', 'pose_hrnet', configs.HRNET_W48, 17, 32, 384, 288)
+
+
+def gen_c4b32(M):
+    tag, net, extra, J, B, H, W = C4_B32_CASE
+    cfg, D, G, _ = build_ref_models(M, net, extra, J, 5)
+    views, tgt, tw = synth_batch(tag, B, J, H, W)
+    calibrate_ref(D, views[2])
+    res = {}
+    with torch.no_grad():
+        D.eval()
+        res[tag + '.eval_out'] = strided(D(views[0]))
+        D.train()
+        yt = D(views[1])
+        loss = M['core.loss'].JointsMSELoss(True)(yt, tgt, tw)
+    res[tag + '.train_out'] = strided(yt)
+    res[tag + '.loss'] = np.array([float(loss)])
+    sd = D.state_dict()
+    bn = [k for k in sd if k.endswith('running_mean')]
+    for k in (bn[0], bn[len(bn) // 2], bn[-1]):
+        res['%s.bn.%s' % (tag, k)] = sd[k].numpy().copy()
+        kv = k.replace('running_mean', 'running_var')
+        res['%s.bn.%s' % (tag, kv)] = sd[kv].numpy().copy()
+    print('forward', tag, float(loss), flush=True)
+    np.savez_compressed(os.path.join(OUT, 'c4_b32_forward.npz'), **res)
+
+
 def gen_c5trunk(M):
     gen_forward(M, (C5_TRUNK_CASE,), 'c5_trunk_forward.npz')
 
@@ -681,7 +710,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     M = import_reference()
-    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe', 'c4', 'b32', 'benchtiles', 'c1', 'autoaug', 'c5trunk', 'nmsvis', 'accuracy']
+    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe', 'c4', 'b32', 'benchtiles', 'c1', 'autoaug', 'c5trunk', 'nmsvis', 'accuracy', 'c4b32']
     for w in which:
         globals()['gen_' + w](M)
         print('done', w, flush=True)

@@ -12,12 +12,15 @@ pytestmark = pytest.mark.gpu
 from helpers import CASES, ALL_FORWARD, DOWNS, gold_files, gold_json, gold_npz, build_states, checksum_close   # noqa: E402
 
 REPORT = {}      # worst err / bound ratio per checked quantity (printed by the tests)
-# median per-tensor D-gradient error vs the fp32 oracle after a device-side update, per case: 3 x the largest value observed
-# for THAT case over its iterations (profiles/r03_gpu_parity_observations.log; B = 2 nets are ill-conditioned)
-# (largest over the round-3 runs; the tiny nets are bimodal - 2e-5 when no ReLU mask flips after the forced update, 1.5e-2
-#  when one does (resnet18_tiny it 1 in one run of three) - so both carry the flipped value)
-GRAD_MEDIAN_OBSERVED = {'hrnet_tiny': 1.5e-2, 'resnet18_tiny': 1.5e-2, 'hrnet_w32': 2.4e-2, 'resnet50': 4.2e-2, 'hrnet_w48': 2.3e-2}
-GRAD_MEDIAN_TOL = {k: 3 * v for k, v in GRAD_MEDIAN_OBSERVED.items()}
+# Median per-tensor D-gradient error after a device-side update (round 5, VERDICT r4 item 6 c): no longer 3 x the device's own
+# worst observation but DERIVED per case and iteration from the fp32 oracle: both the device's and the fp32 oracle's D-step
+# gradients are held against an fp64 evaluation of the same step from the same state, and the device may be at most
+# 3 x as far from it as the fp32 oracle is - or as far as the fp32 oracle itself moves when its input is perturbed by an ulp
+# (its conditioning at this state: a pre-activation within rounding of zero flips a ReLU mask in ANY fp32 evaluation).
+# The two tiny B = 2 networks keep a floor for exactly that event - ONE flipped mask there moves the median by 1.5e-2
+# (bimodal: 2e-5 without; profiles/r03_gpu_parity_observations.log) and a particular flip is not reproduced by a particular
+# perturbation; the three real networks carry no floor.
+GRAD_FLIP_FLOOR = {'hrnet_tiny': 2.5e-2, 'resnet18_tiny': 2.5e-2}
 from smoke_step import (product_models, assert_close, run_smoke, assert_grads,      # noqa: E402
                         pull_params, match_fraction)
 
@@ -36,6 +39,40 @@ def _f64_grads(net, extra, D, names, x, tgt, tw, B, J):
     l = (F.smooth_l1_loss(d, torch.zeros_like(d), reduction='none').mean(dim=(0, 2, 3)) * 0.5).sum() / J
     g = torch.autograd.grad(l, [P[k] for k in names] + [xx])
     return dict(zip(names + ['x'], g))
+
+
+def _loss_any_dtype(y, tgt, tw, B, J):
+    """lib/core/loss.py:25-65 in the dtype of ``y`` (oracle.loss casts to float)."""
+    import torch.nn.functional as F
+    w_ = tw.to(y.dtype).reshape(B, J, 1, 1)
+    d = y * w_ - tgt.to(y.dtype) * w_
+    return (F.smooth_l1_loss(d, torch.zeros_like(d), reduction='none').mean(dim=(0, 2, 3)) * 0.5).sum() / J
+
+
+def _d_step_grads(net, extra, D0, names, tmp, teacher, tgt, tw, B, J, alpha, dtype):
+    """Gradient of loss_D = (1 - alpha) L(D(tmp), target) + alpha L(D(tmp), teacher) (function.py:146-153) w.r.t. D's trainable
+    parameters, evaluated in ``dtype`` from the state ``D0``."""
+    from oracle.posenet import posenet_forward
+    P = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in D0.items()}
+    for k in names:
+        P[k].requires_grad_(True)
+    y = posenet_forward(net, P, tmp.to(dtype), extra, True)
+    l = (1 - alpha) * _loss_any_dtype(y, tgt, tw, B, J) + alpha * _loss_any_dtype(y, teacher, tw, B, J)
+    return dict(zip(names, torch.autograd.grad(l, [P[k] for k in names], allow_unused=True)))
+
+
+def _g_step_grads_f64(net, extra, D1, G0, views, tgt, tw, B, J, downs):
+    """fp64 gradient of loss_G = -L(D'(mix(views, G(views))), target) w.r.t. G (function.py:160-163) through the frozen, already
+    updated student D1."""
+    from oracle.posenet import posenet_forward
+    from oracle.unet import unet_forward
+    from oracle.step import mix_views
+    P = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in D1.items()}
+    G64 = {k: v.detach().clone().double().requires_grad_(True) for k, v in G0.items()}
+    v64 = [x.double() for x in views]
+    tmp, _ = mix_views(v64, unet_forward(G64, torch.cat(v64, 1), num_downs=downs))
+    l = -_loss_any_dtype(posenet_forward(net, P, tmp, extra, True), tgt, tw, B, J)
+    return dict(zip(G0, torch.autograd.grad(l, list(G64.values()), allow_unused=True)))
 
 
 @pytest.mark.parametrize('tag', list(ALL_FORWARD))
@@ -157,9 +194,12 @@ def test_advmix_and_plain_steps_vs_oracle_and_golden(tag):
             fracs.append(match_fraction(mD, D, atol))     # oracle's own update vs the device's
             loose.append(match_fraction(mD, D, 10 * atol))
             pull_params(mD, D)
+        D0 = {k: x_.detach().clone() for k, x_ in D.items()}          # the state both D-step gradients were taken at
+        G0 = {k: x_.detach().clone() for k, x_ in G.items()}
         ref = ostep(net, extra, D, G, T, oD, oG, v, t, w, alpha=0.1, after_D_step=force,
                     unet_kw={'num_downs': downs})
         fracs.append(match_fraction(mG, G, atol))
+        gG_dev = {k: p.grad.detach().cpu().clone() for k, p in mG.named_parameters()}
         pull_params(mG, G)
         assert_close('loss_D', loss_D, ref['loss_D'], report=REPORT)
         assert_close('out2', out, ref['out2'], report=REPORT)
@@ -170,10 +210,30 @@ def test_advmix_and_plain_steps_vs_oracle_and_golden(tag):
                 assert float((p.detach() - before[k]).abs().max()) <= 1e-3 * 1.001, k
         # gradients left in the flat buffers: D grads from the D step, G grads from the G step
         gD = {k: p.grad.detach().cpu() for k, p in mD.named_parameters()}
-        mh = np.median([float((gD[k] - ref['gD'][k]).abs().max()) / (float(ref['gD'][k].abs().max()) + 1e-30)
-                        for k in ref['gD']])
-        print(tag, 'it', it, 'median D-grad error vs fp32 oracle %.3e' % mh)
-        assert mh <= GRAD_MEDIAN_TOL[tag], ('median D-grad error vs fp32 oracle', mh, GRAD_MEDIAN_TOL[tag])
+        dn = [k for k in ref['gD'] if ref['gD'][k] is not None]
+        g64 = _d_step_grads(net, extra, D0, dn, ref['tmp'], ref['teacher'], t, w, B, J, 0.1, torch.float64)
+        from smoke_step import grad_stats
+        mh, mo, outl, _eh, _eo = grad_stats(dn, gD, ref['gD'], g64)
+        spread = 0.0                                      # the fp32 oracle against ITSELF with tmp moved by about an ulp, twice
+        for seed in (1, 2):
+            noise = 1.0 + 2.0 ** -23 * torch.randn(ref['tmp'].shape, generator=torch.Generator().manual_seed(seed))
+            gp = _d_step_grads(net, extra, D0, dn, ref['tmp'] * noise, ref['teacher'], t, w, B, J, 0.1, torch.float32)
+            spread = max(spread, grad_stats(dn, gp, ref['gD'], {k: ref['gD'][k].double() for k in dn})[0])
+        bound = max(3 * max(mo, spread) + 1e-4, GRAD_FLIP_FLOOR.get(tag, 0.0))
+        print(tag, 'it', it, 'median D-grad error vs fp64: hip %.3e fp32-oracle %.3e, oracle under a 1-ulp perturbation %.3e, '
+              'bound %.3e, outliers %d' % (mh, mo, spread, bound, outl))
+        assert mh <= bound, ('median D-grad error vs the fp64 oracle', mh, mo, spread, bound)
+        # the G step's gradient, teacher-forced (round 5, VERDICT r4 item 6 b: this replaces the un-forced generator checksum
+        # bound of 2 units): through the frozen student the device has just updated - which the oracle adopted - against fp64,
+        # statistically no worse than the fp32 oracle's own G gradient
+        gG64 = _g_step_grads_f64(net, extra, D, G0, v, t, w, B, J, downs)
+        gmax = max(float(x_.abs().max()) for x_ in gG64.values())
+        live = [k for k in G0 if float(gG64[k].abs().max()) > 1e-4 * gmax]       # (biases under an InstanceNorm: true gradient 0)
+        gstats = assert_grads('G-step grads it%d' % it, live, gG_dev, ref['gG'], gG64)
+        for k in G0:
+            if k not in live:
+                assert float(gG_dev[k].abs().max()) <= 1e-3 * gmax, k
+        print(tag, 'it', it, 'G-step grad median rel err vs fp64: hip %.2e fp32-oracle %.2e outliers %d' % gstats)
     print(tag, 'worst err/bound ratios', {k: round(v, 3) for k, v in REPORT.items()})
     sd = mD.state_dict()
     assert int(sd['bn1.num_batches_tracked']) == meta['nbt']       # calib + 2 forwards / iteration
@@ -354,6 +414,10 @@ BENCH_TILE_CASES = {
                      [(64, 64, 48, 3), (128, 32, 24, 3), (256, 16, 12, 3), (512, 8, 6, 3), (256, 64, 48, 1), (2048, 8, 6, 1)]),
     'hrnet_w48_b16': ('pose_hrnet', 'HRNET_W48', 17, 16, 384, 288, 5,
                       [(48, 96, 72, 3), (96, 48, 36, 3), (192, 24, 18, 3), (384, 12, 9, 3)]),
+    # C4 at its benchmarked batch itself (round 5, VERDICT r4 item 6 a): forward-only vectors from the real reference
+    # (tests/golden/c4_b32_forward.npz, oracle/gen_golden.py::gen_c4b32 - its backward would not fit the build container)
+    'hrnet_w48_b32': ('pose_hrnet', 'HRNET_W48', 17, 32, 384, 288, 5,
+                      [(48, 96, 72, 3), (96, 48, 36, 3), (192, 24, 18, 3), (384, 12, 9, 3)]),
 }
 
 
@@ -361,8 +425,9 @@ BENCH_TILE_CASES = {
 def test_every_benchmarked_network_at_its_benchmarked_tiles(tag):
     """ResNet-50 (C2) and HRNet-W48 384x288 (C4) are benchmarked at B = 32 but were parity-checked at B = 2,
     where conv_direct picks other tiles.  ResNet-50 at B = 32 itself; HRNet-W48 at B = 16, which reaches every tile
-    configuration B = 32 does (asserted) - eval forward, train forward, loss and running statistics against the CPU
-    oracle (full tensors) and the REAL reference's vectors at that batch (tests/golden/benchtiles_forward.npz)."""
+    configuration B = 32 does (asserted), and since round 5 at B = 32 itself - eval forward, train forward, loss and running
+    statistics against the CPU oracle (full tensors) and the REAL reference's vectors at that batch
+    (tests/golden/benchtiles_forward.npz, c4_b32_forward.npz)."""
     from oracle import configs
     from oracle.posenet import posenet_forward, calibrate
     from oracle.loss import joints_loss
@@ -375,7 +440,7 @@ def test_every_benchmarked_network_at_its_benchmarked_tiles(tag):
     def tiles(b):
         return {lib.advmix_conv_direct_config(m, b, h, w, c, c, k, k, 1) for c, h, w, k in convs for m in (0, 1)}
     assert tiles(B) >= tiles(32) and -1 not in tiles(32), (tiles(B), tiles(32))
-    g = gold_npz('benchtiles_forward.npz')
+    g = gold_npz('c4_b32_forward.npz' if tag == 'hrnet_w48_b32' else 'benchtiles_forward.npz')
     D, T, G = build_states(net, extra, J, unet_downs=downs)
     views, tgt, tw = synth_batch(tag, B, J, H, W)
     calibrate(net, D, views[2], extra)
@@ -461,8 +526,11 @@ def test_unforced_advmix_loop_lands_on_the_reference_checksums(tag):
     numel_G = {k: v.numel() for k, v in mG.state_dict().items()}
     ug = _checksum_units(_device_checksums(mG, meta['G']), meta['G'], numel_G, 1e-3, iters)
     print(tag, 'un-forced checksum drift in units of numel*lr*updates: D %.4f G %.4f' % (u, ug))
+    # D: never more than the all-opposite bound.  G (round 5): no un-forced bound at all - its gradient is held element-wise,
+    # teacher-forced, against fp64 in test_advmix_and_plain_steps_vs_oracle_and_golden instead (the bound of 2 units that
+    # stood here could only catch a skipped or doubled step); ug is printed for the record and only its sanity is asserted
     bound = min(2.0, 3 * CHECKSUM_UNITS_OBSERVED[tag])
-    assert u <= bound and ug <= bound, (u, ug, bound)
+    assert u <= bound and ug == ug and ug <= 2.0, (u, ug, bound)
     assert int(mD.state_dict()['bn1.num_batches_tracked']) == meta['nbt']
 
 

@@ -219,6 +219,7 @@ def test_forward_at_the_benchmarked_batch_matches_reference():
 BENCH_TILE_CASES = {      # oracle/gen_golden.py::BENCH_TILE_CASES - the other two benchmarked networks at benchmark-sized batches
     'resnet50_b32': ('pose_resnet', configs.RES50, 17, 32, 256, 192),
     'hrnet_w48_b16': ('pose_hrnet', configs.HRNET_W48, 17, 16, 384, 288),
+    'hrnet_w48_b32': ('pose_hrnet', configs.HRNET_W48, 17, 32, 384, 288),      # C4's benchmarked batch itself (c4_b32_forward.npz, forward only)
 }
 
 
@@ -227,7 +228,7 @@ def test_forward_of_the_other_benchmarked_networks_matches_reference(tag):
     """ResNet-50 256x192 at B = 32 (C2) and HRNet-W48 384x288 at B = 16 (C4): eval forward, train forward, loss and
     running statistics against the REAL reference's vectors at those batches (tests/golden/benchtiles_forward.npz)."""
     net, extra, J, B, H, W = BENCH_TILE_CASES[tag]
-    g = gold_npz('benchtiles_forward.npz')
+    g = gold_npz('c4_b32_forward.npz' if tag == 'hrnet_w48_b32' else 'benchtiles_forward.npz')
     D, _, _ = build_states(net, extra, J, unet_downs=5 if 'w48' in tag else 6)
     views, tgt, tw = synth_batch(tag, B, J, H, W)
     calibrate(net, D, views[2], extra)

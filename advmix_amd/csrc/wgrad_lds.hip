@@ -221,6 +221,17 @@ __global__ __launch_bounds__(THREADS) void wgrad3x3_c32(LP p) {
 
 }  // namespace wgl
 
+// The dynamic-LDS limit of wgrad3x3_c32, shared by BOTH dispatchers and only ever raised (each kept a tracker of its
+// own, so a smaller grouped launch after a larger single one would have lowered the attribute under the other's feet).
+static bool raise_lds_limit(int lds) {
+    static int attr_lds = 0;
+    if (lds <= attr_lds) return true;
+    if (hipFuncSetAttribute((const void*)wgl::wgrad3x3_c32, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
+    attr_lds = lds;
+    return true;
+}
+
+
 // -1 = not eligible (caller falls back).  part == null: fp32 atomics into dw; else the workgroups store their partial
 // tiles and the CALLER sums ``*nslices`` slices in slab order.
 int advmix_wgrad_lds_dispatch(const float* a, const float* b, float* dw, int N, int Ha, int Wa, int Ca, int Hb, int Wb,
@@ -243,12 +254,7 @@ int advmix_wgrad_lds_dispatch(const float* a, const float* b, float* dw, int N, 
     if (part && (int64_t)slabs * 32 * 9 * 32 > part_floats) return -1;
     int lds = (rows * Wp + (rows + 2) * (Wp + 2)) * 32 * 4;
     if (lds < 9 * wgl::TILE * 4) lds = 9 * wgl::TILE * 4;
-    static int attr_lds = 0;
-    if (lds > attr_lds) {
-        if (hipFuncSetAttribute((const void*)wgl::wgrad3x3_c32, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return -1;
-        attr_lds = lds;
-    }
+    if (!raise_lds_limit(lds)) return -1;
     wgl::LP p{a, b, dw, part, N, Ha, Wa, Wp, rows, (int)bytes, 1, slabs, 1, {a}, {b}, {dw}};
     dim3 g(slabs);
     hipLaunchKernelGGL(wgl::wgrad3x3_c32, g, dim3(wgl::THREADS), lds, st, p);
@@ -288,12 +294,7 @@ int advmix_wgrad_lds_group_dispatch(int n, const float* const* a, const float* c
     if (!nslab) return -1;
     int lds = (rows * Wp + (rows + 2) * (Wp + 2)) * 32 * 4;
     if (lds < 9 * wgl::TILE * 4) lds = 9 * wgl::TILE * 4;
-    static int attr_lds = 0;
-    if (lds > attr_lds) {
-        if (hipFuncSetAttribute((const void*)wgl::wgrad3x3_c32, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return -1;
-        attr_lds = lds;
-    }
+    if (!raise_lds_limit(lds)) return -1;
     wgl::LP p{nullptr, nullptr, nullptr, nullptr, N, Ha, Wa, Wp, rows, (int)bytes, nslab, slabs / nslab, n, {}, {}, {}};
     for (int i = 0; i < 64; ++i) {
         p.dyv[i] = i < n ? a[i] : nullptr;

@@ -145,6 +145,12 @@ class GradSync:
             yield
         cur.wait_stream(side)
 
+    def _collective_device(self):
+        """Where a tensor must live for this group's collectives: the current GPU for RCCL, the host otherwise."""
+        if dist.is_available() and dist.is_initialized() and dist.get_backend(self.group) == 'nccl' and torch.cuda.is_available():
+            return torch.device('cuda', torch.cuda.current_device())
+        return torch.device('cpu')
+
     def _gather(self, t):
         if self.world == 1 or not (dist.is_available() and dist.is_initialized()):
             return [t]
@@ -172,7 +178,7 @@ class GradSync:
             rel = err / scale if scale > 0 else (0.0 if err == 0 else float('inf'))
             worst = max(worst, rel)
             ok = ok and fin and rel <= rtol
-        dev = self.trace[0][3].device if self.trace else torch.device('cpu')
+        dev = self.trace[0][3].device if self.trace else self._collective_device()      # (an NCCL group cannot gather a CPU tensor)
         verdict = torch.stack(self._gather(torch.tensor([0.0 if ok else 1.0, min(worst, 3e38)], device=dev,
                                                         dtype=torch.float32))).cpu()
         return bool((verdict[:, 0] == 0).all()), float(verdict[:, 1].max())          # the same answer on every rank
@@ -182,16 +188,22 @@ class GradSync:
         """Three int64 numbers over the raw bits of ``tensors``: wrapping sum, position-weighted wrapping sum, count of
         non-finite elements.  Equal bits -> equal folds; one flipped bit changes the first two."""
         acc = torch.zeros(3, dtype=torch.int64, device=tensors[0].device)
-        for t in tensors:
+        CH = 1 << 22                                        # fixed-size pieces (ADVICE r4): a flat optimizer buffer of 30-60 M
+        w = None                                            # elements used to be widened to int64 three times over in one go
+        for t in tensors:                                   # (~24 B / parameter of transient memory in the middle of training)
             t = t.detach().contiguous().view(-1)
-            if t.is_floating_point():
-                acc[2] += (~torch.isfinite(t)).sum()
             if t.element_size() % 4:
                 t = t.to(torch.int32)
-            v = t.view(torch.int32).to(torch.int64)
-            w = torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 8191 + 1
-            acc[0] += v.sum()
-            acc[1] += (v * w).sum()
+            bits = t.view(torch.int32)
+            for lo in range(0, bits.numel(), CH):
+                piece = bits[lo:lo + CH]
+                if t.is_floating_point():
+                    acc[2] += (~torch.isfinite(t[lo * 4 // t.element_size():(lo + piece.numel()) * 4 // t.element_size()])).sum()
+                if w is None or w.device != piece.device:
+                    w = torch.arange(CH, device=piece.device, dtype=torch.int64)
+                v = piece.to(torch.int64)
+                acc[0] += v.sum()
+                acc[1] += (v * ((w[:piece.numel()] + lo) % 8191 + 1)).sum()
         return acc
 
     def replicas_state(self, optimizers):
@@ -311,20 +323,45 @@ class ShardedDataLoader(torch.utils.data.DataLoader):
     overlapping samples.  Under an initialised process group of N > 1 ranks a SHUFFLED loader (the training one) instead
     draws from a ``DistributedSampler`` (disjoint shards of one common permutation, re-drawn every epoch: ``set_epoch`` is
     called per ``__iter__``, which the reference loop has no line for) with ``batch_size // N`` samples per iteration -
-    the per-GPU batch when N = len(GPUS).  Unshuffled loaders (validation) are left alone: rank 0 evaluates the whole
-    set (core.function.validate returns at once on the other ranks).  Without a process group this IS DataLoader.
+    the per-GPU batch when N = len(GPUS).  Unshuffled loaders are left whole - core.function.validate shards a validation loader's
+    batches over the ranks itself, and the training loops ask ``for_training()`` for a sharded twin of an unshuffled one.  Without a process group this IS DataLoader.
     Bound by the INTEGRATION.md recipe as ``torch.utils.data.DataLoader``."""
 
     def __init__(self, dataset, batch_size=1, shuffle=False, sampler=None, batch_sampler=None, **kw):
         rank, world = _world()
         self._epoch = 0
-        self._sharded = world > 1 and shuffle and sampler is None and batch_sampler is None
+        self._ctor = (dataset, batch_size, kw) if (sampler is None and batch_sampler is None) else None
+        self._train_copy = None
+        self._sharded = world > 1 and shuffle and sampler is None and batch_sampler is None and batch_size is not None
         if self._sharded:
             if batch_size % world:
                 raise ValueError('global batch %d does not divide over %d ranks' % (batch_size, world))
             sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True)
             shuffle, batch_size = False, batch_size // world
         super().__init__(dataset, batch_size=batch_size, shuffle=shuffle, sampler=sampler, batch_sampler=batch_sampler, **kw)
+
+    def set_epoch(self, epoch):
+        """The permutation the NEXT ``__iter__`` draws: the training loops pass their ``epoch`` argument, so a run
+        resumed at epoch k (AUTO_RESUME, tools/train.py:238-269) continues with permutation k instead of replaying 0..k."""
+        self._epoch = int(epoch)
+
+    def for_training(self):
+        """What a TRAINING loop should iterate.  A shuffled loader is already this rank's shard; an UNSHUFFLED one
+        (TRAIN.SHUFFLE false) was left whole for validation's sake - every rank would load the full global batch of identical
+        samples - so the training loops get a sharded twin of it (DistributedSampler(shuffle=False), batch // N), built once."""
+        rank, world = _world()
+        if self._sharded or world <= 1 or self._ctor is None:
+            return self
+        if self._train_copy is None:
+            dataset, batch_size, kw = self._ctor
+            if batch_size is None or batch_size % world:
+                import warnings
+                warnings.warn('advmix_amd: an unshuffled training loader whose batch does not divide over %d ranks stays whole: '
+                              'every rank loads every sample' % world)
+                return self
+            smp = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=False)
+            self._train_copy = torch.utils.data.DataLoader(dataset, batch_size=batch_size // world, shuffle=False, sampler=smp, **kw)
+        return self._train_copy
 
     def __iter__(self):
         if self._sharded:

@@ -161,6 +161,20 @@ def soft_oks_nms(kpts_db, thresh, sigmas=None, in_vis_thre=None):
     max_dets = 20
     M = _oks_matrix(kpts, areas, sigmas, device=True, in_vis_thre=in_vis_thre)      # [n, n] fp64, stays on the GPU
     order = scores.argsort()[::-1]                          # numpy's initial order (ties: its own), as in the reference
+    if n > 8192 or thresh == 0 or thresh != thresh:
+        # what advmix_soft_oks_greedy refuses (one workgroup holds the candidates; exp(-oks^2 / 0)): the reference's own loop
+        # (nms.py:157-175) on the host over the device's OKS matrix - any n, any threshold, numpy's own arithmetic
+        Mh = M.cpu().numpy()
+        sc, keep = scores[order], []
+        while order.size > 0 and len(keep) < max_dets:
+            i = order[0]
+            ovr = Mh[i, order[1:]]
+            order = order[1:]
+            sc = rescore(ovr, sc[1:], thresh)
+            tmp = sc.argsort()[::-1]
+            order, sc = order[tmp], sc[tmp]
+            keep.append(i)
+        return np.asarray(keep, dtype=np.intp)
     od = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int32)).cuda()
     sc = _dev64(scores[order])
     ws_s = torch.empty(2 * n, dtype=torch.float64, device='cuda')

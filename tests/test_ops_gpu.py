@@ -1374,6 +1374,14 @@ def test_soft_oks_nms_device_loop_ties_caps_and_errors():
         argv = list(ok)
         argv[k] = bad
         assert lib.advmix_soft_oks_greedy(*argv) == 1, (k, bad)
+    # ... and what the device loop refuses, the module serves with the reference's own host loop over the device's OKS matrix
+    # (ADVICE r4): a zero threshold (numpy's exp(-oks^2 / 0), NaNs and all) keeps what the numpy restatement keeps
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        want0 = [int(i) for i in onms.soft_oks_nms(db, 0.0)]
+        got0 = [int(i) for i in pn.soft_oks_nms(db, 0.0)]
+    assert sorted(got0) == sorted(want0) and got0[0] == want0[0], (got0, want0)
 
 
 def test_oks_pairs_engineered_onto_the_threshold():

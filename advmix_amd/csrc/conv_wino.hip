@@ -67,21 +67,26 @@ __device__ __forceinline__ int acc_row(int r, int lk) { return (r & 3) + 8 * (r 
 // stored apart, so the 32 tiles of a wave read CONSECUTIVE positions (not every second one), and with HALF chosen so that
 // a tile row (two pixel rows = 4 HALF positions) advances the 16-byte slot by BW, the 16 lanes the hardware serves per
 // cycle of a ds_read_b128 fall on 16 different slots: no bank conflicts.
-template <int LBW, int C>
+template <int LBW, int C, int KS = 1>
 struct Geo {
     static constexpr int BW = 1 << LBW, BH = 32 >> LBW;
     static constexpr int PH = 2 * BH + 2, PW = 2 * BW + 2;
     static constexpr int HALF = LBW == 3 ? 10 : (LBW == 2 ? 5 : (LBW == 4 ? 20 : PW / 2));
     static constexpr int PWL = 2 * HALF, PP = C + 4;
     static constexpr int PATCH = PH * PWL * PP;             // floats
-    static constexpr int XCH = 4 * 2 * 4 * 64 * 4;          // floats of the inverse transform's exchange
+    static constexpr int XCH = KS * 4 * 2 * 4 * 64 * 4;     // floats of the inverse transform's exchange
     static constexpr int LDS = PATCH > XCH ? PATCH : XCH;
 };
 
 // NQ = Ci / 8 (k groups of 8 channels: two k-lanes x 4 channels per 16-byte load).  ROLE 0: forward epilogues, 1: input gradient.
-template <int NQ, int ROLE, int LBW>
-__global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
-    using G = Geo<LBW, NQ * 8>;
+// KS: K is split over KS sets of four waves (workgroup = 4 KS waves): the 128-channel branch (16 x 12 maps: 64 blocks x 4
+// column tiles = one workgroup per CU at B = 32) gets two waves per SIMD that way, each multiplying half of the channels;
+// the halves meet in the exchange of the inverse transform, which adds across waves anyway.
+template <int NQ, int ROLE, int LBW, int KS = 1>
+__global__ __launch_bounds__(256 * KS, KS == 1 ? 3 : 1) void conv_wino(const WinoP p) {
+    using G = Geo<LBW, NQ * 8, KS>;
+    constexpr int NT = 256 * KS, NQW = NQ / KS;            // threads; k groups per wave
+    static_assert(NQ % KS == 0, "K splits evenly over the wave sets");
     constexpr int C = NQ * 8, BW = G::BW, BH = G::BH, PW = G::PW, PH = G::PH, HALF = G::HALF, PWL = G::PWL, PP = G::PP;
     // one region, four lives (separated by workgroup barriers): the input patch, the exchange of the inverse transform's
     // row half ([wave][b][r / 4][lane][4]), then the wave-private transposers of the epilogue
@@ -91,7 +96,9 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
     float* const Ts = L;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int wid = wv & 3, kh = wv >> 2;                  // row of the transformed patch this wave multiplies; its share of K
+    const bool fin = kh == 0;                               // the four waves that finish an output position each
     const int l31 = lane & 31, lh = lane >> 5;
     int bm = blockIdx.x;
     if (p.xcd_remap && (gridDim.x & 7) == 0 && gridDim.x >= 16)            // each XCD (and its L2) works through a contiguous
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
     f32x4 bn[4];
     auto issue_b = [&](int q) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bn[j] = bload(ur, bo + (unsigned)((j * NQ + q) * 1024));
+        for (int j = 0; j < 4; ++j) bn[j] = bload(ur, bo + (unsigned)((j * NQ + kh * NQW + q) * 1024));
     };
     issue_b(0);
 
@@ -115,12 +122,12 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
     // lane's 8 patch pixels straight into registers: 4x the bytes - neighbouring tiles and the four waves overlap - at a
     // quarter of a cache line per request; the loads, not the MFMAs, set its time: profiles/r05a_knockout_wino_v1.log) ----
     {
-        constexpr int NS = PH * PW * (C / 4), NIT = (NS + 255) / 256;
+        constexpr int NS = PH * PW * (C / 4), NIT = (NS + NT - 1) / NT;
         const int hb = 2 * BH * bby - 1, wb = 2 * BW * bbx - 1;
         f32x4 stg[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int s = tid + 256 * it;
+            const int s = tid + NT * it;
             const int px = s / (C / 4), cs = s % (C / 4);
             const int pr = px / PW, pc = px % PW;
             const int h = hb + pr, w = wb + pc;
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int s = tid + 256 * it;
+            const int s = tid + NT * it;
             const int px = s / (C / 4), cs = s % (C / 4);
             const int pr = px / PW, pc = px % PW;
             if (s < NS) *reinterpret_cast<f32x4*>(&L[(pr * PWL + (pc & 1) * HALF + (pc >> 1)) * PP + cs * 4]) = stg[it];
@@ -147,8 +154,8 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
     const int ra = wid == 0 ? 0 : (wid == 2 ? 2 : 1);
     const int rb = wid == 3 ? 3 : (wid == 2 ? 1 : 2);
     const float sg = wid == 1 ? 1.f : -1.f;
-    const float* const la = L + ((2 * byl + ra) * PWL + bxl) * PP + 4 * lh;
-    const float* const lb = L + ((2 * byl + rb) * PWL + bxl) * PP + 4 * lh;
+    const float* const la = L + ((2 * byl + ra) * PWL + bxl) * PP + 4 * lh + kh * (NQW * 8);
+    const float* const lb = L + ((2 * byl + rb) * PWL + bxl) * PP + 4 * lh + kh * (NQW * 8);
 
     f32x16 acc[4];
 #pragma unroll
@@ -158,12 +165,12 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
 
     __syncthreads();                                        // the patch is complete
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+    for (int q = 0; q < NQW; ++q) {
         f32x4 rc[4], v[4], bc[4];
         __builtin_amdgcn_sched_barrier(0);                  // (nothing of group q + 1 is hoisted above group q's MFMAs)
 #pragma unroll
         for (int j = 0; j < 4; ++j) bc[j] = bn[j];
-        if (q + 1 < NQ) issue_b(q + 1);                     // the next group's filters fly under this group's 16 MFMAs
+        if (q + 1 < NQW) issue_b(q + 1);                     // the next group's filters fly under this group's 16 MFMAs
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int o = ((c & 1) * HALF + (c >> 1)) * PP + 8 * q;
@@ -204,7 +211,8 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
         co4[qq] = pq >= 0 ? (unsigned)(((pq + pos) * p.Co + n0 + ((lane & 7) << 2)) * 4) : OOB;
     }
     const bool bnb = ROLE == 1 && p.bnb_c != nullptr;
-    const bool op_a = p.res != nullptr;
+    const bool bnbf = bnb && fin;
+    const bool op_a = fin && p.res != nullptr;
     const bool mask_on = bnb && p.bnb_mask != nullptr && p.bnb_act != ADVMIX_ACT_NONE;
     f32x4 pq_a[4], pq_c[4];
 #pragma unroll
@@ -212,10 +220,10 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
         pq_a[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
         pq_c[qq] = pq_a[qq];
         if (op_a) pq_a[qq] = bload(rr, co4[qq]);
-        if (ROLE == 1 && bnb) pq_c[qq] = bload(cr, co4[qq]);
+        if (ROLE == 1 && bnbf) pq_c[qq] = bload(cr, co4[qq]);
     }
     unsigned mw = 0u;
-    if (ROLE == 1 && mask_on)       // lane (l31, lh): the 16 channels [16 lh, 16 lh + 16) of ITS tile's pixel = 4 mask bytes
+    if (ROLE == 1 && mask_on && fin)       // lane (l31, lh): the 16 channels [16 lh, 16 lh + 16) of ITS tile's pixel = 4 mask bytes
         mw = __builtin_amdgcn_raw_buffer_load_b32(mkr, pb >= 0 ? (unsigned)((pb + pos) * (p.Co >> 2) + ((n0 + 16 * lh) >> 2)) : OOB, 0, 0);
 
     __syncthreads();                                        // every wave is done with the patch: the region becomes the exchange
@@ -228,27 +236,35 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
         }
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-            *reinterpret_cast<f32x4*>(&X[(((wid * 2 + 0) * 4 + r4) * 64 + lane) * 4]) = f32x4{t0[4 * r4], t0[4 * r4 + 1], t0[4 * r4 + 2], t0[4 * r4 + 3]};
-            *reinterpret_cast<f32x4*>(&X[(((wid * 2 + 1) * 4 + r4) * 64 + lane) * 4]) = f32x4{t1[4 * r4], t1[4 * r4 + 1], t1[4 * r4 + 2], t1[4 * r4 + 3]};
+            *reinterpret_cast<f32x4*>(&X[(((wv * 2 + 0) * 4 + r4) * 64 + lane) * 4]) = f32x4{t0[4 * r4], t0[4 * r4 + 1], t0[4 * r4 + 2], t0[4 * r4 + 3]};
+            *reinterpret_cast<f32x4*>(&X[(((wv * 2 + 1) * 4 + r4) * 64 + lane) * 4]) = f32x4{t1[4 * r4], t1[4 * r4 + 1], t1[4 * r4 + 2], t1[4 * r4 + 3]};
         }
     }
     __syncthreads();
     // ---- row half (across the waves):  Y[0][b] = T0 + T1 + T2,  Y[1][b] = T1 - T2 - T3 -----------------------------------
     float yv[16];
-    {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) yv[r] = 0.f;
+    if (fin) {
         const float s = oa_ ? -1.f : 1.f;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(&X[((((oa_ + 0) * 2 + ob_) * 4 + r4) * 64 + lane) * 4]);
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(&X[((((oa_ + 1) * 2 + ob_) * 4 + r4) * 64 + lane) * 4]);
-            const f32x4 x2 = *reinterpret_cast<const f32x4*>(&X[((((oa_ + 2) * 2 + ob_) * 4 + r4) * 64 + lane) * 4]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) yv[4 * r4 + e] = __builtin_fmaf(s, x1[e] + x2[e], x0[e]);
+            for (int k = 0; k < KS; ++k) {                  // (the K shares of the wave sets add up here)
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(&X[((((4 * k + oa_ + 0) * 2 + ob_) * 4 + r4) * 64 + lane) * 4]);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(&X[((((4 * k + oa_ + 1) * 2 + ob_) * 4 + r4) * 64 + lane) * 4]);
+                const f32x4 x2 = *reinterpret_cast<const f32x4*>(&X[((((4 * k + oa_ + 2) * 2 + ob_) * 4 + r4) * 64 + lane) * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) yv[4 * r4 + e] += __builtin_fmaf(s, x1[e] + x2[e], x0[e]);
+            }
         }
     }
 
     __syncthreads();                                        // the exchange has been read: the region becomes the transposers
     // ---- fused epilogue (conv_direct.hip's, for one tile per wave) -----------------------------------------------------
+    const bool stats = p.stats != nullptr;
+    float s1 = 0.f, s2 = 0.f;
+    if (fin) {                                              // (KS > 1: the other wave sets only keep the barriers company)
     float* const Tx = Ts + wid * (32 * TP);
     auto wave_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
@@ -265,10 +281,9 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { oa[r] = 0.f; oc[r] = 0.f; }
     if (op_a) to_acc_layout(pq_a, oa);
-    if (ROLE == 1 && bnb) to_acc_layout(pq_c, oc);
+    if (ROLE == 1 && bnbf) to_acc_layout(pq_c, oc);
 
     const int col = n0 + l31;                               // (Co % 32 == 0: every column is valid)
-    const bool stats = p.stats != nullptr;
     float bn_is = 1.f, bn_g = 1.f, bn_b = 0.f, bn_m = 0.f;
     const bool bnf = ROLE == 0 && p.bn_gamma != nullptr;
     if (bnf) {
@@ -281,7 +296,6 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
     if (recompute) { bb_g = p.bnb_gamma[col]; bb_b = p.bnb_beta[col]; }
     const float bb_slope = act_neg_slope(p.bnb_act);
     const int mshift = ((l31 >> 2) & 3) * 8 + (l31 & 3);    // this lane's column within its mask word
-    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = acc_row(r, lh);
@@ -316,10 +330,11 @@ __global__ __launch_bounds__(256, 3) void conv_wino(const WinoP p) {
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(&Tx[(8 * qq + (lane >> 3)) * TP + ((lane & 7) << 2)]);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w4), yr, co4[qq], 0, STORE_AUX);
     }
+    }
     if (stats) {                                            // uniform over the grid
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
-        if (lh == 0) {
+        if (lh == 0 && fin) {
             sred[wid * 32 + l31] = s1;
             sred[(4 + wid) * 32 + l31] = s2;
         }
@@ -390,7 +405,7 @@ __global__ __launch_bounds__(256) void wino_weights(const WinoEnt* __restrict__ 
 // Which problems the Winograd kernel serves at all (3x3 / stride 1 / pad 1 is implied by the entry points).
 static bool wino_shape_ok(int N, int H, int W, int Ci, int Co) {
     if (N <= 0 || H < 4 || W < 4 || (H & 1) || (W & 1)) return false;
-    if (!(Ci == 32 || Ci == 64) || Co % 32 != 0 || Co > 4096) return false;
+    if (!(Ci == 32 || Ci == 64 || Ci == 128) || Co % 32 != 0 || Co > 4096) return false;
     if ((int64_t)N * H * W * (Ci > Co ? Ci : Co) * 4 >= 0x7fffffffLL) return false;
     return true;
 }
@@ -400,10 +415,17 @@ static bool wino_shape_ok(int N, int H, int W, int Ci, int Co) {
 static int wino_lbw(int Ht, int Wt, int Ci) {
     const int64_t w3 = (int64_t)cdiv(Wt, 8) * cdiv(Ht, 4), w2 = (int64_t)cdiv(Wt, 4) * cdiv(Ht, 8);
     if (w3 != w2) return w3 < w2 ? 3 : 2;
-    return Ci == 32 ? 3 : 2;
+    return Ci == 32 ? 3 : 2;                                // (128 channels: 95 KB against 106)
 }
 
-extern "C" int advmix_conv_wino_config(int N, int H, int W, int Ci, int Co) { return wino_shape_ok(N, H, W, Ci, Co) ? 1 : 0; }
+// 0: not served; otherwise the number of workgroups the launch would have (blocks of 32 tiles x column tiles of 32) - what a
+// caller needs to decide whether the chip is filled (ops.py: WINO_MIN_WGS).
+extern "C" int advmix_conv_wino_config(int N, int H, int W, int Ci, int Co) {
+    if (!wino_shape_ok(N, H, W, Ci, Co)) return 0;
+    const int lbw = wino_lbw(H / 2, W / 2, Ci);
+    const int64_t wgs = (int64_t)N * cdiv(W / 2, 1 << lbw) * cdiv(H / 2, 32 >> lbw) * (Co / 32);
+    return wgs > 0x7fffffff ? 0x7fffffff : (int)wgs;
+}
 
 // floats of one transformed image (forward or input gradient) of a 3x3 Cn x Ck filter bank
 extern "C" int64_t advmix_wino_u_floats(int Co, int Ci) { return (int64_t)16 * Co * Ci; }
@@ -425,18 +447,20 @@ static int wino_launch(int role, wino::WinoP& p, hipStream_t st) {
     p.nblk = p.nbw * cdiv(p.Ht, 32 >> lbw);
     dim3 g(p.N * p.nblk, p.Co / 32);
     const int NQ = p.Ci / 8;
-#define WL(NQ_, ROLE_, LBW_) hipLaunchKernelGGL((wino::conv_wino<NQ_, ROLE_, LBW_>), g, dim3(256), 0, st, p)
-#define WR(NQ_, LBW_) do { if (role) WL(NQ_, 1, LBW_); else WL(NQ_, 0, LBW_); } while (0)
-    if (NQ == 4 && lbw == 3) WR(4, 3);
-    else if (NQ == 4) WR(4, 2);
-    else if (NQ == 8 && lbw == 3) WR(8, 3);
-    else if (NQ == 8) WR(8, 2);
+#define WL(NQ_, ROLE_, LBW_, KS_) hipLaunchKernelGGL((wino::conv_wino<NQ_, ROLE_, LBW_, KS_>), g, dim3(256 * KS_), 0, st, p)
+#define WR(NQ_, LBW_, KS_) do { if (role) WL(NQ_, 1, LBW_, KS_); else WL(NQ_, 0, LBW_, KS_); } while (0)
+    if (NQ == 4 && lbw == 3) WR(4, 3, 1);
+    else if (NQ == 4) WR(4, 2, 1);
+    else if (NQ == 8 && lbw == 3) WR(8, 3, 1);
+    else if (NQ == 8) WR(8, 2, 1);
+    else if (NQ == 16 && lbw == 3) WR(16, 3, 2);
+    else if (NQ == 16) WR(16, 2, 2);
     else return ADVMIX_EINVAL;
 #undef WR
 #undef WL
     if (advmix_opts().trace_shapes) {
         char nm[48];
-        snprintf(nm, sizeof nm, "conv_wino<%d, %d, %d>", NQ, role, lbw);
+        snprintf(nm, sizeof nm, "conv_wino<%d, %d, %d, %d>", NQ, role, lbw, NQ == 16 ? 2 : 1);
         advmix_trace_launch(nm, g, role == 0 ? (p.stats ? "fwd+sums" : (p.bn_gamma ? "fwd+bn_eval" : "fwd")) : (p.bnb_c ? "dgrad+bnb" : "dgrad"),
                             p.N, p.H, p.W, p.Ci, p.H, p.W, p.Co, 3, 3, 1, 2.0 * p.N * (double)p.H * p.W * p.Co * p.Ci * 9);
     }

@@ -296,7 +296,7 @@ def _det_stats(C, device, lane):
 
 # ---- Winograd F(2x2,3x3) path (csrc/conv_wino.hip) ---------------------------------------------------------------------
 WINO = __import__('os').environ.get('ADVMIX_WINO', '1') != '0'       # A/B switch: 0 = every conv on the direct kernels
-WINO_MIN_TILES = int(__import__('os').environ.get('ADVMIX_WINO_MIN_TILES', '4096'))   # 2x2 output tiles below which the direct kernel stays
+WINO_MIN_WGS = int(__import__('os').environ.get('ADVMIX_WINO_MIN_WGS', '192'))   # workgroups (32 tiles x 32 channels) below which the direct kernel stays
 
 
 class WinoBank:
@@ -368,10 +368,8 @@ def _wino_images(w, B, H, W, Ci, Co, R, S, stride, pad):
     """(forward image, input-gradient image) of ``w`` when this problem goes to the Winograd kernel, else None."""
     if not (WINO and R == 3 and S == 3 and stride == 1 and pad == 1) or DETERMINISTIC or not _direct_ok():
         return None
-    if B * (H // 2) * (W // 2) < WINO_MIN_TILES:
-        return None
     tag = _wino_tag(w)
-    if tag is None or not lib.advmix_conv_wino_config(B, H, W, Ci, Co):
+    if tag is None or lib.advmix_conv_wino_config(B, H, W, Ci, Co) < WINO_MIN_WGS:
         return None
     return tag[1], tag[2]
 

@@ -113,7 +113,8 @@ int advmix_conv_tr_w_bnb(const float* x, const float* w, const float* addend, fl
  * fp32 throughout.  The filters are transformed ONCE per forward pass into a side buffer (advmix_wino_weights), never
  * inside the conv; the conv entry points keep the fused epilogues of advmix_conv_fwd_ex / advmix_conv_tr_w_bnb. */
 
-/* 1 when advmix_conv3x3_wino_fwd / _dgrad serve [N,H,W,Ci] -> [N,H,W,Co] (H, W even, Ci in {32, 64}, Co % 32 == 0), else 0. */
+/* 0 when advmix_conv3x3_wino_fwd / _dgrad do not serve [N,H,W,Ci] -> [N,H,W,Co] (they do for H, W even, Ci in {32, 64, 128},
+ * Co % 32 == 0); otherwise the number of workgroups the launch would have (blocks of 32 output tiles x column tiles of 32). */
 int advmix_conv_wino_config(int N, int H, int W, int Ci, int Co);
 /* floats of ONE transformed image (forward or input gradient) of a [Co][3][3][Ci] filter bank: 16 * Co * Ci. */
 int64_t advmix_wino_u_floats(int Co, int Ci);

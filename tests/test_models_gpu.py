@@ -292,16 +292,17 @@ def test_network_parity_at_the_benchmarked_batch():
     calibrate(net, D, views[2], extra)
     cfg, mD, mG, mT = product_models(net, extra, J, D, T, G)
     rep = {}
-    # ... and the Winograd kernel (round 5): the 64 + 64 branch convs 32 -> 32 @64x48 / 64 -> 64 @32x24 and layer1's four
-    # 3x3 64 -> 64 @64x48, in all three roles - eval forward, train forward + column sums, input gradient + BatchNorm backward
+    # ... and the Winograd kernel (round 5): the 64 + 64 + 56 branch convs 32 -> 32 @64x48 / 64 -> 64 @32x24 / 128 -> 128 @16x12
+    # and layer1's four 3x3 64 -> 64 @64x48, in all three roles - eval forward, train forward + column sums, input gradient + BatchNorm backward
     from advmix_amd import ops as _ops_
-    assert _ops_.WINO and lib.advmix_conv_wino_config(B, 64, 48, 32, 32) == 1 and lib.advmix_conv_wino_config(B, 32, 24, 64, 64) == 1
+    assert _ops_.WINO and lib.advmix_conv_wino_config(B, 64, 48, 32, 32) == 768 and lib.advmix_conv_wino_config(B, 32, 24, 64, 64) == 384 \
+        and lib.advmix_conv_wino_config(B, 16, 12, 128, 128) == 256
     w0 = _ops_.COUNTERS.get('wino', 0)
     mD.eval()
     with torch.no_grad():
         ye = mD(views[0].cuda())
         ye_ref = posenet_forward(net, D, views[0], extra, False)
-    assert _ops_.COUNTERS.get('wino', 0) - w0 == 132, _ops_.COUNTERS
+    assert _ops_.COUNTERS.get('wino', 0) - w0 == 188, _ops_.COUNTERS
     assert_close('eval out', ye, ye_ref, report=rep)
     assert_close('eval out vs golden', strided(ye.cpu().contiguous()), g[tag + '.eval_out'], report=rep)
     mD.train()                                            # train forward + FULL backward at the benchmarked tiles
@@ -310,7 +311,7 @@ def test_network_parity_at_the_benchmarked_batch():
     yt = mD(x)
     loss = JointsMSELoss(True)(yt, tgt.cuda(), tw.cuda())
     loss.backward()
-    assert _ops_.COUNTERS.get('wino', 0) - w0 == 3 * 132, _ops_.COUNTERS     # + train forward + input gradients
+    assert _ops_.COUNTERS.get('wino', 0) - w0 == 3 * 188, _ops_.COUNTERS     # + train forward + input gradients
     names = _trainable(D)
     for k in names:
         D[k].requires_grad_(True)

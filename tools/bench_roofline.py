@@ -111,7 +111,7 @@ def time_conv_family(B, device, iters=100, family=None):
         nbg = ctypes.c_int(0)
         geom = (B, H, W, C, H, W, C, 3, 3, 1, 1)
         flops = 2.0 * rows * C * C * 9
-        wino = bool(ops.WINO and lib.advmix_conv_wino_config(B, H, W, C, C) and B * (H // 2) * (W // 2) >= ops.WINO_MIN_TILES)
+        wino = bool(ops.WINO and lib.advmix_conv_wino_config(B, H, W, C, C) >= ops.WINO_MIN_WGS)
 
         def reset():
             nbg.value = 0

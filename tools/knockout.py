@@ -5,7 +5,8 @@ interleaved A B A B on the headline workload (HRNet-W32 256x192, B = 32, HIP-gra
   wgrad_small    the weight gradients below 0.5 GFLOP only (the fuse layers' strided 3x3 and 1x1 convs: ~57 launches of 8-23 us)
   norm_lowres    norm_apply_slots / norm_bwd_apply_slots launches on the three low-resolution branches (rows <= 32 x 32 x 24:
                  VERDICT r3 item 5) dropped - an upper bound for grouping them (a grouped launch still does their work)
-usage: python tools/knockout.py [steps]"""
+  norm_all       EVERY norm_apply_slots / norm_bwd_apply_slots launch dropped (round 5: what fusing them away could buy at most)
+usage: python tools/knockout.py [steps] [modes, comma separated]"""
 import os, sys, time, types
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -35,6 +36,8 @@ def wgrad(st, lane, a, b, w, geom):
 def call(name, *a):
     if MODE['v'] == 'norm_lowres' and name == 'advmix_norm_bwd_apply_slots' and a[7] <= 32 * 32 * 24:
         return 0
+    if MODE['v'] == 'norm_all' and name == 'advmix_norm_bwd_apply_slots':
+        return 0
     return real_call(name, *a)
 
 
@@ -44,6 +47,8 @@ class Lib:
         if k == 'advmix_norm_apply_slots':
             def g(*a):
                 if MODE['v'] == 'norm_lowres' and a[3] <= 32 * 32 * 24:
+                    return 0
+                if MODE['v'] == 'norm_all':
                     return 0
                 return f(*a)
             return g
@@ -76,5 +81,5 @@ def measure(mode):
 
 
 for rep in range(2):
-    for mode in ('base', 'wgrad_all', 'wgrad_c64plus', 'wgrad_small', 'norm_lowres'):
+    for mode in (sys.argv[2].split(',') if len(sys.argv) > 2 else ('base', 'wgrad_all', 'wgrad_c64plus', 'wgrad_small', 'norm_lowres', 'norm_all')):
         print('%-14s %.2f ms/step' % (mode, measure(mode)), flush=True)

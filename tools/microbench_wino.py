@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip) against the direct kernel, launch to launch through the C ABI, for the
-roles the step uses.  usage: microbench_wino.py [B=32] [iters=200]"""
+roles the step uses.  usage: microbench_wino.py [B=32] [iters=200] [only=C:role, e.g. 32:fwd+sums - 20 launches of that one Winograd variant, for a counter pass]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +9,7 @@ from advmix_amd._lib import lib
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+only = sys.argv[3].split(':') if len(sys.argv) > 3 else None
 dev = torch.device('cuda:0')
 P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -31,6 +32,8 @@ def timed(run):
 
 
 for C, H, W in ((32, 64, 48), (64, 32, 24), (128, 16, 12), (64, 64, 48)):
+    if only and int(only[0]) != C:
+        continue
     x = torch.randn(B, H, W, C, device=dev)
     y = torch.empty(B, H, W, C, device=dev)
     w = (torch.randn(C, 3, 3, C, device=dev) * 0.05).permute(0, 3, 1, 2)
@@ -57,6 +60,12 @@ for C, H, W in ((32, 64, 48), (64, 32, 24), (128, 16, 12), (64, 64, 48)):
         'dgrad+bnb(sign from c)': (lambda: (z(), lib.advmix_conv3x3_wino_dgrad(P(x), ud, None, P(y), B, H, W, C, C, None, P(cc), P(mean), P(invstd), P(gam), P(bet), 1, P(slots), ctypes.byref(ns), st)),
                                    lambda: (z(), lib.advmix_conv_tr_w_bnb(P(x), P(w), None, P(y), B, H, W, C, H, W, C, 3, 3, 1, 1, None, P(cc), P(mean), P(invstd), P(gam), P(bet), 1, P(slots), ctypes.byref(ns), st))),
     }
+    if only:
+        for _ in range(20):
+            runs[only[1]][0]()
+        torch.cuda.synchronize()
+        print('ran 20 launches of', C, only[1])
+        break
     fl = 2.0 * B * H * W * C * C * 9
     t_tr = timed(lambda: bank.refresh(st))
     print('3x3 %d->%d @%dx%d B=%d   (weight transform launch, 2 images: %.1f us)' % (C, C, H, W, B, t_tr))

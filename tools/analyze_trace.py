@@ -40,7 +40,7 @@ for n, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:30]:
 # window has no MFMA (conv / wgrad) kernel in flight at all
 pts = []
 for s, e, n in sel:
-    heavy = ('conv_direct' in n) or ('conv_wgrad' in n) or ('wgrad_direct' in n) or ('conv_igemm' in n)
+    heavy = ('conv_' in n) or ('wgrad' in n)            # every MFMA kernel: conv_direct / conv_wino / conv_igemm / conv_wgrad* / wgrad*
     pts.append((s, 1, heavy)); pts.append((e, -1, heavy))
 pts.sort()
 hist = collections.defaultdict(int)

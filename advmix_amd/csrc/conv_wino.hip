@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 3 : 1) void conv_wino(const Win
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
         const int pq = __shfl(pb, 8 * qq + (lane >> 3), 64);
-        co4[qq] = pq >= 0 ? (unsigned)(((pq + pos) * p.Co + n0 + ((lane & 7) << 2)) * 4) : OOB;
+        co4[qq] = (pq >= 0 && n0 + ((lane & 7) << 2) < p.Co) ? (unsigned)(((pq + pos) * p.Co + n0 + ((lane & 7) << 2)) * 4) : OOB;
     }
     const bool bnb = ROLE == 1 && p.bnb_c != nullptr;
     const bool bnbf = bnb && fin;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 3 : 1) void conv_wino(const Win
     }
     unsigned mw = 0u;
     if (ROLE == 1 && mask_on && fin)       // lane (l31, lh): the 16 channels [16 lh, 16 lh + 16) of ITS tile's pixel = 4 mask bytes
-        mw = __builtin_amdgcn_raw_buffer_load_b32(mkr, pb >= 0 ? (unsigned)((pb + pos) * (p.Co >> 2) + ((n0 + 16 * lh) >> 2)) : OOB, 0, 0);
+        mw = __builtin_amdgcn_raw_buffer_load_b32(mkr, (pb >= 0 && n0 + 16 * lh < p.Co) ? (unsigned)((pb + pos) * (p.Co >> 2) + ((n0 + 16 * lh) >> 2)) : OOB, 0, 0);
 
     __syncthreads();                                        // every wave is done with the patch: the region becomes the exchange
     {
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 3 : 1) void conv_wino(const Win
     if (op_a) to_acc_layout(pq_a, oa);
     if (ROLE == 1 && bnbf) to_acc_layout(pq_c, oc);
 
-    const int col = n0 + l31;                               // (Co % 32 == 0: every column is valid)
+    const bool cvalid = n0 + l31 < p.Co;                    // (Co = 48: the second column tile is half empty - its filters are zero)
+    const int col = cvalid ? n0 + l31 : 0;
     float bn_is = 1.f, bn_g = 1.f, bn_b = 0.f, bn_m = 0.f;
     const bool bnf = ROLE == 0 && p.bn_gamma != nullptr;
     if (bnf) {
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 3 : 1) void conv_wino(const Win
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = acc_row(r, lh);
-        const bool valid = (vmask >> row) & 1u;
+        const bool valid = ((vmask >> row) & 1u) && cvalid;
         float v = yv[r];
         if (ROLE == 0) {
             if (valid) { s1 += v; s2 += v * v; }
@@ -347,8 +348,10 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 3 : 1) void conv_wino(const Win
                 d2 += (double)sred[(4 + k) * 32 + tid];
             }
             const int sl = (int)blockIdx.x % p.stats_nbg;  // slot-major [2][slots][Co]: consecutive doubles per workgroup
-            atomicAdd(p.stats + (int64_t)sl * p.Co + n0 + tid, d1);
-            atomicAdd(p.stats + ((int64_t)p.stats_nbg + sl) * p.Co + n0 + tid, d2);
+            if (n0 + tid < p.Co) {
+                atomicAdd(p.stats + (int64_t)sl * p.Co + n0 + tid, d1);
+                atomicAdd(p.stats + ((int64_t)p.stats_nbg + sl) * p.Co + n0 + tid, d2);
+            }
         }
     }
 }
@@ -371,13 +374,14 @@ __global__ __launch_bounds__(256) void wino_weights(const WinoEnt* __restrict__ 
     const int nt = lb / NQ, q = lb - nt * NQ;
     const int t = threadIdx.x;
     const int cn = nt * 32 + ((t >> 2) & 31), ck = q * 8 + (t >> 7) * 4 + (t & 3);
+    const bool live = cn < e.Cn;                            // (Cn = 48: columns 48 .. 63 of the second tile are zero filters)
     float g[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int s = 0; s < 3; ++s)
-            g[r][s] = e.role == 0 ? e.w[((int64_t)(cn * 3 + r) * 3 + s) * e.Ck + ck]
-                                  : e.w[((int64_t)(ck * 3 + (2 - r)) * 3 + (2 - s)) * e.Cn + cn];
+            g[r][s] = !live ? 0.f : (e.role == 0 ? e.w[((int64_t)(cn * 3 + r) * 3 + s) * e.Ck + ck]
+                                                 : e.w[((int64_t)(ck * 3 + (2 - r)) * 3 + (2 - s)) * e.Cn + cn]);
     float a[4][3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(256) void wino_weights(const WinoEnt* __restrict__ 
 // Which problems the Winograd kernel serves at all (3x3 / stride 1 / pad 1 is implied by the entry points).
 static bool wino_shape_ok(int N, int H, int W, int Ci, int Co) {
     if (N <= 0 || H < 4 || W < 4 || (H & 1) || (W & 1)) return false;
-    if (!(Ci == 32 || Ci == 64 || Ci == 128) || Co % 32 != 0 || Co > 4096) return false;
+    if (!(Ci == 32 || Ci == 48 || Ci == 64 || Ci == 96 || Ci == 128) || Co % 16 != 0 || Co > 4096) return false;
     if ((int64_t)N * H * W * (Ci > Co ? Ci : Co) * 4 >= 0x7fffffffLL) return false;
     return true;
 }
@@ -415,7 +419,7 @@ static bool wino_shape_ok(int N, int H, int W, int Ci, int Co) {
 static int wino_lbw(int Ht, int Wt, int Ci) {
     const int64_t w3 = (int64_t)cdiv(Wt, 8) * cdiv(Ht, 4), w2 = (int64_t)cdiv(Wt, 4) * cdiv(Ht, 8);
     if (w3 != w2) return w3 < w2 ? 3 : 2;
-    return Ci == 32 ? 3 : 2;                                // (128 channels: 95 KB against 106)
+    return Ci <= 48 ? 3 : 2;                                // (96 / 128 channels: 72 / 95 KB against 80 / 106)
 }
 
 // 0: not served; otherwise the number of workgroups the launch would have (blocks of 32 tiles x column tiles of 32) - what a
@@ -423,12 +427,12 @@ static int wino_lbw(int Ht, int Wt, int Ci) {
 extern "C" int advmix_conv_wino_config(int N, int H, int W, int Ci, int Co) {
     if (!wino_shape_ok(N, H, W, Ci, Co)) return 0;
     const int lbw = wino_lbw(H / 2, W / 2, Ci);
-    const int64_t wgs = (int64_t)N * cdiv(W / 2, 1 << lbw) * cdiv(H / 2, 32 >> lbw) * (Co / 32);
+    const int64_t wgs = (int64_t)N * cdiv(W / 2, 1 << lbw) * cdiv(H / 2, 32 >> lbw) * cdiv(Co, 32);
     return wgs > 0x7fffffff ? 0x7fffffff : (int)wgs;
 }
 
 // floats of one transformed image (forward or input gradient) of a 3x3 Cn x Ck filter bank
-extern "C" int64_t advmix_wino_u_floats(int Co, int Ci) { return (int64_t)16 * Co * Ci; }
+extern "C" int64_t advmix_wino_u_floats(int Co, int Ci) { return (int64_t)16 * cdiv(Co, 32) * 32 * Ci; }   // (n padded to whole column tiles)
 
 // Transform the filters of n convs in one launch.  ``ents`` (device): n records {w, u, Cn, Ck, role, first block}, ``blk_ent``
 // (device): the record index of each of the ``blocks`` workgroups (a record owns (Cn / 32) * (Ck / 8) consecutive ones).
@@ -445,7 +449,7 @@ static int wino_launch(int role, wino::WinoP& p, hipStream_t st) {
     const int lbw = wino_lbw(p.Ht, p.Wt, p.Ci);
     p.nbw = cdiv(p.Wt, 1 << lbw);
     p.nblk = p.nbw * cdiv(p.Ht, 32 >> lbw);
-    dim3 g(p.N * p.nblk, p.Co / 32);
+    dim3 g(p.N * p.nblk, cdiv(p.Co, 32));
     const int NQ = p.Ci / 8;
 #define WL(NQ_, ROLE_, LBW_, KS_) hipLaunchKernelGGL((wino::conv_wino<NQ_, ROLE_, LBW_, KS_>), g, dim3(256 * KS_), 0, st, p)
 #define WR(NQ_, LBW_, KS_) do { if (role) WL(NQ_, 1, LBW_, KS_); else WL(NQ_, 0, LBW_, KS_); } while (0)
@@ -455,6 +459,10 @@ static int wino_launch(int role, wino::WinoP& p, hipStream_t st) {
     else if (NQ == 8) WR(8, 2, 1);
     else if (NQ == 16 && lbw == 3) WR(16, 3, 2);
     else if (NQ == 16) WR(16, 2, 2);
+    else if (NQ == 6 && lbw == 3) WR(6, 3, 1);              // HRNet-W48's 48- and 96-channel branches
+    else if (NQ == 6) WR(6, 2, 1);
+    else if (NQ == 12 && lbw == 3) WR(12, 3, 1);
+    else if (NQ == 12) WR(12, 2, 1);
     else return ADVMIX_EINVAL;
 #undef WR
 #undef WL
@@ -476,7 +484,7 @@ static int wino_fill(wino::WinoP& p, const float* x, const float* u, float* y, i
     p.Ht = H / 2; p.Wt = W / 2;
     p.xbytes = (int)((int64_t)N * H * W * Ci * 4);
     p.ybytes = (int)((int64_t)N * H * W * Co * 4);
-    p.ubytes = (int)((int64_t)16 * Co * Ci * 4);
+    p.ubytes = (int)((int64_t)16 * cdiv(Co, 32) * 32 * Ci * 4);
     static const int xcd_remap = [] { const char* e = getenv("ADVMIX_XCD_REMAP"); return e ? atoi(e) : 1; }();
     p.xcd_remap = xcd_remap;
     return ADVMIX_OK;

@@ -313,24 +313,25 @@ class WinoBank:
         import weakref
         dev = weights[0].device
         self.key = tuple(w.data_ptr() for w in weights)
-        sizes = [16 * w.shape[0] * w.shape[1] for w in weights]
-        self.buf = torch.empty(2 * sum(sizes), device=dev, dtype=torch.float32)
+        pad32 = lambda c: (c + 31) // 32 * 32                # noqa: E731  (the n dimension is padded to whole column tiles)
+        sizes = [(16 * pad32(w.shape[0]) * w.shape[1], 16 * pad32(w.shape[1]) * w.shape[0]) for w in weights]
+        self.buf = torch.empty(sum(a + b for a, b in sizes), device=dev, dtype=torch.float32)
         ent = np.zeros(2 * len(weights), dtype=np.dtype([('w', '<u8'), ('u', '<u8'), ('Cn', '<i4'), ('Ck', '<i4'),
                                                          ('role', '<i4'), ('blk0', '<i4')]))
         blk, off, owner = 0, 0, []
         self._tagged = []
         for i, w in enumerate(weights):
             Co, Ci, R, S = w.shape
-            if (R, S) != (3, 3) or Co % 32 or Ci % 32 or not w.is_contiguous(memory_format=_CL):
-                raise ValueError('WinoBank: 3x3 channels_last weights with Cout, Cin multiples of 32')
+            if (R, S) != (3, 3) or Co % 16 or Ci % 16 or not w.is_contiguous(memory_format=_CL):
+                raise ValueError('WinoBank: 3x3 channels_last weights with Cout, Cin multiples of 16')
             ptrs = []
             for role, (Cn, Ck) in enumerate(((Co, Ci), (Ci, Co))):
                 u = self.buf.data_ptr() + 4 * off
                 ent[2 * i + role] = (w.data_ptr(), u, Cn, Ck, role, blk)
-                nb = (Cn // 32) * (Ck // 8)
+                nb = ((Cn + 31) // 32) * (Ck // 8)
                 owner += [2 * i + role] * nb
                 blk += nb
-                off += sizes[i]
+                off += sizes[i][role]
                 ptrs.append(ctypes.c_void_p(u))
             w._wino = (self.buf, ptrs[0], ptrs[1], w.data_ptr())           # (the tag keeps the side buffer alive)
             self._tagged.append(weakref.ref(w))

@@ -113,14 +113,15 @@ int advmix_conv_tr_w_bnb(const float* x, const float* w, const float* addend, fl
  * fp32 throughout.  The filters are transformed ONCE per forward pass into a side buffer (advmix_wino_weights), never
  * inside the conv; the conv entry points keep the fused epilogues of advmix_conv_fwd_ex / advmix_conv_tr_w_bnb. */
 
-/* 0 when advmix_conv3x3_wino_fwd / _dgrad do not serve [N,H,W,Ci] -> [N,H,W,Co] (they do for H, W even, Ci in {32, 64, 128},
- * Co % 32 == 0); otherwise the number of workgroups the launch would have (blocks of 32 output tiles x column tiles of 32). */
+/* 0 when advmix_conv3x3_wino_fwd / _dgrad do not serve [N,H,W,Ci] -> [N,H,W,Co] (they do for H, W even, Ci in {32, 48, 64, 96, 128},
+ * Co % 16 == 0); otherwise the number of workgroups the launch would have (blocks of 32 output tiles x column tiles of 32). */
 int advmix_conv_wino_config(int N, int H, int W, int Ci, int Co);
-/* floats of ONE transformed image (forward or input gradient) of a [Co][3][3][Ci] filter bank: 16 * Co * Ci. */
+/* floats of ONE transformed image (forward or input gradient) of a [Co][3][3][Ci] filter bank: 16 * ceil(Co / 32) * 32 * Ci
+ * (the n dimension is padded to whole column tiles of 32 with zero filters). */
 int64_t advmix_wino_u_floats(int Co, int Ci);
 /* Transform the filters of several convs in one launch.  ents (device): records {const float* w; float* u; int Cn, Ck, role,
  * blk0;} - role 0: the forward image of w[Cn][3][3][Ck] (n = Cout, k = Cin), role 1: the input-gradient image of
- * w[Ck][3][3][Cn] (n = Cin, k = Cout, taps rotated by 180 degrees); a record owns the (Cn / 32) * (Ck / 8) workgroups from
+ * w[Ck][3][3][Cn] (n = Cin, k = Cout, taps rotated by 180 degrees); a record owns the ceil(Cn / 32) * (Ck / 8) workgroups from
  * blk0 on.  blk_ent (device): record index of each of the `blocks` workgroups.  u is written in the order the conv's lanes
  * read it: u[n / 32][xi][k / 8][32 * ((k % 8) / 4) + n % 32][k % 4], xi = 4 * row + column of G g G^T. */
 int advmix_wino_weights(const void* ents, const int* blk_ent, int blocks, void* stream);

@@ -609,6 +609,9 @@ WINO_CASES = [
     (1, 32, 32, 4, 4),           # every tile touches the border
     (32, 128, 128, 16, 12),      # third branch: eight waves per workgroup, K split between two sets of four
     (2, 128, 64, 8, 6),
+    (4, 48, 48, 24, 18),         # HRNet-W48's first branch: 1.5 column tiles (the second one half empty), 6 k groups
+    (2, 96, 96, 12, 10),         # its second branch: three column tiles, 12 k groups
+    (2, 48, 96, 8, 6),
 ]
 
 
@@ -724,7 +727,7 @@ def test_winograd_conv_all_roles(case):
         if 'direct' in results:
             check(tag + ' wino vs direct', results['wino'], results['direct'].double().cpu(), 1e-5)
     # refused without launching: odd sizes, channel counts the kernel has no instance for, a missing image
-    assert lib.advmix_conv_wino_config(B, H + 1, W, Ci, Co) == 0 and lib.advmix_conv_wino_config(B, H, W, 48, 48) == 0
+    assert lib.advmix_conv_wino_config(B, H + 1, W, Ci, Co) == 0 and lib.advmix_conv_wino_config(B, H, W, 40, 40) == 0
     assert lib.advmix_conv3x3_wino_fwd(P(D['x']), None, P(y), B, H, W, Ci, Co, None, None, None, None, 0.0, None, 0, None, None, st) == 1
     bank.release()
 

@@ -39,6 +39,8 @@ SIGNATURES = {
     'advmix_wino_weights': [_p, _p, _i, _p],
     'advmix_conv3x3_wino_fwd': [_p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _f, _p, _i, _p, _p, _p],
     'advmix_conv3x3_wino_dgrad': [_p, _p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p],
+    'advmix_wgrad_wino_config': [_i] * 5,
+    'advmix_conv3x3_wgrad_wino_group': [_i, _p, _p, _p] + [_i] * 5 + [_p],
     'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_wgrad_group': [_i, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_wgrad_det': [_p, _p, _p] + [_i] * 11 + [_p, _l, _p],

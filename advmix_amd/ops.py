@@ -255,6 +255,30 @@ def _wgrad(st, lane, a, b, w, geom):
         call('advmix_conv_wgrad', _p(a), _p(b), _p(g), *geom, st)
 
 
+WGRAD_WINO = __import__('os').environ.get('ADVMIX_WGRAD_WINO', '1') != '0'   # Winograd F(3x3,2x2) weight gradients (A/B switch)
+WGRAD_WINO_MIN_UNITS = int(__import__('os').environ.get('ADVMIX_WGRAD_WINO_MIN_UNITS', '2048'))   # (a lone 32 -> 32 @64x48 problem - 768 units - is no faster than wgrad3x3_c32)
+
+
+def _wgrad_wino(st, grp, geom):
+    """The group's weight gradients through the Winograd kernel (csrc/wgrad_wino.hip) when it serves the geometry and there
+    is enough work to fill the chip; False = not taken."""
+    B, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad = geom       # a = dy [B,Ha,Wa,Ca], b = x [B,Hb,Wb,Cb]
+    if not (WGRAD_WINO and WINO and (R, S, stride, pad) == (3, 3, 1, 1)) or DETERMINISTIC or Ca > 128 or Cb > 128:
+        return False
+    if lib.advmix_wgrad_wino_config(B, Hb, Wb, Cb, Ca) * len(grp) < WGRAD_WINO_MIN_UNITS:
+        return False
+    n = len(grp)
+    arr = ctypes.c_void_p * n
+    rc = lib.advmix_conv3x3_wgrad_wino_group(n, arr(*[x[0].data_ptr() for x in grp]), arr(*[x[1].data_ptr() for x in grp]),
+                                             arr(*[x[2].data_ptr() for x in grp]), B, Hb, Wb, Ca, Cb, st)
+    if rc == 0:
+        COUNTERS['wgrad_wino'] = COUNTERS.get('wgrad_wino', 0) + 1
+        return True
+    if rc != 1:
+        raise RuntimeError('advmix_conv3x3_wgrad_wino_group failed: %d' % rc)
+    return False
+
+
 def _flush_wgrads(st, pending):
     """Launch the collected weight gradients: groups of 2-8 of one geometry as one launch, the rest one by one."""
     by = {}
@@ -264,6 +288,8 @@ def _flush_wgrads(st, pending):
         for i in range(0, len(items), 8):
             grp = items[i:i + 8]
             n = len(grp)
+            if _wgrad_wino(st, grp, geom):
+                continue
             if n >= 2:
                 arr = ctypes.c_void_p * n
                 rc = lib.advmix_conv_wgrad_group(n, arr(*[x[0].data_ptr() for x in grp]), arr(*[x[1].data_ptr() for x in grp]),

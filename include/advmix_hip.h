@@ -137,6 +137,16 @@ int advmix_conv3x3_wino_dgrad(const float* dy, const float* u, const float* adde
                               const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int act,
                               double* stats, int* stats_ns, void* stream);
 
+/* Winograd weight gradient, F(3x3, 2x2) (csrc/wgrad_wino.hip, round 5): 16 multiplies per 2x2 tile of dy and channel pair
+ * instead of 36.  advmix_wgrad_wino_config: 0 = not served (odd H / W, channels not multiples of 32 or > 256), else the
+ * number of (32-tile block, 32 x 32 channel pair) units of one problem.  advmix_conv3x3_wgrad_wino_group: the weight
+ * gradients of n (1-8) 3x3 / stride 1 / pad 1 convs of ONE geometry in one launch, ACCUMULATED (fp32 atomics) into
+ * dw[i] ([Co][3][3][Ci]): dy[i] [N,H,W,Co], x[i] [N,H,W,Ci].  ADVMIX_EINVAL (nothing launched) for unserved shapes and in
+ * deterministic mode.  Replaces autograd's cudnn convolution_backward weight path for pose_hrnet.py:22-57. */
+int advmix_wgrad_wino_config(int N, int H, int W, int Ci, int Co);
+int advmix_conv3x3_wgrad_wino_group(int n, const float* const* dy, const float* const* x, float* const* dw, int N, int H, int W,
+                                    int Co, int Ci, void* stream);
+
 /* Transposed gather with <= 4 output channels: the input gradient of a network's FIRST conv (3 image channels; taken
  * when the images come from the generator - lib/core/function.py:146-160 back-propagates loss_G through the frozen
  * student into G).  Arguments as advmix_conv_tr_w without the bias; one thread per output pixel instead of 32 MFMA

@@ -732,6 +732,45 @@ def test_winograd_conv_all_roles(case):
     bank.release()
 
 
+@pytest.mark.parametrize('case', [(32, 32, 32, 64, 48, 3), (32, 64, 64, 32, 24, 2), (32, 128, 128, 16, 12, 1), (3, 32, 64, 10, 14, 2),
+                                  (2, 64, 32, 8, 6, 8), (1, 32, 32, 4, 4, 1)])
+def test_winograd_weight_gradient(case):
+    """csrc/wgrad_wino.hip (round 5): F(3x3, 2x2) weight gradients - n problems of one geometry in one launch, ACCUMULATED into
+    dw - against a float64 autograd evaluation and against advmix_conv_wgrad for the same operands; ragged blocks, Ci != Co,
+    the group limit of eight."""
+    import ctypes
+    from advmix_amd._lib import call, lib
+    _ops()
+    B, Ci, Co, H, W, n = case
+    d = dev()
+    assert lib.advmix_wgrad_wino_config(B, H, W, Ci, Co) > 0
+    g_ = torch.Generator().manual_seed(31 + Ci + H)
+    R = lambda *s_: torch.randn(*s_, generator=g_)
+    xs, dys, base = [R(B, H, W, Ci) for _ in range(n)], [R(B, H, W, Co) for _ in range(n)], [R(Co, 3, 3, Ci) for _ in range(n)]
+    xd, dyd = [t.to(d) for t in xs], [t.to(d) for t in dys]
+    dw = [t.to(d).clone() for t in base]                    # not zero: the kernel accumulates
+    arr = ctypes.c_void_p * n
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.advmix_conv3x3_wgrad_wino_group(n, arr(*[t.data_ptr() for t in dyd]), arr(*[t.data_ptr() for t in xd]),
+                                             arr(*[t.data_ptr() for t in dw]), B, H, W, Co, Ci, st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    for i in range(n):
+        w64 = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(xs[i].double().permute(0, 3, 1, 2), w64, padding=1)
+        (y * dys[i].double().permute(0, 3, 1, 2)).sum().backward()
+        want = w64.grad.permute(0, 2, 3, 1) + base[i].double()
+        check('wino wgrad %d' % i, dw[i], want, 3e-5)
+        ref = base[i].to(d).clone()
+        call('advmix_conv_wgrad', P(dyd[i]), P(xd[i]), P(ref), B, H, W, Co, H, W, Ci, 3, 3, 1, 1, st)
+        torch.cuda.synchronize()
+        check('wino vs conv_wgrad %d' % i, dw[i], ref.double().cpu(), 2e-5)
+    assert lib.advmix_wgrad_wino_config(B, H + 1, W, Ci, Co) == 0 and lib.advmix_wgrad_wino_config(B, H, W, 48, Co) == 0
+    assert lib.advmix_conv3x3_wgrad_wino_group(9, arr(*[t.data_ptr() for t in dyd]), arr(*[t.data_ptr() for t in xd]),
+                                               arr(*[t.data_ptr() for t in dw]), B, H, W, Co, Ci, st) == 1
+
+
 @pytest.mark.parametrize('case', [(8, 32, 64, 32, 24, 3), (3, 32, 128, 16, 12, 3), (8, 32, 256, 8, 6, 3), (2, 4, 64, 20, 14, 3),
                                   (5, 8, 128, 12, 9, 1), (8, 32, 32, 64, 48, 3), (3, 4, 32, 16, 11, 3), (2, 2, 32, 8, 8, 3),
                                   # more than eight problems: one pixel slice per tile -> the workgroup owns its outputs (plain +=)

@@ -225,7 +225,9 @@ extern "C" int advmix_wgrad_wino_config(int N, int H, int W, int Ci, int Co) {
     if (!wgw_shape_ok(N, H, W, Ci, Co)) return 0;
     const int Ht = H / 2, Wt = W / 2;
     const int64_t w3 = (int64_t)cdiv(Wt, 8) * cdiv(Ht, 4), w2 = (int64_t)cdiv(Wt, 4) * cdiv(Ht, 8);
-    const int64_t units = (int64_t)N * (w3 <= w2 ? w3 : w2) * (Ci / 32) * (Co / 32);
+    const int64_t nblk = w3 <= w2 ? w3 : w2;
+    if ((int64_t)Ht * Wt * 10 < nblk * 32 * 6) return 0;   // blocks less than 60 % full (8 x 6 maps: 12 of 32 tiles): the MFMAs saved are wasted again
+    const int64_t units = (int64_t)N * nblk * (Ci / 32) * (Co / 32);
     return units > 0x7fffffff ? 0x7fffffff : (int)units;
 }
 

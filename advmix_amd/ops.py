@@ -251,7 +251,7 @@ def _wgrad(st, lane, a, b, w, geom):
     elif _WG_DEFER and WGRAD_GROUP and ((geom[3] % 64 == 0 and geom[6] % 4 == 0)
                                         or (geom[3] == 32 and geom[6] == 32 and geom[7:] == (3, 3, 1, 1))):
         _WG_DEFER[-1].append((a, b, g, geom))               # (a - a kept temporary - and b stay alive in the pending list)
-    else:
+    elif not _wgrad_wino(st, [(a, b, g)], geom):            # (a lone 3x3 with enough work, e.g. transition1's 256 -> 32 @64x48)
         call('advmix_conv_wgrad', _p(a), _p(b), _p(g), *geom, st)
 
 
@@ -263,7 +263,7 @@ def _wgrad_wino(st, grp, geom):
     """The group's weight gradients through the Winograd kernel (csrc/wgrad_wino.hip) when it serves the geometry and there
     is enough work to fill the chip; False = not taken."""
     B, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad = geom       # a = dy [B,Ha,Wa,Ca], b = x [B,Hb,Wb,Cb]
-    if not (WGRAD_WINO and WINO and (R, S, stride, pad) == (3, 3, 1, 1)) or DETERMINISTIC or Ca > 128 or Cb > 128:
+    if not (WGRAD_WINO and WINO and (R, S, stride, pad) == (3, 3, 1, 1)) or DETERMINISTIC:
         return False
     if lib.advmix_wgrad_wino_config(B, Hb, Wb, Cb, Ca) * len(grp) < WGRAD_WINO_MIN_UNITS:
         return False

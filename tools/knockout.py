@@ -5,6 +5,8 @@ interleaved A B A B on the headline workload (HRNet-W32 256x192, B = 32, HIP-gra
   wgrad_small    the weight gradients below 0.5 GFLOP only (the fuse layers' strided 3x3 and 1x1 convs: ~57 launches of 8-23 us)
   norm_lowres    norm_apply_slots / norm_bwd_apply_slots launches on the three low-resolution branches (rows <= 32 x 32 x 24:
                  VERDICT r3 item 5) dropped - an upper bound for grouping them (a grouped launch still does their work)
+  small_convs    every direct-kernel conv launch (forward / input gradient) below 0.45 GFLOP dropped: the ~90 strided / 1x1 / fuse
+                 convs of 13-23 us (round 5)
   norm_all       EVERY norm_apply_slots / norm_bwd_apply_slots launch dropped (round 5: what fusing them away could buy at most)
 usage: python tools/knockout.py [steps] [modes, comma separated]"""
 import os, sys, time, types
@@ -44,6 +46,16 @@ def call(name, *a):
 class Lib:
     def __getattr__(self, k):
         f = getattr(real_lib, k)
+        if k in ('advmix_conv_fwd_ex', 'advmix_conv_tr_w_bnb', 'advmix_conv_tr_w_add'):
+            def h(*a):
+                # (x, w, bias|addend, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, ...): FLOPs of the launch
+                fl = 2.0 * a[4] * max(a[5] * a[6], a[8] * a[9]) / (a[13] * a[13]) * a[7] * a[10] * a[11] * a[12]
+                if MODE['v'] == 'small_convs' and fl < 0.45e9:
+                    if hasattr(a[-2], '_obj'):              # (the slot count the skipped launch would have reported)
+                        a[-2]._obj.value = 16
+                    return 0
+                return f(*a)
+            return h
         if k == 'advmix_norm_apply_slots':
             def g(*a):
                 if MODE['v'] == 'norm_lowres' and a[3] <= 32 * 32 * 24:

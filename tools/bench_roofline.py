@@ -57,9 +57,9 @@ def _time_shares():
         elif 'wgrad' in shp or k.startswith(('conv_wgrad', 'wgrad')):
             c = 'single weight gradients'
         elif k.startswith('conv_wino'):
-            c = 'branch 3x3 convs, Winograd kernel (32 / 64 channels)'
+            c = 'branch 3x3 convs, Winograd kernel (32 / 64 / 128 channels)'
         elif k.startswith(('conv_direct', 'conv_group', 'conv_igemm')) and ' 3x3 s1 ' in shp and shp.split(' s1 ')[1].split(' ')[0].split('->')[0] == shp.split(' s1 ')[1].split(' ')[0].split('->')[1]:
-            c = 'branch 3x3 convs, direct kernel (128 / 256 channels)'
+            c = 'branch 3x3 convs, direct kernel (256 channels)'
         elif k.startswith(('conv_direct', 'conv_group', 'conv_igemm', 'conv_tr', 'deconv')):
             c = 'other convs'
         elif k.startswith(('norm_apply_slots', 'norm_bwd_apply_slots')):
@@ -152,8 +152,11 @@ def time_conv_family(B, device, iters=100, family=None):
         gdw = [dw] + [torch.zeros_like(w) for _ in range(NG - 1)]
         arr = ctypes.c_void_p * NG
         ga, gb, gd = arr(*[t.data_ptr() for t in gdy]), arr(*[t.data_ptr() for t in gx]), arr(*[t.data_ptr() for t in gdw])
-        grouped = lib.advmix_conv_wgrad_group(NG, ga, gb, gd, B, H, W, C, H, W, C, 3, 3, 1, 1, st) == 0   # (not every width is served)
-        if grouped:
+        wgw = bool(ops.WGRAD_WINO and ops.WINO and lib.advmix_wgrad_wino_config(B, H, W, C, C) * NG >= ops.WGRAD_WINO_MIN_UNITS)
+        grouped = wgw or lib.advmix_conv_wgrad_group(NG, ga, gb, gd, B, H, W, C, H, W, C, 3, 3, 1, 1, st) == 0   # (not every width is served)
+        if wgw:                                             # what ops._flush_wgrads launches for this geometry (round 5)
+            runs['wgrad'] = lambda: call('advmix_conv3x3_wgrad_wino_group', NG, ga, gb, gd, B, H, W, C, C, st)
+        elif grouped:
             runs['wgrad'] = lambda: call('advmix_conv_wgrad_group', NG, ga, gb, gd, B, H, W, C, H, W, C, 3, 3, 1, 1, st)
         else:
             runs['wgrad'] = lambda: call('advmix_conv_wgrad', P(dy), P(x), P(dw), B, H, W, C, H, W, C, 3, 3, 1, 1, st)
@@ -166,7 +169,7 @@ def time_conv_family(B, device, iters=100, family=None):
             tot_t += wgt * ms * 1e-3
             members.append({
                 'kernel': '3x3 s1 %d->%d @%dx%d %s' % (C, C, H, W, kind if not (kind == 'wgrad' and grouped) else 'wgrad (1 of 8 problems of one launch)'),
-                'path': 'wgrad' if kind == 'wgrad' else ('conv_wino (Winograd F(2x2,3x3))' if wino else 'conv_direct'),
+                'path': ('wgrad_wino (Winograd F(3x3,2x2))' if wgw else 'conv_wgrad_group') if kind == 'wgrad' else ('conv_wino (Winograd F(2x2,3x3))' if wino else 'conv_direct'),
                 'us_per_launch': round(ms * 1e3, 2), 'us_per_launch_runs': [round(v * 1e3, 2) for v in rr],
                 'algorithmic_gflop_per_launch': round(flops / 1e9, 3),
                 'tflops': round(flops / (ms * 1e-3) / 1e12, 2), 'frac': round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),

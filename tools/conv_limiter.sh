@@ -10,7 +10,7 @@ if [ "$1" != "run" ]; then
   mkdir -p $D
   for m in 1 2 3 4 7; do
     objs=""
-    for f in conv_mfma conv_direct conv_wino wgrad_direct wgrad_lds norm pointwise advmix_ops postproc inputpipe nms; do
+    for f in conv_mfma conv_direct conv_wino wgrad_direct wgrad_lds wgrad_wino norm pointwise advmix_ops postproc inputpipe nms; do
       if [ $f = conv_direct ]; then
         /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -std=c++17 -DCD_DBG=$m -c $R/advmix_amd/csrc/$f.hip -o $D/$f.$m.o
         objs="$objs $D/$f.$m.o"

@@ -456,25 +456,6 @@ __global__ __launch_bounds__(256) void norm_apply_slots_kernel(
     const int tid = threadIdx.x;
     const int ct0 = blockIdx.y * SLOT_CT;
     const int ctn = C - ct0 < SLOT_CT ? C - ct0 : SLOT_CT;
-    // The first rows' loads do not depend on the statistics: requested BEFORE the slots are reduced (round 5: a dependent
-    // chain of slot loads -> barrier -> LDS -> barrier -> first loads of c cost every one of the ~575 launches per step a memory
-    // round trip; on the low-resolution branches that is a fifth of a 6 us launch)
-    const RowTile t = row_tile(rows, ctn);
-    const bool live = t.rr < t.rpi;
-    const int cl = t.cv * 4, ch = ct0 + cl;
-    constexpr int U = 4;
-    f32x4 xv[U], rv[U];
-    int64_t r = t.r0 + t.rr;
-    auto fetch = [&](int64_t r_) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t row = r_ + (int64_t)u * t.rpi;
-            const int64_t rr_ = row < t.r1 ? row : r_;
-            xv[u] = *reinterpret_cast<const f32x4*>(c + rr_ * C + ch);
-            if (res) rv[u] = *reinterpret_cast<const f32x4*>(res + rr_ * C + ch);
-        }
-    };
-    if (live && r < t.r1) fetch(r);
     reduce_slots(slots, ns, C, ct0, ctn, sums, red);
     __syncthreads();
     if (tid < ctn) {
@@ -485,23 +466,33 @@ __global__ __launch_bounds__(256) void norm_apply_slots_kernel(
         smu[tid] = mu;
         sis[tid] = is;
         if (blockIdx.x == 0) {
-            const int ch_ = ct0 + tid;
-            mean_out[ch_] = mu;
-            invstd_out[ch_] = is;
+            const int ch = ct0 + tid;
+            mean_out[ch] = mu;
+            invstd_out[ch] = is;
             if (running_mean) {
                 const double unb = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
-                running_mean[ch_] = (float)((1.0 - momentum) * (double)running_mean[ch_] + (double)momentum * m);
-                running_var[ch_] = (float)((1.0 - momentum) * (double)running_var[ch_] + (double)momentum * unb);
+                running_mean[ch] = (float)((1.0 - momentum) * (double)running_mean[ch] + (double)momentum * m);
+                running_var[ch] = (float)((1.0 - momentum) * (double)running_var[ch] + (double)momentum * unb);
             }
-            if (ch_ == 0 && nbt) *nbt += 1;
+            if (ch == 0 && nbt) *nbt += 1;
         }
     }
     __syncthreads();
-    if (!live) return;
+    const RowTile t = row_tile(rows, ctn);
+    if (t.rr >= t.rpi) return;
+    const int cl = t.cv * 4, ch = ct0 + cl;
     const f32x4 mu = *reinterpret_cast<const f32x4*>(&smu[cl]), is = *reinterpret_cast<const f32x4*>(&sis[cl]);
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + ch), b = *reinterpret_cast<const f32x4*>(beta + ch);
-    for (; r < t.r1; r += (int64_t)U * t.rpi) {
-        if (r != t.r0 + t.rr) fetch(r);
+    constexpr int U = 4;
+    for (int64_t r = t.r0 + t.rr; r < t.r1; r += (int64_t)U * t.rpi) {
+        f32x4 xv[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = r + (int64_t)u * t.rpi;
+            const int64_t rr_ = row < t.r1 ? row : r;
+            xv[u] = *reinterpret_cast<const f32x4*>(c + rr_ * C + ch);
+            if (res) rv[u] = *reinterpret_cast<const f32x4*>(res + rr_ * C + ch);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t row = r + (int64_t)u * t.rpi;
@@ -536,22 +527,6 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_slots_kernel(
     const int tid = threadIdx.x;
     const int ct0 = blockIdx.y * SLOT_CT;
     const int ctn = C - ct0 < SLOT_CT ? C - ct0 : SLOT_CT;
-    const RowTile t = row_tile(rows, ctn);                  // (first rows requested before the slots are reduced, as in the forward kernel)
-    const bool live = t.rr < t.rpi;
-    const int cl = t.cv * 4, ch = ct0 + cl;
-    constexpr int U = 4;
-    f32x4 gv[U], xv[U];
-    int64_t r = t.r0 + t.rr;
-    auto fetch = [&](int64_t r_) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t row = r_ + (int64_t)u * t.rpi;
-            const int64_t rr_ = row < t.r1 ? row : r_;
-            gv[u] = *reinterpret_cast<const f32x4*>(g + rr_ * C + ch);
-            xv[u] = *reinterpret_cast<const f32x4*>(c + rr_ * C + ch);
-        }
-    };
-    if (live && r < t.r1) fetch(r);
     reduce_slots(slots, ns, C, ct0, ctn, sums, red);
     __syncthreads();
     if (tid < ctn) {
@@ -563,13 +538,23 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_slots_kernel(
         }
     }
     __syncthreads();
-    if (!live) return;
+    const RowTile t = row_tile(rows, ctn);
+    if (t.rr >= t.rpi) return;
+    const int cl = t.cv * 4, ch = ct0 + cl;
     const f32x4 c1 = *reinterpret_cast<const f32x4*>(&sc1[cl]), c2 = *reinterpret_cast<const f32x4*>(&sc2[cl]);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + ch), is = *reinterpret_cast<const f32x4*>(invstd + ch);
     f32x4 k = is;
     if (gamma) k = k * *reinterpret_cast<const f32x4*>(gamma + ch);
-    for (; r < t.r1; r += (int64_t)U * t.rpi) {
-        if (r != t.r0 + t.rr) fetch(r);
+    constexpr int U = 4;
+    for (int64_t r = t.r0 + t.rr; r < t.r1; r += (int64_t)U * t.rpi) {
+        f32x4 gv[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = r + (int64_t)u * t.rpi;
+            const int64_t rr_ = row < t.r1 ? row : r;
+            gv[u] = *reinterpret_cast<const f32x4*>(g + rr_ * C + ch);
+            xv[u] = *reinterpret_cast<const f32x4*>(c + rr_ * C + ch);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t row = r + (int64_t)u * t.rpi;

@@ -743,7 +743,8 @@ def test_winograd_weight_gradient(case):
     _ops()
     B, Ci, Co, H, W, n = case
     d = dev()
-    assert lib.advmix_wgrad_wino_config(B, H, W, Ci, Co) > 0
+    # (the policy query refuses blocks less than 60 % full - the last two cases - while the entry point itself serves any even size)
+    assert (lib.advmix_wgrad_wino_config(B, H, W, Ci, Co) > 0) == ((H // 2) * (W // 2) >= 20)
     g_ = torch.Generator().manual_seed(31 + Ci + H)
     R = lambda *s_: torch.randn(*s_, generator=g_)
     xs, dys, base = [R(B, H, W, Ci) for _ in range(n)], [R(B, H, W, Co) for _ in range(n)], [R(Co, 3, 3, Ci) for _ in range(n)]

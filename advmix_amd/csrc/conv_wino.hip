@@ -82,8 +82,12 @@ struct Geo {
 // KS: K is split over KS sets of four waves (workgroup = 4 KS waves): the 128-channel branch (16 x 12 maps: 64 blocks x 4
 // column tiles = one workgroup per CU at B = 32) gets two waves per SIMD that way, each multiplying half of the channels;
 // the halves meet in the exchange of the inverse transform, which adds across waves anyway.
+// waves per SIMD the register allocator may assume: what the LDS footprint admits anyway (three workgroups of <= 53 KB per CU)
+template <int NQ, int LBW, int KS>
+constexpr int wino_waves() { return KS > 1 ? 1 : (Geo<LBW, NQ * 8, KS>::LDS * 4 + 1024 <= 53 * 1024 ? 3 : 2); }
+
 template <int NQ, int ROLE, int LBW, int KS = 1>
-__global__ __launch_bounds__(256 * KS, KS == 1 ? 3 : 1) void conv_wino(const WinoP p) {
+__global__ __launch_bounds__(256 * KS, wino_waves<NQ, LBW, KS>()) void conv_wino(const WinoP p) {
     using G = Geo<LBW, NQ * 8, KS>;
     constexpr int NT = 256 * KS, NQW = NQ / KS;            // threads; k groups per wave
     static_assert(NQ % KS == 0, "K splits evenly over the wave sets");

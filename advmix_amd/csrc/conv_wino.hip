@@ -87,7 +87,7 @@ template <int NQ, int LBW, int KS>
 constexpr int wino_waves() { return KS > 1 ? 1 : (Geo<LBW, NQ * 8, KS>::LDS * 4 + 1024 <= 53 * 1024 ? 3 : 2); }
 
 template <int NQ, int ROLE, int LBW, int KS = 1>
-__global__ __launch_bounds__(256 * KS, wino_waves<NQ, LBW, KS>()) void conv_wino(const WinoP p) {
+__global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS>())) void conv_wino(const WinoP p) {
     using G = Geo<LBW, NQ * 8, KS>;
     constexpr int NT = 256 * KS, NQW = NQ / KS;            // threads; k groups per wave
     static_assert(NQ % KS == 0, "K splits evenly over the wave sets");

@@ -180,6 +180,18 @@ def main():
         if sync is not None and not a.no_verify:
             # before anything is timed: the N-rank execution proves itself - three steps through THIS runner
             verification = BP.verify_data_parallel(step, args, (D, G, T), crit, (optD, optG), (views, tgt, tw), sync)
+            if a.exec_mode == 'graph' and (not verification[0] or os.environ.get('ADVMIX_BENCH_FAIL_GRAPH_VERIFY') == '1'):
+                # the replayed graphs did not prove themselves on this machine: the same step WITHOUT graphs, from rank 0's
+                # state again, verified the same way - the line says so (config.exec 'eager', dp_verification.graph_attempt)
+                graph_attempt = dict(verification[1], verified=verification[0])
+                hold.clear()
+                del step
+                torch.cuda.synchronize()
+                sync.broadcast_state([D, G, T], [optD, optG])
+                a.exec_mode = 'eager'
+                step = make_step()
+                verification = BP.verify_data_parallel(step, args, (D, G, T), crit, (optD, optG), (views, tgt, tw), sync)
+                verification[1]['graph_attempt'] = graph_attempt
 
         def launch():
             loss_D, out, target = step()

@@ -1166,6 +1166,25 @@ def test_data_parallel_path_on_one_rank_real_rccl():
     assert out.returncode == 0 and 'DP_ONE_RANK_OK' in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
 
 
+def test_bench_falls_back_to_the_eager_step_when_the_graphs_do_not_verify():
+    """bench.py's N-rank run verifies its own execution before it times anything; when the replayed graphs fail that (forced
+    here: ADVMIX_BENCH_FAIL_GRAPH_VERIFY=1, one rank with real RCCL) the SAME step runs without graphs from rank 0's state,
+    is verified again, and the line says so - a number from an unverified execution is never printed as valid."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ADVMIX_FORCE_SYNC='1', ADVMIX_BENCH_FAIL_GRAPH_VERIFY='1', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT='29671', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--batch', '4', '--steps', '2', '--warmup', '1',
+                          '--no-roofline', '--no-cpu-baseline', '--no-through-loop'], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line['config']['exec'] == 'eager' and line['grad_exchange_verified'] is True
+    assert line['replicas_identical'] is True and line['all_finite'] is True
+    v = line['dp_verification']
+    assert v['exec'] == 'eager' and all(v['checks'].values()) and 'graph_attempt' in v and v['graph_attempt']['verified'] is True
+
+
 @pytest.mark.parametrize('transport', ['device', 'host round trip'])
 def test_seven_graph_runner_equals_the_eager_pieces_bit_for_bit_when_the_exchange_changes_the_data(transport):
     """VERDICT r3 item 1's separating experiment, kept as a test: ONE process, the gradient exchange replaced by a transport

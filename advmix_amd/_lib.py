@@ -43,6 +43,7 @@ SIGNATURES = {
     'advmix_conv3x3_wgrad_wino_group': [_i, _p, _p, _p] + [_i] * 5 + [_p],
     'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_wgrad_group': [_i, _p, _p, _p] + [_i] * 11 + [_p],
+    'advmix_conv_wgrad_multi': [_i, _p, _p, _p, _p, _p],
     'advmix_conv_wgrad_det': [_p, _p, _p] + [_i] * 11 + [_p, _l, _p],
     'advmix_bias_grad_det': [_p, _p, _l, _i, _p, _l, _p],
     'advmix_transpose_w': [_p, _p, _i, _i, _i, _p],

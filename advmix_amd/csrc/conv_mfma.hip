@@ -630,6 +630,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_group(WgP p, WgGroup g) {
     wgrad_body<WM, WN, true, TM, TN>(p, bx, by, bz - prob * g.slices, As, Bs);
 }
 
+// Up to WG_MULTI weight gradients of DIFFERENT geometries in one launch (round 5): the ~70 small convs of the HRNet fuse
+// layers and transitions (3x3 s2 C -> C', 1x1 C -> C': 7-23 us each at 0.02-0.28 of peak - launch latency, a few workgroups)
+// have no consumer before the optimizer step either; block b belongs to problem i with start[i] <= b < start[i + 1] and
+// computes tile (bx, by) of pixel slice bz of THAT problem with the problem's own tile shape (cfg 0: 64 x 64, 1: 32 x 128
+// for Ca <= 32).  Every tile is merged with fp32 atomics (same sums as the single launches, another order).
+constexpr int WG_MULTI = 16;
+struct WgMulti {
+    int n;
+    int start[WG_MULTI + 1];
+    int gx[WG_MULTI], gy[WG_MULTI], cfg[WG_MULTI];
+    WgP p[WG_MULTI];
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_multi(WgMulti g) {
+    __shared__ __attribute__((aligned(16))) float As[2 * 32 * 32 * 2];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * 32 * 32 * 4];
+    const int b = blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < WG_MULTI; ++k)
+        if (k < g.n && b >= g.start[k]) i = k;
+    const int local = b - g.start[i], gx = g.gx[i], gxy = gx * g.gy[i];
+    const int bz = local / gxy, rem = local - bz * gxy;
+    const int by = rem / gx, bx = rem - by * gx;
+    if (g.cfg[i] == 0) wgrad_body<2, 2, true, 1, 1>(g.p[i], bx, by, bz, As, Bs);
+    else wgrad_body<1, 4, true, 1, 1>(g.p[i], bx, by, bz, As, Bs);
+}
+
 __global__ void transpose_w_kernel(const float* __restrict__ in, float* __restrict__ out, int A, int T, int B) {
     int64_t total = (int64_t)A * T * B;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -996,6 +1024,72 @@ extern "C" int advmix_conv_wgrad_group(int n, const float* const* a, const float
         snprintf(kd, sizeof kd, "wgrad x%d", n);
         advmix_trace_launch(nm, grid, kd, N, Hb, Wb, Cb, Ha, Wa, Ca, R, S, stride,
                             2.0 * n * N * (double)Ha * Wa * Ca * Cb * R * S);
+    }
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+// n (1 ... 16) weight gradients of ANY geometries as one launch (see WgMulti).  geoms: n x 11 ints, advmix_conv_wgrad's
+// (N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad) per problem.  Every channel count must be a multiple of 4 (the vector form
+// of wgrad_body).  All problems share one pixel-slice length: the shortest (a multiple of 32, >= ADVMIX_WGRAD_MINPIX) that keeps
+// the launch within ADVMIX_WGM_WGS (768 = three per CU) workgroups, so every workgroup carries about the same work.
+// 0 = launched, 1 = not served (nothing launched: call advmix_conv_wgrad per problem), ADVMIX_EINVAL for bad arguments and
+// in deterministic mode.
+extern "C" int advmix_conv_wgrad_multi(int n, const float* const* a, const float* const* b, float* const* dw,
+                                       const int* geoms, void* stream) {
+    if (n < 1 || n > WG_MULTI || !a || !b || !dw || !geoms) return ADVMIX_EINVAL;
+    if (advmix_opts().deterministic) return ADVMIX_EINVAL;
+    static const int target = [] { const char* e = getenv("ADVMIX_WGM_WGS"); int t = e ? atoi(e) : 768; return t > 0 ? t : 768; }();
+    WgMulti g;
+    g.n = n;
+    int64_t P[WG_MULTI];
+    int tiles[WG_MULTI];
+    int64_t pmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const int* q = geoms + 11 * i;
+        const int N = q[0], Ha = q[1], Wa = q[2], Ca = q[3], Hb = q[4], Wb = q[5], Cb = q[6], R = q[7], S = q[8], stride = q[9], pad = q[10];
+        if (!a[i] || !b[i] || !dw[i] || N <= 0 || Ca <= 0 || Cb <= 0 || stride < 1 || R < 1 || S < 1) return ADVMIX_EINVAL;
+        if (Ha != (Hb + 2 * pad - R) / stride + 1 || Wa != (Wb + 2 * pad - S) / stride + 1) return ADVMIX_EINVAL;
+        if (Ca % 4 != 0 || Cb % 4 != 0) return 1;
+        g.p[i] = WgP{a[i], b[i], dw[i], N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad, 0, nullptr};
+        g.p[i].excl = 0;
+        g.p[i].xcd = 0;
+        g.cfg[i] = Ca <= 32 ? 1 : 0;
+        g.gx[i] = g.cfg[i] ? cdiv(Ca, 32) : cdiv(Ca, 64);
+        g.gy[i] = g.cfg[i] ? cdiv(R * S * Cb, 128) : cdiv(R * S * Cb, 64);
+        tiles[i] = g.gx[i] * g.gy[i];
+        P[i] = (int64_t)N * Ha * Wa;
+        if (P[i] > pmax) pmax = P[i];
+    }
+    int64_t chunk = (advmix_wgrad_min_pix() + 31) / 32 * 32;
+    for (;; chunk += 32) {
+        int64_t total = 0;
+        for (int i = 0; i < n; ++i) total += (int64_t)tiles[i] * cdiv(P[i], chunk);
+        if (total <= target || chunk >= pmax) break;
+    }
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        const int* q = geoms + 11 * i;
+        if (!wgrad_spans_ok(chunk, q[1], q[2], q[3], q[4], q[5], q[6])) return 1;
+        g.p[i].chunk = (int)chunk;
+        g.start[i] = (int)total;
+        total += (int64_t)tiles[i] * cdiv(P[i], chunk);
+        if (total > 0x3fffffff) return 1;
+    }
+    for (int i = n; i <= WG_MULTI; ++i) g.start[i] = (int)total;
+    for (int i = n; i < WG_MULTI; ++i) { g.gx[i] = g.gy[i] = 1; g.cfg[i] = 0; g.p[i] = g.p[0]; }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_wgrad_multi, dim3((unsigned)total), dim3(256), 0, st, g);
+    if (advmix_opts().trace_shapes) {
+        double fl = 0;
+        for (int i = 0; i < n; ++i) {
+            const int* q = geoms + 11 * i;
+            fl += 2.0 * q[0] * (double)q[1] * q[2] * q[3] * q[6] * q[7] * q[8];
+        }
+        char kd[24];
+        snprintf(kd, sizeof kd, "wgrad multi x%d", n);
+        const int* q = geoms;
+        advmix_trace_launch("conv_wgrad_multi", dim3((unsigned)total), kd, q[0], q[4], q[5], q[6], q[1], q[2], q[3], q[7], q[8], q[9], fl);
     }
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;

@@ -242,17 +242,74 @@ WGRAD_GROUP = __import__('os').environ.get('ADVMIX_WGRAD_GROUP', '1') != '0'
 _WG_DEFER = []          # a stack of pending lists: [(a, b, grad, geom)] of the Chain.bwd calls in progress
 
 
-def _wgrad(st, lane, a, b, w, geom):
-    """Weight gradient accumulated into w.grad (atomics, or ordered partials in deterministic mode)."""
+def _wgrad(st, lane, a, b, w, geom, park=False):
+    """Weight gradient accumulated into w.grad (atomics, or ordered partials in deterministic mode).  ``park``: a and b stay
+    as they are until the autograd pass ends (ConvBN.bwd: a fresh dc, a saved activation), so a SMALL problem may wait for
+    a mixed launch (_wgrad_single); the U-Net's plain convs hand over gradients that later backward ops update in place."""
     g = _grad_buf(w, st)
     if DETERMINISTIC:
         ws = _workspace(a.device, 0, lane)
         call('advmix_conv_wgrad_det', _p(a), _p(b), _p(g), *geom, _p(ws), WS_BYTES, st)
     elif _WG_DEFER and WGRAD_GROUP and ((geom[3] % 64 == 0 and geom[6] % 4 == 0)
                                         or (geom[3] == 32 and geom[6] == 32 and geom[7:] == (3, 3, 1, 1))):
-        _WG_DEFER[-1].append((a, b, g, geom))               # (a - a kept temporary - and b stay alive in the pending list)
+        _WG_DEFER[-1].append((a, b, g, geom, park))         # (a - a kept temporary - and b stay alive in the pending list)
     elif not _wgrad_wino(st, [(a, b, g)], geom):            # (a lone 3x3 with enough work, e.g. transition1's 256 -> 32 @64x48)
-        call('advmix_conv_wgrad', _p(a), _p(b), _p(g), *geom, st)
+        _wgrad_single(st, a, b, g, geom, park)
+
+
+# The SMALL weight gradients - the strided 3x3 and 1x1 convs of HRNet's fuse layers and transitions, ~70 per backward pass at
+# 7-23 us of launch latency each - wait in one list across launch groups and go out up to 16 at a time as ONE launch of
+# mixed geometries (advmix_conv_wgrad_multi): at the start of the next multi-lane group's backward on its last lane (beside
+# that group's members), the rest from a callback at the end of the autograd pass - before anything can read a gradient.
+WGRAD_MULTI = __import__('os').environ.get('ADVMIX_WGRAD_MULTI', '1') != '0'
+WGRAD_MULTI_MAX_FLOP = float(__import__('os').environ.get('ADVMIX_WGRAD_MULTI_MAX_GFLOP', '1.0')) * 1e9
+WGRAD_MULTI_FLUSH = int(__import__('os').environ.get('ADVMIX_WGRAD_MULTI_FLUSH', '8'))    # pending problems that trigger a flush
+_WG_SMALL = []          # [(a, b, grad, geom)] across the launch groups of the autograd pass in progress
+
+
+def _wgrad_single(st, a, b, g, geom, park):
+    """One weight gradient on its own: launched now, or - small, ``park``, inside an autograd pass - parked for a mixed launch."""
+    B, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad = geom
+    if (park and WGRAD_MULTI and not DETERMINISTIC and Ca % 4 == 0 and Cb % 4 == 0
+            and 2.0 * B * Ha * Wa * Ca * Cb * R * S <= WGRAD_MULTI_MAX_FLOP):
+        try:                                                 # (one callback per parked problem: the first to run flushes all)
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_small_wgrads_at_end)
+            _WG_SMALL.append((a, b, g, geom))
+            return
+        except RuntimeError:                                 # not inside an autograd pass: nobody would flush
+            pass
+    call('advmix_conv_wgrad', _p(a), _p(b), _p(g), *geom, st)
+
+
+def _flush_small_wgrads(st, count=None, keep_alive=True):
+    """The first ``count`` (default: all) parked weight gradients as mixed launches of up to 16 on stream ``st``;
+    ``keep_alive``: their operands stay referenced until the group in progress has joined its lanes (keep())."""
+    count = len(_WG_SMALL) if count is None else count
+    pending = _WG_SMALL[:count]
+    del _WG_SMALL[:count]
+    for i in range(0, len(pending), 16):
+        grp = pending[i:i + 16]
+        n = len(grp)
+        arr = ctypes.c_void_p * n
+        geoms = (ctypes.c_int * (11 * n))(*[v for x in grp for v in x[3]])
+        rc = lib.advmix_conv_wgrad_multi(n, arr(*[x[0].data_ptr() for x in grp]), arr(*[x[1].data_ptr() for x in grp]),
+                                         arr(*[x[2].data_ptr() for x in grp]), geoms, st) if n >= 2 else 1
+        if rc == 0:
+            COUNTERS['wgrad_multi'] = COUNTERS.get('wgrad_multi', 0) + 1
+        elif rc == 1:
+            for a, b, g, geom in grp:
+                call('advmix_conv_wgrad', _p(a), _p(b), _p(g), *geom, st)
+        else:
+            raise RuntimeError('advmix_conv_wgrad_multi failed: %d' % rc)
+    if keep_alive:
+        _KEEP.extend(t for x in pending for t in x[:2])
+
+
+def _flush_small_wgrads_at_end():
+    """End of the autograd pass (queue_callback): what is still parked goes out on the caller's stream - every lane has
+    joined it."""
+    if _WG_SMALL:
+        _flush_small_wgrads(_st(), keep_alive=False)
 
 
 WGRAD_WINO = __import__('os').environ.get('ADVMIX_WGRAD_WINO', '1') != '0'   # Winograd F(3x3,2x2) weight gradients (A/B switch)
@@ -282,8 +339,8 @@ def _wgrad_wino(st, grp, geom):
 def _flush_wgrads(st, pending):
     """Launch the collected weight gradients: groups of 2-8 of one geometry as one launch, the rest one by one."""
     by = {}
-    for a, b, g, geom in pending:
-        by.setdefault(geom, []).append((a, b, g))
+    for a, b, g, geom, park in pending:
+        by.setdefault(geom, []).append((a, b, g, park))
     for geom, items in by.items():
         for i in range(0, len(items), 8):
             grp = items[i:i + 8]
@@ -299,8 +356,8 @@ def _flush_wgrads(st, pending):
                     continue
                 if rc != 1:
                     raise RuntimeError('advmix_conv_wgrad_group failed: %d' % rc)
-            for a, b, g in grp:
-                call('advmix_conv_wgrad', _p(a), _p(b), _p(g), *geom, st)
+            for a, b, g, park in grp:
+                _wgrad_single(st, a, b, g, geom, park)
 
 
 def _bias_grad(st, lane, dy, bias, rows, C):
@@ -785,7 +842,7 @@ class ConvBN:
         if needs[0]:
             dx = _conv_dgrad(st, dc, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to, bnb, lane)
         if needs[1]:
-            _wgrad(st, lane, dc, x, w, (B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad))
+            _wgrad(st, lane, dc, x, w, (B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad), park=True)
         return dx, None, None, None, None, None, None, dres
 
 
@@ -1333,6 +1390,14 @@ class GroupFn(torch.autograd.Function):
                 return
             r = op.bwd(handle, lane, saved[spos:spos + scnt], extras[i], meta, g, needs)
             grads[ipos:ipos + icnt] = list(r) + [None] * (icnt - len(r))
+        ready = len(_WG_SMALL)                              # small weight gradients parked by EARLIER groups (their lanes
+        if nl > 1 and ready >= WGRAD_MULTI_FLUSH:           # have joined): one mixed launch on this group's last lane,
+            inner = run_member                              # beside its members
+
+            def run_member(i, handle, lane):
+                if i == nl - 1:                             # (the first member that runs on lane nl - 1)
+                    _flush_small_wgrads(handle, ready)
+                inner(i, handle, lane)
         _run_lanes(dev, len(members), nl, run_member)
         del _KEEP[:]
         return (None,) + tuple(grads)

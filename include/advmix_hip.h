@@ -194,6 +194,14 @@ int advmix_conv_wgrad_group(int n, const float* const* a, const float* const* b,
                             int N, int Ha, int Wa, int Ca, int Hb, int Wb, int Cb,
                             int R, int S, int stride, int pad, void* stream);
 
+/* 1-16 weight gradients of ANY geometries as one launch (a / b / dw: HOST arrays of n device pointers; geoms: n x 11 ints,
+ * advmix_conv_wgrad's (N, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad) per problem): the small strided 3x3 and 1x1 convs of
+ * HRNet's fuse layers and transitions (pose_hrnet.py:172-247, 305-337) - 7-23 us of launch latency each alone.  Same sums as
+ * n single calls, in another order (fp32 atomics).  Every channel count a multiple of 4.  0 = launched, 1 = not served
+ * (nothing launched: call advmix_conv_wgrad per problem), ADVMIX_EINVAL for bad arguments and in deterministic mode. */
+int advmix_conv_wgrad_multi(int n, const float* const* a, const float* const* b, float* const* dw,
+                            const int* geoms, void* stream);
+
 /* Deterministic variants (bit-reproducible run to run; ops.set_deterministic): the pixel slices / row blocks STORE
  * their partial results into ws and a second launch adds them in slice order - no fp32 atomics.
  * advmix_conv_wgrad_det needs 4 * slices * Ca * R * S * Cb bytes, never more than advmix_wgrad_det_ws_bytes();

@@ -234,7 +234,13 @@ def test_advmix_and_plain_steps_vs_oracle_and_golden(tag):
         gmh, gmo, gout, _e1, _e2 = grad_stats(live, gG_dev, ref['gG'], gG64)
         gbound = max(GRAD_K * gmo + 1e-4, GRAD_FLIP_FLOOR.get(tag, 0.0))      # (same rule - and the same floor for ONE flipped mask
         assert gmh <= gbound, ('G-step grads it%d' % it, gmh, gmo, gbound)   #  in the two tiny nets - as D's gradients above)
-        assert gout <= max(2, 0.03 * len(live)), ('G-step grads it%d: tensors far outside the fp32-oracle error' % it, gout)
+        if tag in GRAD_FLIP_FLOOR:
+            # ONE flipped mask in the frozen student moves EVERY tensor of the tiny generators' gradient by 1-2.5 % (2 of 6
+            # runs on one box, with or without this round's kernels: profiles/r05w_g_step_outlier_rate.log) - the median
+            # rule above carries that floor, the outlier rule's 1e-2 did not: "far outside" starts at 4 x the floor here
+            gout = int((_e1 > np.maximum(20 * _e2, 4 * GRAD_FLIP_FLOOR[tag])).sum())
+        assert gout <= max(2, 0.03 * len(live)), ('G-step grads it%d: tensors far outside the fp32-oracle error' % it, gout,
+                                                  float(_e1.max()))
         gstats = (gmh, gmo, gout)
         for k in G0:
             if k not in live:
@@ -314,8 +320,11 @@ def test_network_parity_at_the_benchmarked_batch():
     x = views[1].cuda().requires_grad_(True)
     yt = mD(x)
     loss = JointsMSELoss(True)(yt, tgt.cuda(), tw.cuda())
+    m0 = _ops_.COUNTERS.get('wgrad_multi', 0)
     loss.backward()
     assert _ops_.COUNTERS.get('wino', 0) - w0 == 3 * 188, _ops_.COUNTERS     # + train forward + input gradients
+    # the small weight gradients of the fuse layers / transitions went out as mixed launches, none is left parked
+    assert _ops_.COUNTERS.get('wgrad_multi', 0) - m0 >= 4 and not _ops_._WG_SMALL, (_ops_.COUNTERS, len(_ops_._WG_SMALL))
     names = _trainable(D)
     for k in names:
         D[k].requires_grad_(True)

@@ -773,6 +773,75 @@ def test_winograd_weight_gradient(case):
                                                arr(*[t.data_ptr() for t in dw]), B, H, W, Co, Ci, st) == 1
 
 
+@pytest.mark.parametrize('tiny', [False, True])
+def test_mixed_geometry_weight_gradients_in_one_launch(tiny):
+    """advmix_conv_wgrad_multi (round 5): up to 16 weight gradients of DIFFERENT geometries - the strided 3x3 and 1x1 convs of
+    HRNet's fuse layers and transitions (pose_hrnet.py:172-247, 305-337) - as one launch, ACCUMULATED into dw, against a
+    float64 autograd evaluation and against advmix_conv_wgrad problem by problem; both tile shapes (Ca <= 32 / Ca > 32),
+    ragged column tiles, one problem alone, a channel count that is not a multiple of 4 (refused: 1), 17 problems (EINVAL)."""
+    import ctypes
+    from advmix_amd._lib import call, lib
+    _ops()
+    d = dev()
+    # (B, Ci, H, W, Co, k, stride, pad)
+    probs = [(4, 32, 32, 24, 32, 3, 2, 1), (4, 32, 32, 24, 64, 3, 2, 1), (4, 64, 16, 12, 128, 3, 2, 1), (4, 64, 16, 12, 32, 1, 1, 0),
+             (4, 32, 16, 12, 128, 3, 2, 1), (4, 128, 8, 6, 256, 3, 2, 1), (4, 128, 8, 6, 32, 1, 1, 0), (4, 128, 8, 6, 64, 1, 1, 0),
+             (4, 256, 4, 3, 32, 1, 1, 0), (3, 64, 9, 7, 64, 3, 2, 1), (2, 32, 5, 5, 20, 3, 1, 1), (4, 256, 4, 3, 128, 1, 1, 0),
+             (2, 12, 6, 5, 8, 3, 1, 1), (1, 64, 32, 24, 64, 3, 2, 1), (4, 32, 64, 48, 16, 1, 1, 0), (2, 64, 13, 11, 36, 3, 2, 1)]
+    if tiny:                                                # the U-Net's 4x4 / stride 2 convs down to 1 x 1 maps, few images
+        probs = [(2, 64, 16, 12, 128, 4, 2, 1), (2, 128, 8, 6, 256, 4, 2, 1), (2, 256, 4, 4, 512, 4, 2, 1), (2, 512, 2, 2, 512, 4, 2, 1),
+                 (2, 512, 2, 2, 64, 4, 2, 1), (1, 64, 2, 2, 32, 4, 2, 1), (3, 32, 4, 2, 32, 4, 2, 1), (2, 16, 2, 4, 24, 3, 1, 1),
+                 (1, 8, 1, 1, 8, 1, 1, 0), (2, 512, 4, 3, 512, 4, 2, 1)]
+    g_ = torch.Generator().manual_seed(77)
+    R = lambda *s_: torch.randn(*s_, generator=g_)
+    xs, dys, base, geoms = [], [], [], []
+    for B, Ci, H, W, Co, k, s, p in probs:
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        xs.append(R(B, H, W, Ci)); dys.append(R(B, Ho, Wo, Co)); base.append(R(Co, k, k, Ci))
+        geoms.append((B, Ho, Wo, Co, H, W, Ci, k, k, s, p))
+    if tiny:                                                # ... and the same maps seen from a ConvTranspose2d (a = x, b = dy)
+        for B, Ci, H, W, Co in [(2, 512, 1, 1, 512), (2, 1024, 2, 2, 256), (2, 128, 8, 6, 64)]:
+            xs.append(R(B, 2 * H, 2 * W, Co)); dys.append(R(B, H, W, Ci)); base.append(R(Ci, 4, 4, Co))
+            geoms.append((B, H, W, Ci, 2 * H, 2 * W, Co, 4, 4, 2, 1))
+            probs.append((B, Co, 2 * H, 2 * W, Ci, 4, 2, 1))
+    xd, dyd = [t.to(d) for t in xs], [t.to(d) for t in dys]
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def multi(idx, dw):
+        n = len(idx)
+        arr = ctypes.c_void_p * n
+        gs = (ctypes.c_int * (11 * n))(*[v for i in idx for v in geoms[i]])
+        return lib.advmix_conv_wgrad_multi(n, arr(*[dyd[i].data_ptr() for i in idx]), arr(*[xd[i].data_ptr() for i in idx]),
+                                           arr(*[dw[i].data_ptr() for i in idx]), gs, st)
+    dw = [t.to(d).clone() for t in base]                    # not zero: the kernel accumulates
+    assert multi(list(range(len(probs))), dw) == 0
+    torch.cuda.synchronize()
+    for i, (B, Ci, H, W, Co, k, s, p) in enumerate(probs):
+        w64 = torch.zeros(Co, Ci, k, k, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(xs[i].double().permute(0, 3, 1, 2), w64, stride=s, padding=p)
+        (y * dys[i].double().permute(0, 3, 1, 2)).sum().backward()
+        check('multi wgrad %d' % i, dw[i], w64.grad.permute(0, 2, 3, 1) + base[i].double(), 3e-5)
+        ref = base[i].to(d).clone()
+        call('advmix_conv_wgrad', P(dyd[i]), P(xd[i]), P(ref), *geoms[i], st)
+        torch.cuda.synchronize()
+        check('multi vs conv_wgrad %d' % i, dw[i], ref.double().cpu(), 2e-5)
+    if tiny:
+        return
+    one = [t.to(d).clone() for t in base]
+    assert multi([5], one) == 0                             # one problem alone is served too
+    torch.cuda.synchronize()
+    check('multi alone', one[5], dw[5].double().cpu(), 2e-5)
+    # refused without launching: a channel count that is not a multiple of 4; more than 16 problems; deterministic mode
+    xs.append(R(2, 6, 5, 6)); dys.append(R(2, 6, 5, 8)); base.append(R(8, 3, 3, 6)); geoms.append((2, 6, 5, 8, 6, 5, 6, 3, 3, 1, 1))
+    xd.append(xs[-1].to(d)); dyd.append(dys[-1].to(d))
+    bad = [t.to(d).clone() for t in base]
+    assert multi([0, 16], bad) == 1
+    torch.cuda.synchronize()
+    assert torch.equal(bad[0].cpu(), base[0])
+    assert multi(list(range(16)) + [0], bad) != 0
+
+
 @pytest.mark.parametrize('case', [(8, 32, 64, 32, 24, 3), (3, 32, 128, 16, 12, 3), (8, 32, 256, 8, 6, 3), (2, 4, 64, 20, 14, 3),
                                   (5, 8, 128, 12, 9, 1), (8, 32, 32, 64, 48, 3), (3, 4, 32, 16, 11, 3), (2, 2, 32, 8, 8, 3),
                                   # more than eight problems: one pixel slice per tile -> the workgroup owns its outputs (plain +=)

@@ -39,6 +39,10 @@ SIGNATURES = {
     'advmix_wino_weights': [_p, _p, _i, _p],
     'advmix_conv3x3_wino_fwd': [_p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _f, _p, _i, _p, _p, _p],
     'advmix_conv3x3_wino_dgrad': [_p, _p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p],
+    'advmix_conv_smap_config': [_i] * 5,
+    'advmix_smap_weights': [_p, _p, _i, _p],
+    'advmix_conv3x3_smap_fwd': [_p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _f, _p, _i, _p, _p, _p],
+    'advmix_conv3x3_smap_dgrad': [_p, _p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p],
     'advmix_wgrad_wino_config': [_i] * 5,
     'advmix_conv3x3_wgrad_wino_group': [_i, _p, _p, _p] + [_i] * 5 + [_p],
     'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],
@@ -109,6 +113,8 @@ lib.advmix_norm_ws_bytes.argtypes = [_i, _i]
 lib.advmix_norm_ws_bytes.restype = ctypes.c_int64
 lib.advmix_wino_u_floats.argtypes = [_i, _i]
 lib.advmix_wino_u_floats.restype = ctypes.c_int64
+lib.advmix_smap_u_floats.argtypes = [_i, _i]
+lib.advmix_smap_u_floats.restype = ctypes.c_int64
 lib.advmix_wgrad_det_ws_bytes.argtypes = [_i, _i, _i, _i]
 lib.advmix_wgrad_det_ws_bytes.restype = ctypes.c_int64
 lib.advmix_deconv4x4s2_narrow_ws_bytes.argtypes = [_i, _i, _i, _i]

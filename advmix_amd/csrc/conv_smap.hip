@@ -1,0 +1,377 @@
+// 3x3 / stride 1 / pad 1 convolution of SMALL maps with 256 input channels - one workgroup per image (round 5).
+//
+// HRNet's lowest-resolution branch (pose_hrnet.py:22-57 at 256x192: 256 -> 256 @8x6, 24 convs per pass) is the slowest
+// member of stage 4 on every kernel so far: 1,536 pixels x 256 channels are 384 output tiles of 32 x 32 - 192 eight-wave
+// workgroups of conv_direct on 256 CUs, two K-sharing waves per SIMD, each row tile re-staging all 2.36 MB of filters
+// through LDS: 33 us for 11.5 us of MFMA work (0.35 of peak), while the other branches' convs take 14-16.  A Winograd form
+// needs a 32-tile block to span 2 2/3 images and streams 16/9 as many filter bytes.  Here instead:
+//   * a workgroup = ONE image (48 pixels) x 32 output channels, eight waves: grid 8 column tiles x 32 images = 256
+//     workgroups, one per CU, every SIMD two waves with exactly 432 v_mfma_f32_16x16x4_f32 each - the balanced split of
+//     the 442 k MFMAs of the layer (11.5 us at peak);
+//   * the image with its zero halo ((H + 2) x (W + 2) pixels x 256 channels = 83 KB) is staged in LDS ONCE; all nine taps
+//     are 16-byte LDS reads of it (pixel pitch 260 floats: a 16-lane group falls on 16 different slots);
+//   * wave w multiplies channels [32 w, 32 w + 32) of every tap - K is split over the waves, not over workgroups - with
+//     filters pre-laid in MFMA B-fragment order by smap_weights (one launch per forward pass for all such convs, like the
+//     Winograd images): a wave's 36 loads are 36 consecutive KB, four iterations in flight, never staged in LDS.  Column
+//     tile = blockIdx.x, so XCD k always multiplies column tile k: its 288 KB filter slice stays in that XCD's L2;
+//   * the eight partial tiles meet in LDS ([wave][pixel][36] floats); thread (pixel, 4 channels) adds them with 16-byte
+//     reads and runs the fused epilogues of conv_direct / conv_wino in the natural layout: BatchNorm column sums (fp64
+//     slots), eval-mode BatchNorm + residual + activation, or - input-gradient role - addend, activation slope from the
+//     bit mask / from c, BatchNorm-backward sums; 16-byte loads and stores, no transposer.
+#include "common.h"
+#include <stdio.h>
+
+namespace smap {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;      // >= any buffer size accepted -> loads return 0
+constexpr int STORE_AUX = 16;              // sc1 (write-through), as conv_direct's epilogue
+constexpr int C = 256;                     // input channels (= 8 waves x 32)
+constexpr int NT = 512;
+constexpr int PP = C + 4;                  // floats per staged pixel
+constexpr int MAXPOS = 80, MAXPX = 48;     // (H + 2) (W + 2) <= 80 staged pixels, H W <= 48 output pixels (3 MFMA row tiles)
+constexpr int RP = 36;                     // pitch of a pixel row in the reduction image (floats)
+constexpr int NIT = 18;                    // 9 taps x 2 groups of 16 channels per wave
+constexpr int RING = 4;                    // iterations of filter loads in flight
+
+struct SP {
+    const float* x;
+    const float* u;           // filters in fragment order (see smap_weights)
+    float* y;
+    int N, H, W, Co;          // 3x3, stride 1, pad 1: input (256 channels) and output are both H x W
+    int xbytes, ybytes, ubytes;
+    // role 0 (forward): column sums of the raw output and / or eval-mode BatchNorm, residual, activation
+    const float *bn_gamma, *bn_beta, *bn_rm, *bn_rv, *res;
+    float bn_eps;
+    int act;
+    double* stats;            // [2][stats_nbg][Co] fp64 slots (slot-major), zero on entry
+    int stats_nbg;
+    // role 1 (input gradient): ``res`` is the addend; with bnb_c the epilogue is the BatchNorm-backward one (ConvD in
+    // conv_direct.hip: same fields, same arithmetic)
+    const unsigned char* bnb_mask;
+    const float *bnb_c, *bnb_mean, *bnb_invstd, *bnb_gamma, *bnb_beta;
+    int bnb_act;
+};
+
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
+template <int ROLE>
+__global__ __launch_bounds__(NT, 1) void conv_smap(const SP p) {
+    // one region, two lives (separated by workgroup barriers): the padded image, then the eight waves' partial tiles
+    __shared__ __attribute__((aligned(16))) float L[MAXPOS * PP];
+    __shared__ float sred[2 * 8 * 32];
+    static_assert(8 * MAXPX * RP <= MAXPOS * PP, "the reduction image fits the patch region");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;               // MFMA 16x16x4: row / column l15, k-lane q
+    const int nt = blockIdx.x, img = blockIdx.y;
+    const int n0 = nt * 32;
+    const int PX = p.H * p.W, PW = p.W + 2, NPOS = (p.H + 2) * PW;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, p.ubytes, 0x00020000);
+    // this wave's filters: 36 consecutive fragments of 1 KB - iteration it = (tap, 16-channel group) needs 2 it and 2 it + 1
+    const unsigned bo = (unsigned)((((nt * 8 + wv) * (2 * NIT)) * 64 + lane) * 16);
+    f32x4 bq[RING][2];
+    auto issue_b = [&](int it) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) bq[it % RING][u] = bload(ur, bo + (unsigned)((2 * it + u) * 1024));
+    };
+#pragma unroll
+    for (int it = 0; it < RING; ++it) issue_b(it);
+
+    // ---- the image with its zero halo -> LDS (an out-of-image pixel is an out-of-range offset: the load returns 0) -----
+    {
+        constexpr int SIT = (MAXPOS * (C / 4) + NT - 1) / NT;
+        f32x4 stg[SIT];
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int s = tid + NT * it;
+            const int pos = s >> 6, cs = s & 63;
+            const int ph = pos / PW, pw = pos - ph * PW;
+            const int h = ph - 1, w = pw - 1;
+            const bool ok = pos < NPOS && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+            stg[it] = bload(xr, ok ? (unsigned)((((img * p.H + h) * p.W + w) * C + cs * 4) * 4) : OOB);
+        }
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int s = tid + NT * it;
+            const int pos = s >> 6, cs = s & 63;
+            if (pos < NPOS) *reinterpret_cast<f32x4*>(&L[pos * PP + cs * 4]) = stg[it];
+        }
+    }
+
+    // ---- this lane's three pixels (one per MFMA row tile; rows past the image repeat its last pixel: their results are
+    //      never used - a row of A only reaches the same row of D) ---------------------------------------------------------
+    const float* la[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        int m = 16 * t + l15;
+        if (m >= PX) m = PX - 1;
+        const int h = m / p.W, w = m - h * p.W;
+        la[t] = L + (h * PW + w) * PP + 32 * wv + 4 * q;   // tap (0, 0) of the pixel's 3 x 3 window, this wave's channels
+    }
+    f32x4 acc[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();                                        // the image is complete
+    auto toff = [&](int it) { const int tap = it >> 1; return ((tap / 3) * PW + (tap % 3)) * PP + 16 * (it & 1); };
+    f32x4 an[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) an[t] = *reinterpret_cast<const f32x4*>(la[t] + toff(0));
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        f32x4 bc[2], a[3];
+        __builtin_amdgcn_sched_barrier(0);                  // (nothing of iteration it + 1 is hoisted above this one's MFMAs)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) bc[u] = bq[it % RING][u];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) a[t] = an[t];
+        if (it + RING < NIT) issue_b(it + RING);             // four iterations of filters in flight,
+        if (it + 1 < NIT) {                                  // the next iteration's pixels read under this one's 24 MFMAs
+#pragma unroll
+            for (int t = 0; t < 3; ++t) an[t] = *reinterpret_cast<const f32x4*>(la[t] + toff(it + 1));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j], bc[u][j], acc[t][u], 0, 0, 0);
+    }
+
+    // ---- epilogue operands of thread (pixel m, channels 4 cq .. 4 cq + 3): requested now, they arrive under the reduction ----
+    const int m = tid >> 3, cq = tid & 7;
+    const bool live = m < PX;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.y), 0, p.ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bnb_c ? p.bnb_c : p.y), 0, p.ybytes, 0x00020000);
+    const int col = n0 + 4 * cq;
+    const int pix = img * PX + (live ? m : 0);
+    const unsigned yo = live ? (unsigned)((pix * p.Co + col) * 4) : OOB;
+    const bool bnb = ROLE == 1 && p.bnb_c != nullptr;
+    const bool mask_on = bnb && p.bnb_mask != nullptr && p.bnb_act != ADVMIX_ACT_NONE;
+    f32x4 oa = f32x4{0.f, 0.f, 0.f, 0.f}, oc = oa;
+    if (p.res != nullptr) oa = bload(rr, yo);
+    if (ROLE == 1 && bnb) oc = bload(cr, yo);
+    unsigned mbits = 0u;
+    if (ROLE == 1 && mask_on && live) mbits = p.bnb_mask[(int64_t)pix * (p.Co >> 2) + (col >> 2)];   // bit e: channel col + e
+
+    __syncthreads();                                        // every wave is done with the image: the region becomes the reduction image
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)                      // D[row 4 q + r][column l15]
+                L[(wv * MAXPX + 16 * t + 4 * q + r) * RP + 16 * u + l15] = acc[t][u][r];
+    __syncthreads();
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (m < MAXPX) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(&L[(k * MAXPX + m) * RP + 4 * cq]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += x[e];
+        }
+    }
+
+    // ---- fused epilogue (conv_direct.hip's arithmetic, natural layout) ----------------------------------------------------
+    const bool stats = p.stats != nullptr;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool bnf = ROLE == 0 && p.bn_gamma != nullptr;
+    const bool recompute = ROLE == 1 && bnb && !mask_on && p.bnb_act != ADVMIX_ACT_NONE;
+    const float bb_slope = act_neg_slope(p.bnb_act);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float o = v[e];
+        if (ROLE == 0) {
+            if (live) { s1[e] = o; s2[e] = o * o; }
+            if (bnf) o = (o - p.bn_rm[col + e]) * (1.0f / sqrtf(p.bn_rv[col + e] + p.bn_eps)) * p.bn_gamma[col + e] + p.bn_beta[col + e];
+            o += oa[e];
+            o = act_fwd(o, p.act);
+        } else {
+            o += oa[e];
+            if (bnb) {
+                const float xh = (oc[e] - p.bnb_mean[col + e]) * p.bnb_invstd[col + e];
+                if (mask_on) o = ((mbits >> e) & 1u) ? o : o * bb_slope;
+                else if (recompute) o = __builtin_fmaf(xh, p.bnb_gamma[col + e], p.bnb_beta[col + e]) > 0.f ? o : o * bb_slope;
+                if (live) { s1[e] = o; s2[e] = o * xh; }
+            }
+        }
+        v[e] = o;
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yo, 0, STORE_AUX);
+    if (stats) {                                            // uniform over the grid
+        // a wave = 8 pixels x 8 channel quads (lane = 8 (m % 8) + cq): the pixels add up by shuffles, the waves in LDS
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int d = 8; d < 64; d <<= 1) {
+                s1[e] += __shfl_xor(s1[e], d, 64);
+                s2[e] += __shfl_xor(s2[e], d, 64);
+            }
+        }
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sred[wv * 32 + 4 * lane + e] = s1[e];
+                sred[(8 + wv) * 32 + 4 * lane + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                d1 += (double)sred[k * 32 + tid];
+                d2 += (double)sred[(8 + k) * 32 + tid];
+            }
+            const int sl = img % p.stats_nbg;              // slot-major [2][slots][Co]: consecutive doubles per workgroup
+            atomicAdd(p.stats + (int64_t)sl * p.Co + n0 + tid, d1);
+            atomicAdd(p.stats + ((int64_t)p.stats_nbg + sl) * p.Co + n0 + tid, d2);
+        }
+    }
+}
+
+// ---- filter re-layout ---------------------------------------------------------------------------------------------------
+// One block of 256 threads = one 1 KB fragment: (column tile nt of 32, wave w = 32 input channels, tap, 16-channel group g,
+// 16-column half u); thread t = 4 lane + j holds B[k-lane lane / 16, MFMA j][column lane % 16] =
+// filter(n = 32 nt + 16 u + lane % 16, tap, c = 32 w + 16 g + 4 (lane / 16) + j).  role 0: w[n][r][s][c] (forward; n = Cout,
+// c = Cin); role 1: w[c][2 - r][2 - s][n] (input gradient; n = Cin, c = Cout).  Same record as wino::WinoEnt.
+struct SEnt {
+    const float* w;
+    float* u;
+    int Cn, Ck, role, blk0;
+};
+
+__global__ __launch_bounds__(256) void smap_weights(const SEnt* __restrict__ ents, const int* __restrict__ blk_ent) {
+    const SEnt e = ents[blk_ent[blockIdx.x]];
+    const int lb = (int)blockIdx.x - e.blk0;
+    const int u = lb & 1, g = (lb >> 1) & 1;
+    const int rest = lb >> 2;
+    const int tap = rest % 9, r2 = rest / 9;
+    const int nw = e.Ck >> 5;
+    const int w = r2 % nw, nt = r2 / nw;
+    const int t = threadIdx.x, lane = t >> 2, j = t & 3;
+    const int n = 32 * nt + 16 * u + (lane & 15), c = 32 * w + 16 * g + 4 * (lane >> 4) + j;
+    const int r = tap / 3, s = tap % 3;
+    const float val = e.role == 0 ? e.w[((int64_t)(n * 3 + r) * 3 + s) * e.Ck + c]
+                                  : e.w[((int64_t)(c * 3 + (2 - r)) * 3 + (2 - s)) * e.Cn + n];
+    e.u[(int64_t)lb * 256 + t] = val;
+}
+
+}  // namespace smap
+
+// Which problems the kernel serves (3x3 / stride 1 / pad 1 is implied by the entry points).
+static bool smap_shape_ok(int N, int H, int W, int Ci, int Co) {
+    if (N <= 0 || H < 1 || W < 1 || Ci != smap::C || Co % 32 != 0 || Co <= 0 || Co > 4096) return false;
+    if (H * W > smap::MAXPX || (H + 2) * (W + 2) > smap::MAXPOS) return false;
+    if ((int64_t)N * H * W * (Ci > Co ? Ci : Co) * 4 >= 0x7fffffffLL) return false;
+    return true;
+}
+
+// 0: not served; otherwise the number of workgroups of the launch (images x column tiles of 32)
+extern "C" int advmix_conv_smap_config(int N, int H, int W, int Ci, int Co) {
+    if (!smap_shape_ok(N, H, W, Ci, Co)) return 0;
+    const int64_t wgs = (int64_t)N * (Co / 32);
+    return wgs > 0x7fffffff ? 0x7fffffff : (int)wgs;
+}
+
+// floats of one re-laid image (forward or input gradient) of a 3x3 Cn x Ck filter bank
+extern "C" int64_t advmix_smap_u_floats(int Co, int Ci) { return (int64_t)9 * Co * Ci; }
+
+// Re-lay the filters of n convs in one launch.  ``ents`` (device): records {w, u, Cn, Ck, role, first block}, ``blk_ent``
+// (device): the record index of each of the ``blocks`` workgroups (a record owns (Cn / 32) * (Ck / 32) * 36 consecutive ones).
+extern "C" int advmix_smap_weights(const void* ents, const int* blk_ent, int blocks, void* stream) {
+    if (!ents || !blk_ent || blocks <= 0) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(smap::smap_weights, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const smap::SEnt*)ents, blk_ent);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+static int smap_fill(smap::SP& p, const float* x, const float* u, float* y, int N, int H, int W, int Ci, int Co) {
+    if (!x || !u || !y || !smap_shape_ok(N, H, W, Ci, Co)) return ADVMIX_EINVAL;
+    p = smap::SP{};
+    p.x = x; p.u = u; p.y = y;
+    p.N = N; p.H = H; p.W = W; p.Co = Co;
+    p.xbytes = (int)((int64_t)N * H * W * Ci * 4);
+    p.ybytes = (int)((int64_t)N * H * W * Co * 4);
+    p.ubytes = (int)((int64_t)9 * Co * Ci * 4);
+    return ADVMIX_OK;
+}
+
+static int smap_slots(const int* stats_ns) {
+    int ns = stats_ns && *stats_ns > 0 ? *stats_ns : advmix_opts().stat_slots;
+    if (ns <= 0 || ns > ADVMIX_STAT_SLOTS_MAX || (ns & (ns - 1))) ns = 16;
+    return ns;
+}
+
+static int smap_launch(int role, const smap::SP& p, hipStream_t st) {
+    const dim3 g(p.Co / 32, p.N);
+    if (role) hipLaunchKernelGGL(smap::conv_smap<1>, g, dim3(smap::NT), 0, st, p);
+    else hipLaunchKernelGGL(smap::conv_smap<0>, g, dim3(smap::NT), 0, st, p);
+    if (advmix_opts().trace_shapes) {
+        char nm[32];
+        snprintf(nm, sizeof nm, "conv_smap<%d>", role);
+        advmix_trace_launch(nm, g, role == 0 ? (p.stats ? "fwd+sums" : (p.bn_gamma ? "fwd+bn_eval" : "fwd")) : (p.bnb_c ? "dgrad+bnb" : "dgrad"),
+                            p.N, p.H, p.W, smap::C, p.H, p.W, p.Co, 3, 3, 1, 2.0 * p.N * (double)p.H * p.W * p.Co * smap::C * 9);
+    }
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+// advmix_conv3x3_wino_fwd's arguments and semantics for the small-map kernel: ``u`` is the role 0 image of advmix_smap_weights.
+// Returns ADVMIX_EINVAL (nothing launched) for shapes the kernel does not serve (advmix_conv_smap_config == 0).
+// Semantics: lib/models/pose_hrnet.py:22-57 (conv3x3 + BatchNorm2d (+ residual) + ReLU of a BasicBlock).
+extern "C" int advmix_conv3x3_smap_fwd(const float* x, const float* u, float* y, int N, int H, int W, int Ci, int Co,
+                                       const float* bn_gamma, const float* bn_beta, const float* bn_rm, const float* bn_rv,
+                                       float bn_eps, const float* residual, int act, double* stats, int* stats_ns, void* stream) {
+    if ((bn_gamma != nullptr) != (bn_beta && bn_rm && bn_rv)) return ADVMIX_EINVAL;
+    if (stats && !stats_ns) return ADVMIX_EINVAL;
+    if (advmix_opts().deterministic && stats) return ADVMIX_EINVAL;        // fp64 atomics: the ordered form is conv_direct's
+    smap::SP p;
+    int rc = smap_fill(p, x, u, y, N, H, W, Ci, Co);
+    if (rc) return rc;
+    p.bn_gamma = bn_gamma; p.bn_beta = bn_beta; p.bn_rm = bn_rm; p.bn_rv = bn_rv; p.bn_eps = bn_eps;
+    p.res = residual; p.act = act; p.stats = stats;
+    p.stats_nbg = smap_slots(stats_ns);
+    rc = smap_launch(0, p, (hipStream_t)stream);
+    if (rc == ADVMIX_OK && stats_ns) *stats_ns = p.stats_nbg;
+    return rc;
+}
+
+// advmix_conv3x3_wino_dgrad's arguments and semantics: dx = conv(dy, rotated transposed filters) + addend from the role 1
+// image ``u`` (n = Cin, k = Cout = 256); with ``bn_c`` the BatchNorm-backward epilogue of advmix_conv_tr_w_bnb.
+extern "C" int advmix_conv3x3_smap_dgrad(const float* dy, const float* u, const float* addend, float* dx, int N, int H, int W,
+                                         int Co, int Ci, const unsigned char* act_mask, const float* bn_c, const float* bn_mean,
+                                         const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int act,
+                                         double* stats, int* stats_ns, void* stream) {
+    if (bn_c) {
+        if (!bn_mean || !bn_invstd || !stats || !stats_ns) return ADVMIX_EINVAL;
+        if (act != ADVMIX_ACT_NONE && !act_mask && !(bn_gamma && bn_beta)) return ADVMIX_EINVAL;
+        if (advmix_opts().deterministic) return ADVMIX_EINVAL;
+    } else if (stats) {
+        return ADVMIX_EINVAL;
+    }
+    smap::SP p;
+    int rc = smap_fill(p, dy, u, dx, N, H, W, Co, Ci);      // the gradient conv reads Co channels and writes Ci
+    if (rc) return rc;
+    p.res = addend;
+    if (bn_c) {
+        p.stats = stats; p.stats_nbg = smap_slots(stats_ns);
+        p.bnb_mask = act_mask; p.bnb_c = bn_c; p.bnb_mean = bn_mean; p.bnb_invstd = bn_invstd;
+        p.bnb_gamma = bn_gamma; p.bnb_beta = bn_beta; p.bnb_act = act;
+    }
+    rc = smap_launch(1, p, (hipStream_t)stream);
+    if (rc == ADVMIX_OK && bn_c) *stats_ns = p.stats_nbg;
+    return rc;
+}

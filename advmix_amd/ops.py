@@ -380,6 +380,8 @@ def _det_stats(C, device, lane):
 # ---- Winograd F(2x2,3x3) path (csrc/conv_wino.hip) ---------------------------------------------------------------------
 WINO = __import__('os').environ.get('ADVMIX_WINO', '1') != '0'       # A/B switch: 0 = every conv on the direct kernels
 WINO_MIN_WGS = int(__import__('os').environ.get('ADVMIX_WINO_MIN_WGS', '96'))   # workgroups (32 tiles x 32 channels) below which the direct kernel stays
+SMAP = __import__('os').environ.get('ADVMIX_SMAP', '1') != '0'       # A/B switch: 0 = the small 256-channel maps on the direct kernel
+SMAP_C = 256                                                         # (csrc/conv_smap.hip: one workgroup per image, K split over its eight waves)
 
 
 class WinoBank:
@@ -397,36 +399,46 @@ class WinoBank:
         dev = weights[0].device
         self.key = tuple(w.data_ptr() for w in weights)
         pad32 = lambda c: (c + 31) // 32 * 32                # noqa: E731  (the n dimension is padded to whole column tiles)
-        sizes = [(16 * pad32(w.shape[0]) * w.shape[1], 16 * pad32(w.shape[1]) * w.shape[0]) for w in weights]
+        # kind 'smap' (csrc/conv_smap.hip): filters with 256 input channels, plain re-layout in that kernel's fragment order (9 Co Ci floats
+        # per image); everything else 'wino'
+        kinds = ['smap' if (w.shape[1] == SMAP_C and w.shape[0] % 32 == 0) else 'wino' for w in weights]   # (its input-gradient image is only usable for Cout == 256 too)
+        sizes = [(9 * w.shape[0] * w.shape[1],) * 2 if k == 'smap' else
+                 (16 * pad32(w.shape[0]) * w.shape[1], 16 * pad32(w.shape[1]) * w.shape[0]) for w, k in zip(weights, kinds)]
         self.buf = torch.empty(sum(a + b for a, b in sizes), device=dev, dtype=torch.float32)
-        ent = np.zeros(2 * len(weights), dtype=np.dtype([('w', '<u8'), ('u', '<u8'), ('Cn', '<i4'), ('Ck', '<i4'),
-                                                         ('role', '<i4'), ('blk0', '<i4')]))
-        blk, off, owner = 0, 0, []
+        rec = np.dtype([('w', '<u8'), ('u', '<u8'), ('Cn', '<i4'), ('Ck', '<i4'), ('role', '<i4'), ('blk0', '<i4')])
+        ents = {'wino': [], 'smap': []}
+        blk = {'wino': 0, 'smap': 0}
+        owner = {'wino': [], 'smap': []}
+        off = 0
         self._tagged = []
-        for i, w in enumerate(weights):
+        for i, (w, kind) in enumerate(zip(weights, kinds)):
             Co, Ci, R, S = w.shape
             if (R, S) != (3, 3) or Co % 16 or Ci % 16 or not w.is_contiguous(memory_format=_CL):
                 raise ValueError('WinoBank: 3x3 channels_last weights with Cout, Cin multiples of 16')
             ptrs = []
             for role, (Cn, Ck) in enumerate(((Co, Ci), (Ci, Co))):
                 u = self.buf.data_ptr() + 4 * off
-                ent[2 * i + role] = (w.data_ptr(), u, Cn, Ck, role, blk)
-                nb = ((Cn + 31) // 32) * (Ck // 8)
-                owner += [2 * i + role] * nb
-                blk += nb
+                owner[kind] += [len(ents[kind])] * (((Cn + 31) // 32) * (Ck // 8) if kind == 'wino' else (Cn // 32) * (Ck // 32) * 36)
+                ents[kind].append((w.data_ptr(), u, Cn, Ck, role, blk[kind]))
+                blk[kind] = len(owner[kind])
                 off += sizes[i][role]
                 ptrs.append(ctypes.c_void_p(u))
-            w._wino = (self.buf, ptrs[0], ptrs[1], w.data_ptr())           # (the tag keeps the side buffer alive)
+            w._wino = (self.buf, ptrs[0], ptrs[1], w.data_ptr(), kind)     # (the tag keeps the side buffer alive)
             self._tagged.append(weakref.ref(w))
-        self.blocks = blk
-        self.ents = torch.from_numpy(ent.view(np.uint8).copy()).to(dev)
-        self.blk_ent = torch.tensor(owner, dtype=torch.int32).to(dev)
+        self.tables = {}
+        for kind in ('wino', 'smap'):
+            if ents[kind]:
+                ent = np.array(ents[kind], dtype=rec)
+                self.tables[kind] = (torch.from_numpy(ent.view(np.uint8).copy()).to(dev),
+                                     torch.tensor(owner[kind], dtype=torch.int32).to(dev), blk[kind])
 
     def matches(self, weights):
         return self.key == tuple(w.data_ptr() for w in weights) and all(_wino_tag(w) is not None for w in weights)
 
     def refresh(self, st=None):
-        call('advmix_wino_weights', _p(self.ents), _p(self.blk_ent), self.blocks, st if st is not None else _st())
+        st = st if st is not None else _st()
+        for kind, (ents, blk_ent, blocks) in self.tables.items():
+            call('advmix_wino_weights' if kind == 'wino' else 'advmix_smap_weights', _p(ents), _p(blk_ent), blocks, st)
 
     def images(self, w):
         """(forward image, input-gradient image) pointers of one of the bank's weights."""
@@ -448,14 +460,24 @@ def _wino_tag(w):
     return tag if tag is not None and tag[3] == w.data_ptr() else None
 
 
+_W3 = {'wino': (lib.advmix_conv3x3_wino_fwd, lib.advmix_conv3x3_wino_dgrad),      # (forward, input gradient) entry points per image kind
+       'smap': (lib.advmix_conv3x3_smap_fwd, lib.advmix_conv3x3_smap_dgrad)}
+
+
 def _wino_images(w, B, H, W, Ci, Co, R, S, stride, pad):
     """(forward image, input-gradient image) of ``w`` when this problem goes to the Winograd kernel, else None."""
     if not (WINO and R == 3 and S == 3 and stride == 1 and pad == 1) or DETERMINISTIC or not _direct_ok():
         return None
     tag = _wino_tag(w)
-    if tag is None or lib.advmix_conv_wino_config(B, H, W, Ci, Co) < WINO_MIN_WGS:
+    if tag is None:
         return None
-    return tag[1], tag[2]
+    if tag[4] == 'smap':                                    # 256 -> 256 on a map of <= 48 pixels: the image-per-workgroup kernel
+        if not SMAP or lib.advmix_conv_smap_config(B, H, W, Ci, Co) < WINO_MIN_WGS:
+            return None
+        return tag[1], tag[2], 'smap'
+    if lib.advmix_conv_wino_config(B, H, W, Ci, Co) < WINO_MIN_WGS:
+        return None
+    return tag[1], tag[2], 'wino'
 
 
 def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to=None, bnb=None, lane=0):
@@ -477,13 +499,13 @@ def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_
                 raise RuntimeError('advmix_amd: BatchNorm-backward epilogue on a differently laid out tensor')
             if wu is not None:
                 nsv = ctypes.c_int(STAT_SLOTS_ASK)
-                rc = lib.advmix_conv3x3_wino_dgrad(_p(dy), wu[1], _p(add_to), _p(dx), B, Hi, Wi, Co, Ci, _p(bnb['mask']),
+                rc = _W3[wu[2]][1](_p(dy), wu[1], _p(add_to), _p(dx), B, Hi, Wi, Co, Ci, _p(bnb['mask']),
                                                    _p(bnb['c']), _p(bnb['mean']), _p(bnb['invstd']), _p(bnb['gamma']),
                                                    _p(bnb['beta']), bnb['act'], bnb['slots'], ctypes.byref(nsv), st)
                 if rc == 0:
                     bnb['done'] = nsv.value
                     COUNTERS['bnb'] += 1
-                    COUNTERS['wino'] = COUNTERS.get('wino', 0) + 1
+                    COUNTERS[wu[2]] = COUNTERS.get(wu[2], 0) + 1
                     return dx
                 if rc != 1:
                     raise RuntimeError('advmix_conv3x3_wino_dgrad failed: %d' % rc)
@@ -506,10 +528,10 @@ def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_
             if rc != 1:
                 raise RuntimeError('advmix_conv_tr_w_bnb failed: %d' % rc)
         if wu is not None:
-            rc = lib.advmix_conv3x3_wino_dgrad(_p(dy), wu[1], _p(add_to), _p(dx), B, Hi, Wi, Co, Ci, None, None, None, None,
+            rc = _W3[wu[2]][1](_p(dy), wu[1], _p(add_to), _p(dx), B, Hi, Wi, Co, Ci, None, None, None, None,
                                                None, None, 0, None, None, st)
             if rc == 0:
-                COUNTERS['wino'] = COUNTERS.get('wino', 0) + 1
+                COUNTERS[wu[2]] = COUNTERS.get(wu[2], 0) + 1
                 return dx
             if rc != 1:
                 raise RuntimeError('advmix_conv3x3_wino_dgrad failed: %d' % rc)
@@ -710,10 +732,10 @@ class ConvBN:
         if not training:
             rc = 1
             if wu is not None:                              # Winograd F(2x2,3x3): same fused epilogue, 2.25x fewer MFMAs
-                rc = lib.advmix_conv3x3_wino_fwd(_p(x), wu[0], _p(y), B, Hi, Wi, Ci, Co, _p(gamma), _p(beta), _p(rmean),
+                rc = _W3[wu[2]][0](_p(x), wu[0], _p(y), B, Hi, Wi, Ci, Co, _p(gamma), _p(beta), _p(rmean),
                                                  _p(rvar), eps, _p(res), act, None, None, st)
                 if rc == 0:
-                    COUNTERS['wino'] = COUNTERS.get('wino', 0) + 1
+                    COUNTERS[wu[2]] = COUNTERS.get(wu[2], 0) + 1
             if rc == 1:
                 rc = lib.advmix_conv_fwd_ex(_p(x), _p(w), None, _p(y), *geom, _p(gamma), _p(beta), _p(rmean),
                                             _p(rvar), eps, _p(res), act, None, None, st) if fused_ok else 1
@@ -743,10 +765,10 @@ class ConvBN:
             else:
                 nbg, target = ctypes.c_int(STAT_SLOTS_ASK), slots
             if wu is not None and not DETERMINISTIC:
-                rc = lib.advmix_conv3x3_wino_fwd(_p(x), wu[0], _p(c), B, Hi, Wi, Ci, Co, None, None, None, None, 0.0, None, 0,
+                rc = _W3[wu[2]][0](_p(x), wu[0], _p(c), B, Hi, Wi, Ci, Co, None, None, None, None, 0.0, None, 0,
                                                  target, ctypes.byref(nbg), st)
                 if rc == 0:
-                    COUNTERS['wino'] = COUNTERS.get('wino', 0) + 1
+                    COUNTERS[wu[2]] = COUNTERS.get(wu[2], 0) + 1
             if rc == 1:
                 rc = lib.advmix_conv_fwd_ex(_p(x), _p(w), None, _p(c), *geom, None, None, None, None, 0.0, None, 0,
                                             target, ctypes.byref(nbg), st)

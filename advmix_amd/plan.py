@@ -605,7 +605,7 @@ class PlanNet(nn.Module):
 
     def _wino_refresh(self, device):
         """Winograd path (ops.WinoBank, csrc/conv_wino.hip): the 3x3 / stride 1 / pad 1 conv + BatchNorm steps with 32, 48, 64, 96 or
-        128 input channels keep transformed images of their filters in a side buffer; ONE launch re-computes all of them at the
+        128 input channels (and the 256 -> 256 ones: csrc/conv_smap.hip's re-laid filters) keep transformed images of their filters in a side buffer; ONE launch re-computes all of them at the
         start of every forward pass (the filters change once per optimizer step; ~10 us per launch), on the caller's stream
         before any lane forks.  The bank is rebuilt when the parameters have moved (``.to(device)``, FlatAdam's flat
         buffer, ``load_state_dict`` of differently placed tensors)."""
@@ -622,7 +622,8 @@ class PlanNet(nn.Module):
             self._wino_names = names
         T = self._tensors()
         ws = [T[n] for n in names]
-        ws = [w for w in ws if w.is_cuda and tuple(w.shape[2:]) == (3, 3) and w.shape[1] in (32, 48, 64, 96, 128) and w.shape[0] % 16 == 0]
+        ws = [w for w in ws if w.is_cuda and tuple(w.shape[2:]) == (3, 3) and w.shape[0] % 16 == 0 and
+              (w.shape[1] in (32, 48, 64, 96, 128) or (ops.SMAP and tuple(w.shape[:2]) == (ops.SMAP_C, ops.SMAP_C)))]   # (256 -> 256: conv_smap's images)
         if not ws:
             return
         bank = getattr(self, '_wino_bank', None)

@@ -137,6 +137,27 @@ int advmix_conv3x3_wino_dgrad(const float* dy, const float* u, const float* adde
                               const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int act,
                               double* stats, int* stats_ns, void* stream);
 
+/* Small maps with 256 input channels (csrc/conv_smap.hip, round 5): HRNet's lowest-resolution branch (pose_hrnet.py:22-57 at
+ * 256x192: 3x3 256 -> 256 @8x6) - one workgroup per image and 32 output channels, the padded image staged in LDS once, K split
+ * over the workgroup's eight waves, filters read in MFMA fragment order from a side buffer (advmix_smap_weights, once per
+ * forward pass like the Winograd images).  Direct convolution (no transform): same sums as advmix_conv_fwd_ex in another order.
+ * advmix_conv_smap_config: 0 when not served (served: Ci == 256, Co % 32 == 0, H * W <= 48, (H + 2) * (W + 2) <= 80), else the
+ * number of workgroups (N * Co / 32).  advmix_smap_u_floats: floats of ONE image of a [Co][3][3][Ci] bank (9 * Co * Ci).
+ * advmix_smap_weights: records as advmix_wino_weights' (role 0: forward image of w[Cn][3][3][Ck]; role 1: input-gradient
+ * image of w[Ck][3][3][Cn], taps rotated); a record owns (Cn / 32) * (Ck / 32) * 36 workgroups; u is written as
+ * u[n / 32][k / 32][tap][(k % 32) / 16][(n % 32) / 16][16 * ((k % 16) / 4) + n % 16][k % 4].
+ * advmix_conv3x3_smap_fwd / _dgrad: the arguments and epilogues of advmix_conv3x3_wino_fwd / _dgrad. */
+int advmix_conv_smap_config(int N, int H, int W, int Ci, int Co);
+int64_t advmix_smap_u_floats(int Co, int Ci);
+int advmix_smap_weights(const void* ents, const int* blk_ent, int blocks, void* stream);
+int advmix_conv3x3_smap_fwd(const float* x, const float* u, float* y, int N, int H, int W, int Ci, int Co,
+                            const float* bn_gamma, const float* bn_beta, const float* bn_rm, const float* bn_rv,
+                            float bn_eps, const float* residual, int act, double* stats, int* stats_ns, void* stream);
+int advmix_conv3x3_smap_dgrad(const float* dy, const float* u, const float* addend, float* dx, int N, int H, int W,
+                              int Co, int Ci, const unsigned char* act_mask, const float* bn_c, const float* bn_mean,
+                              const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int act,
+                              double* stats, int* stats_ns, void* stream);
+
 /* Winograd weight gradient, F(3x3, 2x2) (csrc/wgrad_wino.hip, round 5): 16 multiplies per 2x2 tile of dy and channel pair
  * instead of 36.  advmix_wgrad_wino_config: 0 = not served (odd H / W, channels not multiples of 32 or > 256), else the
  * number of (32-tile block, 32 x 32 channel pair) units of one problem.  advmix_conv3x3_wgrad_wino_group: the weight

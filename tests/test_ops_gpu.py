@@ -613,6 +613,15 @@ WINO_CASES = [
     (2, 96, 96, 12, 10),         # its second branch: three column tiles, 12 k groups
     (2, 48, 96, 8, 6),
 ]
+SMAP_CASES = [
+    (32, 256, 256, 8, 6),        # HRNet-W32's fourth branch at the bench batch: 256 workgroups, one per CU
+    (3, 256, 256, 6, 8),         # the same map transposed
+    (2, 256, 256, 7, 6),         # 42 pixels: the third row tile is ragged
+    (2, 256, 256, 4, 3),         # 12 pixels: less than one row tile
+    (1, 256, 256, 1, 1),
+    (2, 256, 64, 8, 6),          # forward only (the gradient side would read 64 channels)
+    (5, 256, 96, 5, 5),
+]
 
 
 def _wino_images(w_dev):
@@ -624,19 +633,24 @@ def _wino_images(w_dev):
     return bank, uf, ud
 
 
-@pytest.mark.parametrize('case', WINO_CASES)
+@pytest.mark.parametrize('case', WINO_CASES + SMAP_CASES)
 def test_winograd_conv_all_roles(case):
     """csrc/conv_wino.hip (round 5): the Winograd F(2x2,3x3) kernel in every role the step uses - forward + BatchNorm column
     sums, forward + eval-mode BatchNorm + residual + ReLU, input gradient + addend, input gradient + addend + BatchNorm-
     backward sums with the sign of y from the bit mask and recomputed from c - against a float64 torch evaluation (1e-4 of
     scale like every other kernel; the transforms add ~3 bits of rounding to the direct kernel's) and against the direct
-    kernel's own result for the same arguments."""
+    kernel's own result for the same arguments.  The 256-channel cases run the SAME checks on csrc/conv_smap.hip (one workgroup
+    per image of a small map; identical entry-point arguments): the whole image in one workgroup, maps smaller than the three
+    MFMA row tiles, column tiles of an image's 32 channels, an input-gradient side only where it reads 256 channels."""
     import ctypes
     from advmix_amd._lib import call, lib
     _ops()
     B, Ci, Co, H, W = case
     d = dev()
-    assert lib.advmix_conv_wino_config(B, H, W, Ci, Co) > 0 and lib.advmix_conv_wino_config(B, H, W, Co, Ci) > 0
+    kind = 'smap' if Ci == 256 else 'wino'
+    config, k_fwd, k_dgrad = (getattr(lib, n_ % kind) for n_ in ('advmix_conv_%s_config', 'advmix_conv3x3_%s_fwd', 'advmix_conv3x3_%s_dgrad'))
+    has_dgrad = config(B, H, W, Co, Ci) > 0                 # (conv_smap reads exactly 256 channels: the gradient side needs Co == 256)
+    assert config(B, H, W, Ci, Co) > 0 and (has_dgrad or kind == 'smap')
     g_ = torch.Generator().manual_seed(23 + Ci + H)
     R = lambda *s_: torch.randn(*s_, generator=g_)
     x, dy = R(B, H, W, Ci), R(B, H, W, Co)
@@ -663,7 +677,7 @@ def test_winograd_conv_all_roles(case):
         slots = torch.zeros(2 * Co * 64, device=d, dtype=torch.float64)
         ns = ctypes.c_int(0)
         if entry == 'wino':
-            rc = lib.advmix_conv3x3_wino_fwd(P(D['x']), uf, P(y), B, H, W, Ci, Co, None, None, None, None, 0.0, None, 0,
+            rc = k_fwd(P(D['x']), uf, P(y), B, H, W, Ci, Co, None, None, None, None, 0.0, None, 0,
                                              P(slots), ctypes.byref(ns), st)
         else:
             rc = lib.advmix_conv_fwd_ex(P(D['x']), P(wd), None, P(y), *geom, None, None, None, None, 0.0, None, 0, P(slots),
@@ -679,14 +693,14 @@ def test_winograd_conv_all_roles(case):
     # (2) forward + eval-mode BatchNorm + residual + ReLU (the teacher)
     want = F.relu((y64 - rm.double()) / torch.sqrt(rv.double() + 1e-5) * gamma.double() + beta.double() + res.double())
     y = torch.full((B, H, W, Co), float('nan'), device=d)
-    assert lib.advmix_conv3x3_wino_fwd(P(D['x']), uf, P(y), B, H, W, Ci, Co, P(D['gamma']), P(D['beta']), P(D['rm']), P(D['rv']),
+    assert k_fwd(P(D['x']), uf, P(y), B, H, W, Ci, Co, P(D['gamma']), P(D['beta']), P(D['rm']), P(D['rv']),
                                        1e-5, P(D['res']), 1, None, None, st) == 0
     torch.cuda.synchronize()
     check('fwd eval', y, want, 2e-5)
     # (3) input gradient, with and without the addend
-    for add_ in (None, D['addend']):
+    for add_ in ((None, D['addend']) if has_dgrad else ()):
         gout = torch.full((B, H, W, Ci), float('nan'), device=d)
-        assert lib.advmix_conv3x3_wino_dgrad(P(D['dy']), ud, P(add_), P(gout), B, H, W, Co, Ci, None, None, None, None, None, None,
+        assert k_dgrad(P(D['dy']), ud, P(add_), P(gout), B, H, W, Co, Ci, None, None, None, None, None, None,
                                              0, None, None, st) == 0
         torch.cuda.synchronize()
         check('dgrad', gout, dx64 + (addend.double() if add_ is not None else 0), 2e-5)
@@ -694,7 +708,7 @@ def test_winograd_conv_all_roles(case):
     cd = c_in.double().reshape(-1, Ci)
     fslots = torch.stack([cd.sum(0), (cd * cd).sum(0)]).reshape(2, 1, Ci).contiguous().to(d)
     res_in = R(B, H, W, Ci).to(d)
-    for tag, r_, add_, use_mask in (('mask', res_in, D['addend'], True), ('from c', None, None, False)):
+    for tag, r_, add_, use_mask in ((('mask', res_in, D['addend'], True), ('from c', None, None, False)) if has_dgrad else ()):
         yy = torch.empty(B, H, W, Ci, device=d)
         mean, invstd = torch.empty(Ci, device=d), torch.empty(Ci, device=d)
         mask = torch.zeros(rows * Ci // 4, device=d, dtype=torch.uint8)
@@ -708,7 +722,7 @@ def test_winograd_conv_all_roles(case):
             tail = (P(mask) if use_mask else None, P(D['c']), P(mean), P(invstd), None if use_mask else P(D['gi']),
                     None if use_mask else P(D['bi']), 1, P(bslots), ctypes.byref(ns), st)
             if entry == 'wino':
-                rc = lib.advmix_conv3x3_wino_dgrad(P(D['dy']), ud, P(add_), P(gout), B, H, W, Co, Ci, *tail)
+                rc = k_dgrad(P(D['dy']), ud, P(add_), P(gout), B, H, W, Co, Ci, *tail)
             else:
                 rc = lib.advmix_conv_tr_w_bnb(P(D['dy']), P(wd), P(add_), P(gout), B, H, W, Co, H, W, Ci, 3, 3, 1, 1, *tail)
             if entry == 'direct' and rc == 1:               # (small shapes: the direct kernel would split K across the grid -
@@ -727,8 +741,11 @@ def test_winograd_conv_all_roles(case):
         if 'direct' in results:
             check(tag + ' wino vs direct', results['wino'], results['direct'].double().cpu(), 1e-5)
     # refused without launching: odd sizes, channel counts the kernel has no instance for, a missing image
-    assert lib.advmix_conv_wino_config(B, H + 1, W, Ci, Co) == 0 and lib.advmix_conv_wino_config(B, H, W, 40, 40) == 0
-    assert lib.advmix_conv3x3_wino_fwd(P(D['x']), None, P(y), B, H, W, Ci, Co, None, None, None, None, 0.0, None, 0, None, None, st) == 1
+    if kind == 'wino':
+        assert lib.advmix_conv_wino_config(B, H + 1, W, Ci, Co) == 0 and lib.advmix_conv_wino_config(B, H, W, 40, 40) == 0
+    else:                                                   # more than 48 pixels / 80 padded pixels, other channel counts
+        assert config(B, 7, 7, Ci, Co) == 0 and config(B, 12, 4, Ci, Co) == 0 and config(B, H, W, 128, Co) == 0 and config(B, H, W, Ci, 48) == 0
+    assert k_fwd(P(D['x']), None, P(y), B, H, W, Ci, Co, None, None, None, None, 0.0, None, 0, None, None, st) == 1
     bank.release()
 
 

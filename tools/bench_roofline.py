@@ -58,6 +58,8 @@ def _time_shares():
             c = 'single weight gradients'
         elif k.startswith('conv_wino'):
             c = 'branch 3x3 convs, Winograd kernel (32 / 64 / 128 channels)'
+        elif k.startswith('conv_smap'):
+            c = 'branch 3x3 convs, image-per-workgroup kernel (256 channels @8x6)'
         elif k.startswith(('conv_direct', 'conv_group', 'conv_igemm')) and ' 3x3 s1 ' in shp and shp.split(' s1 ')[1].split(' ')[0].split('->')[0] == shp.split(' s1 ')[1].split(' ')[0].split('->')[1]:
             c = 'branch 3x3 convs, direct kernel (256 channels)'
         elif k.startswith(('conv_direct', 'conv_group', 'conv_igemm', 'conv_tr', 'deconv')):
@@ -112,23 +114,25 @@ def time_conv_family(B, device, iters=100, family=None):
         geom = (B, H, W, C, H, W, C, 3, 3, 1, 1)
         flops = 2.0 * rows * C * C * 9
         wino = bool(ops.WINO and lib.advmix_conv_wino_config(B, H, W, C, C) >= ops.WINO_MIN_WGS)
+        smap = bool(ops.WINO and ops.SMAP and C == ops.SMAP_C and lib.advmix_conv_smap_config(B, H, W, C, C) >= ops.WINO_MIN_WGS)
+        kfwd, kdg = ('advmix_conv3x3_smap_fwd', 'advmix_conv3x3_smap_dgrad') if smap else ('advmix_conv3x3_wino_fwd', 'advmix_conv3x3_wino_dgrad')
 
         def reset():
             nbg.value = 0
-        if wino:                                            # what ops.ConvBN.fwd / ops._conv_dgrad launch for this shape
+        if wino or smap:                                    # what ops.ConvBN.fwd / ops._conv_dgrad launch for this shape
             bank = ops.WinoBank([w])
             bank.refresh()
             uf, ud = bank.images(w)
             runs = {
-                'fwd+BN-sums': lambda: (reset(), call('advmix_conv3x3_wino_fwd', P(x), uf, P(y), B, H, W, C, C, None, None, None, None,
+                'fwd+BN-sums': lambda: (reset(), call(kfwd, P(x), uf, P(y), B, H, W, C, C, None, None, None, None,
                                                       0.0, None, 0, P(slots), ctypes.byref(nbg), st)),
-                'fwd+BN-eval+ReLU': lambda: call('advmix_conv3x3_wino_fwd', P(x), uf, P(y), B, H, W, C, C, P(g), P(b), P(rm), P(rv),
+                'fwd+BN-eval+ReLU': lambda: call(kfwd, P(x), uf, P(y), B, H, W, C, C, P(g), P(b), P(rm), P(rv),
                                                  1e-5, None, 1, None, None, st),
                 'dgrad+addend+BN-bwd-sums (act mask)': lambda: (reset(), call(
-                    'advmix_conv3x3_wino_dgrad', P(dy), ud, P(c2), P(dx), B, H, W, C, C, P(amask), P(c2), P(mean), P(invstd), None,
+                    kdg, P(dy), ud, P(c2), P(dx), B, H, W, C, C, P(amask), P(c2), P(mean), P(invstd), None,
                     None, 1, P(slots), ctypes.byref(nbg), st)),
                 'dgrad+BN-bwd-sums (sign from c)': lambda: (reset(), call(
-                    'advmix_conv3x3_wino_dgrad', P(dy), ud, None, P(dx), B, H, W, C, C, None, P(c2), P(mean), P(invstd), P(g), P(b),
+                    kdg, P(dy), ud, None, P(dx), B, H, W, C, C, None, P(c2), P(mean), P(invstd), P(g), P(b),
                     1, P(slots), ctypes.byref(nbg), st)),
             }
         else:
@@ -169,12 +173,12 @@ def time_conv_family(B, device, iters=100, family=None):
             tot_t += wgt * ms * 1e-3
             members.append({
                 'kernel': '3x3 s1 %d->%d @%dx%d %s' % (C, C, H, W, kind if not (kind == 'wgrad' and grouped) else 'wgrad (1 of 8 problems of one launch)'),
-                'path': ('wgrad_wino (Winograd F(3x3,2x2))' if wgw else 'conv_wgrad_group') if kind == 'wgrad' else ('conv_wino (Winograd F(2x2,3x3))' if wino else 'conv_direct'),
+                'path': ('wgrad_wino (Winograd F(3x3,2x2))' if wgw else 'conv_wgrad_group') if kind == 'wgrad' else ('conv_wino (Winograd F(2x2,3x3))' if wino else ('conv_smap (image per workgroup)' if smap else 'conv_direct')),
                 'us_per_launch': round(ms * 1e3, 2), 'us_per_launch_runs': [round(v * 1e3, 2) for v in rr],
                 'algorithmic_gflop_per_launch': round(flops / 1e9, 3),
                 'tflops': round(flops / (ms * 1e-3) / 1e12, 2), 'frac': round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                 'launches_per_step_weight': wgt, 'weight_x_us': round(wgt * ms * 1e3, 2)})
-        if wino:
+        if wino or smap:
             bank.release()
         if C in (family[0][0], family[2][0]):               # the two BatchNorm kernels left on the train path
             res = torch.randn_like(x)

@@ -37,7 +37,7 @@ counters = collections.Counter()
 for s, e, r in ev:
     name = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
     base = name.split('(')[0]
-    short = base.split('::')[-1] if '<' not in base else base[base.index('::') + 2:] if base.startswith(('direct::', 'wgd::', 'wino::')) else base
+    short = base.split('::')[-1] if '<' not in base else base[base.index('::') + 2:] if base.startswith(('direct::', 'wgd::', 'wino::', 'smap::')) else base
     gx = int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X']))
     gy = int(r['Grid_Size_Y']) // max(1, int(r['Workgroup_Size_Y']))
     gz = int(r['Grid_Size_Z']) // max(1, int(r['Workgroup_Size_Z']))

@@ -31,7 +31,7 @@ def timed(run):
     return sorted(best)[len(best) // 2]
 
 
-for C, H, W in ((32, 64, 48), (64, 32, 24), (128, 16, 12), (64, 64, 48)):
+for C, H, W in ((32, 64, 48), (64, 32, 24), (128, 16, 12), (64, 64, 48), (256, 8, 6)):     # (256 @8x6: csrc/conv_smap.hip)
     if only and int(only[0]) != C:
         continue
     x = torch.randn(B, H, W, C, device=dev)
@@ -47,17 +47,18 @@ for C, H, W in ((32, 64, 48), (64, 32, 24), (128, 16, 12), (64, 64, 48)):
     uf, ud = bank.images(w)
     geom = (B, H, W, C, H, W, C, 3, 3, 1, 1)
     ns = ctypes.c_int(0)
+    k_fwd, k_dg = (lib.advmix_conv3x3_smap_fwd, lib.advmix_conv3x3_smap_dgrad) if C == 256 else (lib.advmix_conv3x3_wino_fwd, lib.advmix_conv3x3_wino_dgrad)
 
     def z():
         ns.value = 0
     runs = {
-        'fwd+sums': (lambda: (z(), lib.advmix_conv3x3_wino_fwd(P(x), uf, P(y), B, H, W, C, C, None, None, None, None, 0.0, None, 0, P(slots), ctypes.byref(ns), st)),
+        'fwd+sums': (lambda: (z(), k_fwd(P(x), uf, P(y), B, H, W, C, C, None, None, None, None, 0.0, None, 0, P(slots), ctypes.byref(ns), st)),
                      lambda: (z(), lib.advmix_conv_fwd_ex(P(x), P(w), None, P(y), *geom, None, None, None, None, 0.0, None, 0, P(slots), ctypes.byref(ns), st))),
-        'fwd+bn_eval+res+relu': (lambda: lib.advmix_conv3x3_wino_fwd(P(x), uf, P(y), B, H, W, C, C, P(gam), P(bet), P(rm), P(rv), 1e-5, P(res), 1, None, None, st),
+        'fwd+bn_eval+res+relu': (lambda: k_fwd(P(x), uf, P(y), B, H, W, C, C, P(gam), P(bet), P(rm), P(rv), 1e-5, P(res), 1, None, None, st),
                                  lambda: lib.advmix_conv_fwd_ex(P(x), P(w), None, P(y), *geom, P(gam), P(bet), P(rm), P(rv), 1e-5, P(res), 1, None, None, st)),
-        'dgrad+addend+bnb(mask)': (lambda: (z(), lib.advmix_conv3x3_wino_dgrad(P(x), ud, P(res), P(y), B, H, W, C, C, P(mk), P(cc), P(mean), P(invstd), None, None, 1, P(slots), ctypes.byref(ns), st)),
+        'dgrad+addend+bnb(mask)': (lambda: (z(), k_dg(P(x), ud, P(res), P(y), B, H, W, C, C, P(mk), P(cc), P(mean), P(invstd), None, None, 1, P(slots), ctypes.byref(ns), st)),
                                    lambda: (z(), lib.advmix_conv_tr_w_bnb(P(x), P(w), P(res), P(y), B, H, W, C, H, W, C, 3, 3, 1, 1, P(mk), P(cc), P(mean), P(invstd), None, None, 1, P(slots), ctypes.byref(ns), st))),
-        'dgrad+bnb(sign from c)': (lambda: (z(), lib.advmix_conv3x3_wino_dgrad(P(x), ud, None, P(y), B, H, W, C, C, None, P(cc), P(mean), P(invstd), P(gam), P(bet), 1, P(slots), ctypes.byref(ns), st)),
+        'dgrad+bnb(sign from c)': (lambda: (z(), k_dg(P(x), ud, None, P(y), B, H, W, C, C, None, P(cc), P(mean), P(invstd), P(gam), P(bet), 1, P(slots), ctypes.byref(ns), st)),
                                    lambda: (z(), lib.advmix_conv_tr_w_bnb(P(x), P(w), None, P(y), B, H, W, C, H, W, C, 3, 3, 1, 1, None, P(cc), P(mean), P(invstd), P(gam), P(bet), 1, P(slots), ctypes.byref(ns), st))),
     }
     if only:
@@ -71,6 +72,6 @@ for C, H, W in ((32, 64, 48), (64, 32, 24), (128, 16, 12), (64, 64, 48)):
     print('3x3 %d->%d @%dx%d B=%d   (weight transform launch, 2 images: %.1f us)' % (C, C, H, W, B, t_tr))
     for name, (wino, direct) in runs.items():
         tw, td = timed(wino), timed(direct)
-        print('  %-26s wino %6.1f us (%.3f of peak on direct FLOPs)   direct %6.1f us (%.3f)   x%.2f' % (
-            name, tw, fl / tw / 1e6 / 157.3, td, fl / td / 1e6 / 157.3, td / tw))
+        print('  %-26s %s %6.1f us (%.3f of peak on direct FLOPs)   direct %6.1f us (%.3f)   x%.2f' % (
+            name, 'smap' if C == 256 else 'wino', tw, fl / tw / 1e6 / 157.3, td, fl / td / 1e6 / 157.3, td / tw))
     bank.release()

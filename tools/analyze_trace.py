@@ -39,24 +39,38 @@ for n, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:30]:
 # concurrency histogram: share of the window with exactly k kernels in flight, and how much of the
 # window has no MFMA (conv / wgrad) kernel in flight at all
 pts = []
-for s, e, n in sel:
-    heavy = ('conv_' in n) or ('wgrad' in n)            # every MFMA kernel: conv_direct / conv_wino / conv_igemm / conv_wgrad* / wgrad*
-    pts.append((s, 1, heavy)); pts.append((e, -1, heavy))
+for i, (s, e, n) in enumerate(sel):
+    heavy = ('conv_' in n) or ('wgrad' in n)            # every MFMA kernel: conv_direct / conv_wino / conv_smap / conv_igemm / conv_wgrad* / wgrad*
+    pts.append((s, 1, heavy, i)); pts.append((e, -1, heavy, i))
 pts.sort()
 hist = collections.defaultdict(int)
 k = h = 0
 no_heavy = 0
 prev = pts[0][0]
-for t, d, heavy in pts:
+live = set()
+alone = collections.defaultdict(int)                        # time a kernel is the ONLY one in flight, by kernel name
+for t, d, heavy, i in pts:
     hist[k] += t - prev
     if h == 0 and k > 0:
         no_heavy += t - prev
+    if k == 1:
+        alone[next(iter(live))] += t - prev
     prev = t
     k += d
+    if d > 0:
+        live.add(i)
+    else:
+        live.discard(i)
     if heavy:
         h += d
 print('kernels in flight: ' + '  '.join('%d: %.1f%%' % (kk, 100 * v / span) for kk, v in sorted(hist.items()) if v > 0.002 * span))
 print('time with kernels in flight but no conv/wgrad kernel among them: %.1f%% of the window' % (100 * no_heavy / span))
+by_name = collections.defaultdict(int)
+for i, dt in alone.items():
+    by_name[sel[i][2].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:80]] += dt
+print('time a kernel runs ALONE (nothing else in flight), by kernel:')
+for n, dt in sorted(by_name.items(), key=lambda kv: -kv[1])[:16]:
+    print('  %6.2f%% of the window  %s' % (100 * dt / span, n))
 
 # idle gaps (no kernel in flight): how long they are, and which kernels bracket them
 def short(n):

@@ -12,8 +12,8 @@
 //     are 16-byte LDS reads of it (pixel pitch 260 floats: a 16-lane group falls on 16 different slots);
 //   * wave w multiplies channels [32 w, 32 w + 32) of every tap - K is split over the waves, not over workgroups - with
 //     filters pre-laid in MFMA B-fragment order by smap_weights (one launch per forward pass for all such convs, like the
-//     Winograd images): a wave's 36 loads are 36 consecutive KB, four iterations in flight, never staged in LDS.  Column
-//     tile = blockIdx.x, so XCD k always multiplies column tile k: its 288 KB filter slice stays in that XCD's L2;
+//     Winograd images): a wave's 36 loads are 36 consecutive KB, four iterations in flight, never staged in LDS.  XCD k
+//     works on two column tiles and every second image: filters and images are each fetched by a few of the 8 L2s only;
 //   * the eight partial tiles meet in LDS ([wave][pixel][36] floats); thread (pixel, 4 channels) adds them with 16-byte
 //     reads and runs the fused epilogues of conv_direct / conv_wino in the natural layout: BatchNorm column sums (fp64
 //     slots), eval-mode BatchNorm + residual + activation, or - input-gradient role - addend, activation slope from the
@@ -68,7 +68,15 @@ __global__ __launch_bounds__(NT, 1) void conv_smap(const SP p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;               // MFMA 16x16x4: row / column l15, k-lane q
-    const int nt = blockIdx.x, img = blockIdx.y;
+    // Workgroups are dealt to the 8 XCDs (and their 8 non-coherent L2s) round-robin in launch order.  With eight column tiles
+    // XCD k = (column-tile pair k % 4, image parity k / 4): an image is fetched by 4 L2s and a filter slice by 2 (6.3 + 4.7 MB
+    // from HBM for 256 -> 256 @8x6 at B = 32, against 12.6 + 2.4 with XCD = column tile and 1.6 + 18.9 with XCD = image group).
+    int nt = blockIdx.x, img = blockIdx.y;
+    if (gridDim.x == 8 && (gridDim.y & 1) == 0) {
+        const int lin = (int)(blockIdx.y * 8 + blockIdx.x), xcd = lin & 7, j = lin >> 3;
+        nt = 2 * (xcd & 3) + (j & 1);
+        img = 2 * (j >> 1) + (xcd >> 2);
+    }
     const int n0 = nt * 32;
     const int PX = p.H * p.W, PW = p.W + 2, NPOS = (p.H + 2) * PW;
 

@@ -19,7 +19,8 @@ ADVMIX_FORCE_SYNC=1 python bench.py --no-cpu-baseline --no-roofline > $O/force_s
 ADVMIX_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/dp2_shared_gpu_bench_line.json 2>> $O/bench.err
 python tools/phase_times.py > $O/phase_times.log 2>&1
 tools/pmc_dominant.sh $T > $O/pmc_dominant.log 2>&1; cp gpurun_out/pmc_$T/pmc_dominant.json gpurun_out/pmc_$T/pmc_wino32.json $O/ 2>/dev/null
-bash tools/pmc_step.sh $T > $O/pmc_step.log 2>&1
+MS=$(python -c "import json; print(json.loads(open('$O/bench_line.json').read().strip().splitlines()[-1])['ms_per_step'])")
+bash tools/pmc_step.sh $T 3 $MS > $O/pmc_step.log 2>&1          # (utilisation against the UNPROFILED step time of this run)
 for f in bench_line resnet50_bench_line hrnet_w48_bench_line hrnet_w32_512_bench_line validate_bench_line inputs_bench_line nms_bench_line deterministic_bench_line force_sync_1rank_bench_line dp2_shared_gpu_bench_line; do python - <<PY
 import json
 try:

@@ -101,6 +101,7 @@ def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, in
     that the caller can all-reduce each finished gradient range beside the next piece, together with G's cut record
     for advmix_phase_b."""
     G_input = ops.cat_views(inputs)                                       # :137
+    getattr(model_teacher, 'module', model_teacher).wino_static = True    # (frozen, eval mode: plan.PlanNet._wino_refresh re-makes its filter images only when they change)
     pair = _PAIR_TEACHER if all(hasattr(m, 'begin') for m in (model, model_G, model_teacher)) else 0
     if pair:
         # the (frozen) teacher's levels as members of the student's launch groups: a sequential network is one chain per

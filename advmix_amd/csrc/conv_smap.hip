@@ -58,6 +58,137 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
     return __builtin_bit_cast(f32x4, v);
 }
 
+// Workgroups are dealt to the 8 XCDs (and their 8 non-coherent L2s) round-robin in launch order.  With eight column tiles
+// XCD k = (column-tile pair k % 4, image parity k / 4): an image is fetched by 4 L2s and a filter slice by 2 (6.3 + 4.7 MB
+// from HBM for 256 -> 256 @8x6 at B = 32, against 12.6 + 2.4 with XCD = column tile and 1.6 + 18.9 with XCD = image group).
+__device__ __forceinline__ void block_map(int& nt, int& img) {
+    nt = blockIdx.x; img = blockIdx.y;
+    if (gridDim.x == 8 && (gridDim.y & 1) == 0) {
+        const int lin = (int)(blockIdx.y * 8 + blockIdx.x), xcd = lin & 7, j = lin >> 3;
+        nt = 2 * (xcd & 3) + (j & 1);
+        img = 2 * (j >> 1) + (xcd >> 2);
+    }
+}
+
+// The epilogue of thread (pixel m = tid / 8, channels col .. col + 3, col = n0 + 4 (tid % 8)) - both kernels of this file end
+// with their result in this natural layout.  Its read operands (residual / addend, the producer's c, its activation mask) are
+// requested early (epi_request) and consumed after the workgroup's reduction (epi_finish).
+struct EpiOps {
+    f32x4 oa, oc;
+    unsigned mbits, yo;
+    int col, pix;
+    bool live;
+};
+
+template <int ROLE>
+__device__ __forceinline__ EpiOps epi_request(const SP& p, int tid, int img, int PX, int n0) {
+    EpiOps o;
+    const int m = tid >> 3, cq = tid & 7;
+    o.live = m < PX;
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.y), 0, p.ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bnb_c ? p.bnb_c : p.y), 0, p.ybytes, 0x00020000);
+    o.col = n0 + 4 * cq;
+    o.pix = img * PX + (o.live ? m : 0);
+    o.yo = o.live ? (unsigned)((o.pix * p.Co + o.col) * 4) : OOB;
+    const bool bnb = ROLE == 1 && p.bnb_c != nullptr;
+    const bool mask_on = bnb && p.bnb_mask != nullptr && p.bnb_act != ADVMIX_ACT_NONE;
+    o.oa = f32x4{0.f, 0.f, 0.f, 0.f};
+    o.oc = o.oa;
+    if (p.res != nullptr) o.oa = bload(rr, o.yo);
+    if (ROLE == 1 && bnb) o.oc = bload(cr, o.yo);
+    o.mbits = 0u;
+    if (ROLE == 1 && mask_on && o.live) o.mbits = p.bnb_mask[(int64_t)o.pix * (p.Co >> 2) + (o.col >> 2)];   // bit e: channel col + e
+    return o;
+}
+
+// conv_direct.hip's epilogue arithmetic in the natural layout: BatchNorm column sums (fp64 slots), eval-mode BatchNorm +
+// residual + activation, or - input-gradient role - addend, activation slope from the bit mask / from c, BatchNorm-backward sums.
+template <int ROLE>
+__device__ __forceinline__ void epi_finish(const SP& p, f32x4 v, const EpiOps& o, float* sred, int tid, int img, int n0) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.ybytes, 0x00020000);
+    const bool stats = p.stats != nullptr;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool bnf = ROLE == 0 && p.bn_gamma != nullptr;
+    const bool bnb = ROLE == 1 && p.bnb_c != nullptr;
+    const bool mask_on = bnb && p.bnb_mask != nullptr && p.bnb_act != ADVMIX_ACT_NONE;
+    const bool recompute = ROLE == 1 && bnb && !mask_on && p.bnb_act != ADVMIX_ACT_NONE;
+    const float bb_slope = act_neg_slope(p.bnb_act);
+    const int col = o.col;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e];
+        if (ROLE == 0) {
+            if (o.live) { s1[e] = x; s2[e] = x * x; }
+            if (bnf) x = (x - p.bn_rm[col + e]) * (1.0f / sqrtf(p.bn_rv[col + e] + p.bn_eps)) * p.bn_gamma[col + e] + p.bn_beta[col + e];
+            x += o.oa[e];
+            x = act_fwd(x, p.act);
+        } else {
+            x += o.oa[e];
+            if (bnb) {
+                const float xh = (o.oc[e] - p.bnb_mean[col + e]) * p.bnb_invstd[col + e];
+                if (mask_on) x = ((o.mbits >> e) & 1u) ? x : x * bb_slope;
+                else if (recompute) x = __builtin_fmaf(xh, p.bnb_gamma[col + e], p.bnb_beta[col + e]) > 0.f ? x : x * bb_slope;
+                if (o.live) { s1[e] = x; s2[e] = x * xh; }
+            }
+        }
+        v[e] = x;
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, o.yo, 0, STORE_AUX);
+    if (stats) {                                            // uniform over the grid
+        // a wave = 8 pixels x 8 channel quads (lane = 8 (m % 8) + cq): the pixels add up by shuffles, the waves in LDS
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int d = 8; d < 64; d <<= 1) {
+                s1[e] += __shfl_xor(s1[e], d, 64);
+                s2[e] += __shfl_xor(s2[e], d, 64);
+            }
+        }
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sred[wv * 32 + 4 * lane + e] = s1[e];
+                sred[(8 + wv) * 32 + 4 * lane + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                d1 += (double)sred[k * 32 + tid];
+                d2 += (double)sred[(8 + k) * 32 + tid];
+            }
+            const int sl = img % p.stats_nbg;              // slot-major [2][slots][Co]: consecutive doubles per workgroup
+            atomicAdd(p.stats + (int64_t)sl * p.Co + n0 + tid, d1);
+            atomicAdd(p.stats + ((int64_t)p.stats_nbg + sl) * p.Co + n0 + tid, d2);
+        }
+    }
+}
+
+// The padded image -> LDS (an out-of-image pixel is an out-of-range offset: the load returns 0).
+__device__ __forceinline__ void stage_image(const SP& p, float* L, int tid, int img, int PW, int NPOS) {
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+    constexpr int SIT = (MAXPOS * (C / 4) + NT - 1) / NT;
+    f32x4 stg[SIT];
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+        const int s = tid + NT * it;
+        const int pos = s >> 6, cs = s & 63;
+        const int ph = pos / PW, pw = pos - ph * PW;
+        const int h = ph - 1, w = pw - 1;
+        const bool ok = pos < NPOS && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+        stg[it] = bload(xr, ok ? (unsigned)((((img * p.H + h) * p.W + w) * C + cs * 4) * 4) : OOB);
+    }
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+        const int s = tid + NT * it;
+        const int pos = s >> 6, cs = s & 63;
+        if (pos < NPOS) *reinterpret_cast<f32x4*>(&L[pos * PP + cs * 4]) = stg[it];
+    }
+}
+
 template <int ROLE>
 __global__ __launch_bounds__(NT, 1) void conv_smap(const SP p) {
     // one region, two lives (separated by workgroup barriers): the padded image, then the eight waves' partial tiles
@@ -68,19 +199,11 @@ __global__ __launch_bounds__(NT, 1) void conv_smap(const SP p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;               // MFMA 16x16x4: row / column l15, k-lane q
-    // Workgroups are dealt to the 8 XCDs (and their 8 non-coherent L2s) round-robin in launch order.  With eight column tiles
-    // XCD k = (column-tile pair k % 4, image parity k / 4): an image is fetched by 4 L2s and a filter slice by 2 (6.3 + 4.7 MB
-    // from HBM for 256 -> 256 @8x6 at B = 32, against 12.6 + 2.4 with XCD = column tile and 1.6 + 18.9 with XCD = image group).
-    int nt = blockIdx.x, img = blockIdx.y;
-    if (gridDim.x == 8 && (gridDim.y & 1) == 0) {
-        const int lin = (int)(blockIdx.y * 8 + blockIdx.x), xcd = lin & 7, j = lin >> 3;
-        nt = 2 * (xcd & 3) + (j & 1);
-        img = 2 * (j >> 1) + (xcd >> 2);
-    }
+    int nt, img;
+    block_map(nt, img);
     const int n0 = nt * 32;
     const int PX = p.H * p.W, PW = p.W + 2, NPOS = (p.H + 2) * PW;
 
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, p.ubytes, 0x00020000);
     // this wave's filters: 36 consecutive fragments of 1 KB - iteration it = (tap, 16-channel group) needs 2 it and 2 it + 1
     const unsigned bo = (unsigned)((((nt * 8 + wv) * (2 * NIT)) * 64 + lane) * 16);
@@ -92,26 +215,7 @@ __global__ __launch_bounds__(NT, 1) void conv_smap(const SP p) {
 #pragma unroll
     for (int it = 0; it < RING; ++it) issue_b(it);
 
-    // ---- the image with its zero halo -> LDS (an out-of-image pixel is an out-of-range offset: the load returns 0) -----
-    {
-        constexpr int SIT = (MAXPOS * (C / 4) + NT - 1) / NT;
-        f32x4 stg[SIT];
-#pragma unroll
-        for (int it = 0; it < SIT; ++it) {
-            const int s = tid + NT * it;
-            const int pos = s >> 6, cs = s & 63;
-            const int ph = pos / PW, pw = pos - ph * PW;
-            const int h = ph - 1, w = pw - 1;
-            const bool ok = pos < NPOS && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-            stg[it] = bload(xr, ok ? (unsigned)((((img * p.H + h) * p.W + w) * C + cs * 4) * 4) : OOB);
-        }
-#pragma unroll
-        for (int it = 0; it < SIT; ++it) {
-            const int s = tid + NT * it;
-            const int pos = s >> 6, cs = s & 63;
-            if (pos < NPOS) *reinterpret_cast<f32x4*>(&L[pos * PP + cs * 4]) = stg[it];
-        }
-    }
+    stage_image(p, L, tid, img, PW, NPOS);                  // ---- the image with its zero halo -> LDS ----
 
     // ---- this lane's three pixels (one per MFMA row tile; rows past the image repeat its last pixel: their results are
     //      never used - a row of A only reaches the same row of D) ---------------------------------------------------------
@@ -156,22 +260,8 @@ __global__ __launch_bounds__(NT, 1) void conv_smap(const SP p) {
                     acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j], bc[u][j], acc[t][u], 0, 0, 0);
     }
 
-    // ---- epilogue operands of thread (pixel m, channels 4 cq .. 4 cq + 3): requested now, they arrive under the reduction ----
+    const EpiOps eo = epi_request<ROLE>(p, tid, img, PX, n0);   // (requested now, they arrive under the reduction)
     const int m = tid >> 3, cq = tid & 7;
-    const bool live = m < PX;
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.ybytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.y), 0, p.ybytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bnb_c ? p.bnb_c : p.y), 0, p.ybytes, 0x00020000);
-    const int col = n0 + 4 * cq;
-    const int pix = img * PX + (live ? m : 0);
-    const unsigned yo = live ? (unsigned)((pix * p.Co + col) * 4) : OOB;
-    const bool bnb = ROLE == 1 && p.bnb_c != nullptr;
-    const bool mask_on = bnb && p.bnb_mask != nullptr && p.bnb_act != ADVMIX_ACT_NONE;
-    f32x4 oa = f32x4{0.f, 0.f, 0.f, 0.f}, oc = oa;
-    if (p.res != nullptr) oa = bload(rr, yo);
-    if (ROLE == 1 && bnb) oc = bload(cr, yo);
-    unsigned mbits = 0u;
-    if (ROLE == 1 && mask_on && live) mbits = p.bnb_mask[(int64_t)pix * (p.Co >> 2) + (col >> 2)];   // bit e: channel col + e
 
     __syncthreads();                                        // every wave is done with the image: the region becomes the reduction image
 #pragma unroll
@@ -191,63 +281,135 @@ __global__ __launch_bounds__(NT, 1) void conv_smap(const SP p) {
             for (int e = 0; e < 4; ++e) v[e] += x[e];
         }
     }
+    epi_finish<ROLE>(p, v, eo, sred, tid, img, n0);
+}
 
-    // ---- fused epilogue (conv_direct.hip's arithmetic, natural layout) ----------------------------------------------------
-    const bool stats = p.stats != nullptr;
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool bnf = ROLE == 0 && p.bn_gamma != nullptr;
-    const bool recompute = ROLE == 1 && bnb && !mask_on && p.bnb_act != ADVMIX_ACT_NONE;
-    const float bb_slope = act_neg_slope(p.bnb_act);
+// ---- the same workgroup shape with Winograd F(2x2, 3x3) inside ------------------------------------------------------------
+// An 8 x 6 map is 4 x 3 = 12 output tiles of 2 x 2: one MFMA row tile (16 rows, 12 used) per position xi of the transformed
+// 4 x 4 patch.  Wave w multiplies xi = 2 w and 2 w + 1 over ALL 256 channels (no K split, no partial tiles to add): 256
+// v_mfma_f32_16x16x4_f32 per wave instead of 432.  The A operand is formed on the way from LDS to the MFMA - (B^T d B)[i][j]
+// is a signed sum of FOUR pixels of the staged image (each row of B^T has two non-zeros) - so nothing transformed is ever
+// stored; filters come as U = G g G^T in fragment order (smapw_weights: [column tile][wave][16-channel group][xi of the
+// wave][column half][lane][4]: 64 consecutive KB per wave).  The sixteen 16 x 32 products meet in LDS; thread (pixel, 4
+// channels) applies A^T . A (nine 16-byte reads) and runs the shared epilogue.
+constexpr int WIT = 16;                    // 16-channel groups of the 256 channels
+template <int ROLE>
+__global__ __launch_bounds__(NT, 1) void conv_smapw(const SP p) {
+    __shared__ __attribute__((aligned(16))) float L[MAXPOS * PP];
+    __shared__ float sred[2 * 8 * 32];
+    static_assert(16 * 16 * RP <= MAXPOS * PP, "the product image fits the patch region");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    int nt, img;
+    block_map(nt, img);
+    const int n0 = nt * 32;
+    const int PX = p.H * p.W, PW = p.W + 2, NPOS = (p.H + 2) * PW;
+    const int Wt = p.W >> 1, NTIL = (p.H >> 1) * Wt;
+
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, p.ubytes, 0x00020000);
+    // this wave's filters: iteration g (16 channels) needs fragments 4 g .. 4 g + 3 = (xi of the wave, column half)
+    const unsigned bo = (unsigned)((((nt * 8 + wv) * (4 * WIT)) * 64 + lane) * 16);
+    f32x4 bq[RING][4];
+    auto issue_b = [&](int it) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float o = v[e];
-        if (ROLE == 0) {
-            if (live) { s1[e] = o; s2[e] = o * o; }
-            if (bnf) o = (o - p.bn_rm[col + e]) * (1.0f / sqrtf(p.bn_rv[col + e] + p.bn_eps)) * p.bn_gamma[col + e] + p.bn_beta[col + e];
-            o += oa[e];
-            o = act_fwd(o, p.act);
-        } else {
-            o += oa[e];
-            if (bnb) {
-                const float xh = (oc[e] - p.bnb_mean[col + e]) * p.bnb_invstd[col + e];
-                if (mask_on) o = ((mbits >> e) & 1u) ? o : o * bb_slope;
-                else if (recompute) o = __builtin_fmaf(xh, p.bnb_gamma[col + e], p.bnb_beta[col + e]) > 0.f ? o : o * bb_slope;
-                if (live) { s1[e] = o; s2[e] = o * xh; }
-            }
-        }
-        v[e] = o;
+        for (int f = 0; f < 4; ++f) bq[it % RING][f] = bload(ur, bo + (unsigned)((4 * it + f) * 1024));
+    };
+#pragma unroll
+    for (int it = 0; it < RING; ++it) issue_b(it);
+
+    stage_image(p, L, tid, img, PW, NPOS);
+
+    // xi = (i, j): i = wv / 2 for both of the wave's positions, j = 2 (wv % 2) + xl.  Row i of B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0;
+    // 0 1 0 -1] picks pixels (ra, rb) with sign sg:  i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3.
+    auto pick = [](int i, int& a, int& b, float& sg) {
+        a = i == 0 ? 0 : (i == 2 ? 2 : 1);
+        b = i == 3 ? 3 : (i == 2 ? 1 : 2);
+        sg = i == 1 ? 1.f : -1.f;
+    };
+    int ra, rb, ca[2], cb[2];
+    float sgi, sgj[2];
+    pick(wv >> 1, ra, rb, sgi);
+    pick(2 * (wv & 1), ca[0], cb[0], sgj[0]);
+    pick(2 * (wv & 1) + 1, ca[1], cb[1], sgj[1]);
+    int t = l15;
+    if (t >= NTIL) t = NTIL - 1;                            // (rows past the last tile repeat it: never used)
+    const int ty = t / Wt, tx = t - ty * Wt;
+    const float* const lt = L + ((2 * ty) * PW + 2 * tx) * PP + 4 * q;     // pixel (0, 0) of the tile's 4 x 4 patch
+    int off[2][4];
+#pragma unroll
+    for (int xl = 0; xl < 2; ++xl) {
+        off[xl][0] = (ra * PW + ca[xl]) * PP; off[xl][1] = (ra * PW + cb[xl]) * PP;
+        off[xl][2] = (rb * PW + ca[xl]) * PP; off[xl][3] = (rb * PW + cb[xl]) * PP;
     }
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yo, 0, STORE_AUX);
-    if (stats) {                                            // uniform over the grid
-        // a wave = 8 pixels x 8 channel quads (lane = 8 (m % 8) + cq): the pixels add up by shuffles, the waves in LDS
+    f32x4 acc[2][2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+    for (int xl = 0; xl < 2; ++xl)
 #pragma unroll
-            for (int d = 8; d < 64; d <<= 1) {
-                s1[e] += __shfl_xor(s1[e], d, 64);
-                s2[e] += __shfl_xor(s2[e], d, 64);
-            }
-        }
-        if (lane < 8) {
+        for (int u = 0; u < 2; ++u) acc[xl][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();                                        // the image is complete
+    auto load_a = [&](int it, f32x4 (&d)[2][4]) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sred[wv * 32 + 4 * lane + e] = s1[e];
-                sred[(8 + wv) * 32 + 4 * lane + e] = s2[e];
-            }
-        }
-        __syncthreads();
-        if (tid < 32) {
-            double d1 = 0.0, d2 = 0.0;
+        for (int xl = 0; xl < 2; ++xl)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                d1 += (double)sred[k * 32 + tid];
-                d2 += (double)sred[(8 + k) * 32 + tid];
-            }
-            const int sl = img % p.stats_nbg;              // slot-major [2][slots][Co]: consecutive doubles per workgroup
-            atomicAdd(p.stats + (int64_t)sl * p.Co + n0 + tid, d1);
-            atomicAdd(p.stats + ((int64_t)p.stats_nbg + sl) * p.Co + n0 + tid, d2);
-        }
+            for (int k = 0; k < 4; ++k) d[xl][k] = *reinterpret_cast<const f32x4*>(lt + off[xl][k] + 16 * it);
+    };
+    f32x4 dn[2][4];
+    load_a(0, dn);
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+        f32x4 bc[4], a[2];
+        __builtin_amdgcn_sched_barrier(0);                  // (nothing of iteration it + 1 is hoisted above this one's MFMAs)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) bc[f] = bq[it % RING][f];
+#pragma unroll
+        for (int xl = 0; xl < 2; ++xl)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                a[xl][e] = __builtin_fmaf(sgi, __builtin_fmaf(sgj[xl], dn[xl][3][e], dn[xl][2][e]), __builtin_fmaf(sgj[xl], dn[xl][1][e], dn[xl][0][e]));
+        if (it + RING < WIT) issue_b(it + RING);
+        if (it + 1 < WIT) load_a(it + 1, dn);               // the next group's pixels read under this group's 16 MFMAs
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int xl = 0; xl < 2; ++xl)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    acc[xl][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[xl][j], bc[2 * xl + u][j], acc[xl][u], 0, 0, 0);
     }
+
+    const EpiOps eo = epi_request<ROLE>(p, tid, img, PX, n0);
+    __syncthreads();                                        // every wave is done with the image: the region becomes the product image
+#pragma unroll
+    for (int xl = 0; xl < 2; ++xl)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)                      // M[xi][tile 4 q + r][column 16 u + l15]
+                L[((2 * wv + xl) * 16 + 4 * q + r) * RP + 16 * u + l15] = acc[xl][u][r];
+    __syncthreads();
+    // ---- inverse transform of thread (pixel m, 4 channels):  Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1] ------------------------
+    const int m = tid >> 3, cq = tid & 7;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (eo.live) {
+        const int h = m / p.W, w = m - h * p.W;
+        const int tl = (h >> 1) * Wt + (w >> 1), oa = h & 1, ob = w & 1;
+        f32x4 rowv[3];
+#pragma unroll
+        for (int di = 0; di < 3; ++di) {
+            const float* const mp = &L[(((oa + di) * 4 + ob) * 16 + tl) * RP + 4 * cq];
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(mp);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(mp + 16 * RP);
+            const f32x4 x2 = *reinterpret_cast<const f32x4*>(mp + 32 * RP);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rowv[di][e] = ob ? (x0[e] - x1[e]) - x2[e] : (x0[e] + x1[e]) + x2[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = oa ? (rowv[0][e] - rowv[1][e]) - rowv[2][e] : (rowv[0][e] + rowv[1][e]) + rowv[2][e];
+    }
+    epi_finish<ROLE>(p, v, eo, sred, tid, img, n0);
 }
 
 // ---- filter re-layout ---------------------------------------------------------------------------------------------------
@@ -275,6 +437,42 @@ __global__ __launch_bounds__(256) void smap_weights(const SEnt* __restrict__ ent
     const float val = e.role == 0 ? e.w[((int64_t)(n * 3 + r) * 3 + s) * e.Ck + c]
                                   : e.w[((int64_t)(c * 3 + (2 - r)) * 3 + (2 - s)) * e.Cn + n];
     e.u[(int64_t)lb * 256 + t] = val;
+}
+
+// U = G g G^T of the same filters for conv_smapw.  One block of 256 threads = (column tile nt, 16-channel group g, column half
+// u): thread t = 4 lane + j loads the 3 x 3 filter of (n = 32 nt + 16 u + lane % 16, c = 16 g + 4 (lane / 16) + j) once and writes
+// its 16 values U[xi] into the 16 fragments (((nt * 8 + xi / 2) * 16 + g) * 2 + xi % 2) * 2 + u - 1 KB per store instruction.
+// G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1] (the arithmetic of wino::wino_weights).
+__global__ __launch_bounds__(256) void smapw_weights(const SEnt* __restrict__ ents, const int* __restrict__ blk_ent) {
+    const SEnt e = ents[blk_ent[blockIdx.x]];
+    const int lb = (int)blockIdx.x - e.blk0;
+    const int u = lb & 1, g = (lb >> 1) & 15, nt = lb >> 5;
+    const int t = threadIdx.x, lane = t >> 2, j = t & 3;
+    const int n = 32 * nt + 16 * u + (lane & 15), c = 16 * g + 4 * (lane >> 4) + j;
+    float f[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            f[r][s] = e.role == 0 ? e.w[((int64_t)(n * 3 + r) * 3 + s) * e.Ck + c]
+                                  : e.w[((int64_t)(c * 3 + (2 - r)) * 3 + (2 - s)) * e.Cn + n];
+    float a[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        a[0][s] = f[0][s];
+        a[1][s] = 0.5f * ((f[0][s] + f[2][s]) + f[1][s]);
+        a[2][s] = 0.5f * ((f[0][s] + f[2][s]) - f[1][s]);
+        a[3][s] = f[2][s];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float u4[4] = {a[i][0], 0.5f * ((a[i][0] + a[i][2]) + a[i][1]), 0.5f * ((a[i][0] + a[i][2]) - a[i][1]), a[i][2]};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int xi = 4 * i + jj;
+            e.u[(int64_t)((((nt * 8 + (xi >> 1)) * 16 + g) * 2 + (xi & 1)) * 2 + u) * 256 + t] = u4[jj];
+        }
+    }
 }
 
 }  // namespace smap
@@ -380,6 +578,87 @@ extern "C" int advmix_conv3x3_smap_dgrad(const float* dy, const float* u, const 
         p.bnb_gamma = bn_gamma; p.bnb_beta = bn_beta; p.bnb_act = act;
     }
     rc = smap_launch(1, p, (hipStream_t)stream);
+    if (rc == ADVMIX_OK && bn_c) *stats_ns = p.stats_nbg;
+    return rc;
+}
+
+// ---- Winograd variant (conv_smapw): even H and W only -------------------------------------------------------------------
+static bool smapw_shape_ok(int N, int H, int W, int Ci, int Co) {
+    return smap_shape_ok(N, H, W, Ci, Co) && !(H & 1) && !(W & 1) && (H / 2) * (W / 2) <= 16;
+}
+
+extern "C" int advmix_conv_smapw_config(int N, int H, int W, int Ci, int Co) {
+    if (!smapw_shape_ok(N, H, W, Ci, Co)) return 0;
+    const int64_t wgs = (int64_t)N * (Co / 32);
+    return wgs > 0x7fffffff ? 0x7fffffff : (int)wgs;
+}
+
+extern "C" int64_t advmix_smapw_u_floats(int Co, int Ci) { return (int64_t)16 * Co * Ci; }
+
+// records as advmix_smap_weights'; a record owns (Cn / 32) * 32 workgroups and needs Ck == 256
+extern "C" int advmix_smapw_weights(const void* ents, const int* blk_ent, int blocks, void* stream) {
+    if (!ents || !blk_ent || blocks <= 0) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(smap::smapw_weights, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const smap::SEnt*)ents, blk_ent);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+static int smapw_launch(int role, const smap::SP& p, hipStream_t st) {
+    const dim3 g(p.Co / 32, p.N);
+    if (role) hipLaunchKernelGGL(smap::conv_smapw<1>, g, dim3(smap::NT), 0, st, p);
+    else hipLaunchKernelGGL(smap::conv_smapw<0>, g, dim3(smap::NT), 0, st, p);
+    if (advmix_opts().trace_shapes) {
+        char nm[32];
+        snprintf(nm, sizeof nm, "conv_smapw<%d>", role);
+        advmix_trace_launch(nm, g, role == 0 ? (p.stats ? "fwd+sums" : (p.bn_gamma ? "fwd+bn_eval" : "fwd")) : (p.bnb_c ? "dgrad+bnb" : "dgrad"),
+                            p.N, p.H, p.W, smap::C, p.H, p.W, p.Co, 3, 3, 1, 2.0 * p.N * (double)p.H * p.W * p.Co * smap::C * 9);
+    }
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+extern "C" int advmix_conv3x3_smapw_fwd(const float* x, const float* u, float* y, int N, int H, int W, int Ci, int Co,
+                                        const float* bn_gamma, const float* bn_beta, const float* bn_rm, const float* bn_rv,
+                                        float bn_eps, const float* residual, int act, double* stats, int* stats_ns, void* stream) {
+    if ((bn_gamma != nullptr) != (bn_beta && bn_rm && bn_rv)) return ADVMIX_EINVAL;
+    if (stats && !stats_ns) return ADVMIX_EINVAL;
+    if (advmix_opts().deterministic && stats) return ADVMIX_EINVAL;
+    if (!smapw_shape_ok(N, H, W, Ci, Co)) return ADVMIX_EINVAL;
+    smap::SP p;
+    int rc = smap_fill(p, x, u, y, N, H, W, Ci, Co);
+    if (rc) return rc;
+    p.ubytes = (int)((int64_t)16 * Co * Ci * 4);
+    p.bn_gamma = bn_gamma; p.bn_beta = bn_beta; p.bn_rm = bn_rm; p.bn_rv = bn_rv; p.bn_eps = bn_eps;
+    p.res = residual; p.act = act; p.stats = stats;
+    p.stats_nbg = smap_slots(stats_ns);
+    rc = smapw_launch(0, p, (hipStream_t)stream);
+    if (rc == ADVMIX_OK && stats_ns) *stats_ns = p.stats_nbg;
+    return rc;
+}
+
+extern "C" int advmix_conv3x3_smapw_dgrad(const float* dy, const float* u, const float* addend, float* dx, int N, int H, int W,
+                                          int Co, int Ci, const unsigned char* act_mask, const float* bn_c, const float* bn_mean,
+                                          const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int act,
+                                          double* stats, int* stats_ns, void* stream) {
+    if (bn_c) {
+        if (!bn_mean || !bn_invstd || !stats || !stats_ns) return ADVMIX_EINVAL;
+        if (act != ADVMIX_ACT_NONE && !act_mask && !(bn_gamma && bn_beta)) return ADVMIX_EINVAL;
+        if (advmix_opts().deterministic) return ADVMIX_EINVAL;
+    } else if (stats) {
+        return ADVMIX_EINVAL;
+    }
+    if (!smapw_shape_ok(N, H, W, Co, Ci)) return ADVMIX_EINVAL;
+    smap::SP p;
+    int rc = smap_fill(p, dy, u, dx, N, H, W, Co, Ci);
+    if (rc) return rc;
+    p.ubytes = (int)((int64_t)16 * Co * Ci * 4);
+    p.res = addend;
+    if (bn_c) {
+        p.stats = stats; p.stats_nbg = smap_slots(stats_ns);
+        p.bnb_mask = act_mask; p.bnb_c = bn_c; p.bnb_mean = bn_mean; p.bnb_invstd = bn_invstd;
+        p.bnb_gamma = bn_gamma; p.bnb_beta = bn_beta; p.bnb_act = act;
+    }
+    rc = smapw_launch(1, p, (hipStream_t)stream);
     if (rc == ADVMIX_OK && bn_c) *stats_ns = p.stats_nbg;
     return rc;
 }

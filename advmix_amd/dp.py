@@ -266,6 +266,9 @@ class GradSync:
         for t in tensors:
             with self.off_null(t):
                 dist.broadcast(t, src, group=self.group)
+        for m in models:                                    # (the collectives wrote the parameters behind torch's back: a frozen
+            if m is not None and hasattr(getattr(m, 'module', m), 'invalidate_filter_images'):   # network's filter images are keyed on their
+                getattr(m, 'module', m).invalidate_filter_images()                               # version counters - plan.PlanNet._wino_refresh)
         if tensors and tensors[0].is_cuda:
             torch.cuda.current_stream(tensors[0].device).synchronize()
 

@@ -382,6 +382,7 @@ WINO = __import__('os').environ.get('ADVMIX_WINO', '1') != '0'       # A/B switc
 WINO_MIN_WGS = int(__import__('os').environ.get('ADVMIX_WINO_MIN_WGS', '96'))   # workgroups (32 tiles x 32 channels) below which the direct kernel stays
 SMAP = __import__('os').environ.get('ADVMIX_SMAP', '1') != '0'       # A/B switch: 0 = the small 256-channel maps on the direct kernel
 SMAP_C = 256                                                         # (csrc/conv_smap.hip: one workgroup per image, K split over its eight waves)
+SMAP_WINO = __import__('os').environ.get('ADVMIX_SMAP_WINO', '1') != '0'   # Winograd F(2x2,3x3) inside that workgroup shape (conv_smapw; 0 = the direct form)
 
 
 class WinoBank:
@@ -401,14 +402,14 @@ class WinoBank:
         pad32 = lambda c: (c + 31) // 32 * 32                # noqa: E731  (the n dimension is padded to whole column tiles)
         # kind 'smap' (csrc/conv_smap.hip): filters with 256 input channels, plain re-layout in that kernel's fragment order (9 Co Ci floats
         # per image); everything else 'wino'
-        kinds = ['smap' if (w.shape[1] == SMAP_C and w.shape[0] % 32 == 0) else 'wino' for w in weights]   # (its input-gradient image is only usable for Cout == 256 too)
-        sizes = [(9 * w.shape[0] * w.shape[1],) * 2 if k == 'smap' else
+        kinds = [('smapw' if SMAP_WINO else 'smap') if (w.shape[1] == SMAP_C and w.shape[0] % 32 == 0) else 'wino' for w in weights]   # (input-gradient images only where Cout == 256 too)
+        sizes = [(9 * w.shape[0] * w.shape[1],) * 2 if k == 'smap' else (16 * w.shape[0] * w.shape[1],) * 2 if k == 'smapw' else
                  (16 * pad32(w.shape[0]) * w.shape[1], 16 * pad32(w.shape[1]) * w.shape[0]) for w, k in zip(weights, kinds)]
         self.buf = torch.empty(sum(a + b for a, b in sizes), device=dev, dtype=torch.float32)
         rec = np.dtype([('w', '<u8'), ('u', '<u8'), ('Cn', '<i4'), ('Ck', '<i4'), ('role', '<i4'), ('blk0', '<i4')])
-        ents = {'wino': [], 'smap': []}
-        blk = {'wino': 0, 'smap': 0}
-        owner = {'wino': [], 'smap': []}
+        ents = {'wino': [], 'smap': [], 'smapw': []}
+        blk = {'wino': 0, 'smap': 0, 'smapw': 0}
+        owner = {'wino': [], 'smap': [], 'smapw': []}
         off = 0
         self._tagged = []
         for i, (w, kind) in enumerate(zip(weights, kinds)):
@@ -418,15 +419,19 @@ class WinoBank:
             ptrs = []
             for role, (Cn, Ck) in enumerate(((Co, Ci), (Ci, Co))):
                 u = self.buf.data_ptr() + 4 * off
-                owner[kind] += [len(ents[kind])] * (((Cn + 31) // 32) * (Ck // 8) if kind == 'wino' else (Cn // 32) * (Ck // 32) * 36)
+                off += sizes[i][role]
+                if kind != 'wino' and Ck != SMAP_C:          # (the small-map kernels read exactly 256 channels: no such image)
+                    ptrs.append(None)
+                    continue
+                nb = {'wino': ((Cn + 31) // 32) * (Ck // 8), 'smap': (Cn // 32) * (Ck // 32) * 36, 'smapw': (Cn // 32) * 32}[kind]
+                owner[kind] += [len(ents[kind])] * nb
                 ents[kind].append((w.data_ptr(), u, Cn, Ck, role, blk[kind]))
                 blk[kind] = len(owner[kind])
-                off += sizes[i][role]
                 ptrs.append(ctypes.c_void_p(u))
             w._wino = (self.buf, ptrs[0], ptrs[1], w.data_ptr(), kind)     # (the tag keeps the side buffer alive)
             self._tagged.append(weakref.ref(w))
         self.tables = {}
-        for kind in ('wino', 'smap'):
+        for kind in ('wino', 'smap', 'smapw'):
             if ents[kind]:
                 ent = np.array(ents[kind], dtype=rec)
                 self.tables[kind] = (torch.from_numpy(ent.view(np.uint8).copy()).to(dev),
@@ -438,7 +443,7 @@ class WinoBank:
     def refresh(self, st=None):
         st = st if st is not None else _st()
         for kind, (ents, blk_ent, blocks) in self.tables.items():
-            call('advmix_wino_weights' if kind == 'wino' else 'advmix_smap_weights', _p(ents), _p(blk_ent), blocks, st)
+            call('advmix_%s_weights' % kind, _p(ents), _p(blk_ent), blocks, st)
 
     def images(self, w):
         """(forward image, input-gradient image) pointers of one of the bank's weights."""
@@ -461,7 +466,8 @@ def _wino_tag(w):
 
 
 _W3 = {'wino': (lib.advmix_conv3x3_wino_fwd, lib.advmix_conv3x3_wino_dgrad),      # (forward, input gradient) entry points per image kind
-       'smap': (lib.advmix_conv3x3_smap_fwd, lib.advmix_conv3x3_smap_dgrad)}
+       'smap': (lib.advmix_conv3x3_smap_fwd, lib.advmix_conv3x3_smap_dgrad),
+       'smapw': (lib.advmix_conv3x3_smapw_fwd, lib.advmix_conv3x3_smapw_dgrad)}
 
 
 def _wino_images(w, B, H, W, Ci, Co, R, S, stride, pad):
@@ -471,10 +477,11 @@ def _wino_images(w, B, H, W, Ci, Co, R, S, stride, pad):
     tag = _wino_tag(w)
     if tag is None:
         return None
-    if tag[4] == 'smap':                                    # 256 -> 256 on a map of <= 48 pixels: the image-per-workgroup kernel
-        if not SMAP or lib.advmix_conv_smap_config(B, H, W, Ci, Co) < WINO_MIN_WGS:
+    if tag[4] != 'wino':                                    # 256 -> 256 on a map of <= 48 pixels: the image-per-workgroup kernels
+        config = lib.advmix_conv_smapw_config if tag[4] == 'smapw' else lib.advmix_conv_smap_config
+        if not SMAP or config(B, H, W, Ci, Co) < WINO_MIN_WGS:
             return None
-        return tag[1], tag[2], 'smap'
+        return tag[1], tag[2], tag[4]
     if lib.advmix_conv_wino_config(B, H, W, Ci, Co) < WINO_MIN_WGS:
         return None
     return tag[1], tag[2], 'wino'
@@ -505,7 +512,7 @@ def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_
                 if rc == 0:
                     bnb['done'] = nsv.value
                     COUNTERS['bnb'] += 1
-                    COUNTERS[wu[2]] = COUNTERS.get(wu[2], 0) + 1
+                    COUNTERS[wu[2][:4]] = COUNTERS.get(wu[2][:4], 0) + 1     # ('wino' / 'smap': both small-map kernels count as smap)
                     return dx
                 if rc != 1:
                     raise RuntimeError('advmix_conv3x3_wino_dgrad failed: %d' % rc)
@@ -531,7 +538,7 @@ def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_
             rc = _W3[wu[2]][1](_p(dy), wu[1], _p(add_to), _p(dx), B, Hi, Wi, Co, Ci, None, None, None, None,
                                                None, None, 0, None, None, st)
             if rc == 0:
-                COUNTERS[wu[2]] = COUNTERS.get(wu[2], 0) + 1
+                COUNTERS[wu[2][:4]] = COUNTERS.get(wu[2][:4], 0) + 1     # ('wino' / 'smap': both small-map kernels count as smap)
                 return dx
             if rc != 1:
                 raise RuntimeError('advmix_conv3x3_wino_dgrad failed: %d' % rc)
@@ -735,7 +742,7 @@ class ConvBN:
                 rc = _W3[wu[2]][0](_p(x), wu[0], _p(y), B, Hi, Wi, Ci, Co, _p(gamma), _p(beta), _p(rmean),
                                                  _p(rvar), eps, _p(res), act, None, None, st)
                 if rc == 0:
-                    COUNTERS[wu[2]] = COUNTERS.get(wu[2], 0) + 1
+                    COUNTERS[wu[2][:4]] = COUNTERS.get(wu[2][:4], 0) + 1     # ('wino' / 'smap': both small-map kernels count as smap)
             if rc == 1:
                 rc = lib.advmix_conv_fwd_ex(_p(x), _p(w), None, _p(y), *geom, _p(gamma), _p(beta), _p(rmean),
                                             _p(rvar), eps, _p(res), act, None, None, st) if fused_ok else 1
@@ -768,7 +775,7 @@ class ConvBN:
                 rc = _W3[wu[2]][0](_p(x), wu[0], _p(c), B, Hi, Wi, Ci, Co, None, None, None, None, 0.0, None, 0,
                                                  target, ctypes.byref(nbg), st)
                 if rc == 0:
-                    COUNTERS[wu[2]] = COUNTERS.get(wu[2], 0) + 1
+                    COUNTERS[wu[2][:4]] = COUNTERS.get(wu[2][:4], 0) + 1     # ('wino' / 'smap': both small-map kernels count as smap)
             if rc == 1:
                 rc = lib.advmix_conv_fwd_ex(_p(x), _p(w), None, _p(c), *geom, None, None, None, None, 0.0, None, 0,
                                             target, ctypes.byref(nbg), st)

@@ -540,7 +540,16 @@ class PlanNet(nn.Module):
     def load_state_dict(self, *a, **kw):
         r = super().load_state_dict(*a, **kw)
         self._cache = None
+        self.invalidate_filter_images()
         return r
+
+    def invalidate_filter_images(self):
+        """Have the next forward pass re-make the Winograd / small-map filter images even for a network marked
+        ``wino_static`` (see _wino_refresh).  Needed only after writing a frozen network's filters in a way torch's version
+        counters do not see: through ``param.data``, a collective, a raw kernel."""
+        bank = getattr(self, '_wino_bank', None)
+        if bank is not None:
+            bank.static_key = None
 
     def _chain_member(self, st, slots, T, train):
         """ops.Chain member of a ('chain', steps, ext_slots, out_slots) super-step.  The static part
@@ -634,6 +643,16 @@ class PlanNet(nn.Module):
             if torch.cuda.is_current_stream_capturing():   # (building allocates and copies tables: not inside a capture -
                 return                                     #  without images these convs take the direct kernels)
             bank = self._wino_bank = ops.WinoBank(ws)
+        if getattr(self, 'wino_static', False) and not self.training:
+            # a FROZEN eval-mode network (the AdvMix teacher: core.function marks it): its filters change only through torch
+            # (load_state_dict, param.copy_ / mul_ ...) - which bumps the parameters' version counters - so the images are re-made
+            # only then; writes torch does not see (param.data, collectives, raw kernels): invalidate_filter_images()
+            key = tuple(w._version for w in ws)
+            if getattr(bank, 'static_key', None) == key:
+                return
+            bank.static_key = key
+        else:
+            bank.static_key = None
         bank.refresh()
 
     def begin(self, x):

@@ -158,6 +158,22 @@ int advmix_conv3x3_smap_dgrad(const float* dy, const float* u, const float* adde
                               const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int act,
                               double* stats, int* stats_ns, void* stream);
 
+/* The same workgroup shape with Winograd F(2x2,3x3) inside (conv_smapw): H and W even as well (an 8x6 map = 12 output tiles =
+ * one MFMA row tile per position of the transformed patch; each of the eight waves multiplies two positions over all 256
+ * channels; the input transform happens on the way from LDS to the MFMA).  Images: 16 * Co * Ci floats (advmix_smapw_u_floats),
+ * written by advmix_smapw_weights (records as above, (Cn / 32) * 32 workgroups each, Ck == 256) as
+ * u[n / 32][xi / 2][k / 16][xi % 2][(n % 32) / 16][16 * ((k % 16) / 4) + n % 16][k % 4], xi = 4 * row + column of G g G^T. */
+int advmix_conv_smapw_config(int N, int H, int W, int Ci, int Co);
+int64_t advmix_smapw_u_floats(int Co, int Ci);
+int advmix_smapw_weights(const void* ents, const int* blk_ent, int blocks, void* stream);
+int advmix_conv3x3_smapw_fwd(const float* x, const float* u, float* y, int N, int H, int W, int Ci, int Co,
+                             const float* bn_gamma, const float* bn_beta, const float* bn_rm, const float* bn_rv,
+                             float bn_eps, const float* residual, int act, double* stats, int* stats_ns, void* stream);
+int advmix_conv3x3_smapw_dgrad(const float* dy, const float* u, const float* addend, float* dx, int N, int H, int W,
+                               int Co, int Ci, const unsigned char* act_mask, const float* bn_c, const float* bn_mean,
+                               const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int act,
+                               double* stats, int* stats_ns, void* stream);
+
 /* Winograd weight gradient, F(3x3, 2x2) (csrc/wgrad_wino.hip, round 5): 16 multiplies per 2x2 tile of dy and channel pair
  * instead of 36.  advmix_wgrad_wino_config: 0 = not served (odd H / W, channels not multiples of 32 or > 256), else the
  * number of (32-tile block, 32 x 32 channel pair) units of one problem.  advmix_conv3x3_wgrad_wino_group: the weight

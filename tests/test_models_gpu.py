@@ -1179,6 +1179,57 @@ def test_data_parallel_path_on_one_rank_real_rccl():
     assert out.returncode == 0 and 'DP_ONE_RANK_OK' in out.stdout, (out.stdout[-2000:], out.stderr[-4000:])
 
 
+def test_frozen_teachers_filter_images_are_remade_only_when_its_filters_change(monkeypatch):
+    """plan.PlanNet._wino_refresh: the Winograd / small-map filter images of a network are re-made at the start of EVERY forward
+    pass - except for a network core.function has marked frozen (``wino_static``: the AdvMix teacher) in eval mode, whose
+    filters only change through torch operations (version counters): once, then again only after such a change; any
+    train-mode forward re-makes them regardless."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    from bench_common import HRNET_STAGES, hrnet_extra
+    from advmix_amd import models, ops
+    from advmix_amd.config import CfgNode
+    cfg = CfgNode({'MODEL': {'NAME': 'pose_hrnet', 'NUM_JOINTS': 17, 'INIT_WEIGHTS': True, 'PRETRAINED': '',
+                             'EXTRA': hrnet_extra(HRNET_STAGES['hrnet_w32'])}})
+    net = models.pose_hrnet.get_pose_net(cfg, is_train=True).cuda()
+    with torch.no_grad():
+        for p_ in net.parameters():                         # (init_weights' N(0, 1e-3) filters: outputs of 1e-10, residual branches invisible)
+            if p_.dim() == 4:
+                torch.nn.init.kaiming_normal_(p_, mode='fan_in')
+    calls = []
+    real = ops.WinoBank.refresh
+    monkeypatch.setattr(ops.WinoBank, 'refresh', lambda self, st=None: (calls.append(1), real(self, st))[1])
+    x = torch.randn(16, 3, 128, 96, device='cuda')          # (16 images: the 32- and 64-channel branches reach the Winograd kernel's 96 workgroups)
+    net.eval()
+    with torch.no_grad():
+        y0 = net(x)
+        net(x)
+        assert len(calls) == 2                              # not marked: every forward
+        net.wino_static = True
+        net(x)
+        y1 = net(x)
+        assert len(calls) == 3, len(calls)                  # marked: once
+        assert float((y0 - y1).abs().max()) <= 1e-5 * float(y0.abs().max())     # (small maps split K over the grid: fp32 atomics, not bit-equal)
+        assert ops.COUNTERS.get('wino', 0) > 0
+        w = next(p for n, p in net.named_parameters() if n.endswith('conv2.weight') and p.shape[1] == 32 and p.dim() == 4)
+        w.mul_(1.5)                                         # a torch operation on one filter bank
+        y2 = net(x)
+        assert len(calls) == 4
+        net(x)
+        assert len(calls) == 4
+    monkeypatch.setattr(ops, 'WINO', False)                 # the same forward on the direct kernels: the images were current
+    with torch.no_grad():
+        y3 = net(x)
+    assert float((y2 - y3).abs().max()) <= 1e-4 * float(y3.abs().max()) and float((y0 - y2).abs().max()) > 1e-3 * float(y0.abs().max())
+    monkeypatch.setattr(ops, 'WINO', True)
+    net.train()
+    n0 = len(calls)
+    net(x)
+    net(x)
+    assert len(calls) == n0 + 2
+
+
 def test_bench_falls_back_to_the_eager_step_when_the_graphs_do_not_verify():
     """bench.py's N-rank run verifies its own execution before it times anything; when the replayed graphs fail that (forced
     here: ADVMIX_BENCH_FAIL_GRAPH_VERIFY=1, one rank with real RCCL) the SAME step runs without graphs from rank 0's state,

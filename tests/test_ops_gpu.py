@@ -621,6 +621,12 @@ SMAP_CASES = [
     (1, 256, 256, 1, 1),
     (2, 256, 64, 8, 6),          # forward only (the gradient side would read 64 channels)
     (5, 256, 96, 5, 5),
+    # the Winograd form of that workgroup (conv_smapw): even maps only
+    (32, 256, 256, 8, 6, 'smapw'),
+    (3, 256, 256, 6, 8, 'smapw'),
+    (2, 256, 256, 4, 2, 'smapw'),      # two tiles
+    (2, 256, 256, 2, 2, 'smapw'),      # one tile, every pixel on the border
+    (2, 256, 64, 8, 6, 'smapw'),       # forward only
 ]
 
 
@@ -634,7 +640,7 @@ def _wino_images(w_dev):
 
 
 @pytest.mark.parametrize('case', WINO_CASES + SMAP_CASES)
-def test_winograd_conv_all_roles(case):
+def test_winograd_conv_all_roles(case, monkeypatch):
     """csrc/conv_wino.hip (round 5): the Winograd F(2x2,3x3) kernel in every role the step uses - forward + BatchNorm column
     sums, forward + eval-mode BatchNorm + residual + ReLU, input gradient + addend, input gradient + addend + BatchNorm-
     backward sums with the sign of y from the bit mask and recomputed from c - against a float64 torch evaluation (1e-4 of
@@ -644,13 +650,14 @@ def test_winograd_conv_all_roles(case):
     MFMA row tiles, column tiles of an image's 32 channels, an input-gradient side only where it reads 256 channels."""
     import ctypes
     from advmix_amd._lib import call, lib
-    _ops()
-    B, Ci, Co, H, W = case
+    ops_ = _ops()
+    B, Ci, Co, H, W = case[:5]
     d = dev()
-    kind = 'smap' if Ci == 256 else 'wino'
+    kind = case[5] if len(case) > 5 else ('smap' if Ci == 256 else 'wino')
+    monkeypatch.setattr(ops_, 'SMAP_WINO', kind == 'smapw')  # (which images WinoBank makes for a 256-channel filter)
     config, k_fwd, k_dgrad = (getattr(lib, n_ % kind) for n_ in ('advmix_conv_%s_config', 'advmix_conv3x3_%s_fwd', 'advmix_conv3x3_%s_dgrad'))
     has_dgrad = config(B, H, W, Co, Ci) > 0                 # (conv_smap reads exactly 256 channels: the gradient side needs Co == 256)
-    assert config(B, H, W, Ci, Co) > 0 and (has_dgrad or kind == 'smap')
+    assert config(B, H, W, Ci, Co) > 0 and (has_dgrad or kind != 'wino')
     g_ = torch.Generator().manual_seed(23 + Ci + H)
     R = lambda *s_: torch.randn(*s_, generator=g_)
     x, dy = R(B, H, W, Ci), R(B, H, W, Co)
@@ -745,6 +752,7 @@ def test_winograd_conv_all_roles(case):
         assert lib.advmix_conv_wino_config(B, H + 1, W, Ci, Co) == 0 and lib.advmix_conv_wino_config(B, H, W, 40, 40) == 0
     else:                                                   # more than 48 pixels / 80 padded pixels, other channel counts
         assert config(B, 7, 7, Ci, Co) == 0 and config(B, 12, 4, Ci, Co) == 0 and config(B, H, W, 128, Co) == 0 and config(B, H, W, Ci, 48) == 0
+        assert kind == 'smap' or config(B, 7, 6, Ci, Co) == 0        # (the Winograd form: odd sizes)
     assert k_fwd(P(D['x']), None, P(y), B, H, W, Ci, Co, None, None, None, None, 0.0, None, 0, None, None, st) == 1
     bank.release()
 

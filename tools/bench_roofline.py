@@ -58,7 +58,7 @@ def _time_shares():
             c = 'single weight gradients'
         elif k.startswith('conv_wino'):
             c = 'branch 3x3 convs, Winograd kernel (32 / 64 / 128 channels)'
-        elif k.startswith('conv_smap'):
+        elif k.startswith('conv_smap'):                     # (conv_smap / conv_smapw)
             c = 'branch 3x3 convs, image-per-workgroup kernel (256 channels @8x6)'
         elif k.startswith(('conv_direct', 'conv_group', 'conv_igemm')) and ' 3x3 s1 ' in shp and shp.split(' s1 ')[1].split(' ')[0].split('->')[0] == shp.split(' s1 ')[1].split(' ')[0].split('->')[1]:
             c = 'branch 3x3 convs, direct kernel (256 channels)'
@@ -115,7 +115,9 @@ def time_conv_family(B, device, iters=100, family=None):
         flops = 2.0 * rows * C * C * 9
         wino = bool(ops.WINO and lib.advmix_conv_wino_config(B, H, W, C, C) >= ops.WINO_MIN_WGS)
         smap = bool(ops.WINO and ops.SMAP and C == ops.SMAP_C and lib.advmix_conv_smap_config(B, H, W, C, C) >= ops.WINO_MIN_WGS)
-        kfwd, kdg = ('advmix_conv3x3_smap_fwd', 'advmix_conv3x3_smap_dgrad') if smap else ('advmix_conv3x3_wino_fwd', 'advmix_conv3x3_wino_dgrad')
+        skind = 'smapw' if (ops.SMAP_WINO and lib.advmix_conv_smapw_config(B, H, W, C, C) >= ops.WINO_MIN_WGS) else 'smap'   # (the images WinoBank makes follow ops.SMAP_WINO)
+        smap = smap and (skind == 'smapw' or not ops.SMAP_WINO)
+        kfwd, kdg = ('advmix_conv3x3_%s_fwd' % skind, 'advmix_conv3x3_%s_dgrad' % skind) if smap else ('advmix_conv3x3_wino_fwd', 'advmix_conv3x3_wino_dgrad')
 
         def reset():
             nbg.value = 0
@@ -173,7 +175,7 @@ def time_conv_family(B, device, iters=100, family=None):
             tot_t += wgt * ms * 1e-3
             members.append({
                 'kernel': '3x3 s1 %d->%d @%dx%d %s' % (C, C, H, W, kind if not (kind == 'wgrad' and grouped) else 'wgrad (1 of 8 problems of one launch)'),
-                'path': ('wgrad_wino (Winograd F(3x3,2x2))' if wgw else 'conv_wgrad_group') if kind == 'wgrad' else ('conv_wino (Winograd F(2x2,3x3))' if wino else ('conv_smap (image per workgroup)' if smap else 'conv_direct')),
+                'path': ('wgrad_wino (Winograd F(3x3,2x2))' if wgw else 'conv_wgrad_group') if kind == 'wgrad' else ('conv_wino (Winograd F(2x2,3x3))' if wino else (('conv_smapw (image per workgroup, Winograd F(2x2,3x3))' if skind == 'smapw' else 'conv_smap (image per workgroup)') if smap else 'conv_direct')),
                 'us_per_launch': round(ms * 1e3, 2), 'us_per_launch_runs': [round(v * 1e3, 2) for v in rr],
                 'algorithmic_gflop_per_launch': round(flops / 1e9, 3),
                 'tflops': round(flops / (ms * 1e-3) / 1e12, 2), 'frac': round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -203,6 +205,7 @@ def time_conv_family(B, device, iters=100, family=None):
     traffic = src = None
     if headline:                                            # HBM bytes per launch of the dominant member, when a PMC pass of it is committed
         d, src = _pmc_file('r*_pmc_dominant.json')
+        d = (d or {}).get('members', {}).get(dominant['kernel']) if d and 'members' in d else d      # (one file, keyed by member)
         if d and d.get('kernel') == dominant['kernel']:
             traffic = round(d['hbm_bytes_per_launch'])
         else:

@@ -47,7 +47,8 @@ for C, H, W in ((32, 64, 48), (64, 32, 24), (128, 16, 12), (64, 64, 48), (256, 8
     uf, ud = bank.images(w)
     geom = (B, H, W, C, H, W, C, 3, 3, 1, 1)
     ns = ctypes.c_int(0)
-    k_fwd, k_dg = (lib.advmix_conv3x3_smap_fwd, lib.advmix_conv3x3_smap_dgrad) if C == 256 else (lib.advmix_conv3x3_wino_fwd, lib.advmix_conv3x3_wino_dgrad)
+    kname = ('smapw' if ops.SMAP_WINO else 'smap') if C == 256 else 'wino'       # (ADVMIX_SMAP_WINO=0: the direct form of the image-per-workgroup kernel)
+    k_fwd, k_dg = getattr(lib, 'advmix_conv3x3_%s_fwd' % kname), getattr(lib, 'advmix_conv3x3_%s_dgrad' % kname)
 
     def z():
         ns.value = 0
@@ -73,5 +74,5 @@ for C, H, W in ((32, 64, 48), (64, 32, 24), (128, 16, 12), (64, 64, 48), (256, 8
     for name, (wino, direct) in runs.items():
         tw, td = timed(wino), timed(direct)
         print('  %-26s %s %6.1f us (%.3f of peak on direct FLOPs)   direct %6.1f us (%.3f)   x%.2f' % (
-            name, 'smap' if C == 256 else 'wino', tw, fl / tw / 1e6 / 157.3, td, fl / td / 1e6 / 157.3, td / tw))
+            name, kname, tw, fl / tw / 1e6 / 157.3, td, fl / td / 1e6 / 157.3, td / tw))
     bank.release()

@@ -380,6 +380,7 @@ def _det_stats(C, device, lane):
 # ---- Winograd F(2x2,3x3) path (csrc/conv_wino.hip) ---------------------------------------------------------------------
 WINO = __import__('os').environ.get('ADVMIX_WINO', '1') != '0'       # A/B switch: 0 = every conv on the direct kernels
 WINO_MIN_WGS = int(__import__('os').environ.get('ADVMIX_WINO_MIN_WGS', '96'))   # workgroups (32 tiles x 32 channels) below which the direct kernel stays
+WINO_ASYNC = __import__('os').environ.get('ADVMIX_WINO_ASYNC', '1') != '0'   # filter transforms beside the stem (plan.PlanNet._wino_refresh; 0 = on the caller's stream)
 SMAP = __import__('os').environ.get('ADVMIX_SMAP', '1') != '0'       # A/B switch: 0 = the small 256-channel maps on the direct kernel
 SMAP_C = 256                                                         # (csrc/conv_smap.hip: one workgroup per image, K split over its eight waves)
 SMAP_WINO = __import__('os').environ.get('ADVMIX_SMAP_WINO', '1') != '0'   # Winograd F(2x2,3x3) inside that workgroup shape (conv_smapw; 0 = the direct form)

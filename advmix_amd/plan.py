@@ -622,12 +622,14 @@ class PlanNet(nn.Module):
             return
         names = getattr(self, '_wino_names', None)
         if names is None:
-            names = []
-            for sts in self._levels:
+            names, self._wino_first_level = [], None
+            for li, sts in enumerate(self._levels):
                 for st in sts:
                     for sub in (st[1] if st[0] == 'chain' else (st,)):
                         if sub[0] == 'convbn' and sub[5] == 1 and sub[6] == 1:
                             names.append(sub[1] + '.weight')
+                            if self._wino_first_level is None:
+                                self._wino_first_level = li    # (the stem's strided convs come first)
             self._wino_names = names
         T = self._tensors()
         ws = [T[n] for n in names]
@@ -653,7 +655,18 @@ class PlanNet(nn.Module):
             bank.static_key = key
         else:
             bank.static_key = None
-        bank.refresh()
+        first = self._wino_first_level or 0
+        if ops.WINO_ASYNC and first > 0:
+            # the ~125 us of filter transforms run on a launch-lane stream BESIDE the levels that need no image (the stem);
+            # PlanRun joins it before the first level with such a conv.  (The side stream first waits for the caller's:
+            # the optimizer step that wrote the filters, and every earlier reader of the images, are behind it.)
+            cur = torch.cuda.current_stream(device)
+            side = ops._lanes(device, 1)[0]
+            side.wait_stream(cur)
+            bank.refresh(ops.ctypes.c_void_p(side.cuda_stream))
+            self._wino_pending = (side, first)
+        else:
+            bank.refresh()
 
     def begin(self, x):
         """Start a level-by-level execution (see PlanRun)."""
@@ -686,6 +699,10 @@ class PlanRun:
         return self.li >= len(self.net._levels)
 
     def members(self):
+        pend = getattr(self.net, '_wino_pending', None)
+        if pend is not None and self.li >= pend[1]:         # the filter images are needed from this level on (see _wino_refresh)
+            torch.cuda.current_stream(pend[0].device).wait_stream(pend[0])
+            self.net._wino_pending = None
         return [self.net._member(st, self.slots, self.T, self.train) for st in self.net._levels[self.li]]
 
     def consume(self, outs):

@@ -18,11 +18,11 @@
 //     straight into the MFMA A-fragment layout (lane = tile, 16 bytes = 4 channels) with bounds-checked buffer loads -
 //     an out-of-image pixel returns 0.0f.  Per 8-channel group: 8 + 4 sixteen-byte loads, 32 additions, 16 MFMAs.
 //   * Inverse transform: the column half (A applied from the right) stays inside the wave's accumulators; the row half
-//     (A^T from the left) adds across the four waves through LDS - one exchange per workgroup.  Wave w then holds output
-//     position (w / 2, w % 2) of the 32 tiles in the accumulator layout and runs the SAME fused epilogues as conv_direct:
-//     BatchNorm column sums (fp64 slots), eval-mode BatchNorm + residual + activation, or - input-gradient role - addend,
-//     activation slope from the bit mask / from c, BatchNorm-backward sums; 16-byte stores through a wave-private
-//     transposer.
+//     (A^T from the left) adds across the four waves through LDS - one exchange per workgroup, written as a [tile][channel]
+//     image, so that what comes out is the NATURAL layout: thread = (tile, output position, 4 channels).  There the SAME
+//     fused epilogues as conv_direct run with 16-byte operand loads and stores and no transposer: BatchNorm column sums (fp64
+//     slots), eval-mode BatchNorm + residual + activation, or - input-gradient role - addend, activation slope from the bit
+//     mask / from c, BatchNorm-backward sums.
 #include "common.h"
 #include <stdio.h>
 
@@ -31,7 +31,6 @@ namespace wino {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB = 0x80000000u;      // >= any buffer size accepted -> loads return 0, stores are dropped
 constexpr int STORE_AUX = 16;              // sc1 (write-through), as conv_direct's epilogue
-constexpr int TP = 36;                     // pitch of the wave-private transposer (floats)
 
 struct WinoP {
     const float* x;
@@ -74,7 +73,7 @@ struct Geo {
     static constexpr int HALF = LBW == 3 ? 10 : (LBW == 2 ? 5 : (LBW == 4 ? 20 : PW / 2));
     static constexpr int PWL = 2 * HALF, PP = C + 4;
     static constexpr int PATCH = PH * PWL * PP;             // floats
-    static constexpr int XCH = KS * 4 * 2 * 4 * 64 * 4;     // floats of the inverse transform's exchange
+    static constexpr int XCH = KS * 4 * 2 * 32 * 40;        // floats of the inverse transform's exchange image ([wave][b][32 tiles][40])
     static constexpr int LDS = PATCH > XCH ? PATCH : XCH;
 };
 
@@ -95,14 +94,12 @@ __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS>())) void conv_wi
     // one region, four lives (separated by workgroup barriers): the input patch, the exchange of the inverse transform's
     // row half ([wave][b][r / 4][lane][4]), then the wave-private transposers of the epilogue
     __shared__ __attribute__((aligned(16))) float L[G::LDS];
-    __shared__ float sred[2 * 4 * 32];
+    __shared__ float sred[2 * 4 * KS * 32];
     float* const X = L;
-    float* const Ts = L;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int wid = wv & 3, kh = wv >> 2;                  // row of the transformed patch this wave multiplies; its share of K
-    const bool fin = kh == 0;                               // the four waves that finish an output position each
     const int l31 = lane & 31, lh = lane >> 5;
     int bm = blockIdx.x;
     if (p.xcd_remap && (gridDim.x & 7) == 0 && gridDim.x >= 16)            // each XCD (and its L2) works through a contiguous
@@ -149,10 +146,6 @@ __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS>())) void conv_wi
 
     // ---- this lane's tile ------------------------------------------------------------------------------------------
     const int bxl = l31 & (BW - 1), byl = l31 >> LBW;
-    const int ty = bby * BH + byl, tx = bbx * BW + bxl;
-    const bool tok = ty < p.Ht && tx < p.Wt;
-    const int pb = tok ? (img * p.H + 2 * ty) * p.W + 2 * tx : -1;         // pixel of the tile's output (0, 0)
-    const unsigned vmask = (unsigned)__ballot(tok);                         // bit t: tile t of the block exists
 
     // wave i multiplies row i of B^T d B:   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]  ->  d[ra] + sg * d[rb]
     const int ra = wid == 0 ? 0 : (wid == 2 ? 2 : 1);
@@ -199,157 +192,140 @@ __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS>())) void conv_wi
     }
 
     // ---- inverse transform, column half (inside the wave):  M A,  A^T = [1 1 1 0; 0 1 -1 -1] ---------------------------
-    const int oa_ = wid >> 1, ob_ = wid & 1;                // the output position this wave finishes
-    // epilogue read operands (residual / addend, the producer's c, its activation mask): requested now, they arrive under the
-    // exchange.  Chunk qq of the 16-byte view = tile rows 8 qq .. 8 qq + 7 x 32 columns, lane -> (row 8 qq + lane / 8, 4 columns).
+    // From here on the workgroup works in the NATURAL layout: item = (tile, output position (oa, ob) of its 2 x 2, 4 consecutive
+    // channels); thread tid owns items tid + NT k, all with the same channel quad cq = tid % 8.  (Until round 5's last kernels
+    // the four finishing waves kept the MFMA accumulator layout - one column, 16 scattered rows per lane - and moved every
+    // read operand and the result through wave-private LDS transposers: 80 LDS operations and five dependent round trips per
+    // lane for the BatchNorm-backward role; here the exchange image itself is the transposer: 32 four-byte writes, 3 KS
+    // sixteen-byte reads per item, operands and stores straight from / to memory in 16-byte pieces.)
+    constexpr int XP = 40;                                  // pitch of a tile row in the exchange image [wave][b][32 tiles][XP]
+    constexpr int NI = 1024 / NT;                           // items per thread (32 tiles x 4 positions x 8 quads)
+    static_assert(KS * 4 * 2 * 32 * XP <= G::LDS, "the exchange image fits the region");
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.ybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.y), 0, p.ybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bnb_c ? p.bnb_c : p.y), 0, p.ybytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t mkr = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.bnb_mask ? (const void*)p.bnb_mask : (const void*)p.y), 0, p.ybytes >> 4, 0x00020000);
-    const int pos = oa_ * p.W + ob_;
-    unsigned co4[4];
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-        const int pq = __shfl(pb, 8 * qq + (lane >> 3), 64);
-        co4[qq] = (pq >= 0 && n0 + ((lane & 7) << 2) < p.Co) ? (unsigned)(((pq + pos) * p.Co + n0 + ((lane & 7) << 2)) * 4) : OOB;
-    }
     const bool bnb = ROLE == 1 && p.bnb_c != nullptr;
-    const bool bnbf = bnb && fin;
-    const bool op_a = fin && p.res != nullptr;
     const bool mask_on = bnb && p.bnb_mask != nullptr && p.bnb_act != ADVMIX_ACT_NONE;
-    f32x4 pq_a[4], pq_c[4];
+    const int cq = tid & 7;
+    const int col = n0 + 4 * cq;
+    const bool cvalid = col < p.Co;                         // (Co = 48: the second column tile is half empty - its filters are zero)
+    unsigned yo[NI];
+    int pixv[NI];
+    f32x4 oa4[NI], oc4[NI];
+    unsigned mb[NI];
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-        pq_a[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
-        pq_c[qq] = pq_a[qq];
-        if (op_a) pq_a[qq] = bload(rr, co4[qq]);
-        if (ROLE == 1 && bnbf) pq_c[qq] = bload(cr, co4[qq]);
+    for (int k = 0; k < NI; ++k) {
+        const int tp = (tid + NT * k) >> 3;                 // 0 .. 127: tile = tp / 4, position = tp % 4
+        const int tl = tp >> 2, oa = (tp >> 1) & 1, ob = tp & 1;
+        const int ty = bby * BH + (tl >> LBW), tx = bbx * BW + (tl & (BW - 1));
+        const bool ok = ty < p.Ht && tx < p.Wt && cvalid;
+        const int pix = (img * p.H + 2 * ty + oa) * p.W + 2 * tx + ob;
+        pixv[k] = ok ? pix : -1;
+        yo[k] = ok ? (unsigned)((pix * p.Co + col) * 4) : OOB;
+        oa4[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        oc4[k] = oa4[k];
+        mb[k] = 0u;
+        if (p.res != nullptr) oa4[k] = bload(rr, yo[k]);     // requested now, they arrive under the exchange
+        if (ROLE == 1 && bnb) oc4[k] = bload(cr, yo[k]);
+        if (ROLE == 1 && mask_on && ok) mb[k] = p.bnb_mask[(int64_t)pix * (p.Co >> 2) + (col >> 2)];   // bit e: channel col + e
     }
-    unsigned mw = 0u;
-    if (ROLE == 1 && mask_on && fin)       // lane (l31, lh): the 16 channels [16 lh, 16 lh + 16) of ITS tile's pixel = 4 mask bytes
-        mw = __builtin_amdgcn_raw_buffer_load_b32(mkr, (pb >= 0 && n0 + 16 * lh < p.Co) ? (unsigned)((pb + pos) * (p.Co >> 2) + ((n0 + 16 * lh) >> 2)) : OOB, 0, 0);
 
-    __syncthreads();                                        // every wave is done with the patch: the region becomes the exchange
+    __syncthreads();                                        // every wave is done with the patch: the region becomes the exchange image
     {
-        f32x16 t0, t1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            t0[r] = (acc[0][r] + acc[1][r]) + acc[2][r];
-            t1[r] = (acc[1][r] - acc[2][r]) - acc[3][r];
-        }
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            *reinterpret_cast<f32x4*>(&X[(((wv * 2 + 0) * 4 + r4) * 64 + lane) * 4]) = f32x4{t0[4 * r4], t0[4 * r4 + 1], t0[4 * r4 + 2], t0[4 * r4 + 3]};
-            *reinterpret_cast<f32x4*>(&X[(((wv * 2 + 1) * 4 + r4) * 64 + lane) * 4]) = f32x4{t1[4 * r4], t1[4 * r4 + 1], t1[4 * r4 + 2], t1[4 * r4 + 3]};
+            const float t0 = (acc[0][r] + acc[1][r]) + acc[2][r];
+            const float t1 = (acc[1][r] - acc[2][r]) - acc[3][r];
+            const int row = acc_row(r, lh);                 // D[tile row][column l31]
+            X[((wv * 2 + 0) * 32 + row) * XP + l31] = t0;
+            X[((wv * 2 + 1) * 32 + row) * XP + l31] = t1;
         }
     }
     __syncthreads();
-    // ---- row half (across the waves):  Y[0][b] = T0 + T1 + T2,  Y[1][b] = T1 - T2 - T3 -----------------------------------
-    float yv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) yv[r] = 0.f;
-    if (fin) {
-        const float s = oa_ ? -1.f : 1.f;
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-#pragma unroll
-            for (int k = 0; k < KS; ++k) {                  // (the K shares of the wave sets add up here)
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(&X[((((4 * k + oa_ + 0) * 2 + ob_) * 4 + r4) * 64 + lane) * 4]);
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(&X[((((4 * k + oa_ + 1) * 2 + ob_) * 4 + r4) * 64 + lane) * 4]);
-                const f32x4 x2 = *reinterpret_cast<const f32x4*>(&X[((((4 * k + oa_ + 2) * 2 + ob_) * 4 + r4) * 64 + lane) * 4]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) yv[4 * r4 + e] += __builtin_fmaf(s, x1[e] + x2[e], x0[e]);
-            }
-        }
-    }
-
-    __syncthreads();                                        // the exchange has been read: the region becomes the transposers
-    // ---- fused epilogue (conv_direct.hip's, for one tile per wave) -----------------------------------------------------
+    // ---- row half (across the waves) and the fused epilogue (conv_direct.hip's arithmetic), per item -----------------------
     const bool stats = p.stats != nullptr;
-    float s1 = 0.f, s2 = 0.f;
-    if (fin) {                                              // (KS > 1: the other wave sets only keep the barriers company)
-    float* const Tx = Ts + wid * (32 * TP);
-    auto wave_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
-    auto to_acc_layout = [&](const f32x4 (&q)[4], float (&o)[16]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<f32x4*>(&Tx[(8 * i + (lane >> 3)) * TP + ((lane & 7) << 2)]) = q[i];
-        wave_fence();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = Tx[acc_row(r, lh) * TP + l31];
-        wave_fence();
-    };
-    float oa[16], oc[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { oa[r] = 0.f; oc[r] = 0.f; }
-    if (op_a) to_acc_layout(pq_a, oa);
-    if (ROLE == 1 && bnbf) to_acc_layout(pq_c, oc);
-
-    const bool cvalid = n0 + l31 < p.Co;                    // (Co = 48: the second column tile is half empty - its filters are zero)
-    const int col = cvalid ? n0 + l31 : 0;
-    float bn_is = 1.f, bn_g = 1.f, bn_b = 0.f, bn_m = 0.f;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     const bool bnf = ROLE == 0 && p.bn_gamma != nullptr;
-    if (bnf) {
-        bn_is = 1.0f / sqrtf(p.bn_rv[col] + p.bn_eps);
-        bn_g = p.bn_gamma[col]; bn_b = p.bn_beta[col]; bn_m = p.bn_rm[col];
-    }
-    float bb_mu = 0.f, bb_is = 0.f, bb_g = 0.f, bb_b = 0.f;
-    if (ROLE == 1 && bnb) { bb_mu = p.bnb_mean[col]; bb_is = p.bnb_invstd[col]; }
     const bool recompute = ROLE == 1 && bnb && !mask_on && p.bnb_act != ADVMIX_ACT_NONE;
-    if (recompute) { bb_g = p.bnb_gamma[col]; bb_b = p.bnb_beta[col]; }
     const float bb_slope = act_neg_slope(p.bnb_act);
-    const int mshift = ((l31 >> 2) & 3) * 8 + (l31 & 3);    // this lane's column within its mask word
+    const int colc = cvalid ? col : 0;
+    f32x4 bn_is = {1.f, 1.f, 1.f, 1.f}, bn_g = bn_is, bn_b = {0.f, 0.f, 0.f, 0.f}, bn_m = bn_b;
+    if (bnf) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, lh);
-        const bool valid = ((vmask >> row) & 1u) && cvalid;
-        float v = yv[r];
-        if (ROLE == 0) {
-            if (valid) { s1 += v; s2 += v * v; }
-            if (bnf) v = (v - bn_m) * bn_is * bn_g + bn_b;
-            if (op_a) v += oa[r];
-            v = act_fwd(v, p.act);
-        } else {
-            if (op_a) v += oa[r];
-            if (bnb) {
-                const float xh = (oc[r] - bb_mu) * bb_is;
-                if (mask_on) {                              // (wave-uniform: every lane takes part in the permute)
-                    const int src = row + ((l31 & 16) << 1);
-                    const unsigned wv = (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)mw);
-                    v = ((wv >> mshift) & 1u) ? v : v * bb_slope;
-                } else if (recompute) {
-                    v = __builtin_fmaf(xh, bb_g, bb_b) > 0.f ? v : v * bb_slope;
-                }
-                if (valid) { s1 += v; s2 += v * xh; }
-            }
+        for (int e = 0; e < 4; ++e) {
+            bn_is[e] = 1.0f / sqrtf(p.bn_rv[colc + e] + p.bn_eps);
+            bn_g[e] = p.bn_gamma[colc + e]; bn_b[e] = p.bn_beta[colc + e]; bn_m[e] = p.bn_rm[colc + e];
         }
-        yv[r] = v;
+    }
+    f32x4 bb_mu = {0.f, 0.f, 0.f, 0.f}, bb_is = bb_mu, bb_g = bb_mu, bb_b = bb_mu;
+    if (ROLE == 1 && bnb) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bb_mu[e] = p.bnb_mean[colc + e]; bb_is[e] = p.bnb_invstd[colc + e];
+            if (recompute) { bb_g[e] = p.bnb_gamma[colc + e]; bb_b[e] = p.bnb_beta[colc + e]; }
+        }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Tx[acc_row(r, lh) * TP + l31] = yv[r];
-    wave_fence();
+    for (int k = 0; k < NI; ++k) {
+        const int tp = (tid + NT * k) >> 3;
+        const int tl = tp >> 2, oa = (tp >> 1) & 1, ob = tp & 1;
+        const float sg2 = oa ? -1.f : 1.f;                  // Y[0][b] = T0 + T1 + T2,  Y[1][b] = T1 - T2 - T3
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(&Tx[(8 * qq + (lane >> 3)) * TP + ((lane & 7) << 2)]);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, w4), yr, co4[qq], 0, STORE_AUX);
-    }
+        for (int kk = 0; kk < KS; ++kk) {                   // (the K shares of the wave sets add up here)
+            const float* const xp = &X[(((4 * kk + oa) * 2 + ob) * 32 + tl) * XP + 4 * cq];
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(xp + 2 * 32 * XP);
+            const f32x4 x2 = *reinterpret_cast<const f32x4*>(xp + 4 * 32 * XP);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += __builtin_fmaf(sg2, x1[e] + x2[e], x0[e]);
+        }
+        const bool valid = pixv[k] >= 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float o = v[e];
+            if (ROLE == 0) {
+                if (valid) { s1[e] += o; s2[e] += o * o; }
+                if (bnf) o = (o - bn_m[e]) * bn_is[e] * bn_g[e] + bn_b[e];
+                o += oa4[k][e];
+                o = act_fwd(o, p.act);
+            } else {
+                o += oa4[k][e];
+                if (bnb) {
+                    const float xh = (oc4[k][e] - bb_mu[e]) * bb_is[e];
+                    if (mask_on) o = ((mb[k] >> e) & 1u) ? o : o * bb_slope;
+                    else if (recompute) o = __builtin_fmaf(xh, bb_g[e], bb_b[e]) > 0.f ? o : o * bb_slope;
+                    if (valid) { s1[e] += o; s2[e] += o * xh; }
+                }
+            }
+            v[e] = o;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yo[k], 0, STORE_AUX);
     }
     if (stats) {                                            // uniform over the grid
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (lh == 0 && fin) {
-            sred[wid * 32 + l31] = s1;
-            sred[(4 + wid) * 32 + l31] = s2;
+        // a wave = 8 (tile, position) items x 8 channel quads (lane = 8 i + cq): the items add up by shuffles, the waves in LDS
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int d = 8; d < 64; d <<= 1) {
+                s1[e] += __shfl_xor(s1[e], d, 64);
+                s2[e] += __shfl_xor(s2[e], d, 64);
+            }
+        }
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sred[wv * 32 + 4 * lane + e] = s1[e];
+                sred[(4 * KS + wv) * 32 + 4 * lane + e] = s2[e];
+            }
         }
         __syncthreads();
         if (tid < 32) {
             double d1 = 0.0, d2 = 0.0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 4 * KS; ++k) {
                 d1 += (double)sred[k * 32 + tid];
-                d2 += (double)sred[(4 + k) * 32 + tid];
+                d2 += (double)sred[(4 * KS + k) * 32 + tid];
             }
             const int sl = (int)blockIdx.x % p.stats_nbg;  // slot-major [2][slots][Co]: consecutive doubles per workgroup
             if (n0 + tid < p.Co) {

@@ -7,7 +7,7 @@ for rep in 1 2; do
   for spec in "${SPECS[@]}"; do
     WL=${spec% *}; ST=${spec#* }
     for tree in $OLD now; do
-      if [ $tree = now ]; then cd $R; EXTRA="--no-through-loop"; else cd $R/tools/_dbg/${OLD}tree; EXTRA=""; fi
+      if [ $tree = now ]; then cd $R; EXTRA="--no-through-loop"; else cd $R/tools/_dbg/${OLD}tree; EXTRA="--no-through-loop"; fi
       python bench.py --workload $WL --no-cpu-baseline --no-roofline --steps $ST --warmup 5 $EXTRA 2>/dev/null | tail -1 | \
         python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tree $WL', d['value'], d['ms_per_step'])" >> $R/$OUT
       cd $R

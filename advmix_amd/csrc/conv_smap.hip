@@ -115,20 +115,33 @@ __device__ __forceinline__ void epi_finish(const SP& p, f32x4 v, const EpiOps& o
     const bool recompute = ROLE == 1 && bnb && !mask_on && p.bnb_act != ADVMIX_ACT_NONE;
     const float bb_slope = act_neg_slope(p.bnb_act);
     const int col = o.col;
+    auto ld4 = [&](const float* q) { return *reinterpret_cast<const f32x4*>(q + col); };    // (col % 4 == 0: one 16-byte load)
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bn_is = z4, bn_g = z4, bn_b = z4, bn_m = z4, bb_mu = z4, bb_is = z4, bb_g = z4, bb_b = z4;
+    if (bnf) {
+        const f32x4 rv = ld4(p.bn_rv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bn_is[e] = 1.0f / sqrtf(rv[e] + p.bn_eps);
+        bn_g = ld4(p.bn_gamma); bn_b = ld4(p.bn_beta); bn_m = ld4(p.bn_rm);
+    }
+    if (ROLE == 1 && bnb) {
+        bb_mu = ld4(p.bnb_mean); bb_is = ld4(p.bnb_invstd);
+        if (recompute) { bb_g = ld4(p.bnb_gamma); bb_b = ld4(p.bnb_beta); }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         float x = v[e];
         if (ROLE == 0) {
             if (o.live) { s1[e] = x; s2[e] = x * x; }
-            if (bnf) x = (x - p.bn_rm[col + e]) * (1.0f / sqrtf(p.bn_rv[col + e] + p.bn_eps)) * p.bn_gamma[col + e] + p.bn_beta[col + e];
+            if (bnf) x = (x - bn_m[e]) * bn_is[e] * bn_g[e] + bn_b[e];
             x += o.oa[e];
             x = act_fwd(x, p.act);
         } else {
             x += o.oa[e];
             if (bnb) {
-                const float xh = (o.oc[e] - p.bnb_mean[col + e]) * p.bnb_invstd[col + e];
+                const float xh = (o.oc[e] - bb_mu[e]) * bb_is[e];
                 if (mask_on) x = ((o.mbits >> e) & 1u) ? x : x * bb_slope;
-                else if (recompute) x = __builtin_fmaf(xh, p.bnb_gamma[col + e], p.bnb_beta[col + e]) > 0.f ? x : x * bb_slope;
+                else if (recompute) x = __builtin_fmaf(xh, bb_g[e], bb_b[e]) > 0.f ? x : x * bb_slope;
                 if (o.live) { s1[e] = x; s2[e] = x * xh; }
             }
         }

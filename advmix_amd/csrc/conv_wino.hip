@@ -250,20 +250,17 @@ __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS>())) void conv_wi
     const float bb_slope = act_neg_slope(p.bnb_act);
     const int colc = cvalid ? col : 0;
     f32x4 bn_is = {1.f, 1.f, 1.f, 1.f}, bn_g = bn_is, bn_b = {0.f, 0.f, 0.f, 0.f}, bn_m = bn_b;
+    auto ld4 = [&](const float* q) { return *reinterpret_cast<const f32x4*>(q + colc); };   // (colc % 4 == 0: one 16-byte load)
     if (bnf) {
+        const f32x4 rv = ld4(p.bn_rv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            bn_is[e] = 1.0f / sqrtf(p.bn_rv[colc + e] + p.bn_eps);
-            bn_g[e] = p.bn_gamma[colc + e]; bn_b[e] = p.bn_beta[colc + e]; bn_m[e] = p.bn_rm[colc + e];
-        }
+        for (int e = 0; e < 4; ++e) bn_is[e] = 1.0f / sqrtf(rv[e] + p.bn_eps);
+        bn_g = ld4(p.bn_gamma); bn_b = ld4(p.bn_beta); bn_m = ld4(p.bn_rm);
     }
     f32x4 bb_mu = {0.f, 0.f, 0.f, 0.f}, bb_is = bb_mu, bb_g = bb_mu, bb_b = bb_mu;
     if (ROLE == 1 && bnb) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            bb_mu[e] = p.bnb_mean[colc + e]; bb_is[e] = p.bnb_invstd[colc + e];
-            if (recompute) { bb_g[e] = p.bnb_gamma[colc + e]; bb_b[e] = p.bnb_beta[colc + e]; }
-        }
+        bb_mu = ld4(p.bnb_mean); bb_is = ld4(p.bnb_invstd);
+        if (recompute) { bb_g = ld4(p.bnb_gamma); bb_b = ld4(p.bnb_beta); }
     }
 #pragma unroll
     for (int k = 0; k < NI; ++k) {

@@ -39,6 +39,10 @@ SIGNATURES = {
     'advmix_wino_weights': [_p, _p, _i, _p],
     'advmix_conv3x3_wino_fwd': [_p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _f, _p, _i, _p, _p, _p],
     'advmix_conv3x3_wino_dgrad': [_p, _p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p],
+    'advmix_conv_pw_config': [_i] * 5,
+    'advmix_pw_weights': [_p, _p, _i, _p],
+    'advmix_conv1x1_pw_fwd': [_p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _f, _p, _i, _p, _p, _p],
+    'advmix_conv1x1_pw_dgrad': [_p, _p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p],
     'advmix_conv_smap_config': [_i] * 5,
     'advmix_conv_smapw_config': [_i] * 5,
     'advmix_smapw_weights': [_p, _p, _i, _p],
@@ -119,6 +123,8 @@ lib.advmix_wino_u_floats.argtypes = [_i, _i]
 lib.advmix_wino_u_floats.restype = ctypes.c_int64
 lib.advmix_smapw_u_floats.argtypes = [_i, _i]
 lib.advmix_smapw_u_floats.restype = ctypes.c_int64
+lib.advmix_pw_u_floats.argtypes = [_i, _i]
+lib.advmix_pw_u_floats.restype = ctypes.c_int64
 lib.advmix_smap_u_floats.argtypes = [_i, _i]
 lib.advmix_smap_u_floats.restype = ctypes.c_int64
 lib.advmix_wgrad_det_ws_bytes.argtypes = [_i, _i, _i, _i]

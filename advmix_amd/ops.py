@@ -381,6 +381,7 @@ def _det_stats(C, device, lane):
 WINO = __import__('os').environ.get('ADVMIX_WINO', '1') != '0'       # A/B switch: 0 = every conv on the direct kernels
 WINO_MIN_WGS = int(__import__('os').environ.get('ADVMIX_WINO_MIN_WGS', '96'))   # workgroups (32 tiles x 32 channels) below which the direct kernel stays
 WINO_ASYNC = __import__('os').environ.get('ADVMIX_WINO_ASYNC', '1') != '0'   # filter transforms beside the stem (plan.PlanNet._wino_refresh; 0 = on the caller's stream)
+PW = __import__('os').environ.get('ADVMIX_PW', '1') != '0'           # A/B switch: 0 = the 64 -> 256 1x1 convs of the bottlenecks on the direct kernel (csrc/conv_pw.hip)
 SMAP = __import__('os').environ.get('ADVMIX_SMAP', '1') != '0'       # A/B switch: 0 = the small 256-channel maps on the direct kernel
 SMAP_C = 256                                                         # (csrc/conv_smap.hip: one workgroup per image, K split over its eight waves)
 SMAP_WINO = __import__('os').environ.get('ADVMIX_SMAP_WINO', '1') != '0'   # Winograd F(2x2,3x3) inside that workgroup shape (conv_smapw; 0 = the direct form)
@@ -403,28 +404,31 @@ class WinoBank:
         pad32 = lambda c: (c + 31) // 32 * 32                # noqa: E731  (the n dimension is padded to whole column tiles)
         # kind 'smap' (csrc/conv_smap.hip): filters with 256 input channels, plain re-layout in that kernel's fragment order (9 Co Ci floats
         # per image); everything else 'wino'
-        kinds = [('smapw' if SMAP_WINO else 'smap') if (w.shape[1] == SMAP_C and w.shape[0] % 32 == 0) else 'wino' for w in weights]   # (input-gradient images only where Cout == 256 too)
+        kinds = ['pw' if tuple(w.shape[2:]) == (1, 1) else
+                 ('smapw' if SMAP_WINO else 'smap') if (w.shape[1] == SMAP_C and w.shape[0] % 32 == 0) else 'wino' for w in weights]   # (input-gradient images only where Cout == 256 too)
         sizes = [(9 * w.shape[0] * w.shape[1],) * 2 if k == 'smap' else (16 * w.shape[0] * w.shape[1],) * 2 if k == 'smapw' else
+                 (w.shape[0] * w.shape[1],) * 2 if k == 'pw' else
                  (16 * pad32(w.shape[0]) * w.shape[1], 16 * pad32(w.shape[1]) * w.shape[0]) for w, k in zip(weights, kinds)]
         self.buf = torch.empty(sum(a + b for a, b in sizes), device=dev, dtype=torch.float32)
         rec = np.dtype([('w', '<u8'), ('u', '<u8'), ('Cn', '<i4'), ('Ck', '<i4'), ('role', '<i4'), ('blk0', '<i4')])
-        ents = {'wino': [], 'smap': [], 'smapw': []}
-        blk = {'wino': 0, 'smap': 0, 'smapw': 0}
-        owner = {'wino': [], 'smap': [], 'smapw': []}
+        ents = {'wino': [], 'smap': [], 'smapw': [], 'pw': []}
+        blk = {'wino': 0, 'smap': 0, 'smapw': 0, 'pw': 0}
+        owner = {'wino': [], 'smap': [], 'smapw': [], 'pw': []}
         off = 0
         self._tagged = []
         for i, (w, kind) in enumerate(zip(weights, kinds)):
             Co, Ci, R, S = w.shape
-            if (R, S) != (3, 3) or Co % 16 or Ci % 16 or not w.is_contiguous(memory_format=_CL):
-                raise ValueError('WinoBank: 3x3 channels_last weights with Cout, Cin multiples of 16')
+            if (R, S) not in ((3, 3), (1, 1)) or Co % 16 or Ci % 16 or not w.is_contiguous(memory_format=_CL):
+                raise ValueError('WinoBank: 3x3 / 1x1 channels_last weights with Cout, Cin multiples of 16')
             ptrs = []
             for role, (Cn, Ck) in enumerate(((Co, Ci), (Ci, Co))):
                 u = self.buf.data_ptr() + 4 * off
                 off += sizes[i][role]
-                if kind != 'wino' and Ck != SMAP_C:          # (the small-map kernels read exactly 256 channels: no such image)
+                if (kind in ('smap', 'smapw') and Ck != SMAP_C) or (kind == 'pw' and (Cn, Ck) != (256, 64)):
+                    # (the small-map kernels read exactly 256 channels, conv_pw reads 64 and writes 256: no such image)
                     ptrs.append(None)
                     continue
-                nb = {'wino': ((Cn + 31) // 32) * (Ck // 8), 'smap': (Cn // 32) * (Ck // 32) * 36, 'smapw': (Cn // 32) * 32}[kind]
+                nb = {'wino': ((Cn + 31) // 32) * (Ck // 8), 'smap': (Cn // 32) * (Ck // 32) * 36, 'smapw': (Cn // 32) * 32, 'pw': 64}[kind]
                 owner[kind] += [len(ents[kind])] * nb
                 ents[kind].append((w.data_ptr(), u, Cn, Ck, role, blk[kind]))
                 blk[kind] = len(owner[kind])
@@ -432,7 +436,7 @@ class WinoBank:
             w._wino = (self.buf, ptrs[0], ptrs[1], w.data_ptr(), kind)     # (the tag keeps the side buffer alive)
             self._tagged.append(weakref.ref(w))
         self.tables = {}
-        for kind in ('wino', 'smap', 'smapw'):
+        for kind in ('wino', 'smap', 'smapw', 'pw'):
             if ents[kind]:
                 ent = np.array(ents[kind], dtype=rec)
                 self.tables[kind] = (torch.from_numpy(ent.view(np.uint8).copy()).to(dev),
@@ -468,15 +472,22 @@ def _wino_tag(w):
 
 _W3 = {'wino': (lib.advmix_conv3x3_wino_fwd, lib.advmix_conv3x3_wino_dgrad),      # (forward, input gradient) entry points per image kind
        'smap': (lib.advmix_conv3x3_smap_fwd, lib.advmix_conv3x3_smap_dgrad),
-       'smapw': (lib.advmix_conv3x3_smapw_fwd, lib.advmix_conv3x3_smapw_dgrad)}
+       'smapw': (lib.advmix_conv3x3_smapw_fwd, lib.advmix_conv3x3_smapw_dgrad),
+       'pw': (lib.advmix_conv1x1_pw_fwd, lib.advmix_conv1x1_pw_dgrad)}
 
 
 def _wino_images(w, B, H, W, Ci, Co, R, S, stride, pad):
     """(forward image, input-gradient image) of ``w`` when this problem goes to the Winograd kernel, else None."""
-    if not (WINO and R == 3 and S == 3 and stride == 1 and pad == 1) or DETERMINISTIC or not _direct_ok():
+    if not WINO or DETERMINISTIC or not _direct_ok() or stride != 1:
         return None
     tag = _wino_tag(w)
     if tag is None:
+        return None
+    if (R, S, pad) == (1, 1, 0):                            # 64 -> 256 over many pixels: the streaming kernel (csrc/conv_pw.hip)
+        if tag[4] != 'pw' or not PW or lib.advmix_conv_pw_config(B, H, W, Ci, Co) < WINO_MIN_WGS:
+            return None
+        return tag[1], tag[2], 'pw'
+    if (R, S, pad) != (3, 3, 1) or tag[4] == 'pw':
         return None
     if tag[4] != 'wino':                                    # 256 -> 256 on a map of <= 48 pixels: the image-per-workgroup kernels
         config = lib.advmix_conv_smapw_config if tag[4] == 'smapw' else lib.advmix_conv_smap_config
@@ -513,7 +524,7 @@ def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_
                 if rc == 0:
                     bnb['done'] = nsv.value
                     COUNTERS['bnb'] += 1
-                    COUNTERS[wu[2][:4]] = COUNTERS.get(wu[2][:4], 0) + 1     # ('wino' / 'smap': both small-map kernels count as smap)
+                    COUNTERS[wu[2][:4]] = COUNTERS.get(wu[2][:4], 0) + 1     # ('wino' / 'smap' / 'pw': both small-map kernels count as smap)
                     return dx
                 if rc != 1:
                     raise RuntimeError('advmix_conv3x3_wino_dgrad failed: %d' % rc)
@@ -539,7 +550,7 @@ def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_
             rc = _W3[wu[2]][1](_p(dy), wu[1], _p(add_to), _p(dx), B, Hi, Wi, Co, Ci, None, None, None, None,
                                                None, None, 0, None, None, st)
             if rc == 0:
-                COUNTERS[wu[2][:4]] = COUNTERS.get(wu[2][:4], 0) + 1     # ('wino' / 'smap': both small-map kernels count as smap)
+                COUNTERS[wu[2][:4]] = COUNTERS.get(wu[2][:4], 0) + 1     # ('wino' / 'smap' / 'pw': both small-map kernels count as smap)
                 return dx
             if rc != 1:
                 raise RuntimeError('advmix_conv3x3_wino_dgrad failed: %d' % rc)
@@ -743,7 +754,7 @@ class ConvBN:
                 rc = _W3[wu[2]][0](_p(x), wu[0], _p(y), B, Hi, Wi, Ci, Co, _p(gamma), _p(beta), _p(rmean),
                                                  _p(rvar), eps, _p(res), act, None, None, st)
                 if rc == 0:
-                    COUNTERS[wu[2][:4]] = COUNTERS.get(wu[2][:4], 0) + 1     # ('wino' / 'smap': both small-map kernels count as smap)
+                    COUNTERS[wu[2][:4]] = COUNTERS.get(wu[2][:4], 0) + 1     # ('wino' / 'smap' / 'pw': both small-map kernels count as smap)
             if rc == 1:
                 rc = lib.advmix_conv_fwd_ex(_p(x), _p(w), None, _p(y), *geom, _p(gamma), _p(beta), _p(rmean),
                                             _p(rvar), eps, _p(res), act, None, None, st) if fused_ok else 1
@@ -776,7 +787,7 @@ class ConvBN:
                 rc = _W3[wu[2]][0](_p(x), wu[0], _p(c), B, Hi, Wi, Ci, Co, None, None, None, None, 0.0, None, 0,
                                                  target, ctypes.byref(nbg), st)
                 if rc == 0:
-                    COUNTERS[wu[2][:4]] = COUNTERS.get(wu[2][:4], 0) + 1     # ('wino' / 'smap': both small-map kernels count as smap)
+                    COUNTERS[wu[2][:4]] = COUNTERS.get(wu[2][:4], 0) + 1     # ('wino' / 'smap' / 'pw': both small-map kernels count as smap)
             if rc == 1:
                 rc = lib.advmix_conv_fwd_ex(_p(x), _p(w), None, _p(c), *geom, None, None, None, None, 0.0, None, 0,
                                             target, ctypes.byref(nbg), st)

@@ -174,6 +174,26 @@ int advmix_conv3x3_smapw_dgrad(const float* dy, const float* u, const float* add
                                const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int act,
                                double* stats, int* stats_ns, void* stream);
 
+/* 1x1 / stride 1 convs reading 64 channels and writing 256 over many pixels (csrc/conv_pw.hip, round 5): the last conv and
+ * the shortcut of a Bottleneck forward, the input gradient of its first conv (pose_hrnet.py:59-98 on the 64x48 map: as much
+ * HBM time as MFMA time).  A workgroup = 128 pixels x all 256 channels, the input tile loaded once, filters read in MFMA
+ * fragment order from a side buffer (advmix_pw_weights, once per forward pass like the Winograd images), eight passes of 32
+ * channels with the fused epilogue in the natural layout after each.  advmix_conv_pw_config: 0 when not served (served: Ci ==
+ * 64 read, Co == 256 written), else the number of workgroups.  advmix_pw_u_floats: floats of one image (Co * Ci).
+ * advmix_pw_weights: records as advmix_wino_weights' (role 0: image of w[256][1][1][64] for the forward; role 1: image of
+ * w[64][1][1][256] for the input gradient), 64 workgroups each; u[n / 32][(k % 32) / 4][32 * (k / 32) + n % 32][k % 4].
+ * advmix_conv1x1_pw_fwd / _dgrad: the arguments and epilogues of advmix_conv3x3_wino_fwd / _dgrad. */
+int advmix_conv_pw_config(int N, int H, int W, int Ci, int Co);
+int64_t advmix_pw_u_floats(int Co, int Ci);
+int advmix_pw_weights(const void* ents, const int* blk_ent, int blocks, void* stream);
+int advmix_conv1x1_pw_fwd(const float* x, const float* u, float* y, int N, int H, int W, int Ci, int Co,
+                          const float* bn_gamma, const float* bn_beta, const float* bn_rm, const float* bn_rv,
+                          float bn_eps, const float* residual, int act, double* stats, int* stats_ns, void* stream);
+int advmix_conv1x1_pw_dgrad(const float* dy, const float* u, const float* addend, float* dx, int N, int H, int W,
+                            int Co, int Ci, const unsigned char* act_mask, const float* bn_c, const float* bn_mean,
+                            const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int act,
+                            double* stats, int* stats_ns, void* stream);
+
 /* Winograd weight gradient, F(3x3, 2x2) (csrc/wgrad_wino.hip, round 5): 16 multiplies per 2x2 tile of dy and channel pair
  * instead of 36.  advmix_wgrad_wino_config: 0 = not served (odd H / W, channels not multiples of 32 or > 256), else the
  * number of (32-tile block, 32 x 32 channel pair) units of one problem.  advmix_conv3x3_wgrad_wino_group: the weight

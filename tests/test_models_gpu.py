@@ -309,6 +309,7 @@ def test_network_parity_at_the_benchmarked_batch():
         and lib.advmix_conv_wino_config(B, 16, 12, 128, 128) == 256
     w0 = _ops_.COUNTERS.get('wino', 0)
     s0 = _ops_.COUNTERS.get('smap', 0)
+    p0 = _ops_.COUNTERS.get('pw', 0)
     mD.eval()
     with torch.no_grad():
         ye = mD(views[0].cuda())
@@ -316,6 +317,8 @@ def test_network_parity_at_the_benchmarked_batch():
     assert _ops_.COUNTERS.get('wino', 0) - w0 == 188, _ops_.COUNTERS
     # ... and stage 4's 24 convs 256 -> 256 @8x6 on the image-per-workgroup kernel (csrc/conv_smap.hip, 256 workgroups)
     assert _ops_.SMAP and lib.advmix_conv_smap_config(B, 8, 6, 256, 256) == 256 and _ops_.COUNTERS.get('smap', 0) - s0 == 24, _ops_.COUNTERS
+    # ... and layer1's 1x1 convs 64 -> 256 (four blocks' last conv + the shortcut) on the streaming kernel (csrc/conv_pw.hip, 768 workgroups)
+    assert _ops_.PW and lib.advmix_conv_pw_config(B, 64, 48, 64, 256) == 768 and _ops_.COUNTERS.get('pw', 0) - p0 == 5, _ops_.COUNTERS
     assert_close('eval out', ye, ye_ref, report=rep)
     assert_close('eval out vs golden', strided(ye.cpu().contiguous()), g[tag + '.eval_out'], report=rep)
     mD.train()                                            # train forward + FULL backward at the benchmarked tiles
@@ -327,6 +330,7 @@ def test_network_parity_at_the_benchmarked_batch():
     loss.backward()
     assert _ops_.COUNTERS.get('wino', 0) - w0 == 3 * 188, _ops_.COUNTERS     # + train forward + input gradients
     assert _ops_.COUNTERS.get('smap', 0) - s0 == 3 * 24, _ops_.COUNTERS
+    assert _ops_.COUNTERS.get('pw', 0) - p0 == 5 + 5 + 3, _ops_.COUNTERS       # + train forward + the input gradients of three 256 -> 64 convs
     # the small weight gradients of the fuse layers / transitions went out as mixed launches, none is left parked
     assert _ops_.COUNTERS.get('wgrad_multi', 0) - m0 >= 4 and not _ops_._WG_SMALL, (_ops_.COUNTERS, len(_ops_._WG_SMALL))
     names = _trainable(D)

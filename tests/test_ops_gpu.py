@@ -628,6 +628,14 @@ SMAP_CASES = [
     (2, 256, 256, 2, 2, 'smapw'),      # one tile, every pixel on the border
     (2, 256, 64, 8, 6, 'smapw'),       # forward only
 ]
+PW_CASES = [
+    # the streaming 1x1 kernel (conv_pw): forward of a 64 -> 256 conv, input gradient of a 256 -> 64 one
+    (32, 64, 256, 64, 48, 'pw'),       # the bottleneck's last conv at the bench batch: 768 workgroups
+    (32, 256, 64, 64, 48, 'pw'),       # its first conv: the gradient side
+    (3, 64, 256, 9, 7, 'pw'),          # 189 pixels: a ragged last workgroup
+    (3, 256, 64, 9, 7, 'pw'),
+    (1, 64, 256, 1, 1, 'pw'),
+]
 
 
 def _wino_images(w_dev):
@@ -639,7 +647,7 @@ def _wino_images(w_dev):
     return bank, uf, ud
 
 
-@pytest.mark.parametrize('case', WINO_CASES + SMAP_CASES)
+@pytest.mark.parametrize('case', WINO_CASES + SMAP_CASES + PW_CASES)
 def test_winograd_conv_all_roles(case, monkeypatch):
     """csrc/conv_wino.hip (round 5): the Winograd F(2x2,3x3) kernel in every role the step uses - forward + BatchNorm column
     sums, forward + eval-mode BatchNorm + residual + ReLU, input gradient + addend, input gradient + addend + BatchNorm-
@@ -655,13 +663,16 @@ def test_winograd_conv_all_roles(case, monkeypatch):
     d = dev()
     kind = case[5] if len(case) > 5 else ('smap' if Ci == 256 else 'wino')
     monkeypatch.setattr(ops_, 'SMAP_WINO', kind == 'smapw')  # (which images WinoBank makes for a 256-channel filter)
-    config, k_fwd, k_dgrad = (getattr(lib, n_ % kind) for n_ in ('advmix_conv_%s_config', 'advmix_conv3x3_%s_fwd', 'advmix_conv3x3_%s_dgrad'))
+    ks = 1 if kind == 'pw' else 3                           # (conv_pw: the 1x1 convs 64 -> 256 of the bottlenecks, csrc/conv_pw.hip)
+    config, k_fwd, k_dgrad = (getattr(lib, n_ % kind) for n_ in ('advmix_conv_%s_config', 'advmix_conv%dx%d_%%s_fwd' % (ks, ks),
+                                                                 'advmix_conv%dx%d_%%s_dgrad' % (ks, ks)))
+    has_fwd = config(B, H, W, Ci, Co) > 0                   # (conv_pw serves 64 -> 256 only: forward of such a conv, gradient of a 256 -> 64 one)
     has_dgrad = config(B, H, W, Co, Ci) > 0                 # (conv_smap reads exactly 256 channels: the gradient side needs Co == 256)
-    assert config(B, H, W, Ci, Co) > 0 and (has_dgrad or kind != 'wino')
+    assert (has_fwd or kind == 'pw') and (has_dgrad or kind != 'wino') and (has_fwd or has_dgrad)
     g_ = torch.Generator().manual_seed(23 + Ci + H)
     R = lambda *s_: torch.randn(*s_, generator=g_)
     x, dy = R(B, H, W, Ci), R(B, H, W, Co)
-    w = R(Co, 3, 3, Ci) * (9 * Ci) ** -0.5                 # [Co][R][S][Ci]
+    w = R(Co, ks, ks, Ci) * (ks * ks * Ci) ** -0.5         # [Co][R][S][Ci]
     res = R(B, H, W, Co)
     gamma, beta, rm, rv = R(Co).abs() + 0.5, R(Co) * 0.3, R(Co) * 0.2, R(Co).abs() + 0.4
     c_in, addend = R(B, H, W, Ci) * 1.5 + 0.3, R(B, H, W, Ci)      # the producer's raw output / the other gradient of its y
@@ -673,13 +684,13 @@ def test_winograd_conv_all_roles(case, monkeypatch):
     wd = w.to(d).permute(0, 3, 1, 2)                        # logical [Co,Ci,3,3], channels_last memory = [Co][3][3][Ci]
     assert wd.is_contiguous(memory_format=torch.channels_last)
     bank, uf, ud = _wino_images(wd)
-    y64 = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
-    dx64 = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    y64 = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=ks // 2).permute(0, 2, 3, 1)
+    dx64 = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=ks // 2).permute(0, 2, 3, 1)
     rows = B * H * W
-    geom = (B, H, W, Ci, H, W, Co, 3, 3, 1, 1)
+    geom = (B, H, W, Ci, H, W, Co, ks, ks, 1, ks // 2)
 
     # (1) forward + column sums of the raw output
-    for entry in ('wino', 'direct'):
+    for entry in (('wino', 'direct') if has_fwd else ()):
         y = torch.full((B, H, W, Co), float('nan'), device=d)
         slots = torch.zeros(2 * Co * 64, device=d, dtype=torch.float64)
         ns = ctypes.c_int(0)
@@ -700,10 +711,11 @@ def test_winograd_conv_all_roles(case, monkeypatch):
     # (2) forward + eval-mode BatchNorm + residual + ReLU (the teacher)
     want = F.relu((y64 - rm.double()) / torch.sqrt(rv.double() + 1e-5) * gamma.double() + beta.double() + res.double())
     y = torch.full((B, H, W, Co), float('nan'), device=d)
-    assert k_fwd(P(D['x']), uf, P(y), B, H, W, Ci, Co, P(D['gamma']), P(D['beta']), P(D['rm']), P(D['rv']),
-                                       1e-5, P(D['res']), 1, None, None, st) == 0
-    torch.cuda.synchronize()
-    check('fwd eval', y, want, 2e-5)
+    if has_fwd:
+        assert k_fwd(P(D['x']), uf, P(y), B, H, W, Ci, Co, P(D['gamma']), P(D['beta']), P(D['rm']), P(D['rv']),
+                     1e-5, P(D['res']), 1, None, None, st) == 0
+        torch.cuda.synchronize()
+        check('fwd eval', y, want, 2e-5)
     # (3) input gradient, with and without the addend
     for add_ in ((None, D['addend']) if has_dgrad else ()):
         gout = torch.full((B, H, W, Ci), float('nan'), device=d)
@@ -731,7 +743,7 @@ def test_winograd_conv_all_roles(case, monkeypatch):
             if entry == 'wino':
                 rc = k_dgrad(P(D['dy']), ud, P(add_), P(gout), B, H, W, Co, Ci, *tail)
             else:
-                rc = lib.advmix_conv_tr_w_bnb(P(D['dy']), P(wd), P(add_), P(gout), B, H, W, Co, H, W, Ci, 3, 3, 1, 1, *tail)
+                rc = lib.advmix_conv_tr_w_bnb(P(D['dy']), P(wd), P(add_), P(gout), B, H, W, Co, H, W, Ci, ks, ks, 1, ks // 2, *tail)
             if entry == 'direct' and rc == 1:               # (small shapes: the direct kernel would split K across the grid -
                 continue                                    #  no fused epilogue there; the float64 reference stands alone)
             assert rc == 0, (tag, entry, rc)
@@ -750,6 +762,8 @@ def test_winograd_conv_all_roles(case, monkeypatch):
     # refused without launching: odd sizes, channel counts the kernel has no instance for, a missing image
     if kind == 'wino':
         assert lib.advmix_conv_wino_config(B, H + 1, W, Ci, Co) == 0 and lib.advmix_conv_wino_config(B, H, W, 40, 40) == 0
+    elif kind == 'pw':
+        assert config(B, H, W, 64, 128) == 0 and config(B, H, W, 128, 256) == 0 and config(B, H, W, 256, 64) == 0
     else:                                                   # more than 48 pixels / 80 padded pixels, other channel counts
         assert config(B, 7, 7, Ci, Co) == 0 and config(B, 12, 4, Ci, Co) == 0 and config(B, H, W, 128, Co) == 0 and config(B, H, W, Ci, 48) == 0
         assert kind == 'smap' or config(B, 7, 6, Ci, Co) == 0        # (the Winograd form: odd sizes)

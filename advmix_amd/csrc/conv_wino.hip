@@ -77,7 +77,7 @@ struct Geo {
     static constexpr int LDS = PATCH > XCH ? PATCH : XCH;
 };
 
-// NQ = Ci / 8 (k groups of 8 channels: two k-lanes x 4 channels per 16-byte load).  ROLE 0: forward epilogues, 1: input gradient.
+// NQ = Ci / 8 (k groups of 8 channels: two k-lanes x 4 channels per 16-byte load).
 // KS: K is split over KS sets of four waves (workgroup = 4 KS waves): the 128-channel branch (16 x 12 maps: 64 blocks x 4
 // column tiles = one workgroup per CU at B = 32) gets two waves per SIMD that way, each multiplying half of the channels;
 // the halves meet in the exchange of the inverse transform, which adds across waves anyway.
@@ -85,7 +85,9 @@ struct Geo {
 template <int NQ, int LBW, int KS>
 constexpr int wino_waves() { return KS > 1 ? 1 : (Geo<LBW, NQ * 8, KS>::LDS * 4 + 1024 <= 53 * 1024 ? 3 : 2); }
 
-template <int NQ, int ROLE, int LBW, int KS = 1>
+// VAR: the epilogue compiled in - 0 forward + BatchNorm column sums, 1 forward + eval-mode BatchNorm (+ residual) + activation,
+// 2 input gradient (+ addend) + BatchNorm-backward epilogue, 3 plain (forward or input gradient, + residual / addend)
+template <int NQ, int VAR, int LBW, int KS = 1>
 __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS>())) void conv_wino(const WinoP p) {
     using G = Geo<LBW, NQ * 8, KS>;
     constexpr int NT = 256 * KS, NQW = NQ / KS;            // threads; k groups per wave
@@ -126,21 +128,42 @@ __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS>())) void conv_wi
         constexpr int NS = PH * PW * (C / 4), NIT = (NS + NT - 1) / NT;
         const int hb = 2 * BH * bby - 1, wb = 2 * BW * bbx - 1;
         f32x4 stg[NIT];
+        if constexpr (NT % (C / 4) == 0) {
+            // a thread keeps its channel quad and walks the patch NT / (C / 4) pixels at a time: (row, column) carried along
+            // instead of divided out of the slot index in every iteration (the SIMD's VALU time adds to its MFMA time)
+            constexpr int Q = C / 4, DPX = NT / Q, DPR = DPX / PW, DPC = DPX % PW;
+            const int cs = tid % Q, px0 = tid / Q;
+            int pr = px0 / PW, pc = px0 - pr * PW;
+            const int gbase = ((img * p.H + hb) * p.W + wb) * C + cs * 4;        // element offset of patch pixel (0, 0) (may be negative)
+            unsigned lo[NIT];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int s = tid + NT * it;
-            const int px = s / (C / 4), cs = s % (C / 4);
-            const int pr = px / PW, pc = px % PW;
-            const int h = hb + pr, w = wb + pc;
-            const bool ok = s < NS && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-            stg[it] = bload(xr, ok ? (unsigned)((((img * p.H + h) * p.W + w) * C + cs * 4) * 4) : OOB);
-        }
+            for (int it = 0; it < NIT; ++it) {
+                const bool ok = pr < PH && (unsigned)(hb + pr) < (unsigned)p.H && (unsigned)(wb + pc) < (unsigned)p.W;
+                stg[it] = bload(xr, ok ? (unsigned)((gbase + (pr * p.W + pc) * C) * 4) : OOB);
+                lo[it] = pr < PH ? (unsigned)((pr * PWL + (pc & 1) * HALF + (pc >> 1)) * PP + cs * 4) : 0xffffffffu;
+                pc += DPC; pr += DPR;
+                if (pc >= PW) { pc -= PW; ++pr; }
+            }
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int s = tid + NT * it;
-            const int px = s / (C / 4), cs = s % (C / 4);
-            const int pr = px / PW, pc = px % PW;
-            if (s < NS) *reinterpret_cast<f32x4*>(&L[(pr * PWL + (pc & 1) * HALF + (pc >> 1)) * PP + cs * 4]) = stg[it];
+            for (int it = 0; it < NIT; ++it)
+                if (lo[it] != 0xffffffffu) *reinterpret_cast<f32x4*>(&L[lo[it]]) = stg[it];
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int s = tid + NT * it;
+                const int px = s / (C / 4), cs = s % (C / 4);
+                const int pr = px / PW, pc = px % PW;
+                const int h = hb + pr, w = wb + pc;
+                const bool ok = s < NS && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+                stg[it] = bload(xr, ok ? (unsigned)((((img * p.H + h) * p.W + w) * C + cs * 4) * 4) : OOB);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int s = tid + NT * it;
+                const int px = s / (C / 4), cs = s % (C / 4);
+                const int pr = px / PW, pc = px % PW;
+                if (s < NS) *reinterpret_cast<f32x4*>(&L[(pr * PWL + (pc & 1) * HALF + (pc >> 1)) * PP + cs * 4]) = stg[it];
+            }
         }
     }
 
@@ -204,102 +227,113 @@ __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS>())) void conv_wi
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.ybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.y), 0, p.ybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bnb_c ? p.bnb_c : p.y), 0, p.ybytes, 0x00020000);
-    const bool bnb = ROLE == 1 && p.bnb_c != nullptr;
-    const bool mask_on = bnb && p.bnb_mask != nullptr && p.bnb_act != ADVMIX_ACT_NONE;
+    const bool mask_on = VAR == 2 && p.bnb_mask != nullptr && p.bnb_act != ADVMIX_ACT_NONE;
+    const bool recompute = VAR == 2 && !mask_on && p.bnb_act != ADVMIX_ACT_NONE;
+    const bool has_res = VAR != 0 && p.res != nullptr;
     const int cq = tid & 7;
     const int col = n0 + 4 * cq;
     const bool cvalid = col < p.Co;                         // (Co = 48: the second column tile is half empty - its filters are zero)
+    // item k of this thread: tile tl0 + (NT / 32) k of the block, output position (oa, ob) = bits 1, 0 of tid / 8 - the SAME for all
+    // its items; the tile walks down the block: BW divides NT / 32, so tx stays and ty advances by (NT / 32) / BW per item
+    const int tl0 = tid >> 5, oa = (tid >> 4) & 1, ob = (tid >> 3) & 1;
+    constexpr int TSTEP = (NT / 32) / BW;                   // tile rows per item
+    static_assert((NT / 32) % BW == 0, "an item step is whole tile rows");
+    const int tx = bbx * BW + (tl0 & (BW - 1)), ty0 = bby * BH + (tl0 >> LBW);
+    const bool xok = tx < p.Wt && cvalid;
+    const int pix0 = (img * p.H + 2 * ty0 + oa) * p.W + 2 * tx + ob;
+    const int pstep = 2 * TSTEP * p.W;                      // pixels per item
     unsigned yo[NI];
-    int pixv[NI];
     f32x4 oa4[NI], oc4[NI];
     unsigned mb[NI];
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
-        const int tp = (tid + NT * k) >> 3;                 // 0 .. 127: tile = tp / 4, position = tp % 4
-        const int tl = tp >> 2, oa = (tp >> 1) & 1, ob = tp & 1;
-        const int ty = bby * BH + (tl >> LBW), tx = bbx * BW + (tl & (BW - 1));
-        const bool ok = ty < p.Ht && tx < p.Wt && cvalid;
-        const int pix = (img * p.H + 2 * ty + oa) * p.W + 2 * tx + ob;
-        pixv[k] = ok ? pix : -1;
+        const bool ok = xok && ty0 + TSTEP * k < p.Ht;
+        const int pix = pix0 + pstep * k;
         yo[k] = ok ? (unsigned)((pix * p.Co + col) * 4) : OOB;
         oa4[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         oc4[k] = oa4[k];
         mb[k] = 0u;
-        if (p.res != nullptr) oa4[k] = bload(rr, yo[k]);     // requested now, they arrive under the exchange
-        if (ROLE == 1 && bnb) oc4[k] = bload(cr, yo[k]);
-        if (ROLE == 1 && mask_on && ok) mb[k] = p.bnb_mask[(int64_t)pix * (p.Co >> 2) + (col >> 2)];   // bit e: channel col + e
+        if (VAR != 0 && has_res) oa4[k] = bload(rr, yo[k]);  // requested now, they arrive under the exchange
+        if constexpr (VAR == 2) {
+            oc4[k] = bload(cr, yo[k]);
+            if (mask_on && ok) mb[k] = p.bnb_mask[(int64_t)pix * (p.Co >> 2) + (col >> 2)];   // bit e: channel col + e
+        }
     }
 
     __syncthreads();                                        // every wave is done with the patch: the region becomes the exchange image
     {
+        float* const xw = &X[(wv * 2 * 32 + 4 * lh) * XP + l31];      // D[tile row acc_row(r, lh)][column l31]
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float t0 = (acc[0][r] + acc[1][r]) + acc[2][r];
             const float t1 = (acc[1][r] - acc[2][r]) - acc[3][r];
-            const int row = acc_row(r, lh);                 // D[tile row][column l31]
-            X[((wv * 2 + 0) * 32 + row) * XP + l31] = t0;
-            X[((wv * 2 + 1) * 32 + row) * XP + l31] = t1;
+            xw[((r & 3) + 8 * (r >> 2)) * XP] = t0;
+            xw[(32 + (r & 3) + 8 * (r >> 2)) * XP] = t1;
         }
     }
     __syncthreads();
-    // ---- row half (across the waves) and the fused epilogue (conv_direct.hip's arithmetic), per item -----------------------
-    const bool stats = p.stats != nullptr;
+    // ---- row half (across the waves) and the fused epilogue (conv_direct.hip's arithmetic), per item.  The epilogue VARIANT
+    // is a template parameter: a SIMD issues VALU and MFMA instructions one after the other (csrc/conv_pw.hip's knock-outs), so
+    // every instruction of an epilogue the launch does not use was paid for in the run-time-generic first version ------------
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool bnf = ROLE == 0 && p.bn_gamma != nullptr;
-    const bool recompute = ROLE == 1 && bnb && !mask_on && p.bnb_act != ADVMIX_ACT_NONE;
     const float bb_slope = act_neg_slope(p.bnb_act);
     const int colc = cvalid ? col : 0;
-    f32x4 bn_is = {1.f, 1.f, 1.f, 1.f}, bn_g = bn_is, bn_b = {0.f, 0.f, 0.f, 0.f}, bn_m = bn_b;
     auto ld4 = [&](const float* q) { return *reinterpret_cast<const f32x4*>(q + colc); };   // (colc % 4 == 0: one 16-byte load)
-    if (bnf) {
+    f32x4 bn_is = {1.f, 1.f, 1.f, 1.f}, bn_g = bn_is, bn_b = {0.f, 0.f, 0.f, 0.f}, bn_m = bn_b;
+    if constexpr (VAR == 1) {
         const f32x4 rv = ld4(p.bn_rv);
 #pragma unroll
         for (int e = 0; e < 4; ++e) bn_is[e] = 1.0f / sqrtf(rv[e] + p.bn_eps);
         bn_g = ld4(p.bn_gamma); bn_b = ld4(p.bn_beta); bn_m = ld4(p.bn_rm);
     }
     f32x4 bb_mu = {0.f, 0.f, 0.f, 0.f}, bb_is = bb_mu, bb_g = bb_mu, bb_b = bb_mu;
-    if (ROLE == 1 && bnb) {
+    if constexpr (VAR == 2) {
         bb_mu = ld4(p.bnb_mean); bb_is = ld4(p.bnb_invstd);
         if (recompute) { bb_g = ld4(p.bnb_gamma); bb_b = ld4(p.bnb_beta); }
     }
+    const float sg2 = oa ? -1.f : 1.f;                      // Y[0][b] = T0 + T1 + T2,  Y[1][b] = T1 - T2 - T3
+    const float* const xr0 = &X[((oa * 2 + ob) * 32 + tl0) * XP + 4 * cq];
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
-        const int tp = (tid + NT * k) >> 3;
-        const int tl = tp >> 2, oa = (tp >> 1) & 1, ob = tp & 1;
-        const float sg2 = oa ? -1.f : 1.f;                  // Y[0][b] = T0 + T1 + T2,  Y[1][b] = T1 - T2 - T3
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {                   // (the K shares of the wave sets add up here)
-            const float* const xp = &X[(((4 * kk + oa) * 2 + ob) * 32 + tl) * XP + 4 * cq];
+            const float* const xp = xr0 + (4 * kk * 2 * 32 + (NT / 32) * k) * XP;
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp);
             const f32x4 x1 = *reinterpret_cast<const f32x4*>(xp + 2 * 32 * XP);
             const f32x4 x2 = *reinterpret_cast<const f32x4*>(xp + 4 * 32 * XP);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += __builtin_fmaf(sg2, x1[e] + x2[e], x0[e]);
         }
-        const bool valid = pixv[k] >= 0;
+        const bool valid = yo[k] != OOB;
+        if constexpr (VAR == 0) {
+            if (valid) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float o = v[e];
-            if (ROLE == 0) {
-                if (valid) { s1[e] += o; s2[e] += o * o; }
-                if (bnf) o = (o - bn_m[e]) * bn_is[e] * bn_g[e] + bn_b[e];
-                o += oa4[k][e];
-                o = act_fwd(o, p.act);
-            } else {
-                o += oa4[k][e];
-                if (bnb) {
-                    const float xh = (oc4[k][e] - bb_mu[e]) * bb_is[e];
-                    if (mask_on) o = ((mb[k] >> e) & 1u) ? o : o * bb_slope;
-                    else if (recompute) o = __builtin_fmaf(xh, bb_g[e], bb_b[e]) > 0.f ? o : o * bb_slope;
-                    if (valid) { s1[e] += o; s2[e] += o * xh; }
-                }
+                for (int e = 0; e < 4; ++e) { s1[e] += v[e]; s2[e] = __builtin_fmaf(v[e], v[e], s2[e]); }
             }
-            v[e] = o;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float o = v[e];
+                if constexpr (VAR == 1) {
+                    o = (o - bn_m[e]) * bn_is[e] * bn_g[e] + bn_b[e];
+                    o += oa4[k][e];
+                    o = act_fwd(o, p.act);
+                } else {
+                    o += oa4[k][e];
+                    if constexpr (VAR == 2) {
+                        const float xh = (oc4[k][e] - bb_mu[e]) * bb_is[e];
+                        if (mask_on) o = ((mb[k] >> e) & 1u) ? o : o * bb_slope;
+                        else if (recompute) o = __builtin_fmaf(xh, bb_g[e], bb_b[e]) > 0.f ? o : o * bb_slope;
+                        if (valid) { s1[e] += o; s2[e] = __builtin_fmaf(o, xh, s2[e]); }
+                    }
+                }
+                v[e] = o;
+            }
         }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yo[k], 0, STORE_AUX);
     }
-    if (stats) {                                            // uniform over the grid
+    if constexpr (VAR == 0 || VAR == 2) {
         // a wave = 8 (tile, position) items x 8 channel quads (lane = 8 i + cq): the items add up by shuffles, the waves in LDS
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -428,8 +462,15 @@ static int wino_launch(int role, wino::WinoP& p, hipStream_t st) {
     p.nblk = p.nbw * cdiv(p.Ht, 32 >> lbw);
     dim3 g(p.N * p.nblk, cdiv(p.Co, 32));
     const int NQ = p.Ci / 8;
-#define WL(NQ_, ROLE_, LBW_, KS_) hipLaunchKernelGGL((wino::conv_wino<NQ_, ROLE_, LBW_, KS_>), g, dim3(256 * KS_), 0, st, p)
-#define WR(NQ_, LBW_, KS_) do { if (role) WL(NQ_, 1, LBW_, KS_); else WL(NQ_, 0, LBW_, KS_); } while (0)
+    // the epilogue variant (template parameter VAR): forward + sums / forward + eval BatchNorm / input gradient + BatchNorm backward / plain
+    int var;
+    if (role == 0 && p.stats && !p.bn_gamma && !p.res && p.act == ADVMIX_ACT_NONE) var = 0;
+    else if (role == 0 && p.bn_gamma && !p.stats) var = 1;
+    else if (role == 1 && p.bnb_c) var = 2;
+    else if (!p.stats && !p.bn_gamma && (role == 1 || p.act == ADVMIX_ACT_NONE)) var = 3;
+    else return ADVMIX_EINVAL;                              // (e.g. sums AND an eval epilogue in one launch: not a combination the step uses)
+#define WL(NQ_, VAR_, LBW_, KS_) hipLaunchKernelGGL((wino::conv_wino<NQ_, VAR_, LBW_, KS_>), g, dim3(256 * KS_), 0, st, p)
+#define WR(NQ_, LBW_, KS_) do { if (var == 0) WL(NQ_, 0, LBW_, KS_); else if (var == 1) WL(NQ_, 1, LBW_, KS_); else if (var == 2) WL(NQ_, 2, LBW_, KS_); else WL(NQ_, 3, LBW_, KS_); } while (0)
     if (NQ == 4 && lbw == 3) WR(4, 3, 1);
     else if (NQ == 4) WR(4, 2, 1);
     else if (NQ == 8 && lbw == 3) WR(8, 3, 1);
@@ -445,7 +486,7 @@ static int wino_launch(int role, wino::WinoP& p, hipStream_t st) {
 #undef WL
     if (advmix_opts().trace_shapes) {
         char nm[48];
-        snprintf(nm, sizeof nm, "conv_wino<%d, %d, %d, %d>", NQ, role, lbw, NQ == 16 ? 2 : 1);
+        snprintf(nm, sizeof nm, "conv_wino<%d, %d, %d, %d>", NQ, var, lbw, NQ == 16 ? 2 : 1);
         advmix_trace_launch(nm, g, role == 0 ? (p.stats ? "fwd+sums" : (p.bn_gamma ? "fwd+bn_eval" : "fwd")) : (p.bnb_c ? "dgrad+bnb" : "dgrad"),
                             p.N, p.H, p.W, p.Ci, p.H, p.W, p.Co, 3, 3, 1, 2.0 * p.N * (double)p.H * p.W * p.Co * p.Ci * 9);
     }

@@ -97,7 +97,7 @@ __device__ __forceinline__ EpiOps epi_request(const SP& p, int tid, int img, int
     if (p.res != nullptr) o.oa = bload(rr, o.yo);
     if (ROLE == 1 && bnb) o.oc = bload(cr, o.yo);
     o.mbits = 0u;
-    if (ROLE == 1 && mask_on && o.live) o.mbits = p.bnb_mask[(int64_t)o.pix * (p.Co >> 2) + (o.col >> 2)];   // bit e: channel col + e
+    if (ROLE == 1 && mask_on && o.live) o.mbits = p.bnb_mask[o.yo >> 4];    // byte (pixel * Co + column) / 4; bit e: channel col + e
     return o;
 }
 

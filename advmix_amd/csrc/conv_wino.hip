@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS>())) void conv_wi
         if (VAR != 0 && has_res) oa4[k] = bload(rr, yo[k]);  // requested now, they arrive under the exchange
         if constexpr (VAR == 2) {
             oc4[k] = bload(cr, yo[k]);
-            if (mask_on && ok) mb[k] = p.bnb_mask[(int64_t)pix * (p.Co >> 2) + (col >> 2)];   // bit e: channel col + e
+            if (mask_on && ok) mb[k] = p.bnb_mask[yo[k] >> 4];      // byte (pixel * Co + column) / 4; bit e: channel col + e
         }
     }
 

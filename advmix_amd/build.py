@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(HERE, 'libadvmix_hip.so')
-SOURCES = ['conv_mfma.hip', 'conv_direct.hip', 'conv_wino.hip', 'conv_smap.hip', 'conv_pw.hip', 'wgrad_direct.hip', 'wgrad_lds.hip', 'wgrad_wino.hip', 'norm.hip', 'pointwise.hip', 'advmix_ops.hip', 'postproc.hip', 'inputpipe.hip', 'nms.hip']
+SOURCES = ['conv_mfma.hip', 'conv_direct.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_smap.hip', 'conv_pw.hip', 'wgrad_direct.hip', 'wgrad_lds.hip', 'wgrad_wino.hip', 'norm.hip', 'pointwise.hip', 'advmix_ops.hip', 'postproc.hip', 'inputpipe.hip', 'nms.hip']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-munsafe-fp-atomics', '-std=c++17',
          '-Wno-unused-result']
 # Every kernel must fit its registers: a kernel with scratch (spilled VGPRs) is refused - none of the library's kernels needs

@@ -63,6 +63,9 @@ int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const 
                                 int stride, int pad, int64_t Mmax, hipStream_t st, int bt = 0,
                                 const ConvEpi* epi = nullptr, int* stats_nbg = nullptr);
 
+// conv_direct.hip: nb independent GEMMs c[b] = a[b] . w[b]^T in one launch (conv_wino4.hip); -1 = not served
+int advmix_conv_direct_gemm_batched(const float* a, const float* w, float* c, int nb, int rows, int K, int Nc, hipStream_t st);
+
 // conv_direct.hip: 2-4 problems of one kind in one launch; -1 = cannot be served as one launch (nothing launched)
 struct ConvProb {
     const float *x, *w, *bias;

@@ -56,6 +56,8 @@ struct ConvD {
     int stats_tiles;        // 1 (deterministic mode): every workgroup STORES its column sums in a slot of its own -
                             // stats[2][Co][stats_nbg] with stats_nbg = row tiles x phases - instead of fp64 atomics
     int xcd_remap;          // 1: row-tile order remapped so that each XCD (and its L2) owns a CONTIGUOUS range of row tiles
+    int wimg;               // > 0 (MODE 0, conv_wino4.hip's batched GEMM): image n multiplies its OWN filters w + n * wimg (floats;
+                            // wbytes = one image's); a row tile never straddles two images (the host checks BM | Ho * Wo)
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -232,7 +234,8 @@ __device__ __forceinline__ void conv_body(const ConvD p, const int bx, const int
         }
     }
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.wbytes, 0x00020000);
+    const float* const wbase = MODE == 0 && p.wimg > 0 ? p.w + (int64_t)(m0 / (Hp * Wp)) * p.wimg : p.w;   // (uniform)
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, p.wbytes, 0x00020000);
     __syncthreads();                                       // taptab visible
 
     // ---- epilogue geometry, and its operands fetched NOW ------------------------------------------------------------
@@ -849,7 +852,7 @@ static int prepare(int mode, const float* x, const float* w, const float* bias, 
     if (xb >= 0x7fffffffLL || wb >= 0x7fffffffLL || yb >= 0x7fffffffLL) return -1;
     direct::ConvD p{x, w, bias, y, N, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, (int)xb, (int)wb, (int)yb, 1,
                     nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0,
-                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
     static const int xcd_remap = [] { const char* e = getenv("ADVMIX_XCD_REMAP"); return e ? atoi(e) : 1; }();
     p.xcd_remap = xcd_remap;
     // Slots per channel the workgroup sums are folded onto: many row blocks hammering few addresses serialise the
@@ -905,6 +908,20 @@ int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const 
 #undef LAUNCH_KC
     if (stats_nbg) *stats_nbg = p.stats_nbg;
     return rc;
+}
+
+// conv_wino4.hip's batched GEMM: c[b] = a[b] . w[b]^T for b < nb, a[b] = a + b * rows * K ([rows][K]), w[b] = w + b * Nc * K ([Nc][K]),
+// c[b] = c + b * rows * Nc - a 1x1 convolution over nb images of ``rows`` pixels in which every image has its own filters
+// (ConvD::wimg).  rows % 128 == 0 (no row tile straddles two images), K % 32 == 0, Nc % 4 == 0.  -1: not served.
+int advmix_conv_direct_gemm_batched(const float* a, const float* w, float* c, int nb, int rows, int K, int Nc, hipStream_t st) {
+    if (nb <= 0 || rows <= 0 || rows % 128 != 0 || K % 32 != 0 || Nc % 4 != 0) return -1;
+    direct::ConvD p;
+    bool bnb = false;
+    const int64_t Mmax = (int64_t)nb * rows;
+    int rc = prepare(0, a, w, nullptr, c, nb, rows / 128, 128, K, rows / 128, 128, Nc, 1, 1, 1, 0, Mmax, 0, nullptr, nullptr, &p, &bnb);
+    if (rc < 0) return -1;
+    p.wimg = Nc * K;
+    return direct::launch<0, 32, false, false>(p, Mmax, st, 0);
 }
 
 // 2-4 problems in one launch (direct::conv_group).  -1: the group cannot be served as one launch (different kernel

@@ -1,0 +1,223 @@
+// Winograd F(3x3, 2x2) per input phase for 4x4 / stride 2 / pad 1 convolutions (gfx950) - round 5.
+//
+// The U-Net generator's down convs and the input gradients of its transposed convs (lib/models/Unet_generator.py:60-112:
+// Conv2d(k 4, s 2, p 1) / ConvTranspose2d(k 4, s 2, p 1)) are 20 % of the AdvMix step on the direct kernel at 0.65-0.77 of the
+// fp32 matrix peak with the MFMA pipe 74 % busy: what is left is the multiply count.  A 4x4 / stride-2 conv is the sum of
+// four 2x2 / stride-1 convs, one per PHASE (p, q) of the input (rows of parity p, columns of parity q):
+//     out[oy][ox] = sum_{p,q} sum_{r,s in {0,1}} X_pq[oy + r][ox + s] . w[2 r + p][2 s + q],   X_pq[i][j] = x[2 i + p - 1][2 j + q - 1]
+// and F(3x3, 2x2) computes a 3x3 output tile of a 2x2 conv from a 4x4 patch with 16 multiplies instead of 36:
+//     Y = A^T [ sum_{p,q} (G g_pq G^T) .* (B^T X_pq B) ] A        (2.25x fewer multiplies; the phases add up BEFORE the inverse)
+//     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0; 1/2 1/2; 1/2 -1/2; 0 1]   A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 -1]
+// i.e. 16 independent GEMMs [tiles x 4 Cin] . [4 Cin x Cout], one per position xi of the transformed patch.  With Cout and
+// 4 Cin in the hundreds to thousands the transforms are small beside the GEMMs, so this first form is NOT fused:
+//     wino4_input   x -> V[xi][tile][(p, q), ci]                 (HBM-bound; V = 16/9 of the input's bytes)
+//     conv_direct   M[xi] = V[xi] . U[xi]^T, all 16 in one launch (advmix_conv_direct_gemm_batched: a 1x1 conv whose 16
+//                   "images" carry their own filters; XCD k works on xi = 2 k, 2 k + 1, so a U slice lives in one L2)
+//     wino4_output  M -> y (+ bias)                              (HBM-bound)
+// The filters are transformed once per forward pass by wino4_weights (ops.py: WinoBank, kind 'w4').
+// Measured against the direct kernel (tools/microbench_wino4.py): profiles/EXPERIMENTS.md section H.
+#include "common.h"
+#include <stdio.h>
+
+namespace w4 {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
+// ---- filters: U[xi][co][(p, q), ci] = (G g_pq G^T)[xi],  g_pq[r][s] = w[co][2 r + p][2 s + q][ci] -------------------------
+// One thread per (co, phase, ci); a record owns Co * 4 * Ci / 256 consecutive blocks.  Same record layout as conv_wino.hip's
+// WinoEnt (ops.py builds one table format for every image kind).
+struct W4Ent {
+    const float* w;
+    float* u;
+    int Cn, Ck, role, blk0;
+};
+
+__global__ __launch_bounds__(256) void wino4_weights(const W4Ent* __restrict__ ents, const int* __restrict__ blk_ent) {
+    const W4Ent e = ents[blk_ent[blockIdx.x]];
+    const int Co = e.Cn, Ci = e.Ck;
+    const int idx = ((int)blockIdx.x - e.blk0) * 256 + (int)threadIdx.x;      // (co * 4 + ph) * Ci + ci
+    const int ci = idx % Ci, cp = idx / Ci;
+    const int ph = cp & 3, co = cp >> 2;
+    if (co >= Co) return;
+    const int p = ph >> 1, q = ph & 1;
+    float g[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) g[r][s] = e.w[((int64_t)(co * 4 + 2 * r + p) * 4 + 2 * s + q) * Ci + ci];
+    float a[4][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        a[0][s] = g[0][s];
+        a[1][s] = 0.5f * (g[0][s] + g[1][s]);
+        a[2][s] = 0.5f * (g[0][s] - g[1][s]);
+        a[3][s] = g[1][s];
+    }
+    const int64_t plane = (int64_t)Co * 4 * Ci;
+    float* const out = e.u + (int64_t)co * 4 * Ci + ph * Ci + ci;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        out[(i * 4 + 0) * plane] = a[i][0];
+        out[(i * 4 + 1) * plane] = 0.5f * (a[i][0] + a[i][1]);
+        out[(i * 4 + 2) * plane] = 0.5f * (a[i][0] - a[i][1]);
+        out[(i * 4 + 3) * plane] = a[i][1];
+    }
+}
+
+struct W4P {
+    const float* x;
+    float* v;
+    const float* m;
+    const float* bias;
+    float* y;
+    int N, H, W, Ci, Co;      // input H x W (even), output H / 2 x W / 2
+    int Th, Tw, tiles, rows;  // 3x3 output tiles per column / row, N * Th * Tw, rows = tiles rounded up to 128
+    int xbytes;
+};
+
+// ---- input transform: thread = (tile, phase, 4 channels); 16 sixteen-byte loads (out-of-image pixels read 0), 16 stores ----
+__global__ __launch_bounds__(256) void wino4_input(const W4P p) {
+    const int gid = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int Q = p.Ci >> 2;                               // channel quads
+    const int tile = gid / p.Ci, rem = gid - tile * p.Ci;  // (4 phases x Q quads = Ci threads per tile)
+    if (tile >= p.tiles) return;
+    const int ph = rem / Q, cq = rem - ph * Q;
+    const int pp = ph >> 1, qq = ph & 1;
+    const int n = tile / (p.Th * p.Tw), tr = tile - n * (p.Th * p.Tw);
+    const int ty = tr / p.Tw, tx = tr - ty * p.Tw;
+    const int h0 = 6 * ty - 1 + pp, w0 = 6 * tx - 1 + qq;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+    f32x4 X[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int h = h0 + 2 * a, w = w0 + 2 * b;
+            const bool ok = (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+            X[a][b] = bload(xr, ok ? (unsigned)((((n * p.H + h) * p.W + w) * p.Ci + 4 * cq) * 4) : OOB);
+        }
+    f32x4 t[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {                          // B^T X
+        t[0][b] = X[0][b] - X[2][b];
+        t[1][b] = X[1][b] + X[2][b];
+        t[2][b] = X[2][b] - X[1][b];
+        t[3][b] = X[1][b] - X[3][b];
+    }
+    const int K = 4 * p.Ci;
+    float* const out = p.v + (int64_t)tile * K + ph * p.Ci + 4 * cq;
+    const int64_t plane = (int64_t)p.rows * K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                          // (B^T X) B
+        *reinterpret_cast<f32x4*>(out + (i * 4 + 0) * plane) = t[i][0] - t[i][2];
+        *reinterpret_cast<f32x4*>(out + (i * 4 + 1) * plane) = t[i][1] + t[i][2];
+        *reinterpret_cast<f32x4*>(out + (i * 4 + 2) * plane) = t[i][2] - t[i][1];
+        *reinterpret_cast<f32x4*>(out + (i * 4 + 3) * plane) = t[i][1] - t[i][3];
+    }
+}
+
+// ---- output transform: thread = (tile, 4 channels); 16 sixteen-byte loads, up to 9 stores --------------------------------
+__global__ __launch_bounds__(256) void wino4_output(const W4P p) {
+    const int gid = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int Q = p.Co >> 2;
+    const int tile = gid / Q, cq = gid - tile * Q;
+    if (tile >= p.tiles) return;
+    const int64_t plane = (int64_t)p.rows * p.Co;
+    const float* const in = p.m + (int64_t)tile * p.Co + 4 * cq;
+    f32x4 M[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) M[i][j] = *reinterpret_cast<const f32x4*>(in + (i * 4 + j) * plane);
+    f32x4 s[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                          // A^T M
+        s[0][j] = (M[0][j] + M[1][j]) + M[2][j];
+        s[1][j] = M[1][j] - M[2][j];
+        s[2][j] = (M[1][j] + M[2][j]) - M[3][j];
+    }
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + 4 * cq);
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+    const int n = tile / (p.Th * p.Tw), tr = tile - n * (p.Th * p.Tw);
+    const int ty = tr / p.Tw, tx = tr - ty * p.Tw;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {                          // (A^T M) A
+        const int oy = 3 * ty + a;
+        if (oy >= Ho) break;
+        f32x4 o[3];
+        o[0] = (s[a][0] + s[a][1]) + s[a][2] + bv;
+        o[1] = (s[a][1] - s[a][2]) + bv;
+        o[2] = ((s[a][1] + s[a][2]) - s[a][3]) + bv;
+        float* const yrow = p.y + ((int64_t)(n * Ho + oy) * Wo + 3 * tx) * p.Co + 4 * cq;
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            if (3 * tx + b < Wo) *reinterpret_cast<f32x4*>(yrow + (int64_t)b * p.Co) = o[b];
+    }
+}
+
+}  // namespace w4
+
+static bool w4_shape_ok(int N, int H, int W, int Ci, int Co) {
+    if (N <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || Ci % 8 != 0 || Co % 4 != 0) return false;
+    const int64_t tiles = (int64_t)N * cdiv(H / 2, 3) * cdiv(W / 2, 3);
+    const int64_t rows = (tiles + 127) / 128 * 128;
+    if ((int64_t)N * H * W * Ci * 4 >= 0x7fffffffLL || 16 * rows * 4 * Ci * 4 >= 0x7fffffffLL || 16 * rows * Co * 4 >= 0x7fffffffLL ||
+        (int64_t)16 * Co * 4 * Ci * 4 >= 0x7fffffffLL)
+        return false;
+    return true;
+}
+
+// floats of the transformed filters of a [Co][4][4][Ci] bank
+extern "C" int64_t advmix_wino4_u_floats(int Co, int Ci) { return (int64_t)16 * Co * 4 * Ci; }
+
+// floats of scratch (V then M) advmix_conv4x4s2_wino_fwd needs; 0 = shape not served
+extern "C" int64_t advmix_conv4x4s2_wino_ws_floats(int N, int H, int W, int Ci, int Co) {
+    if (!w4_shape_ok(N, H, W, Ci, Co)) return 0;
+    const int64_t tiles = (int64_t)N * cdiv(H / 2, 3) * cdiv(W / 2, 3);
+    const int64_t rows = (tiles + 127) / 128 * 128;
+    return 16 * rows * (4 * (int64_t)Ci + Co);
+}
+
+// Transform the filters of n convs in one launch (records / block owners as advmix_wino_weights; a record owns
+// Cn * 4 * Ck / 256 blocks).  Replaces nothing in the reference - cuDNN prepares its own algorithm behind nn.Conv2d.
+extern "C" int advmix_w4_weights(const void* ents, const int* blk_ent, int blocks, void* stream) {
+    if (!ents || !blk_ent || blocks <= 0) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(w4::wino4_weights, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const w4::W4Ent*)ents, blk_ent);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+// advmix_conv_fwd for a 4x4 / stride 2 / pad 1 conv whose filters w[Co][4][4][Ci] were transformed by advmix_w4_weights into
+// ``u``: y[N][H/2][W/2][Co] = conv(x[N][H][W][Ci]) + bias.  ``ws``: advmix_conv4x4s2_wino_ws_floats() floats of scratch, free again
+// when the launches have run.  ADVMIX_EINVAL (nothing launched) for shapes not served: the caller runs advmix_conv_fwd.
+// Semantics: lib/models/Unet_generator.py:60-62 (downconv) and the input gradient of :63-65 / :74-76 / :84-86 (upconv).
+extern "C" int advmix_conv4x4s2_wino_fwd(const float* x, const float* u, const float* bias, float* y, float* ws, int64_t ws_floats,
+                                         int N, int H, int W, int Ci, int Co, void* stream) {
+    if (!x || !u || !y || !ws || !w4_shape_ok(N, H, W, Ci, Co)) return ADVMIX_EINVAL;
+    if (ws_floats < advmix_conv4x4s2_wino_ws_floats(N, H, W, Ci, Co)) return ADVMIX_EINVAL;
+    w4::W4P p{};
+    p.x = x; p.bias = bias; p.y = y;
+    p.N = N; p.H = H; p.W = W; p.Ci = Ci; p.Co = Co;
+    p.Th = cdiv(H / 2, 3); p.Tw = cdiv(W / 2, 3);
+    p.tiles = N * p.Th * p.Tw;
+    p.rows = (p.tiles + 127) / 128 * 128;
+    p.xbytes = (int)((int64_t)N * H * W * Ci * 4);
+    p.v = ws;
+    float* const m = ws + (int64_t)16 * p.rows * 4 * Ci;
+    p.m = m;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(w4::wino4_input, dim3(cdiv((int64_t)p.tiles * Ci, 256)), dim3(256), 0, st, p);
+    ADVMIX_CHECK_LAUNCH();
+    int rc = advmix_conv_direct_gemm_batched(p.v, u, m, 16, p.rows, 4 * Ci, Co, st);
+    if (rc != ADVMIX_OK) return rc < 0 ? ADVMIX_EINVAL : rc;
+    hipLaunchKernelGGL(w4::wino4_output, dim3(cdiv((int64_t)p.tiles * (Co / 4), 256)), dim3(256), 0, st, p);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}

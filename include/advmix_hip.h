@@ -194,6 +194,22 @@ int advmix_conv1x1_pw_dgrad(const float* dy, const float* u, const float* addend
                             const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int act,
                             double* stats, int* stats_ns, void* stream);
 
+/* 4x4 / stride 2 / pad 1 convolutions as Winograd F(3x3, 2x2) per input phase (csrc/conv_wino4.hip, round 5): the U-Net
+ * generator's down convs (lib/models/Unet_generator.py:60-62) and the input gradients of its transposed convs (:63-65, :74-76,
+ * :84-86).  A 4x4 / stride-2 conv is four 2x2 / stride-1 convs on the input's parity phases; F(3x3, 2x2) multiplies 16 times per
+ * 3x3 output tile, phase and channel pair instead of 36.  Not fused: an input transform x -> V[16][tiles][4 Ci], the 16 GEMMs
+ * V[xi] . U[xi]^T in one launch of the direct kernel, an output transform M -> y.
+ * advmix_wino4_u_floats: floats of the transformed filters of w[Co][4][4][Ci] (16 * Co * 4 * Ci), u[xi][co][(p, q), ci].
+ * advmix_w4_weights: records as advmix_wino_weights' (Cn = Co, Ck = Ci, role 0); a record owns Co * 4 * Ci / 256 workgroups.
+ * advmix_conv4x4s2_wino_ws_floats: floats of scratch a launch needs (0: shape not served - H, W even, Ci % 8 == 0, Co % 4 == 0,
+ * every buffer below 2 GiB).  advmix_conv4x4s2_wino_fwd: y[N][H/2][W/2][Co] = conv(x[N][H][W][Ci]) + bias; ADVMIX_EINVAL for
+ * unserved shapes (the caller runs advmix_conv_fwd). */
+int64_t advmix_wino4_u_floats(int Co, int Ci);
+int advmix_w4_weights(const void* ents, const int* blk_ent, int blocks, void* stream);
+int64_t advmix_conv4x4s2_wino_ws_floats(int N, int H, int W, int Ci, int Co);
+int advmix_conv4x4s2_wino_fwd(const float* x, const float* u, const float* bias, float* y, float* ws, int64_t ws_floats,
+                              int N, int H, int W, int Ci, int Co, void* stream);
+
 /* Winograd weight gradient, F(3x3, 2x2) (csrc/wgrad_wino.hip, round 5): 16 multiplies per 2x2 tile of dy and channel pair
  * instead of 36.  advmix_wgrad_wino_config: 0 = not served (odd H / W, channels not multiples of 32 or > 256), else the
  * number of (32-tile block, 32 x 32 channel pair) units of one problem.  advmix_conv3x3_wgrad_wino_group: the weight

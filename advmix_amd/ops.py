@@ -382,6 +382,8 @@ WINO = __import__('os').environ.get('ADVMIX_WINO', '1') != '0'       # A/B switc
 WINO_MIN_WGS = int(__import__('os').environ.get('ADVMIX_WINO_MIN_WGS', '96'))   # workgroups (32 tiles x 32 channels) below which the direct kernel stays
 WINO_ASYNC = __import__('os').environ.get('ADVMIX_WINO_ASYNC', '1') != '0'   # filter transforms beside the stem (plan.PlanNet._wino_refresh; 0 = on the caller's stream)
 PW = __import__('os').environ.get('ADVMIX_PW', '1') != '0'           # A/B switch: 0 = the 64 -> 256 1x1 convs of the bottlenecks on the direct kernel (csrc/conv_pw.hip)
+WINO4 = __import__('os').environ.get('ADVMIX_WINO4', '1') != '0'     # A/B switch: 0 = the U-Net's 4x4 / stride-2 convs on the direct kernel (csrc/conv_wino4.hip)
+WINO4_MIN_TILES = int(__import__('os').environ.get('ADVMIX_WINO4_MIN_TILES', '128'))   # 3x3 output tiles below which the direct kernel stays (B = 32: the 4x3 bottleneck has 64)
 SMAP = __import__('os').environ.get('ADVMIX_SMAP', '1') != '0'       # A/B switch: 0 = the small 256-channel maps on the direct kernel
 SMAP_C = 256                                                         # (csrc/conv_smap.hip: one workgroup per image, K split over its eight waves)
 SMAP_WINO = __import__('os').environ.get('ADVMIX_SMAP_WINO', '1') != '0'   # Winograd F(2x2,3x3) inside that workgroup shape (conv_smapw; 0 = the direct form)
@@ -404,31 +406,32 @@ class WinoBank:
         pad32 = lambda c: (c + 31) // 32 * 32                # noqa: E731  (the n dimension is padded to whole column tiles)
         # kind 'smap' (csrc/conv_smap.hip): filters with 256 input channels, plain re-layout in that kernel's fragment order (9 Co Ci floats
         # per image); everything else 'wino'
-        kinds = ['pw' if tuple(w.shape[2:]) == (1, 1) else
+        kinds = ['w4' if tuple(w.shape[2:]) == (4, 4) else 'pw' if tuple(w.shape[2:]) == (1, 1) else
                  ('smapw' if SMAP_WINO else 'smap') if (w.shape[1] == SMAP_C and w.shape[0] % 32 == 0) else 'wino' for w in weights]   # (input-gradient images only where Cout == 256 too)
-        sizes = [(9 * w.shape[0] * w.shape[1],) * 2 if k == 'smap' else (16 * w.shape[0] * w.shape[1],) * 2 if k == 'smapw' else
+        sizes = [(64 * w.shape[0] * w.shape[1], 0) if k == 'w4' else (9 * w.shape[0] * w.shape[1],) * 2 if k == 'smap' else (16 * w.shape[0] * w.shape[1],) * 2 if k == 'smapw' else
                  (w.shape[0] * w.shape[1],) * 2 if k == 'pw' else
                  (16 * pad32(w.shape[0]) * w.shape[1], 16 * pad32(w.shape[1]) * w.shape[0]) for w, k in zip(weights, kinds)]
         self.buf = torch.empty(sum(a + b for a, b in sizes), device=dev, dtype=torch.float32)
         rec = np.dtype([('w', '<u8'), ('u', '<u8'), ('Cn', '<i4'), ('Ck', '<i4'), ('role', '<i4'), ('blk0', '<i4')])
-        ents = {'wino': [], 'smap': [], 'smapw': [], 'pw': []}
-        blk = {'wino': 0, 'smap': 0, 'smapw': 0, 'pw': 0}
-        owner = {'wino': [], 'smap': [], 'smapw': [], 'pw': []}
+        ents = {'wino': [], 'smap': [], 'smapw': [], 'pw': [], 'w4': []}
+        blk = {'wino': 0, 'smap': 0, 'smapw': 0, 'pw': 0, 'w4': 0}
+        owner = {'wino': [], 'smap': [], 'smapw': [], 'pw': [], 'w4': []}
         off = 0
         self._tagged = []
         for i, (w, kind) in enumerate(zip(weights, kinds)):
             Co, Ci, R, S = w.shape
-            if (R, S) not in ((3, 3), (1, 1)) or Co % 16 or Ci % 16 or not w.is_contiguous(memory_format=_CL):
-                raise ValueError('WinoBank: 3x3 / 1x1 channels_last weights with Cout, Cin multiples of 16')
+            if (R, S) not in ((3, 3), (1, 1), (4, 4)) or Co % 16 or Ci % 16 or not w.is_contiguous(memory_format=_CL):
+                raise ValueError('WinoBank: 3x3 / 1x1 / 4x4 channels_last weights with Cout, Cin multiples of 16')
             ptrs = []
             for role, (Cn, Ck) in enumerate(((Co, Ci), (Ci, Co))):
                 u = self.buf.data_ptr() + 4 * off
                 off += sizes[i][role]
-                if (kind in ('smap', 'smapw') and Ck != SMAP_C) or (kind == 'pw' and (Cn, Ck) != (256, 64)):
+                if (kind in ('smap', 'smapw') and Ck != SMAP_C) or (kind == 'pw' and (Cn, Ck) != (256, 64)) or (kind == 'w4' and role == 1):
                     # (the small-map kernels read exactly 256 channels, conv_pw reads 64 and writes 256: no such image)
                     ptrs.append(None)
                     continue
-                nb = {'wino': ((Cn + 31) // 32) * (Ck // 8), 'smap': (Cn // 32) * (Ck // 32) * 36, 'smapw': (Cn // 32) * 32, 'pw': 64}[kind]
+                nb = {'wino': ((Cn + 31) // 32) * (Ck // 8), 'smap': (Cn // 32) * (Ck // 32) * 36, 'smapw': (Cn // 32) * 32, 'pw': 64,
+                      'w4': Cn * 4 * Ck // 256}[kind]       # (w4: the memory-major dimension is the forward-form conv's Cout - a Conv2d's own, a ConvTranspose2d's Cin)
                 owner[kind] += [len(ents[kind])] * nb
                 ents[kind].append((w.data_ptr(), u, Cn, Ck, role, blk[kind]))
                 blk[kind] = len(owner[kind])
@@ -436,7 +439,7 @@ class WinoBank:
             w._wino = (self.buf, ptrs[0], ptrs[1], w.data_ptr(), kind)     # (the tag keeps the side buffer alive)
             self._tagged.append(weakref.ref(w))
         self.tables = {}
-        for kind in ('wino', 'smap', 'smapw', 'pw'):
+        for kind in ('wino', 'smap', 'smapw', 'pw', 'w4'):
             if ents[kind]:
                 ent = np.array(ents[kind], dtype=rec)
                 self.tables[kind] = (torch.from_numpy(ent.view(np.uint8).copy()).to(dev),
@@ -497,6 +500,27 @@ def _wino_images(w, B, H, W, Ci, Co, R, S, stride, pad):
     if lib.advmix_conv_wino_config(B, H, W, Ci, Co) < WINO_MIN_WGS:
         return None
     return tag[1], tag[2], 'wino'
+
+
+def _conv4x4s2_wino(st, x, w, bias, y, B, Hi, Wi, Ci, Co):
+    """The forward-form 4x4 / stride 2 / pad 1 conv x[B,Hi,Wi,Ci] -> y[B,Hi/2,Wi/2,Co] with filters w (memory [Co][4][4][Ci]) on
+    csrc/conv_wino4.hip when ``w`` carries a 'w4' image and the shape is served; False = nothing launched."""
+    if not (WINO and WINO4) or DETERMINISTIC or not _direct_ok():
+        return False
+    tag = _wino_tag(w)
+    if tag is None or tag[4] != 'w4' or B * (-(-Hi // 6)) * (-(-Wi // 6)) < WINO4_MIN_TILES:
+        return False
+    wsf = lib.advmix_conv4x4s2_wino_ws_floats(B, Hi, Wi, Ci, Co)
+    if wsf <= 0:
+        return False
+    ws = keep(torch.empty(wsf, device=x.device, dtype=torch.float32))
+    rc = lib.advmix_conv4x4s2_wino_fwd(_p(x), tag[1], _p(bias), _p(y), _p(ws), wsf, B, Hi, Wi, Ci, Co, st)
+    if rc == 0:
+        COUNTERS['w4'] = COUNTERS.get('w4', 0) + 1
+        return True
+    if rc != 1:
+        raise RuntimeError('advmix_conv4x4s2_wino_fwd failed: %d' % rc)
+    return False
 
 
 def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to=None, bnb=None, lane=0):
@@ -586,8 +610,9 @@ class Conv:
         Ho = (Hi + 2 * pad - R) // stride + 1
         Wo = (Wi + 2 * pad - S) // stride + 1
         y = empty_nhwc(B, Co, Ho, Wo, x.device)
-        call('advmix_conv_fwd', _p(x), _p(w), _p(bias), _p(y), B, Hi, Wi, Ci, Ho, Wo, Co, R, S,
-             stride, pad, st)
+        if not ((R, S, stride, pad) == (4, 4, 2, 1) and _conv4x4s2_wino(st, x, w, bias, y, B, Hi, Wi, Ci, Co)):
+            call('advmix_conv_fwd', _p(x), _p(w), _p(bias), _p(y), B, Hi, Wi, Ci, Ho, Wo, Co, R, S,
+                 stride, pad, st)
         return (y,), (x, w, bias), None
 
     ADD_TO = True    # bwd(..., add_to): another gradient of the input, summed in the dgrad epilogue
@@ -659,8 +684,9 @@ class Deconv:
         dx = None
         if needs[0]:
             dx = empty_nhwc(B, Ci, Hi, Wi, x.device)
-            call('advmix_conv_fwd', _p(dy), _p(w), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
-                 stride, pad, st)
+            if not ((R, S, stride, pad) == (4, 4, 2, 1) and _conv4x4s2_wino(st, dy, w, None, dx, B, Ho, Wo, Co, Ci)):
+                call('advmix_conv_fwd', _p(dy), _p(w), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
+                     stride, pad, st)
         if needs[1]:
             _wgrad(st, lane, x, dy, w, (B, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad))
         if bias is not None and needs[2]:

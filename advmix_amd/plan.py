@@ -626,7 +626,8 @@ class PlanNet(nn.Module):
             for li, sts in enumerate(self._levels):
                 for st in sts:
                     for sub in (st[1] if st[0] == 'chain' else (st,)):
-                        if sub[0] == 'convbn' and sub[5] == 1 and sub[6] in (0, 1):      # stride 1: 3x3 / pad 1, or 1x1 / pad 0
+                        if (sub[0] == 'convbn' and sub[5] == 1 and sub[6] in (0, 1)) or \
+                                (ops.WINO4 and sub[0] in ('conv', 'deconv') and sub[4] == 2 and sub[5] == 1):   # stride 1: 3x3 / pad 1, or 1x1 / pad 0; the U-Net's 4x4 / stride 2 / pad 1 (csrc/conv_wino4.hip)
                             names.append(sub[1] + '.weight')
                             if self._wino_first_level is None:
                                 self._wino_first_level = li    # (the stem's strided convs come first)
@@ -635,6 +636,7 @@ class PlanNet(nn.Module):
         ws = [T[n] for n in names]
         ws = [w for w in ws if w.is_cuda and w.shape[0] % 16 == 0 and (
               (tuple(w.shape[2:]) == (3, 3) and (w.shape[1] in (32, 48, 64, 96, 128) or (ops.SMAP and tuple(w.shape[:2]) == (ops.SMAP_C, ops.SMAP_C))))   # (256 -> 256: conv_smap's images)
+              or (tuple(w.shape[2:]) == (4, 4) and ops.WINO4 and w.shape[1] % 16 == 0)                                                              # (conv_wino4: forward-form image; the 3-channel ends of the U-Net stay direct)
               or (tuple(w.shape[2:]) == (1, 1) and ops.PW and tuple(w.shape[:2]) in ((256, 64), (64, 256))))]                                       # (conv_pw: forward of 64 -> 256, input gradient of 256 -> 64)
         if not ws:
             return

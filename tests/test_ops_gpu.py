@@ -647,6 +647,77 @@ def _wino_images(w_dev):
     return bank, uf, ud
 
 
+WINO4_CASES = [
+    # B, Ci, Co, H, W (input map), bias
+    (32, 64, 128, 128, 96, True),     # the U-Net's second down conv at the bench batch: 11,264 tiles, 64 x 48 outputs (a ragged tile column: 64 = 21 x 3 + 1)
+    (2, 512, 512, 16, 12, True),      # 8 x 6 outputs: 12 tiles of which the last row / column are partly outside
+    (3, 32, 64, 20, 28, True),        # 10 x 14 outputs: both tile axes ragged
+    (2, 16, 32, 16, 12, False),
+    (1, 64, 128, 8, 6, False),        # 4 x 3 outputs
+    (2, 128, 64, 4, 2, True),         # 2 x 1 outputs: one tile, mostly outside
+    (5, 256, 1024, 6, 6, False),      # the forward form of a ConvTranspose2d(1024, 256)'s input gradient: 5 tiles, 123 padded rows
+]
+
+
+@pytest.mark.parametrize('case', WINO4_CASES)
+def test_winograd_4x4_stride2_conv(case):
+    """csrc/conv_wino4.hip (round 5): a 4x4 / stride 2 / pad 1 conv as Winograd F(3x3, 2x2) on the four parity phases of its
+    input - input transform, the 16 GEMMs as ONE launch of the direct kernel (per-image filters), output transform - against a
+    float64 torch evaluation (1e-4 of scale like every kernel) and the direct kernel; then through the ops the U-Net uses:
+    Conv2d forward and ConvTranspose2d backward take it when the weight carries a bank image (counter asserted), their
+    results against float64 autograd."""
+    import ctypes
+    from advmix_amd._lib import call, lib
+    ops = _ops()
+    B, Ci, Co, H, W, hb = case
+    d = dev()
+    g_ = torch.Generator().manual_seed(41 + Ci + H)
+    R = lambda *s_: torch.randn(*s_, generator=g_)
+    x, w, b = R(B, H, W, Ci), R(Co, 4, 4, Ci) * (16 * Ci) ** -0.5, (R(Co) if hb else None)
+    xd = x.to(d)
+    wd = w.to(d).permute(0, 3, 1, 2)                        # logical [Co,Ci,4,4], channels_last memory = [Co][4][4][Ci]
+    bd = b.to(d) if hb else None
+    bank = ops.WinoBank([wd])
+    bank.refresh()
+    assert wd._wino[4] == 'w4' and wd._wino[2] is None      # a forward-form image only
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    wsf = lib.advmix_conv4x4s2_wino_ws_floats(B, H, W, Ci, Co)
+    assert wsf == 16 * ((B * -(-H // 6) * -(-W // 6) + 127) // 128 * 128) * (4 * Ci + Co)
+    ws = torch.full((wsf,), float('nan'), device=d)
+    y = torch.full((B, H // 2, W // 2, Co), float('nan'), device=d)
+    assert lib.advmix_conv4x4s2_wino_fwd(P(xd), wd._wino[1], P(bd), P(y), P(ws), wsf - 1, B, H, W, Ci, Co, st) == 1   # scratch too small: refused
+    assert lib.advmix_conv4x4s2_wino_fwd(P(xd), wd._wino[1], P(bd), P(y), P(ws), wsf, B, H + 1, W, Ci, Co, st) == 1     # odd map: refused
+    torch.cuda.synchronize()
+    assert torch.isnan(y).all()
+    call('advmix_conv4x4s2_wino_fwd', P(xd), wd._wino[1], P(bd), P(y), P(ws), wsf, B, H, W, Ci, Co, st)
+    y0 = torch.empty_like(y)
+    call('advmix_conv_fwd', P(xd), P(wd), P(bd), P(y0), B, H, W, Ci, H // 2, W // 2, Co, 4, 4, 2, 1, st)
+    y64 = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), b.double() if hb else None, 2, 1).permute(0, 2, 3, 1)
+    sc = y64.abs().max().item()
+    assert (y.double().cpu() - y64).abs().max().item() <= 1e-4 * sc
+    assert (y - y0).abs().max().item() <= 1e-4 * sc
+    # through the ops: Conv2d forward ...
+    tiles = B * -(-H // 6) * -(-W // 6)
+    served = tiles >= ops.WINO4_MIN_TILES
+    n0 = ops.COUNTERS.get('w4', 0)
+    xg = xd.permute(0, 3, 1, 2).requires_grad_(True)
+    wp = torch.nn.Parameter(wd)
+    wp._wino = wd._wino                                     # (tagged for the same storage)
+    yo = ops.conv2d(xg, wp, bd, 2, 1)
+    assert ops.COUNTERS.get('w4', 0) == n0 + (1 if served else 0)
+    assert (yo.permute(0, 2, 3, 1).double().cpu() - y64).abs().max().item() <= 1e-4 * sc
+    # ... and ConvTranspose2d backward: the input gradient of a deconv with THESE filters (logical [Cin = Co][Cout = Ci][4][4]) is this conv
+    n0 = ops.COUNTERS.get('w4', 0)
+    xt = torch.randn(B, Co, H // 2, W // 2, generator=g_).to(d).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yt = ops.conv_transpose2d(xt, wp, None, 2, 1)
+    yt.backward(xg.detach())                                # dL/dy of the deconv = x: its dx is conv(x, w)
+    assert ops.COUNTERS.get('w4', 0) == n0 + (1 if served else 0)
+    dx64 = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), None, 2, 1)
+    assert (xt.grad.double().cpu() - dx64).abs().max().item() <= 1e-4 * dx64.abs().max().item()
+    bank.release()
+
+
 @pytest.mark.parametrize('case', WINO_CASES + SMAP_CASES + PW_CASES)
 def test_winograd_conv_all_roles(case, monkeypatch):
     """csrc/conv_wino.hip (round 5): the Winograd F(2x2,3x3) kernel in every role the step uses - forward + BatchNorm column

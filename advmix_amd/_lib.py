@@ -53,6 +53,7 @@ SIGNATURES = {
     'advmix_conv3x3_smap_dgrad': [_p, _p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p],
     'advmix_w4_weights': [_p, _p, _i, _p],
     'advmix_conv4x4s2_wino_fwd': [_p, _p, _p, _p, _p, _l] + [_i] * 5 + [_p],
+    'advmix_conv4x4s2_wino_wgrad': [_p, _p, _p, _p, _p, _l] + [_i] * 5 + [_p],
     'advmix_wgrad_wino_config': [_i] * 5,
     'advmix_conv3x3_wgrad_wino_group': [_i, _p, _p, _p] + [_i] * 5 + [_p],
     'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],
@@ -131,6 +132,8 @@ lib.advmix_wino4_u_floats.argtypes = [_i, _i]
 lib.advmix_wino4_u_floats.restype = ctypes.c_int64
 lib.advmix_conv4x4s2_wino_ws_floats.argtypes = [_i] * 5
 lib.advmix_conv4x4s2_wino_ws_floats.restype = ctypes.c_int64
+lib.advmix_conv4x4s2_wino_wgrad_ws_floats.argtypes = [_i] * 6
+lib.advmix_conv4x4s2_wino_wgrad_ws_floats.restype = ctypes.c_int64
 lib.advmix_smap_u_floats.argtypes = [_i, _i]
 lib.advmix_smap_u_floats.restype = ctypes.c_int64
 lib.advmix_wgrad_det_ws_bytes.argtypes = [_i, _i, _i, _i]

@@ -86,8 +86,14 @@ __global__ __launch_bounds__(256) void wino4_input(const W4P p) {
     const int gid = (int)blockIdx.x * 256 + (int)threadIdx.x;
     const int Q = p.Ci >> 2;                               // channel quads
     const int tile = gid / p.Ci, rem = gid - tile * p.Ci;  // (4 phases x Q quads = Ci threads per tile)
-    if (tile >= p.tiles) return;
+    if (tile >= p.rows) return;
     const int ph = rem / Q, cq = rem - ph * Q;
+    if (tile >= p.tiles) {                                 // rows that pad the tile count to a multiple of 128: zeros (the weight
+        float* const o = p.v + (int64_t)tile * (4 * p.Ci) + ph * p.Ci + 4 * cq;     // gradient's GEMMs reduce over ALL rows)
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) *reinterpret_cast<f32x4*>(o + xi * (int64_t)p.rows * (4 * p.Ci)) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
     const int pp = ph >> 1, qq = ph & 1;
     const int n = tile / (p.Th * p.Tw), tr = tile - n * (p.Th * p.Tw);
     const int ty = tr / p.Tw, tx = tr - ty * p.Tw;
@@ -162,6 +168,81 @@ __global__ __launch_bounds__(256) void wino4_output(const W4P p) {
     }
 }
 
+// ---- weight gradient ------------------------------------------------------------------------------------------------------
+// dL/dg_pq = G^T [ sum_tiles (A dy A^T) .* (B^T X_pq B) ] G: the adjoint of the output transform applied to the low-resolution
+// operand (3x3 tile -> 4x4), the SAME input transform of the high-resolution one, 16 weight-gradient GEMMs
+// dU[xi] = dM[xi]^T . V[xi] (one grouped launch of conv_mfma.hip's kernel), and the adjoint of the filter transform.
+
+// dM[xi][tile][c] = (A d A^T)[xi], d = the tile's 3x3 pixels of ``lo`` (outside the map: 0); A = [1 0 0; 1 1 1; 1 -1 1; 0 0 -1].
+// thread = (tile, 4 channels); rows that pad the tile count are written as zeros.
+__global__ __launch_bounds__(256) void wino4_output_adj(const float* __restrict__ lo, float* __restrict__ dm, int N, int Ho, int Wo, int C,
+                                                        int Th, int Tw, int tiles, int rows) {
+    const int gid = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int Q = C >> 2;
+    const int tile = gid / Q, cq = gid - tile * Q;
+    if (tile >= rows) return;
+    const int64_t plane = (int64_t)rows * C;
+    float* const out = dm + (int64_t)tile * C + 4 * cq;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (tile >= tiles) {
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) *reinterpret_cast<f32x4*>(out + xi * plane) = z;
+        return;
+    }
+    const int n = tile / (Th * Tw), tr = tile - n * (Th * Tw);
+    const int ty = tr / Tw, tx = tr - ty * Tw;
+    f32x4 d[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int oy = 3 * ty + a, ox = 3 * tx + b;
+            d[a][b] = (oy < Ho && ox < Wo) ? *reinterpret_cast<const f32x4*>(lo + ((int64_t)(n * Ho + oy) * Wo + ox) * C + 4 * cq) : z;
+        }
+    f32x4 s[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {                          // A d
+        s[0][b] = d[0][b];
+        s[1][b] = (d[0][b] + d[2][b]) + d[1][b];
+        s[2][b] = (d[0][b] + d[2][b]) - d[1][b];
+        s[3][b] = -d[2][b];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                          // (A d) A^T
+        *reinterpret_cast<f32x4*>(out + (i * 4 + 0) * plane) = s[i][0];
+        *reinterpret_cast<f32x4*>(out + (i * 4 + 1) * plane) = (s[i][0] + s[i][2]) + s[i][1];
+        *reinterpret_cast<f32x4*>(out + (i * 4 + 2) * plane) = (s[i][0] + s[i][2]) - s[i][1];
+        *reinterpret_cast<f32x4*>(out + (i * 4 + 3) * plane) = -s[i][2];
+    }
+}
+
+// dw[cl][2 r + p][2 s + q][ch] += (G^T dU_pq G)[r][s], dU[xi][cl][(p, q), ch]; thread = (cl, phase, 4 channels).
+__global__ __launch_bounds__(256) void wino4_wgrad_out(const float* __restrict__ du, float* __restrict__ dw, int Cl, int Ch) {
+    const int gid = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int Q = Ch >> 2;
+    const int cq = gid % Q, cp = gid / Q;
+    const int ph = cp & 3, cl = cp >> 2;
+    if (cl >= Cl) return;
+    const int p = ph >> 1, q = ph & 1;
+    const int64_t plane = (int64_t)Cl * 4 * Ch;
+    const float* const in = du + (int64_t)cl * 4 * Ch + ph * Ch + 4 * cq;
+    f32x4 t[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                          // G^T dU
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(in + (0 * 4 + j) * plane), u1 = *reinterpret_cast<const f32x4*>(in + (1 * 4 + j) * plane);
+        const f32x4 u2 = *reinterpret_cast<const f32x4*>(in + (2 * 4 + j) * plane), u3 = *reinterpret_cast<const f32x4*>(in + (3 * 4 + j) * plane);
+        t[0][j] = u0 + 0.5f * (u1 + u2);
+        t[1][j] = 0.5f * (u1 - u2) + u3;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {                          // (G^T dU) G
+        f32x4* const d0 = reinterpret_cast<f32x4*>(dw + ((int64_t)(cl * 4 + 2 * r + p) * 4 + q) * Ch + 4 * cq);
+        f32x4* const d1 = reinterpret_cast<f32x4*>(dw + ((int64_t)(cl * 4 + 2 * r + p) * 4 + 2 + q) * Ch + 4 * cq);
+        *d0 = *d0 + (t[r][0] + 0.5f * (t[r][1] + t[r][2]));
+        *d1 = *d1 + (0.5f * (t[r][1] - t[r][2]) + t[r][3]);
+    }
+}
+
 }  // namespace w4
 
 static bool w4_shape_ok(int N, int H, int W, int Ci, int Co) {
@@ -213,11 +294,69 @@ extern "C" int advmix_conv4x4s2_wino_fwd(const float* x, const float* u, const f
     float* const m = ws + (int64_t)16 * p.rows * 4 * Ci;
     p.m = m;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(w4::wino4_input, dim3(cdiv((int64_t)p.tiles * Ci, 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(w4::wino4_input, dim3(cdiv((int64_t)p.rows * Ci, 256)), dim3(256), 0, st, p);
     ADVMIX_CHECK_LAUNCH();
     int rc = advmix_conv_direct_gemm_batched(p.v, u, m, 16, p.rows, 4 * Ci, Co, st);
     if (rc != ADVMIX_OK) return rc < 0 ? ADVMIX_EINVAL : rc;
     hipLaunchKernelGGL(w4::wino4_output, dim3(cdiv((int64_t)p.tiles * (Co / 4), 256)), dim3(256), 0, st, p);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+// floats of scratch advmix_conv4x4s2_wino_wgrad needs (V unless handed in, dM, dU); 0 = shape not served (as the forward's, and
+// Cl a multiple of 64: the grouped weight-gradient kernel's row tile)
+extern "C" int64_t advmix_conv4x4s2_wino_wgrad_ws_floats(int N, int H, int W, int Ch, int Cl, int have_v) {
+    if (!w4_shape_ok(N, H, W, Ch, Cl) || Cl % 64 != 0 || (4 * Ch) % 128 != 0) return 0;
+    const int64_t tiles = (int64_t)N * cdiv(H / 2, 3) * cdiv(W / 2, 3);
+    const int64_t rows = (tiles + 127) / 128 * 128;
+    return 16 * rows * ((have_v ? 0 : 4 * (int64_t)Ch) + Cl) + (int64_t)16 * Cl * 4 * Ch;
+}
+
+// Weight gradient of a 4x4 / stride 2 / pad 1 conv with filters [Cl][4][4][Ch], ACCUMULATED into dw:
+// dw[cl][ky][kx][ch] += sum lo[n][oy][ox][cl] * hi[n][2 oy + ky - 1][2 ox + kx - 1][ch]; hi [N][H][W][Ch] is the conv's input (a
+// transposed conv's output gradient), lo [N][H/2][W/2][Cl] its output gradient (a transposed conv's input).  ``v``: the input
+// transform of ``hi`` if a preceding advmix_conv4x4s2_wino_fwd(hi, ...) left it at the start of ITS scratch (same stream), else
+// null (made here).  ADVMIX_EINVAL (nothing launched) for unserved shapes and in deterministic mode.
+// Replaces autograd's convolution_backward weight path for lib/models/Unet_generator.py:60-65,74-76,84-86.
+extern "C" int advmix_conv4x4s2_wino_wgrad(const float* hi, const float* lo, float* dw, const float* v, float* ws, int64_t ws_floats,
+                                           int N, int H, int W, int Ch, int Cl, void* stream) {
+    if (!hi || !lo || !dw || !ws || advmix_opts().deterministic) return ADVMIX_EINVAL;
+    const int64_t need = advmix_conv4x4s2_wino_wgrad_ws_floats(N, H, W, Ch, Cl, v != nullptr);
+    if (need <= 0 || ws_floats < need) return ADVMIX_EINVAL;
+    w4::W4P p{};
+    p.x = hi;
+    p.N = N; p.H = H; p.W = W; p.Ci = Ch; p.Co = Cl;
+    p.Th = cdiv(H / 2, 3); p.Tw = cdiv(W / 2, 3);
+    p.tiles = N * p.Th * p.Tw;
+    p.rows = (p.tiles + 127) / 128 * 128;
+    p.xbytes = (int)((int64_t)N * H * W * Ch * 4);
+    hipStream_t st = (hipStream_t)stream;
+    const int K = 4 * Ch;
+    float* cur = ws;
+    if (!v) {
+        p.v = cur;
+        cur += (int64_t)16 * p.rows * K;
+        hipLaunchKernelGGL(w4::wino4_input, dim3(cdiv((int64_t)p.rows * Ch, 256)), dim3(256), 0, st, p);
+        ADVMIX_CHECK_LAUNCH();
+        v = p.v;
+    }
+    float* const dm = cur;
+    float* const du = dm + (int64_t)16 * p.rows * Cl;
+    hipLaunchKernelGGL(w4::wino4_output_adj, dim3(cdiv((int64_t)p.rows * (Cl / 4), 256)), dim3(256), 0, st, lo, dm, N, H / 2, W / 2, Cl,
+                       p.Th, p.Tw, p.tiles, p.rows);
+    ADVMIX_CHECK_LAUNCH();
+    if (hipMemsetAsync(du, 0, (size_t)16 * Cl * K * sizeof(float), st) != hipSuccess) return ADVMIX_ELAUNCH;
+    const float* a[16];
+    const float* b[16];
+    float* d[16];
+    for (int xi = 0; xi < 16; ++xi) {
+        a[xi] = dm + (int64_t)xi * p.rows * Cl;
+        b[xi] = v + (int64_t)xi * p.rows * K;
+        d[xi] = du + (int64_t)xi * Cl * K;
+    }
+    int rc = advmix_conv_wgrad_group(16, a, b, d, p.rows / 128, 8, 16, Cl, 8, 16, K, 1, 1, 1, 0, stream);
+    if (rc != ADVMIX_OK) return rc;
+    hipLaunchKernelGGL(w4::wino4_wgrad_out, dim3(cdiv((int64_t)Cl * Ch, 256)), dim3(256), 0, st, du, dw, Cl, Ch);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }

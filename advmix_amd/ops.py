@@ -242,7 +242,7 @@ WGRAD_GROUP = __import__('os').environ.get('ADVMIX_WGRAD_GROUP', '1') != '0'
 _WG_DEFER = []          # a stack of pending lists: [(a, b, grad, geom)] of the Chain.bwd calls in progress
 
 
-def _wgrad(st, lane, a, b, w, geom, park=False):
+def _wgrad(st, lane, a, b, w, geom, park=False, v=None):
     """Weight gradient accumulated into w.grad (atomics, or ordered partials in deterministic mode).  ``park``: a and b stay
     as they are until the autograd pass ends (ConvBN.bwd: a fresh dc, a saved activation), so a SMALL problem may wait for
     a mixed launch (_wgrad_single); the U-Net's plain convs hand over gradients that later backward ops update in place."""
@@ -250,6 +250,8 @@ def _wgrad(st, lane, a, b, w, geom, park=False):
     if DETERMINISTIC:
         ws = _workspace(a.device, 0, lane)
         call('advmix_conv_wgrad_det', _p(a), _p(b), _p(g), *geom, _p(ws), WS_BYTES, st)
+    elif geom[7:] == (4, 4, 2, 1) and _wgrad4x4s2_wino(st, a, b, g, geom, v):     # (the U-Net's convs: csrc/conv_wino4.hip; ``v``: the
+        pass                                                                     #  input transform of b a preceding launch left)
     elif _WG_DEFER and WGRAD_GROUP and ((geom[3] % 64 == 0 and geom[6] % 4 == 0)
                                         or (geom[3] == 32 and geom[6] == 32 and geom[7:] == (3, 3, 1, 1))):
         _WG_DEFER[-1].append((a, b, g, geom, park))         # (a - a kept temporary - and b stay alive in the pending list)
@@ -383,6 +385,9 @@ WINO_MIN_WGS = int(__import__('os').environ.get('ADVMIX_WINO_MIN_WGS', '96'))   
 WINO_ASYNC = __import__('os').environ.get('ADVMIX_WINO_ASYNC', '1') != '0'   # filter transforms beside the stem (plan.PlanNet._wino_refresh; 0 = on the caller's stream)
 PW = __import__('os').environ.get('ADVMIX_PW', '1') != '0'           # A/B switch: 0 = the 64 -> 256 1x1 convs of the bottlenecks on the direct kernel (csrc/conv_pw.hip)
 WINO4 = __import__('os').environ.get('ADVMIX_WINO4', '1') != '0'     # A/B switch: 0 = the U-Net's 4x4 / stride-2 convs on the direct kernel (csrc/conv_wino4.hip)
+WINO4_KEEP_V = __import__('os').environ.get('ADVMIX_WINO4_KEEP_V', '1') != '0'   # a Conv2d's forward keeps its input transform for its weight gradient (0 = made again)
+WINO4_WGRAD = __import__('os').environ.get('ADVMIX_WINO4_WGRAD', '1') != '0'   # A/B switch: 0 = their weight gradients on the direct kernel
+WINO4_WGRAD_MIN_TILES = int(__import__('os').environ.get('ADVMIX_WINO4_WGRAD_MIN_TILES', '512'))   # (8 x 6 maps, 192 tiles at B = 32: the 16 dU planes - up to 134 MB - cost more than the multiplies saved)
 WINO4_MIN_TILES = int(__import__('os').environ.get('ADVMIX_WINO4_MIN_TILES', '128'))   # 3x3 output tiles below which the direct kernel stays (B = 32: the 4x3 bottleneck has 64)
 SMAP = __import__('os').environ.get('ADVMIX_SMAP', '1') != '0'       # A/B switch: 0 = the small 256-channel maps on the direct kernel
 SMAP_C = 256                                                         # (csrc/conv_smap.hip: one workgroup per image, K split over its eight waves)
@@ -504,22 +509,43 @@ def _wino_images(w, B, H, W, Ci, Co, R, S, stride, pad):
 
 def _conv4x4s2_wino(st, x, w, bias, y, B, Hi, Wi, Ci, Co):
     """The forward-form 4x4 / stride 2 / pad 1 conv x[B,Hi,Wi,Ci] -> y[B,Hi/2,Wi/2,Co] with filters w (memory [Co][4][4][Ci]) on
-    csrc/conv_wino4.hip when ``w`` carries a 'w4' image and the shape is served; False = nothing launched."""
+    csrc/conv_wino4.hip when ``w`` carries a 'w4' image and the shape is served; None = nothing launched, else the launch's
+    scratch tensor - the input transform of x sits at its start (the weight gradient of a transposed conv reads it again)."""
     if not (WINO and WINO4) or DETERMINISTIC or not _direct_ok():
-        return False
+        return None
     tag = _wino_tag(w)
     if tag is None or tag[4] != 'w4' or B * (-(-Hi // 6)) * (-(-Wi // 6)) < WINO4_MIN_TILES:
-        return False
+        return None
     wsf = lib.advmix_conv4x4s2_wino_ws_floats(B, Hi, Wi, Ci, Co)
     if wsf <= 0:
-        return False
+        return None
     ws = keep(torch.empty(wsf, device=x.device, dtype=torch.float32))
     rc = lib.advmix_conv4x4s2_wino_fwd(_p(x), tag[1], _p(bias), _p(y), _p(ws), wsf, B, Hi, Wi, Ci, Co, st)
     if rc == 0:
         COUNTERS['w4'] = COUNTERS.get('w4', 0) + 1
-        return True
+        return ws
     if rc != 1:
         raise RuntimeError('advmix_conv4x4s2_wino_fwd failed: %d' % rc)
+    return None
+
+
+def _wgrad4x4s2_wino(st, lo, hi, g, geom, v=None):
+    """Weight gradient of a 4x4 / stride 2 / pad 1 conv (filters [Cl][4][4][Ch]) on csrc/conv_wino4.hip, accumulated into ``g``:
+    lo [B,Ha,Wa,Cl] (the conv's output gradient / a transposed conv's input), hi [B,2Ha,2Wa,Ch].  ``v``: the scratch tensor of a
+    preceding _conv4x4s2_wino(hi, ...) on the same stream (its input transform is reused).  False = nothing launched."""
+    B, Ha, Wa, Cl, Hb, Wb, Ch = geom[:7]
+    if not (WINO and WINO4 and WINO4_WGRAD) or DETERMINISTIC or not _direct_ok() or B * (-(-Hb // 6)) * (-(-Wb // 6)) < WINO4_WGRAD_MIN_TILES:
+        return False
+    wsf = lib.advmix_conv4x4s2_wino_wgrad_ws_floats(B, Hb, Wb, Ch, Cl, 1 if v is not None else 0)
+    if wsf <= 0:
+        return False
+    ws = keep(torch.empty(wsf, device=hi.device, dtype=torch.float32))
+    rc = lib.advmix_conv4x4s2_wino_wgrad(_p(hi), _p(lo), _p(g), _p(v), _p(ws), wsf, B, Hb, Wb, Ch, Cl, st)
+    if rc == 0:
+        COUNTERS['w4_wgrad'] = COUNTERS.get('w4_wgrad', 0) + 1
+        return True
+    if rc != 1:
+        raise RuntimeError('advmix_conv4x4s2_wino_wgrad failed: %d' % rc)
     return False
 
 
@@ -610,10 +636,12 @@ class Conv:
         Ho = (Hi + 2 * pad - R) // stride + 1
         Wo = (Wi + 2 * pad - S) // stride + 1
         y = empty_nhwc(B, Co, Ho, Wo, x.device)
-        if not ((R, S, stride, pad) == (4, 4, 2, 1) and _conv4x4s2_wino(st, x, w, bias, y, B, Hi, Wi, Ci, Co)):
+        v = _conv4x4s2_wino(st, x, w, bias, y, B, Hi, Wi, Ci, Co) if (R, S, stride, pad) == (4, 4, 2, 1) else None
+        if v is None:
             call('advmix_conv_fwd', _p(x), _p(w), _p(bias), _p(y), B, Hi, Wi, Ci, Ho, Wo, Co, R, S,
                  stride, pad, st)
-        return (y,), (x, w, bias), None
+        # (the Winograd launch's scratch starts with the input transform of x: the weight gradient multiplies the same one)
+        return (y,), (x, w, bias), (v if needs[1] and WINO4_KEEP_V else None)
 
     ADD_TO = True    # bwd(..., add_to): another gradient of the input, summed in the dgrad epilogue
 
@@ -629,7 +657,7 @@ class Conv:
         if needs[0]:
             dx = _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to, bnb, lane)
         if needs[1]:
-            _wgrad(st, lane, dy, x, w, (B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad))
+            _wgrad(st, lane, dy, x, w, (B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad), v=extra if torch.is_tensor(extra) else None)
         if bias is not None and needs[2]:
             _bias_grad(st, lane, dy, bias, B * Ho * Wo, Co)
         return dx, None, None
@@ -681,14 +709,15 @@ class Deconv:
         B, Ci, Hi, Wi = x.shape
         _, Co, R, S = w.shape
         Ho, Wo = dy.shape[2], dy.shape[3]
-        dx = None
+        dx, v = None, None
         if needs[0]:
             dx = empty_nhwc(B, Ci, Hi, Wi, x.device)
-            if not ((R, S, stride, pad) == (4, 4, 2, 1) and _conv4x4s2_wino(st, dy, w, None, dx, B, Ho, Wo, Co, Ci)):
+            v = _conv4x4s2_wino(st, dy, w, None, dx, B, Ho, Wo, Co, Ci) if (R, S, stride, pad) == (4, 4, 2, 1) else None
+            if v is None:
                 call('advmix_conv_fwd', _p(dy), _p(w), None, _p(dx), B, Ho, Wo, Co, Hi, Wi, Ci, R, S,
                      stride, pad, st)
         if needs[1]:
-            _wgrad(st, lane, x, dy, w, (B, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad))
+            _wgrad(st, lane, x, dy, w, (B, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad), v=v)
         if bias is not None and needs[2]:
             _bias_grad(st, lane, dy, bias, B * Ho * Wo, Co)
         return dx, None, None

@@ -203,8 +203,16 @@ int advmix_conv1x1_pw_dgrad(const float* dy, const float* u, const float* addend
  * advmix_w4_weights: records as advmix_wino_weights' (Cn = Co, Ck = Ci, role 0); a record owns Co * 4 * Ci / 256 workgroups.
  * advmix_conv4x4s2_wino_ws_floats: floats of scratch a launch needs (0: shape not served - H, W even, Ci % 8 == 0, Co % 4 == 0,
  * every buffer below 2 GiB).  advmix_conv4x4s2_wino_fwd: y[N][H/2][W/2][Co] = conv(x[N][H][W][Ci]) + bias; ADVMIX_EINVAL for
- * unserved shapes (the caller runs advmix_conv_fwd). */
+ * unserved shapes (the caller runs advmix_conv_fwd).
+ * advmix_conv4x4s2_wino_wgrad: the weight gradient of such a conv (filters [Cl][4][4][Ch]) ACCUMULATED into dw, from its input
+ * hi[N][H][W][Ch] and its output gradient lo[N][H/2][W/2][Cl] (a transposed conv: output gradient / input): the adjoint output
+ * transform of lo, the input transform of hi (or ``v``: the one a preceding advmix_conv4x4s2_wino_fwd(hi, ...) left at the start
+ * of its scratch), 16 weight-gradient GEMMs as one grouped launch, the adjoint filter transform.  Served: the forward's shapes
+ * with Cl % 64 == 0 and Ch % 32 == 0; not in deterministic mode.  _wgrad_ws_floats: its scratch (0 = not served). */
 int64_t advmix_wino4_u_floats(int Co, int Ci);
+int64_t advmix_conv4x4s2_wino_wgrad_ws_floats(int N, int H, int W, int Ch, int Cl, int have_v);
+int advmix_conv4x4s2_wino_wgrad(const float* hi, const float* lo, float* dw, const float* v, float* ws, int64_t ws_floats,
+                                int N, int H, int W, int Ch, int Cl, void* stream);
 int advmix_w4_weights(const void* ents, const int* blk_ent, int blocks, void* stream);
 int64_t advmix_conv4x4s2_wino_ws_floats(int N, int H, int W, int Ci, int Co);
 int advmix_conv4x4s2_wino_fwd(const float* x, const float* u, const float* bias, float* y, float* ws, int64_t ws_floats,

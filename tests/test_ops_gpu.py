@@ -715,6 +715,30 @@ def test_winograd_4x4_stride2_conv(case):
     assert ops.COUNTERS.get('w4', 0) == n0 + (1 if served else 0)
     dx64 = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), None, 2, 1)
     assert (xt.grad.double().cpu() - dx64).abs().max().item() <= 1e-4 * dx64.abs().max().item()
+    # the weight gradient: hi = x, lo = a gradient of the conv's output; accumulated into a non-zero dw
+    lo = R(B, H // 2, W // 2, Co)
+    x64 = x.double().permute(0, 3, 1, 2)
+    w64 = w.double().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    F.conv2d(x64, w64, None, 2, 1).backward(lo.double().permute(0, 3, 1, 2))
+    dw64 = w64.grad.permute(0, 2, 3, 1)                     # [Co][4][4][Ci]
+    base = R(Co, 4, 4, Ci)
+    lod = lo.to(d)
+    wg_served = Co % 64 == 0 and Ci % 32 == 0
+    for have_v in (0, 1):
+        wsg = lib.advmix_conv4x4s2_wino_wgrad_ws_floats(B, H, W, Ci, Co, have_v)
+        assert (wsg > 0) == wg_served
+        if not wg_served:
+            continue
+        dwd = base.to(d).clone()
+        wsw = torch.full((wsg,), float('nan'), device=d)
+        call('advmix_conv4x4s2_wino_wgrad', P(xd), P(lod), P(dwd), P(ws) if have_v else None, P(wsw), wsg, B, H, W, Ci, Co, st)
+        err = ((dwd.double().cpu() - base.double()) - dw64).abs().max().item()
+        assert err <= 1e-4 * dw64.abs().max().item(), (have_v, err, dw64.abs().max().item())
+    # through the ops: a ConvTranspose2d's backward (one input transform of dy for dx and dw) and a Conv2d's
+    n0, g0 = ops.COUNTERS.get('w4_wgrad', 0), wp.grad.clone()
+    yo.backward(lod.permute(0, 3, 1, 2))
+    assert ops.COUNTERS.get('w4_wgrad', 0) == n0 + (1 if served and wg_served else 0)
+    assert ((wp.grad - g0).permute(0, 2, 3, 1).double().cpu() - dw64).abs().max().item() <= 2e-4 * dw64.abs().max().item()
     bank.release()
 
 

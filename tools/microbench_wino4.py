@@ -74,3 +74,20 @@ for Ci, Co, Ho, Wo in [(64, 256, 64, 48), (128, 512, 32, 24), (256, 1024, 16, 12
     fl = 2.0 * B * Ho * Wo * Co * Ci * 16
     print('%4d->%4d @%dx%d: direct %.1f us (%.3f of peak)  wino4 %.1f us (%.3f on direct flops)  x%.2f   |direct - wino4| %.1e of scale'
           % (Ci, Co, Ho, Wo, td, fl / td / 1e6 / 157.3, tw, fl / tw / 1e6 / 157.3, td / tw, err), flush=True)
+    # weight gradient: hi = x, lo = a gradient of y
+    lo = torch.randn_like(y0)
+    dw0, dw1 = torch.zeros_like(w), torch.zeros_like(w)
+    wsg = [lib.advmix_conv4x4s2_wino_wgrad_ws_floats(B, 2 * Ho, 2 * Wo, Ci, Co, hv) for hv in (0, 1)]
+    if wsg[0] > 0:
+        wsw = torch.empty(wsg[0], device=dev)
+        wsf = lib.advmix_conv4x4s2_wino_ws_floats(B, 2 * Ho, 2 * Wo, Ci, Co)
+        vbuf = torch.empty(wsf, device=dev)
+        call('advmix_conv4x4s2_wino_fwd', P(x), P(transform(w)), None, P(y1), P(vbuf), wsf, B, 2 * Ho, 2 * Wo, Ci, Co, st)   # leaves V(x) in vbuf
+        dwg = lambda: call('advmix_conv_wgrad', P(lo), P(x), P(dw0), B, Ho, Wo, Co, 2 * Ho, 2 * Wo, Ci, 4, 4, 2, 1, st)
+        wwg = lambda: call('advmix_conv4x4s2_wino_wgrad', P(x), P(lo), P(dw1), None, P(wsw), wsg[0], B, 2 * Ho, 2 * Wo, Ci, Co, st)
+        wwv = lambda: call('advmix_conv4x4s2_wino_wgrad', P(x), P(lo), P(dw1), P(vbuf), P(wsw), wsg[1], B, 2 * Ho, 2 * Wo, Ci, Co, st)
+        dwg(); wwg(); torch.cuda.synchronize()
+        errw = (dw0 - dw1).abs().max().item() / dw0.abs().max().item()
+        t0, t1, t2 = timeit(dwg), timeit(wwg), timeit(wwv)
+        print('      weight gradient: direct %.1f us (%.3f)  wino4 %.1f us (x%.2f)  with V handed in %.1f us (x%.2f)   |direct - wino4| %.1e of scale'
+              % (t0, fl / t0 / 1e6 / 157.3, t1, t0 / t1, t2, t0 / t2, errw), flush=True)

@@ -54,6 +54,8 @@ SIGNATURES = {
     'advmix_w4_weights': [_p, _p, _i, _p],
     'advmix_conv4x4s2_wino_fwd': [_p, _p, _p, _p, _p, _l] + [_i] * 5 + [_p],
     'advmix_conv4x4s2_wino_wgrad': [_p, _p, _p, _p, _p, _l] + [_i] * 5 + [_p],
+    'advmix_w4t_weights': [_p, _p, _i, _p],
+    'advmix_deconv4x4s2_wino_fwd': [_p, _p, _p, _p, _p, _p, _l] + [_i] * 5 + [_p],
     'advmix_wgrad_wino_config': [_i] * 5,
     'advmix_conv3x3_wgrad_wino_group': [_i, _p, _p, _p] + [_i] * 5 + [_p],
     'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],
@@ -134,6 +136,8 @@ lib.advmix_conv4x4s2_wino_ws_floats.argtypes = [_i] * 5
 lib.advmix_conv4x4s2_wino_ws_floats.restype = ctypes.c_int64
 lib.advmix_conv4x4s2_wino_wgrad_ws_floats.argtypes = [_i] * 6
 lib.advmix_conv4x4s2_wino_wgrad_ws_floats.restype = ctypes.c_int64
+lib.advmix_deconv4x4s2_wino_ws_floats.argtypes = [_i] * 5
+lib.advmix_deconv4x4s2_wino_ws_floats.restype = ctypes.c_int64
 lib.advmix_smap_u_floats.argtypes = [_i, _i]
 lib.advmix_smap_u_floats.restype = ctypes.c_int64
 lib.advmix_wgrad_det_ws_bytes.argtypes = [_i, _i, _i, _i]

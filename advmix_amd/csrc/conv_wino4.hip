@@ -243,6 +243,173 @@ __global__ __launch_bounds__(256) void wino4_wgrad_out(const float* __restrict__
     }
 }
 
+// ---- the transposed form: ConvTranspose2d(k 4, s 2, p 1) forward / the input gradient of a Conv2d(k 4, s 2, p 1) ---------------
+// y[2 i - 1 + ky] += x[i] w[ky]: output rows of parity 0 are y[2 m] = x[m] w[1] + x[m - 1] w[3], of parity 1 y[2 m + 1] = x[m + 1] w[0] +
+// x[m] w[2] - each a 2-tap correlation over the LOW-resolution map.  With the patch d[a] = x[3 t - 1 + a], a = 0..3, BOTH parities are
+// F(3, 2) on the same patch: parity 0 with taps (w[3], w[1]) gives rows 6 t + 2 mu, parity 1 with taps (w[2], w[0]) gives rows
+// 6 t - 1 + 2 mu (mu = 0..2) - together the six rows 6 t - 1 ... 6 t + 4, so tile t of floor(H / 3) + 1 per axis owns them and ONE input
+// transform per tile serves the four output phases: 16 GEMMs [tiles x Cl] . [Cl x 4 Ch], the phase is part of the column index.
+struct W4T {
+    const float* x;           // [N][Hl][Wl][Cl]
+    float* v;                 // [16][rows][Cl]
+    const float* m;           // [16][rows][4 Ch]
+    const float* bias;
+    const float* add;         // [N][2 Hl][2 Wl][Ch] or null
+    float* y;                 // [N][2 Hl][2 Wl][Ch]
+    int N, Hl, Wl, Cl, Ch;
+    int Th, Tw, tiles, rows;
+    int xbytes;
+};
+
+// filters: U'[xi][(P, Q), ch][cl] = (G g G^T)[xi], g[r][s] = w[cl][ky(P, r)][kx(Q, s)][ch], ky(0, .) = (3, 1), ky(1, .) = (2, 0).
+// w is ch-contiguous, U' is cl-contiguous: a workgroup = 32 cl x 32 ch of one phase, transposed through LDS (both sides coalesced).
+// A record (W4Ent: Cn = Cl, Ck = Ch, role 1) owns (Cl / 32) * (Ch / 32) * 4 consecutive blocks.
+__global__ __launch_bounds__(256) void wino4t_weights(const W4Ent* __restrict__ ents, const int* __restrict__ blk_ent) {
+    __shared__ float S[8][32][33];
+    const W4Ent e = ents[blk_ent[blockIdx.x]];
+    const int Cl = e.Cn, Ch = e.Ck;
+    const int lb = (int)blockIdx.x - e.blk0;
+    const int ph = lb & 3, t = lb >> 2;
+    const int nct = Ch >> 5;
+    const int cl0 = (t / nct) * 32, ch0 = (t % nct) * 32;
+    const int P = ph >> 1, Q = ph & 1;
+    const int tid = threadIdx.x, j = tid & 31, i0 = tid >> 5;
+    float U[4][16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int cl = cl0 + i0 + 8 * k;
+        float g[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_)
+                g[r][s_] = e.w[((int64_t)(cl * 4 + (3 - P) - 2 * r) * 4 + (3 - Q) - 2 * s_) * Ch + ch0 + j];
+        float a[4][2];
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            a[0][s_] = g[0][s_];
+            a[1][s_] = 0.5f * (g[0][s_] + g[1][s_]);
+            a[2][s_] = 0.5f * (g[0][s_] - g[1][s_]);
+            a[3][s_] = g[1][s_];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            U[k][i * 4 + 0] = a[i][0];
+            U[k][i * 4 + 1] = 0.5f * (a[i][0] + a[i][1]);
+            U[k][i * 4 + 2] = 0.5f * (a[i][0] - a[i][1]);
+            U[k][i * 4 + 3] = a[i][1];
+        }
+    }
+    const int64_t plane = (int64_t)4 * Ch * Cl;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int x = 0; x < 8; ++x) S[x][j][i0 + 8 * k] = U[k][half * 8 + x];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int chl = i0 + 8 * k;
+            float* const out = e.u + (int64_t)(ph * Ch + ch0 + chl) * Cl + cl0 + j;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) out[(half * 8 + x) * plane] = S[x][chl][j];
+        }
+        __syncthreads();
+    }
+}
+
+// input transform: thread = (tile, 4 channels); the tile's 4x4 low-resolution patch starts at (3 ty - 1, 3 tx - 1)
+__global__ __launch_bounds__(256) void wino4t_input(const W4T p) {
+    const int gid = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int Q = p.Cl >> 2;
+    const int tile = gid / Q, cq = gid - tile * Q;
+    if (tile >= p.rows) return;
+    const int64_t plane = (int64_t)p.rows * p.Cl;
+    float* const out = p.v + (int64_t)tile * p.Cl + 4 * cq;
+    if (tile >= p.tiles) {
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) *reinterpret_cast<f32x4*>(out + xi * plane) = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const int n = tile / (p.Th * p.Tw), tr = tile - n * (p.Th * p.Tw);
+    const int ty = tr / p.Tw, tx = tr - ty * p.Tw;
+    const int h0 = 3 * ty - 1, w0 = 3 * tx - 1;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
+    f32x4 X[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int h = h0 + a, w = w0 + b;
+            const bool ok = (unsigned)h < (unsigned)p.Hl && (unsigned)w < (unsigned)p.Wl;
+            X[a][b] = bload(xr, ok ? (unsigned)((((n * p.Hl + h) * p.Wl + w) * p.Cl + 4 * cq) * 4) : OOB);
+        }
+    f32x4 t[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        t[0][b] = X[0][b] - X[2][b];
+        t[1][b] = X[1][b] + X[2][b];
+        t[2][b] = X[2][b] - X[1][b];
+        t[3][b] = X[1][b] - X[3][b];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<f32x4*>(out + (i * 4 + 0) * plane) = t[i][0] - t[i][2];
+        *reinterpret_cast<f32x4*>(out + (i * 4 + 1) * plane) = t[i][1] + t[i][2];
+        *reinterpret_cast<f32x4*>(out + (i * 4 + 2) * plane) = t[i][2] - t[i][1];
+        *reinterpret_cast<f32x4*>(out + (i * 4 + 3) * plane) = t[i][1] - t[i][3];
+    }
+}
+
+// output transform: thread = (tile, output phase, 4 channels); its 3x3 results go to rows 6 ty + 2 mu (P = 0) / 6 ty - 1 + 2 mu (P = 1)
+__global__ __launch_bounds__(256) void wino4t_output(const W4T p) {
+    const int gid = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int Q = p.Ch >> 2;
+    const int tile = gid / p.Ch, rem = gid - tile * p.Ch;
+    if (tile >= p.tiles) return;
+    const int ph = rem / Q, cq = rem - ph * Q;
+    const int P = ph >> 1, Qp = ph & 1;
+    const int N4 = 4 * p.Ch;
+    const int64_t plane = (int64_t)p.rows * N4;
+    const float* const in = p.m + (int64_t)tile * N4 + ph * p.Ch + 4 * cq;
+    f32x4 M[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) M[i][j] = *reinterpret_cast<const f32x4*>(in + (i * 4 + j) * plane);
+    f32x4 s[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[0][j] = (M[0][j] + M[1][j]) + M[2][j];
+        s[1][j] = M[1][j] - M[2][j];
+        s[2][j] = (M[1][j] + M[2][j]) - M[3][j];
+    }
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + 4 * cq);
+    const int Hh = 2 * p.Hl, Wh = 2 * p.Wl;
+    const int n = tile / (p.Th * p.Tw), tr = tile - n * (p.Th * p.Tw);
+    const int ty = tr / p.Tw, tx = tr - ty * p.Tw;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int Y = 6 * ty - P + 2 * a;
+        if ((unsigned)Y >= (unsigned)Hh) continue;
+        f32x4 o[3];
+        o[0] = (s[a][0] + s[a][1]) + s[a][2] + bv;
+        o[1] = (s[a][1] - s[a][2]) + bv;
+        o[2] = ((s[a][1] + s[a][2]) - s[a][3]) + bv;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int X = 6 * tx - Qp + 2 * b;
+            if ((unsigned)X >= (unsigned)Wh) continue;
+            const int64_t off = ((int64_t)(n * Hh + Y) * Wh + X) * p.Ch + 4 * cq;
+            f32x4 r = o[b];
+            if (p.add) r += *reinterpret_cast<const f32x4*>(p.add + off);
+            *reinterpret_cast<f32x4*>(p.y + off) = r;
+        }
+    }
+}
+
 }  // namespace w4
 
 static bool w4_shape_ok(int N, int H, int W, int Ci, int Co) {
@@ -357,6 +524,61 @@ extern "C" int advmix_conv4x4s2_wino_wgrad(const float* hi, const float* lo, flo
     int rc = advmix_conv_wgrad_group(16, a, b, d, p.rows / 128, 8, 16, Cl, 8, 16, K, 1, 1, 1, 0, stream);
     if (rc != ADVMIX_OK) return rc;
     hipLaunchKernelGGL(w4::wino4_wgrad_out, dim3(cdiv((int64_t)Cl * Ch, 256)), dim3(256), 0, st, du, dw, Cl, Ch);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+static bool w4t_shape_ok(int N, int Hl, int Wl, int Cl, int Ch) {
+    if (N <= 0 || Hl < 1 || Wl < 1 || Cl % 32 != 0 || Ch % 32 != 0) return false;
+    const int64_t tiles = (int64_t)N * (Hl / 3 + 1) * (Wl / 3 + 1);
+    const int64_t rows = (tiles + 127) / 128 * 128;
+    if ((int64_t)N * Hl * Wl * Cl * 4 >= 0x7fffffffLL || (int64_t)N * Hl * Wl * Ch * 16 >= 0x7fffffffLL || 16 * rows * Cl * 4 >= 0x7fffffffLL ||
+        16 * rows * 4 * Ch * 4 >= 0x7fffffffLL || (int64_t)16 * Cl * 4 * Ch * 4 >= 0x7fffffffLL)
+        return false;
+    return true;
+}
+
+// floats of scratch advmix_deconv4x4s2_wino_fwd needs; 0 = shape not served (served: Cl, Ch multiples of 32, every buffer below 2 GiB)
+extern "C" int64_t advmix_deconv4x4s2_wino_ws_floats(int N, int Hl, int Wl, int Cl, int Ch) {
+    if (!w4t_shape_ok(N, Hl, Wl, Cl, Ch)) return 0;
+    const int64_t tiles = (int64_t)N * (Hl / 3 + 1) * (Wl / 3 + 1);
+    const int64_t rows = (tiles + 127) / 128 * 128;
+    return 16 * rows * ((int64_t)Cl + 4 * Ch);
+}
+
+// Transposed-form filter images of n banks [Cl][4][4][Ch] in one launch (records as advmix_w4_weights with role 1; a record owns
+// (Cl / 32) * (Ch / 32) * 4 workgroups); u'[xi][(P, Q), ch][cl], 16 * 4 * Ch * Cl floats (advmix_wino4_u_floats(Cl, Ch)).
+extern "C" int advmix_w4t_weights(const void* ents, const int* blk_ent, int blocks, void* stream) {
+    if (!ents || !blk_ent || blocks <= 0) return ADVMIX_EINVAL;
+    hipLaunchKernelGGL(w4::wino4t_weights, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const w4::W4Ent*)ents, blk_ent);
+    ADVMIX_CHECK_LAUNCH();
+    return ADVMIX_OK;
+}
+
+// advmix_conv_tr_w / advmix_conv_tr_w_add for k 4 / stride 2 / pad 1 with filters w[Cl][4][4][Ch] transformed by advmix_w4t_weights
+// into ``u``: y[N][2 Hl][2 Wl][Ch] = conv_transpose(x[N][Hl][Wl][Cl]) + bias + addend.  ADVMIX_EINVAL (nothing launched) for unserved
+// shapes.  Semantics: lib/models/Unet_generator.py:63-65,74-76,84-86 (upconv) and the input gradient of :60-62 (downconv).
+extern "C" int advmix_deconv4x4s2_wino_fwd(const float* x, const float* u, const float* bias, const float* addend, float* y, float* ws,
+                                           int64_t ws_floats, int N, int Hl, int Wl, int Cl, int Ch, void* stream) {
+    if (!x || !u || !y || !ws) return ADVMIX_EINVAL;
+    const int64_t need = advmix_deconv4x4s2_wino_ws_floats(N, Hl, Wl, Cl, Ch);
+    if (need <= 0 || ws_floats < need) return ADVMIX_EINVAL;
+    w4::W4T p{};
+    p.x = x; p.bias = bias; p.add = addend; p.y = y;
+    p.N = N; p.Hl = Hl; p.Wl = Wl; p.Cl = Cl; p.Ch = Ch;
+    p.Th = Hl / 3 + 1; p.Tw = Wl / 3 + 1;
+    p.tiles = N * p.Th * p.Tw;
+    p.rows = (p.tiles + 127) / 128 * 128;
+    p.xbytes = (int)((int64_t)N * Hl * Wl * Cl * 4);
+    p.v = ws;
+    float* const m = ws + (int64_t)16 * p.rows * Cl;
+    p.m = m;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(w4::wino4t_input, dim3(cdiv((int64_t)p.rows * (Cl / 4), 256)), dim3(256), 0, st, p);
+    ADVMIX_CHECK_LAUNCH();
+    int rc = advmix_conv_direct_gemm_batched(p.v, u, m, 16, p.rows, Cl, 4 * Ch, st);
+    if (rc != ADVMIX_OK) return rc < 0 ? ADVMIX_EINVAL : rc;
+    hipLaunchKernelGGL(w4::wino4t_output, dim3(cdiv((int64_t)p.tiles * Ch, 256)), dim3(256), 0, st, p);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
 }

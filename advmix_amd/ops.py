@@ -385,6 +385,9 @@ WINO_MIN_WGS = int(__import__('os').environ.get('ADVMIX_WINO_MIN_WGS', '96'))   
 WINO_ASYNC = __import__('os').environ.get('ADVMIX_WINO_ASYNC', '1') != '0'   # filter transforms beside the stem (plan.PlanNet._wino_refresh; 0 = on the caller's stream)
 PW = __import__('os').environ.get('ADVMIX_PW', '1') != '0'           # A/B switch: 0 = the 64 -> 256 1x1 convs of the bottlenecks on the direct kernel (csrc/conv_pw.hip)
 WINO4 = __import__('os').environ.get('ADVMIX_WINO4', '1') != '0'     # A/B switch: 0 = the U-Net's 4x4 / stride-2 convs on the direct kernel (csrc/conv_wino4.hip)
+WINO4_T = __import__('os').environ.get('ADVMIX_WINO4_T', '0') != '0'   # 1 = the transposed form (ConvTranspose2d forward, Conv2d input gradient) on csrc/conv_wino4.hip too: +1.0 % on the step, but the 6-down
+#   U-Net's gradient median against float64 moves from 2.4-3.1e-3 to 4.2-4.7e-3 at 512x512 / B = 2 where the test allows 3 x the fp32 oracle's own 1.5e-3 - off by default (profiles/EXPERIMENTS.md K)
+WINO4_T_MIN_TILES = int(__import__('os').environ.get('ADVMIX_WINO4_T_MIN_TILES', '192'))
 WINO4_KEEP_V = __import__('os').environ.get('ADVMIX_WINO4_KEEP_V', '1') != '0'   # a Conv2d's forward keeps its input transform for its weight gradient (0 = made again)
 WINO4_WGRAD = __import__('os').environ.get('ADVMIX_WINO4_WGRAD', '1') != '0'   # A/B switch: 0 = their weight gradients on the direct kernel
 WINO4_WGRAD_MIN_TILES = int(__import__('os').environ.get('ADVMIX_WINO4_WGRAD_MIN_TILES', '512'))   # (8 x 6 maps, 192 tiles at B = 32: the 16 dU planes - up to 134 MB - cost more than the multiplies saved)
@@ -413,14 +416,14 @@ class WinoBank:
         # per image); everything else 'wino'
         kinds = ['w4' if tuple(w.shape[2:]) == (4, 4) else 'pw' if tuple(w.shape[2:]) == (1, 1) else
                  ('smapw' if SMAP_WINO else 'smap') if (w.shape[1] == SMAP_C and w.shape[0] % 32 == 0) else 'wino' for w in weights]   # (input-gradient images only where Cout == 256 too)
-        sizes = [(64 * w.shape[0] * w.shape[1], 0) if k == 'w4' else (9 * w.shape[0] * w.shape[1],) * 2 if k == 'smap' else (16 * w.shape[0] * w.shape[1],) * 2 if k == 'smapw' else
+        sizes = [(64 * w.shape[0] * w.shape[1], 64 * w.shape[0] * w.shape[1] if WINO4_T and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0 else 0) if k == 'w4' else (9 * w.shape[0] * w.shape[1],) * 2 if k == 'smap' else (16 * w.shape[0] * w.shape[1],) * 2 if k == 'smapw' else
                  (w.shape[0] * w.shape[1],) * 2 if k == 'pw' else
                  (16 * pad32(w.shape[0]) * w.shape[1], 16 * pad32(w.shape[1]) * w.shape[0]) for w, k in zip(weights, kinds)]
         self.buf = torch.empty(sum(a + b for a, b in sizes), device=dev, dtype=torch.float32)
         rec = np.dtype([('w', '<u8'), ('u', '<u8'), ('Cn', '<i4'), ('Ck', '<i4'), ('role', '<i4'), ('blk0', '<i4')])
-        ents = {'wino': [], 'smap': [], 'smapw': [], 'pw': [], 'w4': []}
-        blk = {'wino': 0, 'smap': 0, 'smapw': 0, 'pw': 0, 'w4': 0}
-        owner = {'wino': [], 'smap': [], 'smapw': [], 'pw': [], 'w4': []}
+        ents = {'wino': [], 'smap': [], 'smapw': [], 'pw': [], 'w4': [], 'w4t': []}
+        blk = {'wino': 0, 'smap': 0, 'smapw': 0, 'pw': 0, 'w4': 0, 'w4t': 0}
+        owner = {'wino': [], 'smap': [], 'smapw': [], 'pw': [], 'w4': [], 'w4t': []}
         off = 0
         self._tagged = []
         for i, (w, kind) in enumerate(zip(weights, kinds)):
@@ -431,20 +434,24 @@ class WinoBank:
             for role, (Cn, Ck) in enumerate(((Co, Ci), (Ci, Co))):
                 u = self.buf.data_ptr() + 4 * off
                 off += sizes[i][role]
-                if (kind in ('smap', 'smapw') and Ck != SMAP_C) or (kind == 'pw' and (Cn, Ck) != (256, 64)) or (kind == 'w4' and role == 1):
+                if (kind in ('smap', 'smapw') and Ck != SMAP_C) or (kind == 'pw' and (Cn, Ck) != (256, 64)) or (kind == 'w4' and role == 1 and not sizes[i][1]):
                     # (the small-map kernels read exactly 256 channels, conv_pw reads 64 and writes 256: no such image)
                     ptrs.append(None)
                     continue
+                tk = kind
+                if kind == 'w4':                            # filters [Co][4][4][Ci] in memory (a Conv2d's own, a ConvTranspose2d's [Cin][4][4][Cout]): role 0 = the
+                    Cn, Ck = Co, Ci                         # forward-form image (csrc/conv_wino4.hip), role 1 = the transposed form's, a table and a launch of its own
+                    tk = 'w4t' if role == 1 else 'w4'
                 nb = {'wino': ((Cn + 31) // 32) * (Ck // 8), 'smap': (Cn // 32) * (Ck // 32) * 36, 'smapw': (Cn // 32) * 32, 'pw': 64,
-                      'w4': Cn * 4 * Ck // 256}[kind]       # (w4: the memory-major dimension is the forward-form conv's Cout - a Conv2d's own, a ConvTranspose2d's Cin)
-                owner[kind] += [len(ents[kind])] * nb
-                ents[kind].append((w.data_ptr(), u, Cn, Ck, role, blk[kind]))
-                blk[kind] = len(owner[kind])
+                      'w4': Cn * 4 * Ck // 256, 'w4t': (Cn // 32) * (Ck // 32) * 4}[tk]
+                owner[tk] += [len(ents[tk])] * nb
+                ents[tk].append((w.data_ptr(), u, Cn, Ck, role, blk[tk]))
+                blk[tk] = len(owner[tk])
                 ptrs.append(ctypes.c_void_p(u))
             w._wino = (self.buf, ptrs[0], ptrs[1], w.data_ptr(), kind)     # (the tag keeps the side buffer alive)
             self._tagged.append(weakref.ref(w))
         self.tables = {}
-        for kind in ('wino', 'smap', 'smapw', 'pw', 'w4'):
+        for kind in ('wino', 'smap', 'smapw', 'pw', 'w4', 'w4t'):
             if ents[kind]:
                 ent = np.array(ents[kind], dtype=rec)
                 self.tables[kind] = (torch.from_numpy(ent.view(np.uint8).copy()).to(dev),
@@ -529,6 +536,27 @@ def _conv4x4s2_wino(st, x, w, bias, y, B, Hi, Wi, Ci, Co):
     return None
 
 
+def _deconv4x4s2_wino(st, x, w, bias, add_to, y, B, Hl, Wl, Cl, Ch):
+    """The transposed form, x[B,Hl,Wl,Cl] -> y[B,2Hl,2Wl,Ch] (+ bias + add_to) with filters w (memory [Cl][4][4][Ch]), on
+    csrc/conv_wino4.hip when ``w`` carries a transposed-form image and the shape is served; False = nothing launched."""
+    if not (WINO and WINO4 and WINO4_T) or DETERMINISTIC or not _direct_ok():
+        return False
+    tag = _wino_tag(w)
+    if tag is None or tag[4] != 'w4' or tag[2] is None or B * (Hl // 3 + 1) * (Wl // 3 + 1) < WINO4_T_MIN_TILES:
+        return False
+    wsf = lib.advmix_deconv4x4s2_wino_ws_floats(B, Hl, Wl, Cl, Ch)
+    if wsf <= 0:
+        return False
+    ws = keep(torch.empty(wsf, device=x.device, dtype=torch.float32))
+    rc = lib.advmix_deconv4x4s2_wino_fwd(_p(x), tag[2], _p(bias), _p(add_to), _p(y), _p(ws), wsf, B, Hl, Wl, Cl, Ch, st)
+    if rc == 0:
+        COUNTERS['w4t'] = COUNTERS.get('w4t', 0) + 1
+        return True
+    if rc != 1:
+        raise RuntimeError('advmix_deconv4x4s2_wino_fwd failed: %d' % rc)
+    return False
+
+
 def _wgrad4x4s2_wino(st, lo, hi, g, geom, v=None):
     """Weight gradient of a 4x4 / stride 2 / pad 1 conv (filters [Cl][4][4][Ch]) on csrc/conv_wino4.hip, accumulated into ``g``:
     lo [B,Ha,Wa,Cl] (the conv's output gradient / a transposed conv's input), hi [B,2Ha,2Wa,Ch].  ``v``: the scratch tensor of a
@@ -562,6 +590,9 @@ def _conv_dgrad(st, dy, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_
     if Co % 16 == 0 and Ci % 4 == 0 and _direct_ok():          # weights consumed in their own layout
         if add_to is not None and (add_to.shape != dx.shape or add_to.stride() != dx.stride()):
             raise RuntimeError('advmix_amd: gradient fan-in of differently laid out tensors')
+        if (R, S, stride, pad) == (4, 4, 2, 1) and bnb is None and (Hi, Wi) == (2 * Ho, 2 * Wo) and \
+                _deconv4x4s2_wino(st, dy, w, None, add_to, dx, B, Ho, Wo, Co, Ci):       # (the U-Net's down convs: csrc/conv_wino4.hip)
+            return dx
         wu = _wino_images(w, B, Hi, Wi, Co, Ci, R, S, stride, pad)      # (the gradient conv reads Co channels, writes Ci)
         if bnb is not None and BNB_FUSED:
             if tuple(bnb['c'].shape) != tuple(dx.shape) or bnb['c'].stride() != dx.stride():
@@ -687,6 +718,8 @@ class Deconv:
                 if rc != 1:
                     raise RuntimeError('advmix_deconv4x4s2_narrow_gemm failed: %d' % rc)
             call('advmix_deconv4x4s2_narrow', _p(x), _p(w), _p(bias), _p(y), B, Hi, Wi, Ci, Co, st)
+            return (y,), (x, w, bias), None
+        if (R, S, stride, pad) == (4, 4, 2, 1) and _deconv4x4s2_wino(st, x, w, bias, None, y, B, Hi, Wi, Ci, Co):
             return (y,), (x, w, bias), None
         if Ci % 16 == 0 and Co % 4 == 0 and _direct_ok():
             rc = lib.advmix_conv_tr_w(_p(x), _p(w), _p(bias), _p(y), B, Hi, Wi, Ci, Ho, Wo, Co, R, S,

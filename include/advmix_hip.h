@@ -208,8 +208,18 @@ int advmix_conv1x1_pw_dgrad(const float* dy, const float* u, const float* addend
  * hi[N][H][W][Ch] and its output gradient lo[N][H/2][W/2][Cl] (a transposed conv: output gradient / input): the adjoint output
  * transform of lo, the input transform of hi (or ``v``: the one a preceding advmix_conv4x4s2_wino_fwd(hi, ...) left at the start
  * of its scratch), 16 weight-gradient GEMMs as one grouped launch, the adjoint filter transform.  Served: the forward's shapes
- * with Cl % 64 == 0 and Ch % 32 == 0; not in deterministic mode.  _wgrad_ws_floats: its scratch (0 = not served). */
+ * with Cl % 64 == 0 and Ch % 32 == 0; not in deterministic mode.  _wgrad_ws_floats: its scratch (0 = not served).
+ *
+ * The transposed form (ConvTranspose2d(k 4, s 2, p 1) forward, Unet_generator.py:63-65,74-76,84-86; the input gradient of the down
+ * convs): tile t of floor(Hl / 3) + 1 per axis owns output rows 6 t - 1 ... 6 t + 4, one 4x4 low-resolution patch serves the four
+ * output phases, 16 GEMMs [tiles x Cl] . [Cl x 4 Ch].  advmix_w4t_weights: records as advmix_w4_weights with role 1 (a record
+ * owns (Cl / 32) * (Ch / 32) * 4 workgroups), u'[xi][(P, Q), ch][cl].  advmix_deconv4x4s2_wino_fwd: y[N][2 Hl][2 Wl][Ch] =
+ * conv_transpose(x[N][Hl][Wl][Cl]) + bias + addend with filters [Cl][4][4][Ch]; served: Cl, Ch multiples of 32. */
 int64_t advmix_wino4_u_floats(int Co, int Ci);
+int advmix_w4t_weights(const void* ents, const int* blk_ent, int blocks, void* stream);
+int64_t advmix_deconv4x4s2_wino_ws_floats(int N, int Hl, int Wl, int Cl, int Ch);
+int advmix_deconv4x4s2_wino_fwd(const float* x, const float* u, const float* bias, const float* addend, float* y, float* ws,
+                                int64_t ws_floats, int N, int Hl, int Wl, int Cl, int Ch, void* stream);
 int64_t advmix_conv4x4s2_wino_wgrad_ws_floats(int N, int H, int W, int Ch, int Cl, int have_v);
 int advmix_conv4x4s2_wino_wgrad(const float* hi, const float* lo, float* dw, const float* v, float* ws, int64_t ws_floats,
                                 int N, int H, int W, int Ch, int Cl, void* stream);

@@ -23,7 +23,7 @@ def test_library_exports_every_header_symbol():
     assert len(names) >= 28
     for n in names:
         assert hasattr(L.lib, n), n
-    sizes = {'advmix_norm_ws_bytes', 'advmix_wgrad_det_ws_bytes', 'advmix_deconv4x4s2_narrow_ws_bytes', 'advmix_wino_u_floats', 'advmix_smap_u_floats', 'advmix_smapw_u_floats', 'advmix_pw_u_floats', 'advmix_wino4_u_floats', 'advmix_conv4x4s2_wino_ws_floats', 'advmix_conv4x4s2_wino_wgrad_ws_floats',   # int64 results, bound separately
+    sizes = {'advmix_norm_ws_bytes', 'advmix_wgrad_det_ws_bytes', 'advmix_deconv4x4s2_narrow_ws_bytes', 'advmix_wino_u_floats', 'advmix_smap_u_floats', 'advmix_smapw_u_floats', 'advmix_pw_u_floats', 'advmix_wino4_u_floats', 'advmix_conv4x4s2_wino_ws_floats', 'advmix_conv4x4s2_wino_wgrad_ws_floats', 'advmix_deconv4x4s2_wino_ws_floats',   # int64 results, bound separately
              'advmix_conv_group'}                                          # struct argument, bound separately
     assert names - sizes == set(L.SIGNATURES), (names ^ set(L.SIGNATURES))
     assert hasattr(L.lib, '_Z4_nmsPiS_PKfiifi')            # the reference's own C++-linkage `_nms` (include/gpu_nms.hpp; lib/nms/gpu_nms.hpp:1-2)

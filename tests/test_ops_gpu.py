@@ -660,7 +660,7 @@ WINO4_CASES = [
 
 
 @pytest.mark.parametrize('case', WINO4_CASES)
-def test_winograd_4x4_stride2_conv(case):
+def test_winograd_4x4_stride2_conv(case, monkeypatch):
     """csrc/conv_wino4.hip (round 5): a 4x4 / stride 2 / pad 1 conv as Winograd F(3x3, 2x2) on the four parity phases of its
     input - input transform, the 16 GEMMs as ONE launch of the direct kernel (per-image filters), output transform - against a
     float64 torch evaluation (1e-4 of scale like every kernel) and the direct kernel; then through the ops the U-Net uses:
@@ -669,6 +669,7 @@ def test_winograd_4x4_stride2_conv(case):
     import ctypes
     from advmix_amd._lib import call, lib
     ops = _ops()
+    monkeypatch.setattr(ops, 'WINO4_T', True)               # the transposed form is off in the step by default (EXPERIMENTS K); tested here all the same
     B, Ci, Co, H, W, hb = case
     d = dev()
     g_ = torch.Generator().manual_seed(41 + Ci + H)
@@ -679,7 +680,7 @@ def test_winograd_4x4_stride2_conv(case):
     bd = b.to(d) if hb else None
     bank = ops.WinoBank([wd])
     bank.refresh()
-    assert wd._wino[4] == 'w4' and wd._wino[2] is None      # a forward-form image only
+    assert wd._wino[4] == 'w4' and (wd._wino[2] is not None) == (Ci % 32 == 0 and Co % 32 == 0)   # forward-form image; transposed-form one where served
     P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     wsf = lib.advmix_conv4x4s2_wino_ws_floats(B, H, W, Ci, Co)
@@ -734,11 +735,30 @@ def test_winograd_4x4_stride2_conv(case):
         call('advmix_conv4x4s2_wino_wgrad', P(xd), P(lod), P(dwd), P(ws) if have_v else None, P(wsw), wsg, B, H, W, Ci, Co, st)
         err = ((dwd.double().cpu() - base.double()) - dw64).abs().max().item()
         assert err <= 1e-4 * dw64.abs().max().item(), (have_v, err, dw64.abs().max().item())
+    # the transposed form with the same filters ([Cl = Co][4][4][Ch = Ci]): y_hi = conv_transpose(lo) + bias + addend
+    if wd._wino[2] is not None:
+        bt, addend = R(Ci), R(B, H, W, Ci)
+        yt64 = F.conv_transpose2d(lo.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), bt.double(), 2, 1).permute(0, 2, 3, 1) + addend.double()
+        wst = lib.advmix_deconv4x4s2_wino_ws_floats(B, H // 2, W // 2, Co, Ci)
+        assert wst == 16 * ((B * (H // 6 + 1) * (W // 6 + 1) + 127) // 128 * 128) * (Co + 4 * Ci)
+        wt_, ytd = torch.full((wst,), float('nan'), device=d), torch.full((B, H, W, Ci), float('nan'), device=d)
+        btd, addd = bt.to(d), addend.to(d)
+        assert lib.advmix_deconv4x4s2_wino_fwd(P(lod), wd._wino[2], P(btd), P(addd), P(ytd), P(wt_), wst - 1, B, H // 2, W // 2, Co, Ci, st) == 1
+        call('advmix_deconv4x4s2_wino_fwd', P(lod), wd._wino[2], P(btd), P(addd), P(ytd), P(wt_), wst, B, H // 2, W // 2, Co, Ci, st)
+        assert (ytd.double().cpu() - yt64).abs().max().item() <= 1e-4 * yt64.abs().max().item()
+        # ... through the ops: ConvTranspose2d forward, and the Conv2d's input gradient below
+        t_served = B * (H // 6 + 1) * (W // 6 + 1) >= ops.WINO4_T_MIN_TILES
+        n0 = ops.COUNTERS.get('w4t', 0)
+        yt2 = ops.conv_transpose2d(lod.permute(0, 3, 1, 2), wp, btd, 2, 1)
+        assert ops.COUNTERS.get('w4t', 0) == n0 + (1 if t_served else 0)
+        assert (yt2.permute(0, 2, 3, 1).double().cpu() - (yt64 - addend.double())).abs().max().item() <= 1e-4 * yt64.abs().max().item()
     # through the ops: a ConvTranspose2d's backward (one input transform of dy for dx and dw) and a Conv2d's
     n0, g0 = ops.COUNTERS.get('w4_wgrad', 0), wp.grad.clone()
     yo.backward(lod.permute(0, 3, 1, 2))
     assert ops.COUNTERS.get('w4_wgrad', 0) == n0 + (1 if served and wg_served else 0)
     assert ((wp.grad - g0).permute(0, 2, 3, 1).double().cpu() - dw64).abs().max().item() <= 2e-4 * dw64.abs().max().item()
+    dxc64 = F.conv_transpose2d(lo.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), None, 2, 1)      # the Conv2d's input gradient
+    assert (xg.grad.double().cpu() - dxc64).abs().max().item() <= 1e-4 * dxc64.abs().max().item()
     bank.release()
 
 

@@ -74,8 +74,24 @@ for Ci, Co, Ho, Wo in [(64, 256, 64, 48), (128, 512, 32, 24), (256, 1024, 16, 12
     fl = 2.0 * B * Ho * Wo * Co * Ci * 16
     print('%4d->%4d @%dx%d: direct %.1f us (%.3f of peak)  wino4 %.1f us (%.3f on direct flops)  x%.2f   |direct - wino4| %.1e of scale'
           % (Ci, Co, Ho, Wo, td, fl / td / 1e6 / 157.3, tw, fl / tw / 1e6 / 157.3, td / tw, err), flush=True)
-    # weight gradient: hi = x, lo = a gradient of y
     lo = torch.randn_like(y0)
+    # the transposed form with the same filters: lo [Cl = Co] -> hi [Ch = Ci]
+    bankw = w.permute(0, 3, 1, 2)
+    from advmix_amd import ops as _ops
+    bank = _ops.WinoBank([bankw]); bank.refresh(); torch.cuda.synchronize()
+    if bankw._wino[2] is not None:
+        yh0, yh1 = torch.empty_like(x), torch.empty_like(x)
+        wst = lib.advmix_deconv4x4s2_wino_ws_floats(B, Ho, Wo, Co, Ci)
+        wtb = torch.empty(wst, device=dev)
+        dtr = lambda: call('advmix_conv_tr_w', P(lo), P(w), None, P(yh0), B, Ho, Wo, Co, 2 * Ho, 2 * Wo, Ci, 4, 4, 2, 1, st)
+        wtr = lambda: call('advmix_deconv4x4s2_wino_fwd', P(lo), bankw._wino[2], None, None, P(yh1), P(wtb), wst, B, Ho, Wo, Co, Ci, st)
+        dtr(); wtr(); torch.cuda.synchronize()
+        errt = (yh0 - yh1).abs().max().item() / yh0.abs().max().item()
+        t0, t1 = timeit(dtr), timeit(wtr)
+        print('      transposed form %d->%d: direct %.1f us (%.3f)  wino4 %.1f us (x%.2f)   |direct - wino4| %.1e of scale'
+              % (Co, Ci, t0, fl / t0 / 1e6 / 157.3, t1, t0 / t1, errt), flush=True)
+    bank.release()
+    # weight gradient: hi = x, lo = a gradient of y
     dw0, dw1 = torch.zeros_like(w), torch.zeros_like(w)
     wsg = [lib.advmix_conv4x4s2_wino_wgrad_ws_floats(B, 2 * Ho, 2 * Wo, Ci, Co, hv) for hv in (0, 1)]
     if wsg[0] > 0:

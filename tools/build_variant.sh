@@ -9,7 +9,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd); D=$R/tools/_dbg; mkdir -p $D
 NAME=$1; SRC=$2; DEFS=$3
 objs=""
-for f in conv_mfma conv_direct conv_wino conv_smap conv_pw wgrad_direct wgrad_lds wgrad_wino norm pointwise advmix_ops postproc inputpipe nms; do
+for f in conv_mfma conv_direct conv_wino conv_wino4 conv_smap conv_pw wgrad_direct wgrad_lds wgrad_wino norm pointwise advmix_ops postproc inputpipe nms; do
   if [ $f = $SRC ]; then
     in=$R/advmix_amd/csrc/$f.hip
     if [ $f = conv_direct ] && echo "$DEFS" | grep -q "CD_DBG\|CD_PRELOAD\|CD_CLK\|CD_NO_PRE"; then

@@ -52,7 +52,11 @@ def _time_shares():
         if k.startswith('ALL MFMA'):
             continue
         tf = float(r['tflops'] or 0)
-        if 'wgrad' in shp and ' x8 ' in shp:
+        if k.startswith('wino4'):                            # (csrc/conv_wino4.hip's input / output / filter transforms: no FLOPs counted)
+            c = "U-Net 4x4 s2 convs in the Winograd domain: transforms"
+        elif ' 1x1 ' in shp and shp.endswith('(B 16)'):       # (its 16 GEMMs, one launch of conv_direct / conv_wgrad_group over 16
+            c = "U-Net 4x4 s2 convs in the Winograd domain: the 16 GEMMs (their own FLOPs, 2.25x fewer than the direct form's)"   # 'images')
+        elif 'wgrad' in shp and ' x8 ' in shp:
             c = 'grouped weight gradients'
         elif 'wgrad' in shp or k.startswith(('conv_wgrad', 'wgrad')):
             c = 'single weight gradients'

@@ -56,14 +56,18 @@ def problem(Bn, Ci, Co, H, W, bias=False):
 
 
 # numerics: small ragged cases against torch fp64 (CPU)
-for (Bn, Ci, Co, H, W, bias) in [(2, 16, 32, 16, 12, False), (3, 32, 64, 20, 28, True), (1, 64, 128, 8, 6, False), (2, 128, 64, 4, 2, True)]:
+# (+ two layers of the 6-down U-Net at 512x512 / B = 2 - the case whose gradient-median bound EXPERIMENTS K is about - with rms errors)
+for (Bn, Ci, Co, H, W, bias) in [(2, 16, 32, 16, 12, False), (3, 32, 64, 20, 28, True), (1, 64, 128, 8, 6, False), (2, 128, 64, 4, 2, True),
+                                 (2, 64, 128, 256, 256, True), (2, 256, 512, 64, 64, True)]:
     x, w, b, y0, y1, direct, wino = problem(Bn, Ci, Co, H, W, bias)
     direct(); wino(); torch.cuda.synchronize()
     ref = torch.nn.functional.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu().permute(0, 3, 1, 2),
                                      b.double().cpu() if bias else None, stride=2, padding=1).permute(0, 2, 3, 1)
     sc = ref.abs().max().item()
-    print('numerics B%d %d->%d %dx%d bias=%d: direct %.2e  wino4 %.2e of scale (|ref| max %.3f)' % (
-        Bn, Ci, Co, H, W, bias, (y0.double().cpu() - ref).abs().max().item() / sc, (y1.double().cpu() - ref).abs().max().item() / sc, sc), flush=True)
+    e0, e1 = y0.double().cpu() - ref, y1.double().cpu() - ref
+    print('numerics B%d %d->%d %dx%d bias=%d: direct %.2e  wino4 %.2e of scale (|ref| max %.3f); rms error / rms value: direct %.2e  wino4 %.2e' % (
+        Bn, Ci, Co, H, W, bias, e0.abs().max().item() / sc, e1.abs().max().item() / sc, sc,
+        (e0.pow(2).mean() / ref.pow(2).mean()).sqrt().item(), (e1.pow(2).mean() / ref.pow(2).mean()).sqrt().item()), flush=True)
 
 for Ci, Co, Ho, Wo in [(64, 256, 64, 48), (128, 512, 32, 24), (256, 1024, 16, 12), (512, 1024, 8, 6),
                        (64, 128, 64, 48), (128, 256, 32, 24), (256, 512, 16, 12), (512, 512, 8, 6), (512, 512, 4, 3)]:

@@ -402,8 +402,14 @@ def test_network_parity_at_the_benchmarked_batch():
     mD.train(); mG.train(); mT.eval()
     args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
     v, t, w = synth_batch(tag + '.it0', B, J, H, W)
+    f0, g0 = _ops_.COUNTERS.get('w4', 0), _ops_.COUNTERS.get('w4_wgrad', 0)
     loss_D, out = advmix_step(args, mD, mG, mT, JointsMSELoss(True), optD, optG,
                               [x.cuda().contiguous() for x in v], t.cuda(), w.cuda())
+    # ... and the U-Net's 4x4 / stride-2 convs in the Winograd domain (csrc/conv_wino4.hip): in the generator's forward the four
+    # down convs 64 -> 128 ... 512 -> 512 with >= 128 tiles, in its backward the input gradients of the four transposed convs
+    # 1024 -> 512 ... 256 -> 64, and the six weight gradients with >= 512 tiles
+    assert _ops_.WINO4 and _ops_.WINO4_WGRAD and not _ops_.WINO4_T
+    assert _ops_.COUNTERS.get('w4', 0) - f0 == 8 and _ops_.COUNTERS.get('w4_wgrad', 0) - g0 == 6, _ops_.COUNTERS
     want = ga[tag + '.losses'][0]
     assert_close('loss_D vs golden', [float(loss_D)], [0.9 * want[0] + 0.1 * want[1]], report=rep)
     # out2 = D(tmp) AFTER the first Adam update: teacher-forced against the oracle (it adopts the device's updated D,

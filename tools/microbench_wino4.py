@@ -41,8 +41,10 @@ def timeit(run):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-def problem(Bn, Ci, Co, H, W, bias=False):
+def problem(Bn, Ci, Co, H, W, bias=False, relu_input=False):
     x = torch.randn(Bn, H, W, Ci, device=dev)
+    if relu_input:                                         # (what the U-Net's up path feeds its transposed convs: non-negative, mean 0.8 sigma)
+        x = x.abs()
     w = torch.randn(Co, 4, 4, Ci, device=dev) * (1.0 / (16 * Ci) ** 0.5)
     b = torch.randn(Co, device=dev) if bias else None
     y0 = torch.empty(Bn, H // 2, W // 2, Co, device=dev)
@@ -58,14 +60,15 @@ def problem(Bn, Ci, Co, H, W, bias=False):
 # numerics: small ragged cases against torch fp64 (CPU)
 # (+ two layers of the 6-down U-Net at 512x512 / B = 2 - the case whose gradient-median bound EXPERIMENTS K is about - with rms errors)
 for (Bn, Ci, Co, H, W, bias) in [(2, 16, 32, 16, 12, False), (3, 32, 64, 20, 28, True), (1, 64, 128, 8, 6, False), (2, 128, 64, 4, 2, True),
-                                 (2, 64, 128, 256, 256, True), (2, 256, 512, 64, 64, True)]:
-    x, w, b, y0, y1, direct, wino = problem(Bn, Ci, Co, H, W, bias)
+                                 (2, 64, 128, 256, 256, True), (2, 256, 512, 64, 64, True), (-2, 64, 128, 256, 256, True), (-2, 256, 512, 64, 64, True)]:
+    relu_in, Bn = Bn < 0, abs(Bn)                          # (negative batch = the same case on a rectified input)
+    x, w, b, y0, y1, direct, wino = problem(Bn, Ci, Co, H, W, bias, relu_in)
     direct(); wino(); torch.cuda.synchronize()
     ref = torch.nn.functional.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu().permute(0, 3, 1, 2),
                                      b.double().cpu() if bias else None, stride=2, padding=1).permute(0, 2, 3, 1)
     sc = ref.abs().max().item()
     e0, e1 = y0.double().cpu() - ref, y1.double().cpu() - ref
-    print('numerics B%d %d->%d %dx%d bias=%d: direct %.2e  wino4 %.2e of scale (|ref| max %.3f); rms error / rms value: direct %.2e  wino4 %.2e' % (
+    print('numerics' + (' |x|' if relu_in else '') + ' B%d %d->%d %dx%d bias=%d: direct %.2e  wino4 %.2e of scale (|ref| max %.3f); rms error / rms value: direct %.2e  wino4 %.2e' % (
         Bn, Ci, Co, H, W, bias, e0.abs().max().item() / sc, e1.abs().max().item() / sc, sc,
         (e0.pow(2).mean() / ref.pow(2).mean()).sqrt().item(), (e1.pow(2).mean() / ref.pow(2).mean()).sqrt().item()), flush=True)
 

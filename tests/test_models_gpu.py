@@ -420,6 +420,51 @@ def test_network_parity_at_the_benchmarked_batch():
     print(tag, 'worst err/bound ratios', {k: round(x, 3) for k, x in rep.items()})
 
 
+PINNED_TOL = 2e-5    # of the fp64 tensor's max; observed <= 2.8e-6 (512x512, B = 2) / see the printed worst ratio (profiles/r05zq_*)
+
+
+@pytest.mark.parametrize('wino4_t', [False, True])
+@pytest.mark.parametrize('case', [('512x512 B2', 512, 512, 2, 6, (6, 4, 6)), ('256x192 B32', 256, 192, 32, 6, (8, 6, 8))])   # (.., launches of csrc/conv_wino4.hip: forward form, weight gradients, transposed form)
+def test_generator_gradients_with_pinned_masks(case, wino4_t, monkeypatch):
+    """Round 5 (profiles/EXPERIMENTS.md K2): the generator's forward + backward, launch for launch, against fp64 - EVERY
+    intermediate value, EVERY intermediate gradient and EVERY parameter gradient element-wise within 2e-5 of the tensor's
+    scale (heat-map-style bounds are 1e-3), at the 512x512 / B = 2 shapes and at the benchmarked batch (where the Winograd-
+    domain kernels of csrc/conv_wino4.hip take the 4x4 / stride-2 convs, forward form and weight gradients; with
+    ``wino4_t`` the transposed form too - built, tested, off in the step).  The fp64 evaluation takes its ReLU / LeakyReLU
+    MASKS from the device's activations (tests/unet_functional.py): an InstanceNorm output within rounding of zero takes
+    either side of a ReLU in any fp32 evaluation and moves a weight gradient by 1e-2 of its scale when it carries a large
+    gradient - the reason the un-pinned criteria above are statistical (a median against the fp32 oracle's own error).  Pinned,
+    nothing statistical is left: this is the arithmetic of Conv2d / InstanceNorm / ConvTranspose2d / cat + ReLU and their
+    backward kernels (Unet_generator.py:39-88)."""
+    from oracle import detinit, configs
+    from advmix_amd import ops
+    from unet_functional import run
+    name, H, W, B, downs, want = case
+    monkeypatch.setattr(ops, 'WINO4_T', wino4_t)
+    _, _, G = build_states('pose_hrnet', configs.HRNET_W32, 17, unet_downs=downs)
+    x0 = torch.cat([detinit.normal('pinned.%s.view%d' % (name, k), (B, 3, H, W)) for k in range(3)], 1)
+    proj = detinit.normal('pinned.%s.gproj' % name, (B, 3, H, W))
+    c0 = dict(ops.COUNTERS)
+    vh, gh, ph, order = run('hip', G, x0, proj, downs)
+    took = {k: ops.COUNTERS.get(k, 0) - c0.get(k, 0) for k in ('w4', 'w4_wgrad', 'w4t')}
+    assert (took['w4'], took['w4_wgrad'], took['w4t']) == (want[0], want[1], want[2] if wino4_t else 0), took
+    v64, g64, p64, _ = run('f64', G, x0, proj, downs, pin={n: t.float() for n, t in vh.items()})
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    worst = {}
+    for n in order:
+        worst['value ' + n] = rel(vh[n], v64[n])
+        worst['grad ' + n] = rel(gh[n], g64[n])
+    gmax = max(float(g.abs().max()) for g in p64.values())
+    for k in G:
+        if float(p64[k].abs().max()) > 1e-6 * gmax:
+            worst['param ' + k] = rel(ph[k], p64[k])
+        else:                                               # a bias under an InstanceNorm: true gradient 0, the device's is rounding noise
+            assert float(ph[k].abs().max()) <= 1e-4 * gmax, (k, float(ph[k].abs().max()), gmax)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    print(name, 'wino4_t', wino4_t, 'launches', took, 'worst of %d tensors:' % len(worst), [(k, '%.2e' % v) for k, v in top])
+    assert top[0][1] <= PINNED_TOL, top
+
+
 @pytest.mark.parametrize('tag', ['hrnet_tiny', 'resnet18_tiny'])
 def test_gradient_fan_in_by_separate_add_gives_the_same_gradients(tag):
     """with ADVMIX_FANIN=0 the gradients pending for a slot are NOT folded into the consumer's input-gradient

@@ -465,6 +465,150 @@ def test_generator_gradients_with_pinned_masks(case, wino4_t, monkeypatch):
     assert top[0][1] <= PINNED_TOL, top
 
 
+@pytest.mark.parametrize('case', [(32, 32, 64, 48), (32, 64, 32, 24), (32, 128, 16, 12), (32, 256, 8, 6), (2, 32, 64, 48)])
+def test_branch_of_basic_blocks_with_pinned_masks(case):
+    """The dominant path of the step element-wise (round 5): one HRNet branch - four BasicBlocks, eight 3x3 convs each
+    followed by a train-mode BatchNorm, residual adds and ReLUs (pose_hrnet.py:22-57, 247-265) - forward and backward through
+    the functional ops at the benchmarked batch, against fp64 with the ReLU masks taken from the device's signs (see
+    test_generator_gradients_with_pinned_masks): every block output, its gradient, and every weight / gamma / beta gradient
+    within 2e-5 of the tensor's scale.  At B = 32 these are the launches of csrc/conv_wino.hip (32 / 64 / 128 channels) and
+    csrc/conv_smap.hip (256 channels @8x6) with the BatchNorm column sums in the forward's epilogue, norm_apply_slots,
+    the input gradient + BatchNorm-backward epilogues (mask / sign-from-c) and the weight gradients; the B = 2 case takes the
+    direct kernels."""
+    import torch.nn.functional as F
+    from oracle import detinit
+    from advmix_amd import ops
+    B, C, H, W = case
+    tag = 'branch.%d.%d.%d' % (B, C, H)
+    x0 = detinit.normal(tag + '.x', (B, C, H, W))
+    proj = detinit.normal(tag + '.proj', (B, C, H, W))
+    Wt = [detinit.normal(tag + '.w%d' % i, (C, C, 3, 3), std=(9 * C) ** -0.5) for i in range(8)]
+    Ga = [detinit.normal(tag + '.g%d' % i, (C,), std=0.2, mean=1.0) for i in range(8)]
+    Be = [detinit.normal(tag + '.b%d' % i, (C,), std=0.2) for i in range(8)]
+
+    def net(x, Wt, Ga, Be, conv_bn):
+        outs = []
+        for blk in range(4):
+            t = conv_bn(x, Wt[2 * blk], Ga[2 * blk], Be[2 * blk], None, 'b%d.relu1' % blk)
+            x = conv_bn(t, Wt[2 * blk + 1], Ga[2 * blk + 1], Be[2 * blk + 1], x, 'b%d.out' % blk)
+            for n, v in (('b%d.relu1' % blk, t), ('b%d.out' % blk, x)):
+                v.retain_grad()
+                outs.append((n, v))
+        return x, outs
+
+    # the device
+    cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last)
+    Wd = [torch.nn.Parameter(cl(w)) for w in Wt]
+    Gd, Bd = [torch.nn.Parameter(g.cuda()) for g in Ga], [torch.nn.Parameter(b.cuda()) for b in Be]
+    bank = ops.WinoBank(Wd)
+    bank.refresh()
+    stats = lambda: (torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), torch.zeros((), dtype=torch.int64, device='cuda'))
+    c0 = dict(ops.COUNTERS)
+    xd = cl(x0).requires_grad_(True)
+    yd, rec_d = net(xd, Wd, Gd, Bd, lambda x, w, g, b, res, n: ops.conv_bn(x, w, g, b, *stats(), res, 1, 1, ops.ACT_RELU, True))
+    (yd * proj.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    took = {k: v - c0.get(k, 0) for k, v in ops.COUNTERS.items() if v != c0.get(k, 0)}
+    pin = {n: v.detach().cpu() for n, v in rec_d}
+    # fp64, masks pinned to the device's signs
+    W6 = [w.double().requires_grad_(True) for w in Wt]
+    G6, B6 = [g.double().requires_grad_(True) for g in Ga], [b.double().requires_grad_(True) for b in Be]
+    x6 = x0.double().requires_grad_(True)
+
+    def conv_bn64(x, w, g, b, res, n):
+        pre = F.batch_norm(F.conv2d(x, w, None, 1, 1), None, None, g, b, True, 0.1, 1e-5)
+        return (pre if res is None else pre + res) * (pin[n] > 0).double()
+    y6, rec_6 = net(x6, W6, G6, B6, conv_bn64)
+    (y6 * proj.double()).sum().backward()
+    rel = lambda a, b: float((a.detach().double().cpu() - b).abs().max() / b.abs().max())
+    worst = {'grad x': rel(xd.grad, x6.grad)}
+    for (n, vd), (_, v6) in zip(rec_d, rec_6):
+        worst['value ' + n] = rel(vd, v6.detach())
+        worst['grad ' + n] = rel(vd.grad, v6.grad)
+    for i in range(8):
+        worst['dw%d' % i], worst['dgamma%d' % i], worst['dbeta%d' % i] = rel(Wd[i].grad, W6[i].grad), rel(Gd[i].grad, G6[i].grad), rel(Bd[i].grad, B6[i].grad)
+    bank.release()
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    print(case, 'launches', took, 'worst of %d tensors:' % len(worst), [(k, '%.2e' % v) for k, v in top])
+    assert top[0][1] <= PINNED_TOL, top
+
+
+@pytest.mark.parametrize('case', [(32, 32, 64, 48), (32, 64, 32, 24), (32, 128, 16, 12), (32, 256, 8, 6)])
+def test_branch_through_the_plan_executor_with_pinned_masks(case):
+    """The same branch of four BasicBlocks through the PRODUCT's executor (plan.PlanNet: the launch chain as one autograd node,
+    the BatchNorm-backward sums in the input-gradient epilogues, a branch's eight weight gradients as one grouped launch)
+    instead of op by op.  To see the activations whose signs pin the fp64 masks, every ReLU output is also summed into the
+    network's output (three fuse sums), so each is a chain output - and receives a direct gradient besides the one through
+    the blocks, which the fp64 graph mirrors.  Output, input gradient and all 24 parameter gradients within 2e-5 of scale."""
+    import torch.nn.functional as F
+    from oracle import detinit
+    from advmix_amd import ops
+    from advmix_amd.plan import Plan, PlanNet
+    B, C, H, W = case
+    tag = 'planbranch.%d.%d.%d' % (B, C, H)
+    P = Plan(C)
+    P.tag = 'branch'
+    x, taps = 0, []
+    for k in range(4):
+        t = P.conv_bn(x, 'b%d.conv1' % k, 'b%d.bn1' % k, C, 3, 1, 1, ops.ACT_RELU)
+        x = P.bn(P.conv(t, 'b%d.conv2' % k, C, 3, 1, 1), 'b%d.bn2' % k, ops.ACT_RELU, x)
+        taps += [t, x]
+    P.tag = None
+    P.out = P.fuse([P.fuse(taps[:4], [0] * 4, ops.ACT_NONE), P.fuse(taps[4:], [0] * 4, ops.ACT_NONE)], [0, 0], ops.ACT_NONE)
+    net = PlanNet(P)
+    init = {}
+    for n, p_ in net.named_parameters():
+        if p_.dim() == 4:
+            init[n] = detinit.normal(tag + '.' + n, tuple(p_.shape), std=(9 * C) ** -0.5)
+        else:
+            init[n] = detinit.normal(tag + '.' + n, tuple(p_.shape), std=0.2, mean=1.0 if n.endswith('.weight') else 0.0)
+        with torch.no_grad():
+            p_.copy_(init[n])
+    net = net.cuda().train()
+    x0 = detinit.normal(tag + '.x', (B, C, H, W))
+    proj = detinit.normal(tag + '.proj', (B, C, H, W))
+    c0 = dict(ops.COUNTERS)
+    xd = x0.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    run = net.begin(xd)
+    seen = {}
+    while not run.done:
+        for s_ in taps:                                     # (the chain's outputs, alive until the sums have read them)
+            if torch.is_tensor(run.slots[s_]) and s_ not in seen:
+                seen[s_] = run.slots[s_]
+        run.consume(ops.run_group(run.members()))
+    assert len(seen) == 8, sorted(seen)
+    yd = run.result
+    pin = {s_: v.detach().cpu() for s_, v in seen.items()}
+    (yd * proj.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    took = {k: v - c0.get(k, 0) for k, v in ops.COUNTERS.items() if v != c0.get(k, 0)}
+    # fp64 with the masks pinned to the device's signs
+    P6 = {n: v.double().requires_grad_(True) for n, v in init.items()}
+    x6 = x0.double().requires_grad_(True)
+
+    def cb(x, k, j, res, slot):
+        pre = F.batch_norm(F.conv2d(x, P6['b%d.conv%d.weight' % (k, j)], None, 1, 1), None, None, P6['b%d.bn%d.weight' % (k, j)],
+                           P6['b%d.bn%d.bias' % (k, j)], True, 0.1, 1e-5)
+        return (pre if res is None else pre + res) * (pin[slot] > 0).double()
+    cur, tot = x6, 0
+    for k in range(4):
+        t6 = cb(cur, k, 1, None, taps[2 * k])
+        cur = cb(t6, k, 2, cur, taps[2 * k + 1])
+        tot = tot + t6 + cur
+    (tot * proj.double()).sum().backward()
+    rel = lambda a, b: float((a.detach().double().cpu() - b).abs().max() / b.abs().max())
+    worst = {'out': rel(yd, tot.detach()), 'grad x': rel(xd.grad, x6.grad)}
+    for n, p_ in net.named_parameters():
+        worst['d ' + n] = rel(p_.grad, P6[n].grad)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    print(case, 'launches', took, 'worst of %d tensors:' % len(worst), [(k, '%.2e' % v) for k, v in top])
+    assert top[0][1] <= PINNED_TOL, top
+    # ... and it was the product's path: Winograd / small-map kernels forward and backward, BatchNorm backward in the input-gradient
+    # epilogues, the eight weight gradients as one grouped launch
+    assert took.get('wino', 0) + took.get('smap', 0) == 16 and took.get('bnb', 0) >= 7, took
+    assert took.get('wgrad_wino', 0) + took.get('wgrad_group', 0) >= 1, took
+
+
 @pytest.mark.parametrize('tag', ['hrnet_tiny', 'resnet18_tiny'])
 def test_gradient_fan_in_by_separate_add_gives_the_same_gradients(tag):
     """with ADVMIX_FANIN=0 the gradients pending for a slot are NOT folded into the consumer's input-gradient

@@ -385,8 +385,7 @@ WINO_MIN_WGS = int(__import__('os').environ.get('ADVMIX_WINO_MIN_WGS', '96'))   
 WINO_ASYNC = __import__('os').environ.get('ADVMIX_WINO_ASYNC', '1') != '0'   # filter transforms beside the stem (plan.PlanNet._wino_refresh; 0 = on the caller's stream)
 PW = __import__('os').environ.get('ADVMIX_PW', '1') != '0'           # A/B switch: 0 = the 64 -> 256 1x1 convs of the bottlenecks on the direct kernel (csrc/conv_pw.hip)
 WINO4 = __import__('os').environ.get('ADVMIX_WINO4', '1') != '0'     # A/B switch: 0 = the U-Net's 4x4 / stride-2 convs on the direct kernel (csrc/conv_wino4.hip)
-WINO4_T = __import__('os').environ.get('ADVMIX_WINO4_T', '0') != '0'   # 1 = the transposed form (ConvTranspose2d forward, Conv2d input gradient) on csrc/conv_wino4.hip too: +1.0 % on the step, but the 6-down
-#   U-Net's gradient median against float64 moves from 2.4-3.1e-3 to 4.2-4.7e-3 at 512x512 / B = 2 where the test allows 3 x the fp32 oracle's own 1.5e-3 - off by default (profiles/EXPERIMENTS.md K)
+WINO4_T = __import__('os').environ.get('ADVMIX_WINO4_T', '1') != '0'   # A/B switch: 0 = the transposed form (ConvTranspose2d forward, Conv2d input gradient) on the direct kernel
 WINO4_T_MIN_TILES = int(__import__('os').environ.get('ADVMIX_WINO4_T_MIN_TILES', '192'))
 WINO4_KEEP_V = __import__('os').environ.get('ADVMIX_WINO4_KEEP_V', '1') != '0'   # a Conv2d's forward keeps its input transform for its weight gradient (0 = made again)
 WINO4_WGRAD = __import__('os').environ.get('ADVMIX_WINO4_WGRAD', '1') != '0'   # A/B switch: 0 = their weight gradients on the direct kernel

@@ -148,7 +148,11 @@ def test_forward_backward_vs_oracle_and_golden(tag):
     # against the network's gradient scale instead of their own (pure rounding noise)
     live = [k for k in G if float(gg64[k].abs().max()) > 1e-4 * gmax]
     gotG = {k: p.grad.detach().cpu() for k, p in mG.named_parameters()}
-    stats = assert_grads('G grads', live, gotG, gg32, gg64)
+    # (k = GRAD_K like the step tests' medians, not 3: WHICH ReLU masks flip is a lottery over forward values that agree to 2e-6,
+    #  not a noise level - the 6-down U-Net at 512x512 drew 1.5-3.8e-3 / 4.2-4.7e-3 without / with the transposed Winograd form
+    #  against the fp32 oracle's 1.5e-3, and with the masks pinned both agree with fp64 to 3e-6 on every tensor:
+    #  test_generator_gradients_with_pinned_masks is the criterion that measures kernels; profiles/EXPERIMENTS.md K2)
+    stats = assert_grads('G grads', live, gotG, gg32, gg64, k=GRAD_K)
     for k in G:
         if k not in live:
             assert float(gotG[k].abs().max()) <= 1e-3 * gmax, k
@@ -402,14 +406,15 @@ def test_network_parity_at_the_benchmarked_batch():
     mD.train(); mG.train(); mT.eval()
     args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
     v, t, w = synth_batch(tag + '.it0', B, J, H, W)
-    f0, g0 = _ops_.COUNTERS.get('w4', 0), _ops_.COUNTERS.get('w4_wgrad', 0)
+    f0, g0, t0 = _ops_.COUNTERS.get('w4', 0), _ops_.COUNTERS.get('w4_wgrad', 0), _ops_.COUNTERS.get('w4t', 0)
     loss_D, out = advmix_step(args, mD, mG, mT, JointsMSELoss(True), optD, optG,
                               [x.cuda().contiguous() for x in v], t.cuda(), w.cuda())
     # ... and the U-Net's 4x4 / stride-2 convs in the Winograd domain (csrc/conv_wino4.hip): in the generator's forward the four
     # down convs 64 -> 128 ... 512 -> 512 with >= 128 tiles, in its backward the input gradients of the four transposed convs
-    # 1024 -> 512 ... 256 -> 64, and the six weight gradients with >= 512 tiles
-    assert _ops_.WINO4 and _ops_.WINO4_WGRAD and not _ops_.WINO4_T
-    assert _ops_.COUNTERS.get('w4', 0) - f0 == 8 and _ops_.COUNTERS.get('w4_wgrad', 0) - g0 == 6, _ops_.COUNTERS
+    # 1024 -> 512 ... 256 -> 64, and the six weight gradients with >= 512 tiles; the transposed form: the four transposed convs'
+    # forward and the four down convs' input gradients with >= 192 tiles
+    assert _ops_.WINO4 and _ops_.WINO4_WGRAD and _ops_.WINO4_T
+    assert _ops_.COUNTERS.get('w4', 0) - f0 == 8 and _ops_.COUNTERS.get('w4_wgrad', 0) - g0 == 6 and _ops_.COUNTERS.get('w4t', 0) - t0 == 8, _ops_.COUNTERS
     want = ga[tag + '.losses'][0]
     assert_close('loss_D vs golden', [float(loss_D)], [0.9 * want[0] + 0.1 * want[1]], report=rep)
     # out2 = D(tmp) AFTER the first Adam update: teacher-forced against the oracle (it adopts the device's updated D,
@@ -430,7 +435,7 @@ def test_generator_gradients_with_pinned_masks(case, wino4_t, monkeypatch):
     intermediate value, EVERY intermediate gradient and EVERY parameter gradient element-wise within 2e-5 of the tensor's
     scale (heat-map-style bounds are 1e-3), at the 512x512 / B = 2 shapes and at the benchmarked batch (where the Winograd-
     domain kernels of csrc/conv_wino4.hip take the 4x4 / stride-2 convs, forward form and weight gradients; with
-    ``wino4_t`` the transposed form too - built, tested, off in the step).  The fp64 evaluation takes its ReLU / LeakyReLU
+    ``wino4_t`` the transposed form too; both settings, whatever the default).  The fp64 evaluation takes its ReLU / LeakyReLU
     MASKS from the device's activations (tests/unet_functional.py): an InstanceNorm output within rounding of zero takes
     either side of a ReLU in any fp32 evaluation and moves a weight gradient by 1e-2 of its scale when it carries a large
     gradient - the reason the un-pinned criteria above are statistical (a median against the fp32 oracle's own error).  Pinned,

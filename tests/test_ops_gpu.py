@@ -669,7 +669,7 @@ def test_winograd_4x4_stride2_conv(case, monkeypatch):
     import ctypes
     from advmix_amd._lib import call, lib
     ops = _ops()
-    monkeypatch.setattr(ops, 'WINO4_T', True)               # the transposed form is off in the step by default (EXPERIMENTS K); tested here all the same
+    monkeypatch.setattr(ops, 'WINO4_T', True)               # (whatever ADVMIX_WINO4_T says: the transposed form is tested here)
     B, Ci, Co, H, W, hb = case
     d = dev()
     g_ = torch.Generator().manual_seed(41 + Ci + H)

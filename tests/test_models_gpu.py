@@ -425,6 +425,8 @@ def test_network_parity_at_the_benchmarked_batch():
     print(tag, 'worst err/bound ratios', {k: round(x, 3) for k, x in rep.items()})
 
 
+PINNED_TOL_NET = 3e-4   # the same through all ~290 convs of HRNet-W32 (rounding compounds with depth): observed 8.2e-5, beside the fp32 CPU
+                        # arithmetic's own worst under the same masks (printed; profiles/r05zt_*); heat-map bounds are 1e-3
 PINNED_TOL = 2e-5    # of the fp64 tensor's max; observed <= 2.8e-6 (512x512, B = 2) / see the printed worst ratio (profiles/r05zq_*)
 
 
@@ -538,6 +540,76 @@ def test_branch_of_basic_blocks_with_pinned_masks(case):
     assert top[0][1] <= PINNED_TOL, top
 
 
+def _pinned_plan_check(P, taps, shape, tag, fp32_too=False):
+    """Runs Plan ``P`` through plan.PlanNet (train mode) on a seeded input of ``shape``, backward from a seeded projection of
+    the output, and the SAME plan through a small fp64 interpreter of its steps (conv / bn / fuse with shift 0) whose ReLU masks
+    are the device's signs at ``taps`` - which must be every slot a ReLU produces, each also reaching the output through fuse
+    sums so that the executor hands it out.  Returns ({tensor: error relative to the fp64 tensor's max}, launch counters)."""
+    import torch.nn.functional as F
+    from oracle import detinit
+    from advmix_amd import ops
+    from advmix_amd.plan import PlanNet
+    relu_slots = {st[3] for st in P.steps if (st[0] == 'bn' and st[5] != ops.ACT_NONE) or (st[0] == 'fuse' and st[4] != ops.ACT_NONE)}
+    assert relu_slots == set(taps) and all(st[0] in ('conv', 'bn', 'fuse') for st in P.steps), (sorted(relu_slots), sorted(taps))
+    net = PlanNet(P)
+    init = {}
+    for n, p_ in net.named_parameters():
+        if p_.dim() == 4:
+            init[n] = detinit.normal(tag + '.' + n, tuple(p_.shape), std=(p_.shape[1] * p_.shape[2] * p_.shape[3]) ** -0.5)
+        else:
+            init[n] = detinit.normal(tag + '.' + n, tuple(p_.shape), std=0.2, mean=1.0 if n.endswith('.weight') else 0.0)
+        with torch.no_grad():
+            p_.copy_(init[n])
+    net = net.cuda().train()
+    x0 = detinit.normal(tag + '.x', shape)
+    c0 = dict(ops.COUNTERS)
+    xd = x0.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    run = net.begin(xd)
+    seen = {}
+    while not run.done:
+        for s_ in taps:                                     # (chain outputs, alive until the sums have read them)
+            if torch.is_tensor(run.slots[s_]) and s_ not in seen:
+                seen[s_] = run.slots[s_]
+        run.consume(ops.run_group(run.members()))
+    assert len(seen) == len(taps), (sorted(seen), sorted(taps))
+    yd = run.result
+    proj = detinit.normal(tag + '.proj', tuple(yd.shape))
+    pin = {s_: v.detach().cpu() for s_, v in seen.items()}
+    (yd * proj.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    took = {k: v - c0.get(k, 0) for k, v in ops.COUNTERS.items() if v != c0.get(k, 0)}
+    # fp64 (and, for scale, the fp32 CPU arithmetic): the plan's steps, masks pinned to the device's signs
+    def interpret(dt):
+        Pm = {n: v.to(dt).requires_grad_(True) for n, v in init.items()}
+        xm = x0.to(dt).requires_grad_(True)
+        val = {0: xm}
+        for st in P.steps:
+            if st[0] == 'conv':
+                _, name, s_, d_, stride, pad, hb = st
+                val[d_] = F.conv2d(val[s_], Pm[name + '.weight'], Pm[name + '.bias'] if hb else None, stride, pad)
+            elif st[0] == 'bn':
+                _, name, s_, d_, res, act = st
+                pre = F.batch_norm(val[s_], None, None, Pm[name + '.weight'], Pm[name + '.bias'], True, 0.1, 1e-5)
+                pre = pre if res is None else pre + val[res]
+                val[d_] = pre * (pin[d_] > 0).to(dt) if act != ops.ACT_NONE else pre
+            else:
+                _, xs, shifts, d_, act = st                   # pose_hrnet.py:254-265: nearest up-sampling by 2^shift, sum, ReLU
+                pre = sum(val[s_] if sh == 0 else F.interpolate(val[s_], scale_factor=2 ** sh, mode='nearest') for s_, sh in zip(xs, shifts))
+                val[d_] = pre * (pin[d_] > 0).to(dt) if act != ops.ACT_NONE else pre
+        out = val[P.out]
+        (out * proj.to(dt)).sum().backward()
+        return out.detach(), xm.grad, {n: v.grad for n, v in Pm.items()}
+    y6, gx6, g6 = interpret(torch.float64)
+    rel = lambda a, b: float((a.detach().double().cpu() - b).abs().max() / b.abs().max())
+    worst = {'out': rel(yd, y6), 'grad x': rel(xd.grad, gx6)}
+    for n, p_ in net.named_parameters():
+        worst['d ' + n] = rel(p_.grad, g6[n])
+    if fp32_too:
+        y3, gx3, g3 = interpret(torch.float32)
+        took['fp32 CPU arithmetic, same masks: worst'] = '%.2e' % max([rel(y3, y6), rel(gx3, gx6)] + [rel(g3[n], g6[n]) for n in g6])
+    return worst, took
+
+
 @pytest.mark.parametrize('case', [(32, 32, 64, 48), (32, 64, 32, 24), (32, 128, 16, 12), (32, 256, 8, 6)])
 def test_branch_through_the_plan_executor_with_pinned_masks(case):
     """The same branch of four BasicBlocks through the PRODUCT's executor (plan.PlanNet: the launch chain as one autograd node,
@@ -545,12 +617,9 @@ def test_branch_through_the_plan_executor_with_pinned_masks(case):
     instead of op by op.  To see the activations whose signs pin the fp64 masks, every ReLU output is also summed into the
     network's output (three fuse sums), so each is a chain output - and receives a direct gradient besides the one through
     the blocks, which the fp64 graph mirrors.  Output, input gradient and all 24 parameter gradients within 2e-5 of scale."""
-    import torch.nn.functional as F
-    from oracle import detinit
     from advmix_amd import ops
-    from advmix_amd.plan import Plan, PlanNet
+    from advmix_amd.plan import Plan
     B, C, H, W = case
-    tag = 'planbranch.%d.%d.%d' % (B, C, H)
     P = Plan(C)
     P.tag = 'branch'
     x, taps = 0, []
@@ -560,51 +629,7 @@ def test_branch_through_the_plan_executor_with_pinned_masks(case):
         taps += [t, x]
     P.tag = None
     P.out = P.fuse([P.fuse(taps[:4], [0] * 4, ops.ACT_NONE), P.fuse(taps[4:], [0] * 4, ops.ACT_NONE)], [0, 0], ops.ACT_NONE)
-    net = PlanNet(P)
-    init = {}
-    for n, p_ in net.named_parameters():
-        if p_.dim() == 4:
-            init[n] = detinit.normal(tag + '.' + n, tuple(p_.shape), std=(9 * C) ** -0.5)
-        else:
-            init[n] = detinit.normal(tag + '.' + n, tuple(p_.shape), std=0.2, mean=1.0 if n.endswith('.weight') else 0.0)
-        with torch.no_grad():
-            p_.copy_(init[n])
-    net = net.cuda().train()
-    x0 = detinit.normal(tag + '.x', (B, C, H, W))
-    proj = detinit.normal(tag + '.proj', (B, C, H, W))
-    c0 = dict(ops.COUNTERS)
-    xd = x0.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    run = net.begin(xd)
-    seen = {}
-    while not run.done:
-        for s_ in taps:                                     # (the chain's outputs, alive until the sums have read them)
-            if torch.is_tensor(run.slots[s_]) and s_ not in seen:
-                seen[s_] = run.slots[s_]
-        run.consume(ops.run_group(run.members()))
-    assert len(seen) == 8, sorted(seen)
-    yd = run.result
-    pin = {s_: v.detach().cpu() for s_, v in seen.items()}
-    (yd * proj.cuda()).sum().backward()
-    torch.cuda.synchronize()
-    took = {k: v - c0.get(k, 0) for k, v in ops.COUNTERS.items() if v != c0.get(k, 0)}
-    # fp64 with the masks pinned to the device's signs
-    P6 = {n: v.double().requires_grad_(True) for n, v in init.items()}
-    x6 = x0.double().requires_grad_(True)
-
-    def cb(x, k, j, res, slot):
-        pre = F.batch_norm(F.conv2d(x, P6['b%d.conv%d.weight' % (k, j)], None, 1, 1), None, None, P6['b%d.bn%d.weight' % (k, j)],
-                           P6['b%d.bn%d.bias' % (k, j)], True, 0.1, 1e-5)
-        return (pre if res is None else pre + res) * (pin[slot] > 0).double()
-    cur, tot = x6, 0
-    for k in range(4):
-        t6 = cb(cur, k, 1, None, taps[2 * k])
-        cur = cb(t6, k, 2, cur, taps[2 * k + 1])
-        tot = tot + t6 + cur
-    (tot * proj.double()).sum().backward()
-    rel = lambda a, b: float((a.detach().double().cpu() - b).abs().max() / b.abs().max())
-    worst = {'out': rel(yd, tot.detach()), 'grad x': rel(xd.grad, x6.grad)}
-    for n, p_ in net.named_parameters():
-        worst['d ' + n] = rel(p_.grad, P6[n].grad)
+    worst, took = _pinned_plan_check(P, taps, (B, C, H, W), 'planbranch.%d.%d.%d' % (B, C, H))
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
     print(case, 'launches', took, 'worst of %d tensors:' % len(worst), [(k, '%.2e' % v) for k, v in top])
     assert top[0][1] <= PINNED_TOL, top
@@ -612,6 +637,101 @@ def test_branch_through_the_plan_executor_with_pinned_masks(case):
     # epilogues, the eight weight gradients as one grouped launch
     assert took.get('wino', 0) + took.get('smap', 0) == 16 and took.get('bnb', 0) >= 7, took
     assert took.get('wgrad_wino', 0) + took.get('wgrad_group', 0) >= 1, took
+
+
+def test_layer1_bottlenecks_through_the_plan_executor_with_pinned_masks():
+    """HRNet's layer1 (pose_hrnet.py:59-98, 286: four Bottlenecks 64 -> 256 @64x48, the first with its 1x1 shortcut conv) at the
+    benchmarked batch the same way: the streaming 1x1 kernel of csrc/conv_pw.hip (64 -> 256: forward + sums, and the input
+    gradients of the 256 -> 64 convs), the direct kernel's 256 -> 64 1x1 convs, the Winograd kernel's 64 -> 64 @64x48, BatchNorm
+    over 256 channels.  The 64-channel ReLU outputs reach the output through one extra 1x1 conv (64 -> 256) on their sum."""
+    from advmix_amd import ops
+    from advmix_amd.plan import Plan
+    B, H, W = 32, 64, 48
+    P = Plan(64)
+    P.tag = 'layer1'
+    x, narrow, wide = 0, [], []
+    for k in range(4):
+        t1 = P.conv_bn(x, 'l%d.conv1' % k, 'l%d.bn1' % k, 64, 1, 1, 0, ops.ACT_RELU)
+        t2 = P.conv_bn(t1, 'l%d.conv2' % k, 'l%d.bn2' % k, 64, 3, 1, 1, ops.ACT_RELU)
+        o = P.conv(t2, 'l%d.conv3' % k, 256, 1, 1, 0)
+        res = x if P.ch[x] == 256 else P.conv_bn(x, 'l%d.downsample.0' % k, 'l%d.downsample.1' % k, 256, 1, 1, 0, ops.ACT_NONE)
+        x = P.bn(o, 'l%d.bn3' % k, ops.ACT_RELU, res)
+        narrow += [t1, t2]
+        wide.append(x)
+    P.tag = None
+    n64 = P.fuse([P.fuse(narrow[:4], [0] * 4, ops.ACT_NONE), P.fuse(narrow[4:], [0] * 4, ops.ACT_NONE)], [0, 0], ops.ACT_NONE)
+    P.out = P.fuse([P.fuse(wide, [0] * 4, ops.ACT_NONE), P.conv(n64, 'tap', 256, 1, 1, 0)], [0, 0], ops.ACT_NONE)
+    worst, took = _pinned_plan_check(P, narrow + wide, (B, 64, H, W), 'planlayer1')
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    print('layer1', 'launches', took, 'worst of %d tensors:' % len(worst), [(k, '%.2e' % v) for k, v in top])
+    assert top[0][1] <= PINNED_TOL, top
+    assert took.get('pw', 0) >= 5 and took.get('wino', 0) >= 8 and took.get('bnb', 0) >= 8, took
+
+
+def _tap_every_relu(P, out_ch=32):
+    """Extends Plan ``P`` so that every slot a ReLU produces also reaches the output: per shape the slots are summed by trees of
+    fuse sums (<= 4 inputs each), every shape's sum goes through a 1x1 'tap' conv to ``out_ch`` channels and is up-sampled
+    (fuse shifts) to the finest shape, and the network's own output joins the same way.  Returns the tapped slots."""
+    from advmix_amd import ops
+    scale = {0: 0}                                          # log2 of the down-sampling of each slot
+    for st in P.steps:
+        if st[0] == 'conv':
+            scale[st[3]] = scale[st[2]] + (st[4] - 1)
+        elif st[0] == 'bn':
+            scale[st[3]] = scale[st[2]]
+        else:
+            scale[st[3]] = scale[st[1][st[2].index(0)]]
+    taps = [st[3] for st in P.steps if (st[0] == 'bn' and st[5] != ops.ACT_NONE) or (st[0] == 'fuse' and st[4] != ops.ACT_NONE)]
+    P.tag = None
+    groups = {}
+    for s_ in taps + [P.out]:
+        groups.setdefault((P.ch[s_], scale[s_]), []).append(s_)
+
+    def tree(xs, shifts):
+        while len(xs) > 1:
+            nx, ns = [], []
+            for i in range(0, len(xs), 4):
+                part, ps = xs[i:i + 4], shifts[i:i + 4]
+                if len(part) == 1:
+                    nx.append(part[0]); ns.append(ps[0])
+                else:
+                    base = min(ps)                          # (the sum lives at its finest member's shape)
+                    order = sorted(range(len(part)), key=lambda q: ps[q])
+                    nx.append(P.fuse([part[q] for q in order], [ps[q] - base for q in order], ops.ACT_NONE)); ns.append(base)
+            xs, shifts = nx, ns
+        return xs[0]
+    finest = min(sc for _, sc in groups)
+    tops, shifts = [], []
+    for gi, ((c, sc), slots) in enumerate(sorted(groups.items())):
+        tops.append(P.conv(tree(slots, [0] * len(slots)), 'tap%d' % gi, out_ch, 1, 1, 0))
+        shifts.append(sc - finest)
+    P.out = tree(tops, shifts)
+    return taps
+
+
+def test_whole_hrnet_w32_through_the_plan_executor_with_pinned_masks():
+    """The whole pose network element-wise (round 5): HRNet-W32 256x192 (pose_hrnet.py:270-500; plan.hrnet_plan's 316 steps) at
+    B = 16 - every kernel family of the benchmarked step is reached from that batch on (asserted) - through plan.PlanNet in
+    train mode, forward and backward, against an fp64 evaluation of the same plan whose ReLU masks are the device's signs
+    (every ReLU output is tapped into the output, _tap_every_relu): the output, the input gradient and every one of the
+    network's parameter gradients within 3e-4 of the tensor's scale (PINNED_TOL_NET)."""
+    from oracle import configs
+    from advmix_amd import ops
+    from advmix_amd._lib import lib
+    from advmix_amd.plan import hrnet_plan
+    B, H, W = 16, 256, 192
+    assert lib.advmix_conv_wino_config(B, 16, 12, 128, 128) >= ops.WINO_MIN_WGS and lib.advmix_conv_smapw_config(B, 8, 6, 256, 256) >= ops.WINO_MIN_WGS \
+        and lib.advmix_conv_pw_config(B, 64, 48, 64, 256) >= ops.WINO_MIN_WGS
+    P = hrnet_plan(configs.HRNET_W32, 17)
+    n_own = len(P.params)
+    taps = _tap_every_relu(P)
+    worst, took = _pinned_plan_check(P, taps, (B, 3, H, W), 'planhrnet', fp32_too=True)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    print('hrnet_w32 B', B, 'taps', len(taps), 'own parameters', n_own, 'launches', took, 'worst of %d tensors:' % len(worst),
+          [(k, '%.2e' % v) for k, v in top])
+    assert top[0][1] <= PINNED_TOL_NET, top
+    assert took.get('wino', 0) >= 2 * 188 and took.get('smap', 0) >= 2 * 24 and took.get('pw', 0) >= 8 and took.get('bnb', 0) >= 200 \
+        and took.get('wgrad_wino', 0) >= 1 and took.get('wgrad_multi', 0) >= 1, took
 
 
 @pytest.mark.parametrize('tag', ['hrnet_tiny', 'resnet18_tiny'])

@@ -709,9 +709,11 @@ def _tap_every_relu(P, out_ch=32):
     return taps
 
 
-def test_whole_hrnet_w32_through_the_plan_executor_with_pinned_masks():
+@pytest.mark.parametrize('case', [('hrnet_w32', 16, 256, 192), ('hrnet_w48', 8, 384, 288)])
+def test_whole_hrnet_through_the_plan_executor_with_pinned_masks(case):
     """The whole pose network element-wise (round 5): HRNet-W32 256x192 (pose_hrnet.py:270-500; plan.hrnet_plan's 316 steps) at
-    B = 16 - every kernel family of the benchmarked step is reached from that batch on (asserted) - through plan.PlanNet in
+    B = 16 - every kernel family of the benchmarked step is reached from that batch on (asserted) - and HRNet-W48 384x288 (C4) at
+    B = 8, through plan.PlanNet in
     train mode, forward and backward, against an fp64 evaluation of the same plan whose ReLU masks are the device's signs
     (every ReLU output is tapped into the output, _tap_every_relu): the output, the input gradient and every one of the
     network's parameter gradients within 3e-4 of the tensor's scale (PINNED_TOL_NET)."""
@@ -719,19 +721,20 @@ def test_whole_hrnet_w32_through_the_plan_executor_with_pinned_masks():
     from advmix_amd import ops
     from advmix_amd._lib import lib
     from advmix_amd.plan import hrnet_plan
-    B, H, W = 16, 256, 192
-    assert lib.advmix_conv_wino_config(B, 16, 12, 128, 128) >= ops.WINO_MIN_WGS and lib.advmix_conv_smapw_config(B, 8, 6, 256, 256) >= ops.WINO_MIN_WGS \
-        and lib.advmix_conv_pw_config(B, 64, 48, 64, 256) >= ops.WINO_MIN_WGS
-    P = hrnet_plan(configs.HRNET_W32, 17)
+    name, B, H, W = case
+    w32 = name == 'hrnet_w32'
+    assert not w32 or (lib.advmix_conv_wino_config(B, 16, 12, 128, 128) >= ops.WINO_MIN_WGS and lib.advmix_conv_pw_config(B, 64, 48, 64, 256) >= ops.WINO_MIN_WGS
+                       and lib.advmix_conv_smapw_config(B, 8, 6, 256, 256) >= ops.WINO_MIN_WGS)
+    P = hrnet_plan(configs.HRNET_W32 if w32 else configs.HRNET_W48, 17)
     n_own = len(P.params)
     taps = _tap_every_relu(P)
-    worst, took = _pinned_plan_check(P, taps, (B, 3, H, W), 'planhrnet', fp32_too=True)
+    worst, took = _pinned_plan_check(P, taps, (B, 3, H, W), 'plan' + name, fp32_too=True)
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
-    print('hrnet_w32 B', B, 'taps', len(taps), 'own parameters', n_own, 'launches', took, 'worst of %d tensors:' % len(worst),
+    print(name, 'B', B, 'taps', len(taps), 'own parameters', n_own, 'launches', took, 'worst of %d tensors:' % len(worst),
           [(k, '%.2e' % v) for k, v in top])
     assert top[0][1] <= PINNED_TOL_NET, top
-    assert took.get('wino', 0) >= 2 * 188 and took.get('smap', 0) >= 2 * 24 and took.get('pw', 0) >= 8 and took.get('bnb', 0) >= 200 \
-        and took.get('wgrad_wino', 0) >= 1 and took.get('wgrad_multi', 0) >= 1, took
+    assert took.get('wino', 0) >= (2 * 188 if w32 else 100) and took.get('bnb', 0) >= 200 and took.get('wgrad_wino', 0) >= 1, took
+    assert not w32 or (took.get('smap', 0) >= 2 * 24 and took.get('pw', 0) >= 8 and took.get('wgrad_multi', 0) >= 1), took
 
 
 @pytest.mark.parametrize('tag', ['hrnet_tiny', 'resnet18_tiny'])

@@ -1,0 +1,115 @@
+"""CPU: what the pinned-mask GPU tests take for the truth IS the oracle's function.  tests/test_models_gpu.py evaluates a
+plan.Plan's steps in fp64 (conv / deconv / bn / inorm / act / catact / fuse) with the device's ReLU masks; here the same
+reading of the steps - with each activation's OWN mask - is held against the oracle's forward passes (oracle/posenet.py,
+oracle/unet.py, themselves pinned to the real reference by tests/test_oracle_golden.py), for HRNet-W32, ResNet-free plans of
+both generators depths, in fp64; and the tapping transformation (_tap_every_relu) is checked to leave the tapped values alone."""
+import importlib.util
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.dirname(HERE), HERE]
+from helpers import build_states                                             # noqa: E402
+from oracle import configs, detinit                                          # noqa: E402
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+def interpret(P, W, x):
+    """The steps of ``P`` on torch CPU in x's dtype, train-mode BatchNorm, every activation with its own mask; {slot: value}."""
+    act = lambda t, a: t if a == ACT_NONE else (F.relu(t) if a == ACT_RELU else F.leaky_relu(t, 0.2))   # noqa: E731
+    val = {0: x}
+    for st in P.steps:
+        k = st[0]
+        if k in ('conv', 'deconv'):
+            _, name, s_, d_, stride, pad, hb = st
+            val[d_] = (F.conv2d if k == 'conv' else F.conv_transpose2d)(val[s_], W[name + '.weight'], W[name + '.bias'] if hb else None,
+                                                                         stride, pad)
+        elif k == 'bn':
+            _, name, s_, d_, res, a = st
+            pre = F.batch_norm(val[s_], None, None, W[name + '.weight'], W[name + '.bias'], True, 0.1, 1e-5)
+            val[d_] = act(pre if res is None else pre + val[res], a)
+        elif k == 'inorm':
+            val[st[2]] = act(F.instance_norm(val[st[1]], eps=1e-5), st[3])
+        elif k == 'act':
+            val[st[2]] = act(val[st[1]], st[3])
+        elif k == 'catact':
+            val[st[3]] = act(torch.cat([val[st[1]], val[st[2]]], 1), st[4])
+        elif k == 'fuse':
+            _, xs, shifts, d_, a = st
+            val[d_] = act(sum(val[s_] if sh == 0 else F.interpolate(val[s_], scale_factor=2 ** sh, mode='nearest')
+                              for s_, sh in zip(xs, shifts)), a)
+        else:
+            raise ValueError(k)
+    return val
+
+
+def _gpu_test_module():
+    spec = importlib.util.spec_from_file_location('_tm_gpu', os.path.join(HERE, 'test_models_gpu.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_plan_steps_read_functionally_are_the_oracles_hrnet():
+    from advmix_amd.plan import hrnet_plan
+    from oracle.posenet import posenet_forward
+    D, _, _ = build_states('pose_hrnet', configs.HRNET_W32, 17)
+    P = hrnet_plan(configs.HRNET_W32, 17)
+    assert {n for n, _, _ in P.params} | {n for n, _, _ in P.buffers} == set(D)          # the reference's state-dict keys
+    x = detinit.normal('interp.hrnet.x', (2, 3, 128, 96)).double()
+    W = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in D.items()}
+    got = interpret(P, W, x)[P.out]
+    want = posenet_forward('pose_hrnet', {k: v.clone() for k, v in W.items()}, x, configs.HRNET_W32, True)
+    assert got.shape == want.shape == (2, 17, 32, 24)
+    assert float((got - want).abs().max()) <= 1e-12 * float(want.abs().max())
+
+
+def test_plan_steps_read_functionally_are_the_oracles_generator():
+    from advmix_amd.plan import unet_plan
+    from oracle.unet import unet_forward
+    for downs, hw in ((6, (128, 64)), (5, (64, 96))):
+        _, _, G = build_states('pose_hrnet', configs.HRNET_W32, 17, unet_downs=downs)
+        P = unet_plan(9, 3, downs)
+        assert {n for n, _, _ in P.params} == set(G)
+        x = detinit.normal('interp.unet%d.x' % downs, (2, 9) + hw).double()
+        W = {k: v.double() for k, v in G.items()}
+        got = interpret(P, W, x)[P.out]
+        want = unet_forward(W, x, num_downs=downs)
+        assert float((got - want).abs().max()) <= 1e-12 * float(want.abs().max())
+
+
+def test_tapping_every_activation_leaves_the_network_alone():
+    """_tap_every_relu (tests/test_models_gpu.py): every activated slot is tapped, the original steps are untouched, every tap
+    reaches the new output (its gradient is non-zero), and the new output has the finest tapped shape."""
+    from advmix_amd.plan import hrnet_plan, unet_plan
+    tm = _gpu_test_module()
+    for make, cin, hw in ((lambda: hrnet_plan(configs.HRNET_W32, 17), 3, (64, 64)), (lambda: unet_plan(9, 3, 6), 9, (128, 64))):
+        P0, P = make(), make()
+        taps = tm._tap_every_relu(P)
+        assert P.steps[:len(P0.steps)] == P0.steps and sorted(taps) == sorted(tm._activated_slots(P0)) and len(taps) >= 11
+        assert all(st[0] in ('conv', 'fuse') for st in P.steps[len(P0.steps):])
+        g = torch.Generator().manual_seed(5)
+        W = {n: (torch.randn(shape, generator=g, dtype=torch.float64) * (0.05 if len(shape) == 4 else 0.1) + (1.0 if kind == 'bn_w' else 0.0))
+             for n, shape, kind in P.params}
+        x = torch.randn((1, cin) + hw, generator=g, dtype=torch.float64)
+        v0, v1 = interpret(P0, W, x), interpret(P, W, x)
+        assert all(torch.equal(v0[s_], v1[s_]) for s_ in taps) and torch.equal(v0[P0.out], v1[P0.out])
+        for s_ in taps:
+            v1[s_].retain_grad() if v1[s_].requires_grad else None
+        finest = max(v1[s_].shape[2] for s_ in taps + [P0.out])
+        assert v1[P.out].shape[1:] == (32, finest, finest * hw[1] // hw[0])
+        # every tap feeds the output: perturbing it moves the output
+        xs = {s_: v1[s_].detach().clone().requires_grad_(True) for s_ in taps}
+        val = dict(v1)
+        val.update(xs)
+        for st in P.steps[len(P0.steps):]:
+            if st[0] == 'conv':
+                val[st[3]] = F.conv2d(val[st[2]], W[st[1] + '.weight'], None, st[4], st[5])
+            else:
+                val[st[3]] = sum(val[s_] if sh == 0 else F.interpolate(val[s_], scale_factor=2 ** sh, mode='nearest') for s_, sh in zip(st[1], st[2]))
+        grads = torch.autograd.grad(val[P.out].sum(), list(xs.values()))
+        assert all(float(g_.abs().max()) > 0 for g_ in grads)

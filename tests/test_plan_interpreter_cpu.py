@@ -1,8 +1,8 @@
 """CPU: what the pinned-mask GPU tests take for the truth IS the oracle's function.  tests/test_models_gpu.py evaluates a
 plan.Plan's steps in fp64 (conv / deconv / bn / inorm / act / catact / fuse) with the device's ReLU masks; here the same
 reading of the steps - with each activation's OWN mask - is held against the oracle's forward passes (oracle/posenet.py,
-oracle/unet.py, themselves pinned to the real reference by tests/test_oracle_golden.py), for HRNet-W32, ResNet-free plans of
-both generators depths, in fp64; and the tapping transformation (_tap_every_relu) is checked to leave the tapped values alone."""
+oracle/unet.py, themselves pinned to the real reference by tests/test_oracle_golden.py), for HRNet-W32, ResNet-50 / the tiny
+ResNet-18 and both generator depths, in fp64; and the tapping transformation (_tap_every_relu) is checked to leave the tapped values alone."""
 import importlib.util
 import os
 import sys
@@ -42,6 +42,8 @@ def interpret(P, W, x):
             _, xs, shifts, d_, a = st
             val[d_] = act(sum(val[s_] if sh == 0 else F.interpolate(val[s_], scale_factor=2 ** sh, mode='nearest')
                               for s_, sh in zip(xs, shifts)), a)
+        elif k == 'maxpool':
+            val[st[2]] = F.max_pool2d(val[st[1]], 3, 2, 1)
         else:
             raise ValueError(k)
     return val
@@ -66,6 +68,20 @@ def test_plan_steps_read_functionally_are_the_oracles_hrnet():
     want = posenet_forward('pose_hrnet', {k: v.clone() for k, v in W.items()}, x, configs.HRNET_W32, True)
     assert got.shape == want.shape == (2, 17, 32, 24)
     assert float((got - want).abs().max()) <= 1e-12 * float(want.abs().max())
+
+
+def test_plan_steps_read_functionally_are_the_oracles_resnet():
+    from advmix_amd.plan import resnet_plan
+    from oracle.posenet import posenet_forward
+    for extra, tag in ((configs.RES50, "r50"), (configs.RES18_TINY, "r18")):
+        D, _, _ = build_states('pose_resnet', extra, 17)
+        P = resnet_plan(extra, 17)
+        assert {n for n, _, _ in P.params} | {n for n, _, _ in P.buffers} == set(D)
+        x = detinit.normal('interp.%s.x' % tag, (2, 3, 64, 64)).double()
+        W = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in D.items()}
+        got = interpret(P, W, x)[P.out]
+        want = posenet_forward('pose_resnet', {k: v.clone() for k, v in W.items()}, x, extra, True)
+        assert got.shape == want.shape and float((got - want).abs().max()) <= 1e-12 * float(want.abs().max())
 
 
 def test_plan_steps_read_functionally_are_the_oracles_generator():

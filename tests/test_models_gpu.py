@@ -169,13 +169,13 @@ def test_advmix_and_plain_steps_vs_oracle_and_golden(tag):
     """Reference lr (1e-3), teacher-forced: after each device-side update the oracle adopts the
     device weights, so every compared quantity is computed from identical parameters.
 
-    The two tiny B = 2 networks (the ones with a GRAD_FLIP_FLOOR) get up to three attempts at the STATISTICAL gradient
+    The two tiny B = 2 networks (the ones with a GRAD_FLIP_FLOOR) get up to five attempts at the STATISTICAL gradient
     criteria only: one ReLU mask of the frozen student flipped by the order of the device's atomics moves every tensor of
     the tiny generator's gradient by 1-6 % of its scale (1 of 4-6 runs on one box with any library of the round,
     profiles/r05w_g_step_outlier_rate.log, r05zk_*), a legitimate fp32 outcome no fixed floor covers; a wrong gradient
     misses the criteria on every attempt.  Outputs, losses, golden values, update match fractions and running statistics
     are asserted on every attempt and never retried; the three real networks have one attempt and no floor."""
-    attempts = 3 if tag in GRAD_FLIP_FLOOR else 1
+    attempts = 5 if tag in GRAD_FLIP_FLOOR else 1          # (a flip costs ~1 attempt in 4-6: five in a row is < 1e-3)
     for attempt in range(attempts):
         try:
             return _advmix_and_plain_steps(tag)

@@ -129,3 +129,19 @@ def test_tapping_every_activation_leaves_the_network_alone():
                 val[st[3]] = sum(val[s_] if sh == 0 else F.interpolate(val[s_], scale_factor=2 ** sh, mode='nearest') for s_, sh in zip(st[1], st[2]))
         grads = torch.autograd.grad(val[P.out].sum(), list(xs.values()))
         assert all(float(g_.abs().max()) > 0 for g_ in grads)
+
+
+def test_probe_tool_runs_without_a_gpu():
+    """tools/probe_unet_grads.py (EXPERIMENTS K2) on the CPU: the fp64 / fp32 columns and the pinned pass (without a GPU the
+    'hip' column repeats fp32) - the tool shares tests/unet_functional.py with test_generator_gradients_with_pinned_masks."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), 'tools', 'probe_unet_grads.py'), '64', '64', '2', '5'],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert '== against fp64 with the masks pinned to the HIP run' in out.stdout and 'L4 relu' in out.stdout
+    rows = [ln.split() for ln in out.stdout.splitlines() if ln.startswith('model.') and ln.split()[0].endswith('.weight')]
+    assert len(rows) == 2 * 10
+    # first pass: fp32 against fp64, each with its OWN masks - on this container's CPU the fp32 evaluation itself flips a mask
+    # at this size (weight gradients up to 2e-1 of scale off); second pass, masks pinned: rounding level on every weight
+    print('own masks: worst %.2e   pinned: worst %.2e' % (max(float(r[1]) for r in rows[:10]), max(float(r[1]) for r in rows[10:])))
+    assert all(float(r[1]) < 1e-4 for r in rows[10:]), rows[10:]

@@ -191,14 +191,17 @@ class GradSync:
         CH = 1 << 22                                        # fixed-size pieces: a flat optimizer buffer of 30-60 M
         w = None                                            # elements used to be widened to int64 three times over in one go
         for t in tensors:                                   # (~24 B / parameter of transient memory in the middle of training)
-            t = t.detach().contiguous().view(-1)
-            if t.element_size() % 4:
-                t = t.to(torch.int32)
-            bits = t.view(torch.int32)
+            src = t.detach().contiguous().view(-1)          # the ORIGINAL elements: the finiteness count reads these (ADVICE r5:
+            if src.element_size() % 4:                      # the widened copy of an fp16 / bf16 buffer is integer, so its NaNs
+                # were never counted); 1- and 2-byte elements are widened to one int32 word each (raw bit pattern for floats)
+                bits = (src.view(torch.int16) if src.is_floating_point() else src).to(torch.int32)
+            else:
+                bits = src.view(torch.int32)
+            wide = max(1, src.element_size() // 4)          # int32 words per source element (fp64 / int64: 2)
             for lo in range(0, bits.numel(), CH):
                 piece = bits[lo:lo + CH]
-                if t.is_floating_point():
-                    acc[2] += (~torch.isfinite(t[lo * 4 // t.element_size():(lo + piece.numel()) * 4 // t.element_size()])).sum()
+                if src.is_floating_point():                 # (an element is counted with the piece that holds its first word)
+                    acc[2] += (~torch.isfinite(src[-(-lo // wide):-(-(lo + piece.numel()) // wide)])).sum()
                 if w is None or w.device != piece.device:
                     w = torch.arange(CH, device=piece.device, dtype=torch.int64)
                 v = piece.to(torch.int64)
@@ -385,3 +388,26 @@ def rank0_only(fn):
             return None
         return fn(*a, **k)
     return guarded
+
+
+def atomic_copy(fn):
+    """``shutil.copy2``-shaped ``fn`` whose destination appears in ONE step: the copy goes to a private temporary name in
+    the destination's directory and is renamed over the target.  For the reference's three ``shutil.copy2`` calls into
+    ``final_output_dir`` (tools/train.py:73-84), which N ranks would otherwise write through the same path at the same
+    time (open-for-write truncates: a reader - or the other writer's ``copystat`` - can meet a half-written file).  Every
+    caller keeps ``copy2``'s semantics and return value; without a process group the rename is the only difference."""
+    import functools
+    import os
+
+    @functools.wraps(fn)
+    def copy(src, dst, *a, **k):
+        target = os.path.join(dst, os.path.basename(src)) if os.path.isdir(dst) else dst
+        tmp = '%s.tmp.%d.%d' % (target, os.getpid(), _world()[0])
+        try:
+            fn(src, tmp, *a, **k)
+            os.replace(tmp, target)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        return target
+    return copy

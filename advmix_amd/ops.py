@@ -266,7 +266,37 @@ def _wgrad(st, lane, a, b, w, geom, park=False, v=None):
 WGRAD_MULTI = __import__('os').environ.get('ADVMIX_WGRAD_MULTI', '1') != '0'
 WGRAD_MULTI_MAX_FLOP = float(__import__('os').environ.get('ADVMIX_WGRAD_MULTI_MAX_GFLOP', '1.0')) * 1e9
 WGRAD_MULTI_FLUSH = int(__import__('os').environ.get('ADVMIX_WGRAD_MULTI_FLUSH', '8'))    # pending problems that trigger a flush
-_WG_SMALL = []          # [(a, b, grad, geom)] across the launch groups of the autograd pass in progress
+_WG_SMALL = {}          # {(thread, autograd graph task): [(a, b, grad, geom)]} across the launch groups of THAT pass
+
+
+def _pass_key():
+    """The autograd pass in progress on this thread.  ADVICE r5 (medium): the parked problems used to live in one
+    process-global list, so what a pass that RAISED had parked (its end-of-pass callback never runs) went out with the next
+    pass - stale dc / x products accumulated into live gradients - and a nested ``autograd.grad`` could flush its outer
+    pass's problems.  Graph-task ids grow monotonically and a nested pass runs inside one node of its outer pass."""
+    import threading
+    return threading.get_ident(), torch._C._current_graph_task_id()
+
+
+def _park_list(key, create=False):
+    """This pass's parked problems; on the way, what can no longer belong to a live pass of this thread is dropped: lists of
+    a LATER task id (a nested pass that has returned, or raised, before its outer pass reached this point)."""
+    th, tid = key
+    for k in [k for k in _WG_SMALL if k[0] == th and k[1] > tid]:
+        del _WG_SMALL[k]
+    if create:
+        return _WG_SMALL.setdefault(key, [])
+    return _WG_SMALL.get(key, [])
+
+
+def drop_stale_parked():
+    """Outside any autograd pass (forward side of a launch group): whatever this thread still holds was parked by a pass
+    that raised - never launched, only released."""
+    if _WG_SMALL and torch._C._current_graph_task_id() < 0:
+        import threading
+        th = threading.get_ident()
+        for k in [k for k in _WG_SMALL if k[0] == th]:
+            del _WG_SMALL[k]
 
 
 def _wgrad_single(st, a, b, g, geom, park):
@@ -274,21 +304,25 @@ def _wgrad_single(st, a, b, g, geom, park):
     B, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad = geom
     if (park and WGRAD_MULTI and not DETERMINISTIC and Ca % 4 == 0 and Cb % 4 == 0
             and 2.0 * B * Ha * Wa * Ca * Cb * R * S <= WGRAD_MULTI_MAX_FLOP):
-        try:                                                 # (one callback per parked problem: the first to run flushes all)
-            torch.autograd.Variable._execution_engine.queue_callback(_flush_small_wgrads_at_end)
-            _WG_SMALL.append((a, b, g, geom))
+        key = _pass_key()
+        if key[1] >= 0:                                      # (not inside an autograd pass: nobody would flush)
+            lst = _park_list(key, create=True)
+            if not lst:                                      # one callback per pass, bound to THIS pass's list
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_small_wgrads_at_end(key))
+            lst.append((a, b, g, geom))
             return
-        except RuntimeError:                                 # not inside an autograd pass: nobody would flush
-            pass
     call('advmix_conv_wgrad', _p(a), _p(b), _p(g), *geom, st)
 
 
-def _flush_small_wgrads(st, count=None, keep_alive=True):
-    """The first ``count`` (default: all) parked weight gradients as mixed launches of up to 16 on stream ``st``;
-    ``keep_alive``: their operands stay referenced until the group in progress has joined its lanes (keep())."""
-    count = len(_WG_SMALL) if count is None else count
-    pending = _WG_SMALL[:count]
-    del _WG_SMALL[:count]
+def _flush_small_wgrads(st, key, count=None, keep_alive=True):
+    """The first ``count`` (default: all) weight gradients parked by pass ``key`` as mixed launches of up to 16 on stream
+    ``st``; ``keep_alive``: their operands stay referenced until the group in progress has joined its lanes (keep())."""
+    lst = _WG_SMALL.get(key, [])
+    count = len(lst) if count is None else count
+    pending = lst[:count]
+    del lst[:count]
+    if not lst:
+        _WG_SMALL.pop(key, None)
     for i in range(0, len(pending), 16):
         grp = pending[i:i + 16]
         n = len(grp)
@@ -307,11 +341,12 @@ def _flush_small_wgrads(st, count=None, keep_alive=True):
         _KEEP.extend(t for x in pending for t in x[:2])
 
 
-def _flush_small_wgrads_at_end():
-    """End of the autograd pass (queue_callback): what is still parked goes out on the caller's stream - every lane has
-    joined it."""
-    if _WG_SMALL:
-        _flush_small_wgrads(_st(), keep_alive=False)
+def _flush_small_wgrads_at_end(key):
+    """End of the autograd pass ``key`` (queue_callback): what it still has parked goes out on the caller's stream - every
+    lane has joined it."""
+    if _WG_SMALL.get(key):
+        _flush_small_wgrads(_st(), key, keep_alive=False)
+    _WG_SMALL.pop(key, None)
 
 
 WGRAD_WINO = __import__('os').environ.get('ADVMIX_WGRAD_WINO', '1') != '0'   # Winograd F(3x3,2x2) weight gradients (A/B switch)
@@ -1240,6 +1275,13 @@ def _add(st, a, b):
     return out
 
 
+# Observation hook of the parity tests (never set by the product): callable(owner, slot, tensor, stream handle) called for
+# every slot a plan step produces as soon as it has been launched - inside a chain (owner = the chain's ``subs`` tuple) and by
+# plan.PlanRun for single steps (owner = the PlanNet).  The pinned-mask tests read the signs of the activations of the step's OWN
+# forward passes through it (tests/plan_functional.py); the callee synchronises before it reads.  Not legal during graph capture.
+SLOT_TAP = None
+
+
 class Chain:
     """A dependent run of members executed back to back on ONE lane: an HRNet branch with its fuse
     convolutions, a bottleneck stack, a whole U-Net.  Inside a chain nothing waits for the other
@@ -1277,6 +1319,8 @@ class Chain:
                 sv = ()
             keep(o[0])                                     # an intermediate nobody saved must outlive the lanes
             val[dst], need[dst] = o[0], wants
+            if SLOT_TAP is not None:
+                SLOT_TAP(subs, dst, o[0], st)
             rec.append((len(saved), len(sv), ex, nin))
             saved += list(sv)
         return tuple(val[s_] for s_ in out_slots), tuple(saved), rec
@@ -1453,6 +1497,8 @@ class GroupFn(torch.autograd.Function):
         n = len(members)
         cur = torch.cuda.current_stream(dev)
         nl = min(n, MAX_LANES)
+        if _WG_SMALL:
+            drop_stale_parked()                             # (what a backward pass that raised left parked: released, not run)
         # layout conversions are torch kernels on the caller's stream: do them BEFORE the fork so
         # no side lane can start ahead of a copy it depends on
         flat = list(flat)
@@ -1518,13 +1564,14 @@ class GroupFn(torch.autograd.Function):
                 return
             r = op.bwd(handle, lane, saved[spos:spos + scnt], extras[i], meta, g, needs)
             grads[ipos:ipos + icnt] = list(r) + [None] * (icnt - len(r))
-        ready = len(_WG_SMALL)                              # small weight gradients parked by EARLIER groups (their lanes
-        if nl > 1 and ready >= WGRAD_MULTI_FLUSH:           # have joined): one mixed launch on this group's last lane,
+        key = _pass_key()
+        ready = len(_park_list(key))                        # small weight gradients parked by EARLIER groups of THIS pass (their
+        if nl > 1 and ready >= WGRAD_MULTI_FLUSH:           # lanes have joined): one mixed launch on this group's last lane,
             inner = run_member                              # beside its members
 
             def run_member(i, handle, lane):
                 if i == nl - 1:                             # (the first member that runs on lane nl - 1)
-                    _flush_small_wgrads(handle, ready)
+                    _flush_small_wgrads(handle, key, ready)
                 inner(i, handle, lane)
         _run_lanes(dev, len(members), nl, run_member)
         del _KEEP[:]

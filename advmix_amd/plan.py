@@ -716,6 +716,8 @@ class PlanRun:
                     self.slots[d] = t
             else:
                 self.slots[net._dst(st)] = o
+                if ops.SLOT_TAP is not None:
+                    ops.SLOT_TAP(net, net._dst(st), o, None)
         for st in sts:                                     # drop dead activations early
             for s in net._srcs(st):
                 if net._last_use[s] == self.li and s != net.plan.out:

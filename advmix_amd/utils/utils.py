@@ -266,3 +266,88 @@ def save_checkpoint(states, is_best, output_dir, filename='checkpoint.pth', suff
         torch.save(states, os.path.join(output_dir, filename))
         if is_best and 'state_dict' in states:
             torch.save(states['best_state_dict'], os.path.join(output_dir, 'model_best.pth'))
+
+
+_LOGGER_CALLS = [0]
+
+
+def create_logger(args, cfg, cfg_name, phase='train'):
+    """lib/utils/utils.py:22-75 for N processes: same arguments, same ``(logger, final_output_dir, tensorboard_log_dir)``
+    triple, same directory names and log format.  The reference's version belongs to ONE process - ``if not exists():
+    mkdir()`` (:24-27) lets two ranks both pass the test and the second ``mkdir`` raise FileExistsError, and every rank
+    stamps its own minute into the names.  Here rank 0 makes the three directories (``exist_ok``) and publishes its time
+    stamp through the process group's store; the other ranks wait for that key, so every rank returns the SAME two
+    paths; log files carry a ``_rank<r>`` suffix on ranks > 0 (one writer per file).  Without a process group this is
+    the reference's behaviour with ``exist_ok``."""
+    import logging
+    import time
+    from pathlib import Path
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if multi else 0
+
+    dataset = cfg.DATASET.DATASET + '_' + cfg.DATASET.HYBRID_JOINTS_TYPE if cfg.DATASET.HYBRID_JOINTS_TYPE \
+        else cfg.DATASET.DATASET
+    dataset = dataset.replace(':', '_')
+    model = cfg.MODEL.NAME
+    cfg_name = os.path.basename(cfg_name).split('.')[0]
+    suffix = getattr(args, 'save_suffix', '')
+    cfg_name = suffix if suffix != '' else cfg_name
+    robust = bool(getattr(args, 'test_robust', False))
+    root_output_dir = Path('output_robustness') if robust else Path(cfg.OUTPUT_DIR)
+    final_output_dir = root_output_dir / dataset / model / cfg_name
+    if robust:
+        final_output_dir = final_output_dir / 'test_corruption'
+
+    _LOGGER_CALLS[0] += 1
+    key = 'advmix_create_logger_%d_%s' % (_LOGGER_CALLS[0], phase)
+    if rank == 0:
+        time_str = time.strftime('%Y-%m-%d-%H-%M')
+    else:
+        import datetime
+        store = dist.distributed_c10d._get_default_store()
+        store.wait([key], datetime.timedelta(minutes=10))
+        time_str = store.get(key).decode()
+    tensorboard_log_dir = Path(cfg.LOG_DIR) / dataset / model / (cfg_name + '_' + time_str)
+    if robust:
+        tensorboard_log_dir = Path(cfg.LOG_DIR) / dataset / model / 'test_robustness' / (cfg_name + '_' + time_str) / \
+            args.corruption_type / str(args.severity)
+    if rank == 0:
+        print('=> creating {}'.format(final_output_dir))
+        final_output_dir.mkdir(parents=True, exist_ok=True)
+        print('=> creating {}'.format(tensorboard_log_dir))
+        tensorboard_log_dir.mkdir(parents=True, exist_ok=True)
+        if multi:                                           # only now may the other ranks open files in there
+            dist.distributed_c10d._get_default_store().set(key, time_str)
+
+    log_file = '{}_{}'.format(cfg_name, phase) if robust else '{}_{}_{}'.format(cfg_name, time_str, phase)
+    log_file += ('_rank%d' % rank if rank else '') + '.log'
+    logging.basicConfig(filename=str(final_output_dir / log_file), format='%(asctime)-15s %(message)s')
+    logger = logging.getLogger()
+    logger.setLevel(logging.INFO if rank == 0 else logging.WARNING)     # one voice on the console and in the main log
+    logging.getLogger('').addHandler(logging.StreamHandler())
+    return logger, str(final_output_dir), str(tensorboard_log_dir)
+
+
+class NullSummaryWriter:
+    """What ranks > 0 get for ``tensorboardX.SummaryWriter(log_dir=...)`` (tools/train.py:87-91): every method is a no-op,
+    so the loops' ``writer.add_scalar`` / ``writer_dict['writer'].close()`` lines run unchanged and rank 0's event file is
+    the only one."""
+
+    def __init__(self, *a, **k):
+        self.log_dir = k.get('log_dir', a[0] if a else None)
+
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return lambda *a, **k: None
+
+
+def rank0_summary_writer(cls):
+    """``cls`` on rank 0 (or without a process group), NullSummaryWriter on the others - decided when the writer is made."""
+    def make(*a, **k):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+            return NullSummaryWriter(*a, **k)
+        return cls(*a, **k)
+    return make

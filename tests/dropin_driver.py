@@ -86,12 +86,18 @@ def main():
     assert ref_utils.__file__.startswith(REF), ref_utils.__file__
     ref_utils.get_optimizer = _u.get_optimizer
     ref_utils.save_checkpoint = _u.save_checkpoint
+    ref_utils.create_logger = _u.create_logger              # N-process safe (the reference's mkdir races between ranks)
     from advmix_amd.dp import Replica
     torch.nn.DataParallel = Replica                         # one process per GPU: DataParallel's shape, none of its mechanics
     torch.nn.parallel.DataParallel = Replica
     from advmix_amd.dp import ShardedDataLoader, rank0_only
     torch.utils.data.DataLoader = ShardedDataLoader         # per-rank shard + per-GPU batch under a process group; DataLoader otherwise
     torch.save = rank0_only(torch.save)                     # tools/train.py:337 writes final_state.pth unguarded
+    import shutil
+    from advmix_amd.dp import atomic_copy
+    shutil.copy2 = atomic_copy(shutil.copy2)                # tools/train.py:73-84: N ranks copy three files to ONE directory
+    import tensorboardX
+    tensorboardX.SummaryWriter = _u.rank0_summary_writer(tensorboardX.SummaryWriter)    # :87-91: one event file, rank 0's
 
     # ---- "the only edit multi-GPU needs" (INTEGRATION.md section 2): the process group, before main() builds anything.
     # gloo stands in for nccl here (no GPU in this container).
@@ -107,7 +113,8 @@ def main():
     def probe_advmix(config, args, train_loader, models, criterion, optimizers, epoch, output_dir, tb_log_dir,
                      writer_dict, grad_sync=None):
         got.update(kind='train_advmix', config=config, args=args, loader=train_loader, models=models,
-                   criterion=criterion, optimizers=optimizers, epoch=epoch, output_dir=output_dir)
+                   criterion=criterion, optimizers=optimizers, epoch=epoch, output_dir=output_dir, tb_log_dir=tb_log_dir,
+                   writer=writer_dict['writer'])
         raise Reached()
 
     def probe_plain(config, args, train_loader, model, criterion, optimizer, epoch, output_dir, tb_log_dir,
@@ -156,7 +163,9 @@ def main():
            'batch_size': got['loader'].batch_size, 'gpus': list(cfg.GPUS),
            'sampler': type(got['loader'].sampler).__name__, 'loader_len': len(got['loader']),
            'shard': sorted(int(i) for i in got['loader'].sampler)[:4] + [len(list(got['loader'].sampler))],
-           'real_loop_signature_ok': True, 'output_dir_files': sorted(os.listdir(got['output_dir']))}
+           'real_loop_signature_ok': True, 'output_dir_files': sorted(os.listdir(got['output_dir'])),
+           'output_dir': got['output_dir'], 'tb_log_dir': got.get('tb_log_dir'),
+           'writer': type(got.get('writer')).__name__, 'logger_level': __import__('logging').getLogger().level}
     if len(models) == 3:
         G, T = models[1], models[2]
         assert type(G.module) is pm.Unet_generator.UnetGenerator

@@ -240,6 +240,35 @@ sys.exit(0 if ok else 3)
 '''
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16, torch.float64, torch.int64, torch.uint8])
+def test_state_fold_counts_non_finite_in_every_float_width(dtype):
+    """the chunked fold widened 2-byte buffers to int32 BEFORE asking ``is_floating_point()``, so a
+    bf16 / fp16 state with inf / NaN folded to ``finite``.  Every float width must count its non-finite elements - across
+    the 4 Mi-word piece boundaries too - and any changed element must move the two checksums."""
+    from advmix_amd.dp import GradSync
+    n = (1 << 22) + 7 if dtype != torch.float64 else (1 << 21) + 7           # just past one piece
+    g = torch.Generator().manual_seed(3)
+    if dtype.is_floating_point:
+        a = torch.randn(n, generator=g).to(dtype)
+    else:
+        a = torch.randint(0, 200, (n,), generator=g).to(dtype)
+    f0 = GradSync.state_fold([a])
+    assert int(f0[2]) == 0
+    b = a.clone()
+    b[5] = b[5] + (8 if dtype == torch.bfloat16 else 1)
+    f1 = GradSync.state_fold([b])
+    assert (f1[:2] != f0[:2]).all() and int(f1[2]) == 0
+    if dtype.is_floating_point:
+        c = a.clone()
+        words = 2 if dtype == torch.float64 else 1
+        edge = (1 << 22) // words                                            # first element of the second piece
+        for i, v in ((0, float('inf')), (edge - 1, float('nan')), (edge, float('-inf')), (n - 1, float('nan'))):
+            c[i] = v
+        f2 = GradSync.state_fold([c])
+        assert int(f2[2]) == 4 and (f2[:2] != f0[:2]).all()
+        assert int(GradSync.state_fold([a, c, a])[2]) == 4
+
+
 @pytest.mark.parametrize('mode', ['ok', 'flip', 'nan', 'bad_exchange'])
 def test_replica_fold_and_exchange_trace_two_ranks_gloo(tmp_path, mode):
     """an N-rank run must prove itself.  dp.GradSync.replicas_state (a 24-byte all-gather of a fold over

@@ -461,6 +461,85 @@ def _conv_bn_fused_member(case):
                 check('dres', rg.grad, rr.grad)
 
 
+def test_parked_weight_gradients_belong_to_their_autograd_pass():
+    """small weight gradients parked for a mixed launch lived in one process-global list.  (1) A
+    backward pass that raises after parking must not hand its problems to the next pass (stale dc / x products added into a
+    live gradient); (2) a nested ``autograd.grad`` inside a node of the outer pass must flush only its own.  Both through
+    ops.conv_bn (the only parking call site: ConvBN.bwd)."""
+    ops = _ops()
+    d = dev()
+
+    def member(seed):
+        x = cl(rnd(2, 32, 16, 12, seed=seed)).requires_grad_(True)
+        w = torch.nn.Parameter(cl(rnd(64, 32, 3, 3, seed=seed + 1, scale=0.06)))
+        g, b = torch.nn.Parameter(torch.ones(64, device=d)), torch.nn.Parameter(torch.zeros(64, device=d))
+        st = (torch.zeros(64, device=d), torch.ones(64, device=d), torch.zeros((), dtype=torch.int64, device=d))
+        return x, w, g, b, st
+
+    def run(x, w, g, b, st):
+        return ops.conv_bn(x, w, g, b, *st, None, 2, 1, ops.ACT_RELU, True)
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, gr):
+            raise RuntimeError('boom')
+
+    class Nested(torch.autograd.Function):
+        """A node of the outer pass that runs a whole inner pass (its own parked problem) before returning."""
+        seen = {}
+
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, gr):
+            x2, w2, g2, b2, st2 = member(40)
+            with torch.enable_grad():
+                y2 = run(x2, w2, g2, b2, st2)
+            outer = {k: len(v) for k, v in ops._WG_SMALL.items()}
+            (gw,) = torch.autograd.grad(y2.sum(), w2)
+            Nested.seen = {'outer_before': outer, 'after': {k: len(v) for k, v in ops._WG_SMALL.items()},
+                           'inner_grad_nonzero': bool(gw.abs().max() > 0)}
+            return gr
+
+    # (1) the failing pass parks w1's problem (ConvBN.bwd runs before Boom.backward), then raises
+    x1, w1, g1, b1, st1 = member(10)
+    y1 = run(Boom.apply(x1), w1, g1, b1, st1)
+    with pytest.raises(RuntimeError, match='boom'):
+        y1.sum().backward()
+    torch.cuda.synchronize()
+    assert sum(len(v) for v in ops._WG_SMALL.values()) == 1            # parked, never flushed: its callback did not run
+    w1.grad = torch.zeros_like(w1)
+    x3, w3, g3, b3, st3 = member(20)
+    y3 = run(x3, w3, g3, b3, st3)                                        # the forward side releases the stale list
+    assert not ops._WG_SMALL
+    y3.sum().backward()
+    torch.cuda.synchronize()
+    assert not ops._WG_SMALL
+    assert float(w1.grad.abs().max()) == 0.0                             # nothing stale was added to the live buffer
+    assert float(w3.grad.abs().max()) > 0.0
+
+    # (2) nested pass.  Outer graph: x4 -> Nested -> conv_bn(w4): ConvBN.bwd parks w4's problem FIRST, then Nested.backward
+    # runs a whole inner pass (parks and flushes its own w2); the outer list must come through untouched
+    x4, w4, g4, b4, st4 = member(30)
+    y4 = run(Nested.apply(x4), w4, g4, b4, st4)
+    y4.sum().backward()
+    torch.cuda.synchronize()
+    seen = Nested.seen
+    assert seen['inner_grad_nonzero'] and not ops._WG_SMALL
+    assert list(seen['outer_before'].values()) == [1] and seen['after'] == seen['outer_before'], seen
+    x5, w5, g5, b5, st5 = member(30)                                     # the same problem without the nested pass
+    run(x5, w5, g5, b5, st5).sum().backward()
+    torch.cuda.synchronize()
+    check('dw through a nested pass', w4.grad, w5.grad.double().cpu(), 1e-5)
+    check('dx through a nested pass', x4.grad, x5.grad.double().cpu(), 1e-5)
+
+
 @pytest.mark.parametrize('C,ns', [(6, 16), (32, 16), (10, 4), (64, 64), (7, 1)])
 def test_norm_finalize_reads_and_clears_slot_major_slots(C, ns):
     """advmix_norm_finalize on the conv epilogues' slots, slot-major [2][ns][C] since round 4 (the path ConvBN takes when

@@ -15,38 +15,7 @@ sys.path[:0] = [os.path.dirname(HERE), HERE]
 from helpers import build_states                                             # noqa: E402
 from oracle import configs, detinit                                          # noqa: E402
 
-ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
-
-
-def interpret(P, W, x):
-    """The steps of ``P`` on torch CPU in x's dtype, train-mode BatchNorm, every activation with its own mask; {slot: value}."""
-    act = lambda t, a: t if a == ACT_NONE else (F.relu(t) if a == ACT_RELU else F.leaky_relu(t, 0.2))   # noqa: E731
-    val = {0: x}
-    for st in P.steps:
-        k = st[0]
-        if k in ('conv', 'deconv'):
-            _, name, s_, d_, stride, pad, hb = st
-            val[d_] = (F.conv2d if k == 'conv' else F.conv_transpose2d)(val[s_], W[name + '.weight'], W[name + '.bias'] if hb else None,
-                                                                         stride, pad)
-        elif k == 'bn':
-            _, name, s_, d_, res, a = st
-            pre = F.batch_norm(val[s_], None, None, W[name + '.weight'], W[name + '.bias'], True, 0.1, 1e-5)
-            val[d_] = act(pre if res is None else pre + val[res], a)
-        elif k == 'inorm':
-            val[st[2]] = act(F.instance_norm(val[st[1]], eps=1e-5), st[3])
-        elif k == 'act':
-            val[st[2]] = act(val[st[1]], st[3])
-        elif k == 'catact':
-            val[st[3]] = act(torch.cat([val[st[1]], val[st[2]]], 1), st[4])
-        elif k == 'fuse':
-            _, xs, shifts, d_, a = st
-            val[d_] = act(sum(val[s_] if sh == 0 else F.interpolate(val[s_], scale_factor=2 ** sh, mode='nearest')
-                              for s_, sh in zip(xs, shifts)), a)
-        elif k == 'maxpool':
-            val[st[2]] = F.max_pool2d(val[st[1]], 3, 2, 1)
-        else:
-            raise ValueError(k)
-    return val
+from plan_functional import interpret, activated_slots, pooled_slots           # noqa: E402
 
 
 def _gpu_test_module():
@@ -145,3 +114,29 @@ def test_probe_tool_runs_without_a_gpu():
     # at this size (weight gradients up to 2e-1 of scale off); second pass, masks pinned: rounding level on every weight
     print('own masks: worst %.2e   pinned: worst %.2e' % (max(float(r[1]) for r in rows[:10]), max(float(r[1]) for r in rows[10:])))
     assert all(float(r[1]) < 1e-4 for r in rows[10:]), rows[10:]
+
+
+def test_pinning_an_evaluation_to_its_own_masks_changes_nothing():
+    """tests/plan_functional.py: ``interpret(pin=..., pool_src=...)`` handed the slots of an un-pinned evaluation reproduces its
+    values AND gradients exactly (ReLU, LeakyReLU, max-pool winners) - and handed the masks of a DIFFERENT input it stays on
+    that input's linear piece (the output then differs from the un-pinned one, the gradient is finite and non-zero)."""
+    from advmix_amd.plan import resnet_plan, unet_plan
+    for P, cin, hw in ((resnet_plan(configs.RES18_TINY, 5), 3, (64, 64)), (unet_plan(9, 3, 5), 9, (64, 96))):
+        g = torch.Generator().manual_seed(11)
+        W = {n: (torch.randn(shape, generator=g, dtype=torch.float64) * (0.05 if len(shape) == 4 else 0.1) + (1.0 if kind == 'bn_w' else 0.0)).requires_grad_(True)
+             for n, shape, kind in P.params}
+        x = torch.randn((2, cin) + hw, generator=g, dtype=torch.float64)
+        free = interpret(P, W, x)
+        pin = {s_: free[s_].detach() for s_, _ in activated_slots(P)}
+        pool = {dst: free[src].detach() for src, dst in pooled_slots(P)}
+        assert len(pin) >= 8 and (len(pool) == 1) == (cin == 3)
+        held = interpret(P, W, x, pin=pin, pool_src=pool)
+        assert torch.equal(held[P.out], free[P.out])
+        proj = torch.randn(free[P.out].shape, generator=g, dtype=torch.float64)
+        ga = torch.autograd.grad((free[P.out] * proj).sum(), list(W.values()), allow_unused=True)
+        gb = torch.autograd.grad((held[P.out] * proj).sum(), list(W.values()), allow_unused=True)
+        for n, a_, b_ in zip(W, ga, gb):
+            assert (a_ is None) == (b_ is None) and (a_ is None or float((a_ - b_).abs().max()) <= 1e-12 * (float(a_.abs().max()) + 1e-300)), n
+        x2 = x + 0.05 * torch.randn(x.shape, generator=g, dtype=torch.float64)
+        other = interpret(P, W, x2, pin=pin, pool_src=pool)[P.out]
+        assert not torch.equal(other, interpret(P, W, x2)[P.out]) and bool(torch.isfinite(other).all())

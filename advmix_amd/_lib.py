@@ -87,6 +87,7 @@ SIGNATURES = {
     'advmix_mix_bwd': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     'advmix_joints_loss': [_p, _p, _i, _p, _p, _p, _f, _i, _i, _i, _i, _p],
     'advmix_joints_loss_det': [_p, _p, _i, _p, _p, _p, _f, _i, _i, _i, _i, _p, _p],
+    'advmix_joints_loss_blend': [_p, _p, _i, _p, _i, _p, _p, _p, _f, _f, _i, _i, _i, _i, _p, _p],
     'advmix_heatmap_argmax': [_p, _i, _p, _p, _i, _i, _i, _p],
     'advmix_adam': [_p, _p, _p, _p, _l, _p, _p, _p],
     'advmix_sgd': [_p, _p, _p, _l, _p, _p],

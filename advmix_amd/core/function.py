@@ -34,12 +34,27 @@ def _cuda(t):
     return t.cuda(non_blocking=True) if not t.is_cuda else t
 
 
+def _backward(loss):
+    """``loss.backward()`` seeded with the cached constant 1.0 (ops.unit_grad) instead of the engine's ones_like launch."""
+    seed = ops.unit_grad(loss.device) if loss.is_cuda and loss.dim() == 0 and loss.dtype == torch.float32 else None
+    loss.backward(seed)
+
+
+def _blend(criterion, output, target_a, scale_a, target_b, scale_b, target_weight):
+    """scale_a L(output, target_a) + scale_b L(output, target_b) (function.py:151-153, :161): one fused op when the criterion
+    is this package's (core.loss.JointsMSELoss.blend), the reference's arithmetic around any other criterion."""
+    if hasattr(criterion, 'blend'):
+        return criterion.blend(output, target_a, scale_a, target_b, scale_b, target_weight)
+    loss = criterion(output, target_a, target_weight) * scale_a
+    return loss if target_b is None else loss + criterion(output, target_b, target_weight) * scale_b
+
+
 def plain_step(model, criterion, optimizer, input, target, target_weight, grad_sync=None):
     """function.py:48-59: forward, loss, zero_grad, backward, step.  Returns (loss, outputs)."""
     outputs = model(_cuda(input).float())
     loss = criterion(outputs, target, target_weight)
     optimizer.zero_grad()
-    loss.backward()
+    _backward(loss)
     if grad_sync is not None:
         grad_sync.sync(optimizer)
     optimizer.step()
@@ -62,7 +77,7 @@ def _backward_pieces(loss, net, cuts, pairs):
     def make(k):                                            # k counts DOWN from the top piece (k = len(cuts))
         def run():
             if k == len(cuts):
-                loss.backward()
+                _backward(loss)
             else:
                 live = [(o, t.grad) for o, t in pairs[k] if t.grad is not None]
                 torch.autograd.backward([o for o, _ in live], [g for _, g in live])
@@ -133,12 +148,10 @@ def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, in
             teacher_output = model_teacher(inputs[0])                     # :148-149
     pairs_D = model.last_cuts if cuts else None
     model.cut_levels = ()
-    loss_D_hm = criterion(D_output_detach, target, target_weight)
-    loss_D_kd = criterion(D_output_detach, teacher_output, target_weight)
-    loss_D = loss_D_hm * (1 - args.alpha) + loss_D_kd * args.alpha        # :151-153
+    loss_D = _blend(criterion, D_output_detach, target, 1 - args.alpha, teacher_output, args.alpha, target_weight)   # :151-153
     if cuts:
         return loss_D.detach(), tmp, _backward_pieces(loss_D, model, cuts[0], pairs_D), pairs_G
-    loss_D.backward()
+    _backward(loss_D)
     return loss_D.detach(), tmp
 
 
@@ -151,10 +164,10 @@ def advmix_phase_b(args, model, criterion, optimizer, optimizer_G, tmp, target, 
     set_require_grad(model, False)                                        # :158
     optimizer_G.zero_grad()
     output = model(tmp)                                                   # :160
-    loss_G = -criterion(output, target, target_weight) * args.adv_loss_weight
+    loss_G = _blend(criterion, output, target, -args.adv_loss_weight, None, 0.0, target_weight)                     # :161
     if cuts_G is not None:
         return output.detach(), _backward_pieces(loss_G, model_G, cuts_G, pairs_G)
-    loss_G.backward()
+    _backward(loss_G)
     return output.detach()
 
 

@@ -16,3 +16,11 @@ class JointsMSELoss(nn.Module):
         if output.dim() != 4:
             raise NotImplementedError('coordinate-regression outputs are not on the hot path')
         return ops.joints_loss(output, target, target_weight, self.use_target_weight, self.mse)
+
+    def blend(self, output, target_a, scale_a, target_b, scale_b, target_weight):
+        """``scale_a * self(output, target_a, w) + scale_b * self(output, target_b, w)`` as one launch and one autograd node
+        (``target_b`` None: ``scale_a * self(output, target_a, w)``): what lib/core/function.py:151-153 and :161 spell with
+        torch arithmetic around the criterion.  The loops use it when the criterion offers it."""
+        if output.dim() != 4:
+            raise NotImplementedError('coordinate-regression outputs are not on the hot path')
+        return ops.joints_loss_blend(output, target_a, scale_a, target_b, scale_b, target_weight, self.use_target_weight, self.mse)

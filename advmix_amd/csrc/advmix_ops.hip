@@ -86,34 +86,48 @@ __global__ __launch_bounds__(256) void mix_bwd_kernel(const float* __restrict__ 
     }
 }
 
-// pred NHWC [B,HW,J]; element index e = (b*HW + p)*J + j
+// pred NHWC [B,HW,J]; element index e = (b*HW + p)*J + j.  One or two targets: loss_out += la L(pred, target) + lb L(pred,
+// target_b), grad = ga dL(pred, target) + gb dL(pred, target_b) - the AdvMix student's heat-map + distillation loss
+// (function.py:151-153) is one pass over pred; (la, ga, lb, gb) = (1, grad_scale, 0, 0) with target_b NULL is the single loss.
 __global__ __launch_bounds__(256) void joints_loss_kernel(const float* __restrict__ pred,
                                                           const float* __restrict__ target, int target_nhwc,
+                                                          const float* __restrict__ target_b, int b_nhwc,
                                                           const float* __restrict__ tw, float* __restrict__ loss_out,
-                                                          float* __restrict__ grad, float grad_scale, int B, int J,
-                                                          int HW, int mse, double* part) {
+                                                          float* __restrict__ grad, float la, float ga, float lb, float gb,
+                                                          int B, int J, int HW, int mse, double* part) {
     __shared__ double red[4];
     const int64_t total = (int64_t)B * HW * J;
     const float norm = 0.5f / ((float)J * (float)B * (float)HW);
-    double acc = 0.0;
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        int j = (int)(e % J);
-        int64_t bp = e / J;
-        int64_t b = bp / HW, p = bp - b * HW;
-        float w = tw ? tw[b * J + j] : 1.0f;
-        float t = target_nhwc ? target[e] : target[(b * J + j) * HW + p];
-        float d = pred[e] * w - t * w;                    // loss.py:58-60: pred.mul(w), gt.mul(w)
-        float l, g;
+    double acc = 0.0, accb = 0.0;
+    auto term = [&](float d, float& l, float& g) {
         if (mse) { l = d * d; g = 2.0f * d; }
         else {
             float ad = fabsf(d);
             if (ad < 1.0f) { l = 0.5f * d * d; g = d; }
             else { l = ad - 0.5f; g = d > 0.f ? 1.0f : -1.0f; }
         }
+    };
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int j = (int)(e % J);
+        int64_t bp = e / J;
+        int64_t b = bp / HW, p = bp - b * HW;
+        float w = tw ? tw[b * J + j] : 1.0f;
+        float t = target_nhwc ? target[e] : target[(b * J + j) * HW + p];
+        float pw = pred[e] * w;                           // loss.py:58-60: pred.mul(w), gt.mul(w)
+        float l, g;
+        term(pw - t * w, l, g);
         acc += (double)l;
-        if (grad) grad[e] = grad_scale * norm * w * g;
+        float gsum = ga * norm * w * g;
+        if (target_b) {
+            float tb = b_nhwc ? target_b[e] : target_b[(b * J + j) * HW + p];
+            float l2, g2;
+            term(pw - tb * w, l2, g2);
+            accb += (double)l2;
+            gsum += gb * norm * w * g2;
+        }
+        if (grad) grad[e] = gsum;
     }
-    acc = wave_sum_d(acc);
+    acc = wave_sum_d(acc * (double)la + accb * (double)lb);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -440,15 +454,15 @@ extern "C" int advmix_mix_bwd(const float* v0, const float* v1, const float* v2,
     return ADVMIX_OK;
 }
 
-static int joints_loss_impl(const float* pred, const float* target, int target_nhwc, const float* tw,
-                            float* loss_out, float* grad, float grad_scale, int B, int J, int HW, int mse,
-                            double* part, void* stream) {
+static int joints_loss_impl(const float* pred, const float* target, int target_nhwc, const float* target_b, int b_nhwc,
+                            const float* tw, float* loss_out, float* grad, float la, float ga, float lb, float gb, int B, int J,
+                            int HW, int mse, double* part, void* stream) {
     if (!pred || !target || !loss_out || B <= 0 || J <= 0 || HW <= 0) return ADVMIX_EINVAL;
     int64_t total = (int64_t)B * J * HW;
     int blocks = stream_blocks(total);
     if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(joints_loss_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, target, target_nhwc,
-                       tw, loss_out, grad, grad_scale, B, J, HW, mse, part);
+                       target_b, b_nhwc, tw, loss_out, grad, la, ga, lb, gb, B, J, HW, mse, part);
     if (part) hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, blocks, loss_out);
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
@@ -457,7 +471,8 @@ static int joints_loss_impl(const float* pred, const float* target, int target_n
 extern "C" int advmix_joints_loss(const float* pred, const float* target, int target_nhwc, const float* tw,
                                   float* loss_out, float* grad, float grad_scale, int B, int J, int HW, int mse,
                                   void* stream) {
-    return joints_loss_impl(pred, target, target_nhwc, tw, loss_out, grad, grad_scale, B, J, HW, mse, nullptr, stream);
+    return joints_loss_impl(pred, target, target_nhwc, nullptr, 0, tw, loss_out, grad, 1.0f, grad_scale, 0.f, 0.f, B, J, HW, mse,
+                            nullptr, stream);
 }
 
 // deterministic variant: the <= 512 block sums go to ws (>= 4 KiB) and are added in block order
@@ -465,7 +480,18 @@ extern "C" int advmix_joints_loss_det(const float* pred, const float* target, in
                                       float* loss_out, float* grad, float grad_scale, int B, int J, int HW, int mse,
                                       void* ws, void* stream) {
     if (!ws) return ADVMIX_EINVAL;
-    return joints_loss_impl(pred, target, target_nhwc, tw, loss_out, grad, grad_scale, B, J, HW, mse, (double*)ws, stream);
+    return joints_loss_impl(pred, target, target_nhwc, nullptr, 0, tw, loss_out, grad, 1.0f, grad_scale, 0.f, 0.f, B, J, HW, mse,
+                            (double*)ws, stream);
+}
+
+// loss_out += scale_a L(pred, target_a) + scale_b L(pred, target_b), grad = the same blend of the two gradients, in ONE pass
+// over pred (target_b may be NULL: a scaled single loss, e.g. the generator's -adv_loss_weight L).  Replaces the torch
+// arithmetic around two criterion calls at lib/core/function.py:151-153 (and :161).  ws != NULL: deterministic block order.
+extern "C" int advmix_joints_loss_blend(const float* pred, const float* target_a, int a_nhwc, const float* target_b, int b_nhwc,
+                                        const float* tw, float* loss_out, float* grad, float scale_a, float scale_b, int B,
+                                        int J, int HW, int mse, void* ws, void* stream) {
+    return joints_loss_impl(pred, target_a, a_nhwc, target_b, b_nhwc, tw, loss_out, grad, scale_a, scale_a, scale_b, scale_b, B, J,
+                            HW, mse, (double*)ws, stream);
 }
 
 extern "C" int advmix_heatmap_argmax(const float* hm, int nhwc, int32_t* idx_out, float* max_out, int B, int J,

@@ -174,7 +174,7 @@ class PlainGraphRunner:
             outputs = model(self.input)
             loss = criterion(outputs, self.target, self.tw)
             optimizer.zero_grad()
-            loss.backward()
+            loss.backward(ops.unit_grad(loss.device))       # (the constant seed: core.function._backward)
             self.loss, self.output = loss.detach(), outputs.detach()
         self.s1, _ = self.seq.capture(seg_a)
         self.s2, _ = self.seq.capture(lambda: optimizer.step(sync_hyper=False))

@@ -266,23 +266,22 @@ def _wgrad(st, lane, a, b, w, geom, park=False, v=None):
 WGRAD_MULTI = __import__('os').environ.get('ADVMIX_WGRAD_MULTI', '1') != '0'
 WGRAD_MULTI_MAX_FLOP = float(__import__('os').environ.get('ADVMIX_WGRAD_MULTI_MAX_GFLOP', '1.0')) * 1e9
 WGRAD_MULTI_FLUSH = int(__import__('os').environ.get('ADVMIX_WGRAD_MULTI_FLUSH', '8'))    # pending problems that trigger a flush
-_WG_SMALL = {}          # {(thread, autograd graph task): [(a, b, grad, geom)]} across the launch groups of THAT pass
+_WG_SMALL = {}          # {autograd graph task id: [(a, b, grad, geom)]} across the launch groups of THAT pass
 
 
 def _pass_key():
-    """The autograd pass in progress on this thread.  ADVICE r5 (medium): the parked problems used to live in one
-    process-global list, so what a pass that RAISED had parked (its end-of-pass callback never runs) went out with the next
-    pass - stale dc / x products accumulated into live gradients - and a nested ``autograd.grad`` could flush its outer
-    pass's problems.  Graph-task ids grow monotonically and a nested pass runs inside one node of its outer pass."""
-    import threading
-    return threading.get_ident(), torch._C._current_graph_task_id()
+    """The autograd pass in progress (-1: none).  ADVICE r5 (medium): the parked problems used to live in one process-global
+    list, so what a pass that RAISED had parked (its end-of-pass callback never runs) went out with the next pass - stale
+    dc / x products accumulated into live gradients - and a nested ``autograd.grad`` could flush its outer pass's problems.
+    Graph-task ids grow monotonically and a nested pass runs inside one node of its outer pass.  (Not keyed by thread: the
+    engine runs a pass's CUDA nodes on its device thread, the forward that cleans up runs on the caller's.)"""
+    return torch._C._current_graph_task_id()
 
 
 def _park_list(key, create=False):
-    """This pass's parked problems; on the way, what can no longer belong to a live pass of this thread is dropped: lists of
-    a LATER task id (a nested pass that has returned, or raised, before its outer pass reached this point)."""
-    th, tid = key
-    for k in [k for k in _WG_SMALL if k[0] == th and k[1] > tid]:
+    """This pass's parked problems; on the way, what can no longer belong to a live pass is dropped: lists of a LATER task
+    id (a nested pass that has returned, or raised, before its outer pass reached this point)."""
+    for k in [k for k in _WG_SMALL if k > key]:
         del _WG_SMALL[k]
     if create:
         return _WG_SMALL.setdefault(key, [])
@@ -290,13 +289,11 @@ def _park_list(key, create=False):
 
 
 def drop_stale_parked():
-    """Outside any autograd pass (forward side of a launch group): whatever this thread still holds was parked by a pass
-    that raised - never launched, only released."""
+    """Outside any autograd pass (forward side of a launch group): whatever is still held was parked by a pass that raised -
+    never launched, only released.  (One process drives one GPU from one thread at a time; a forward on one thread beside
+    another thread's backward pass is not a supported way to use the library.)"""
     if _WG_SMALL and torch._C._current_graph_task_id() < 0:
-        import threading
-        th = threading.get_ident()
-        for k in [k for k in _WG_SMALL if k[0] == th]:
-            del _WG_SMALL[k]
+        _WG_SMALL.clear()
 
 
 def _wgrad_single(st, a, b, g, geom, park):
@@ -305,7 +302,7 @@ def _wgrad_single(st, a, b, g, geom, park):
     if (park and WGRAD_MULTI and not DETERMINISTIC and Ca % 4 == 0 and Cb % 4 == 0
             and 2.0 * B * Ha * Wa * Ca * Cb * R * S <= WGRAD_MULTI_MAX_FLOP):
         key = _pass_key()
-        if key[1] >= 0:                                      # (not inside an autograd pass: nobody would flush)
+        if key >= 0:                                         # (not inside an autograd pass: nobody would flush)
             lst = _park_list(key, create=True)
             if not lst:                                      # one callback per pass, bound to THIS pass's list
                 torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_small_wgrads_at_end(key))
@@ -1224,30 +1221,44 @@ class Mix:
 class JointsLoss:
     NHWC = (0,)      # inputs made dense NHWC BEFORE the lanes fork (None = all)
     """JointsMSELoss.forward (lib/core/loss.py:25-65); fused forward + gradient.
-    tensors = (pred, target, tw|None); meta = (use_tw, mse)."""
+    tensors = (pred, target, tw|None[, target_b|None]); meta = (use_tw, mse[, scale_a, scale_b]).
+    With scales (round 6) the op is the BLEND ``scale_a L(pred, target) + scale_b L(pred, target_b)`` in one pass over pred
+    (advmix_joints_loss_blend): the student's heat-map + distillation loss (function.py:151-153), the generator's negated
+    loss (:161) - no torch arithmetic around the criterion."""
 
     @staticmethod
-    def fwd(st, lane, t, meta, needs):
-        pred, target, tw = t
-        use_tw, mse = meta
-        pred = nhwc(pred)
-        B, J, H, W = pred.shape
+    def _target(target, pred):
         if target.shape != pred.shape:
             raise ValueError('target shape %s != output shape %s' % (tuple(target.shape), tuple(pred.shape)))
         target = keep(target.float())
         if target.is_contiguous():
-            t_nhwc = 0
-        elif target.is_contiguous(memory_format=_CL):
-            t_nhwc = 1
-        else:
-            target, t_nhwc = keep(target.contiguous()), 0
+            return target, 0
+        if target.is_contiguous(memory_format=_CL):
+            return target, 1
+        return keep(target.contiguous()), 0
+
+    @staticmethod
+    def fwd(st, lane, t, meta, needs):
+        pred, target, tw = t[:3]
+        target_b = t[3] if len(t) > 3 else None
+        use_tw, mse = meta[:2]
+        blend = len(meta) > 2
+        sa, sb = (float(meta[2]), float(meta[3])) if blend else (1.0, 0.0)
+        pred = nhwc(pred)
+        B, J, H, W = pred.shape
+        target, t_nhwc = JointsLoss._target(target, pred)
+        tb, b_nhwc = JointsLoss._target(target_b, pred) if target_b is not None else (None, 0)
         w = keep(tw.float().reshape(B, J).contiguous()) if use_tw else None
         loss = torch.empty((), device=pred.device, dtype=torch.float32)
         call('advmix_fill', _p(loss), 0.0, 1, st)
         grad = empty_nhwc(B, J, H, W, pred.device) if needs[0] else None
-        if DETERMINISTIC:
+        ws = _p(_workspace(pred.device, 0, lane)) if DETERMINISTIC else None
+        if blend:
+            call('advmix_joints_loss_blend', _p(pred), _p(target), t_nhwc, _p(tb), b_nhwc, _p(w), _p(loss), _p(grad), sa, sb,
+                 B, J, H * W, 1 if mse else 0, ws, st)
+        elif DETERMINISTIC:
             call('advmix_joints_loss_det', _p(pred), _p(target), t_nhwc, _p(w), _p(loss), _p(grad), 1.0,
-                 B, J, H * W, 1 if mse else 0, _p(_workspace(pred.device, 0, lane)), st)
+                 B, J, H * W, 1 if mse else 0, ws, st)
         else:
             call('advmix_joints_loss', _p(pred), _p(target), t_nhwc, _p(w), _p(loss), _p(grad), 1.0,
                  B, J, H * W, 1 if mse else 0, st)
@@ -1256,10 +1267,29 @@ class JointsLoss:
     @staticmethod
     def bwd(st, lane, saved, extra, meta, grads, needs):
         (grad,) = saved
+        unit = _UNIT.get(grad.device.index)
+        if unit is not None and grads[0].data_ptr() == unit.data_ptr():
+            return (grad,) + (None,) * (len(needs) - 1)     # d loss = 1 (unit_grad): the gradient the forward left IS the result
         out = torch.empty_like(grad, memory_format=torch.preserve_format)
         dl = keep(grads[0].float().contiguous())
         call('advmix_scale_dev', _p(out), _p(grad), _p(dl), 1.0, grad.numel(), st)
-        return out, None, None
+        return (out,) + (None,) * (len(needs) - 1)
+
+
+_UNIT = {}
+
+
+def unit_grad(device):
+    """The constant 1.0 on ``device`` to seed a backward pass with: ``loss.backward(ops.unit_grad(loss.device))``.  The
+    engine's own seed is a ones_like() - a torch fill launch per pass on the critical path between forward and backward -
+    and JointsLoss.bwd recognises THIS tensor and hands the gradient its forward computed on without the scaling launch.
+    Created on first use (the runners' eager warm-up steps: never inside a capture)."""
+    t = _UNIT.get(device.index)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None                                     # (the engine's default seed: correct, one launch more)
+        t = _UNIT[device.index] = torch.ones((), device=device, dtype=torch.float32)
+    return t
 
 
 FANIN_FUSED = __import__('os').environ.get('ADVMIX_FANIN', '1') != '0'
@@ -1647,6 +1677,11 @@ def softmax_mix(logits, views):
 
 def joints_loss(pred, target, tw, use_target_weight=True, mse=False):
     return _one(JointsLoss, (pred, target, tw), (use_target_weight, mse))
+
+
+def joints_loss_blend(pred, target_a, scale_a, target_b, scale_b, tw, use_target_weight=True, mse=False):
+    """scale_a L(pred, target_a) + scale_b L(pred, target_b) as ONE op (``target_b`` None: a scaled single loss)."""
+    return _one(JointsLoss, (pred, target_a, tw, target_b), (use_target_weight, mse, float(scale_a), float(scale_b)))
 
 
 def cat_views(views):

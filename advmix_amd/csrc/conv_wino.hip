@@ -82,13 +82,17 @@ struct Geo {
 // column tiles = one workgroup per CU at B = 32) gets two waves per SIMD that way, each multiplying half of the channels;
 // the halves meet in the exchange of the inverse transform, which adds across waves anyway.
 // waves per SIMD the register allocator may assume: what the LDS footprint admits anyway (three workgroups of <= 53 KB per CU)
-template <int NQ, int LBW, int KS>
-constexpr int wino_waves() { return KS > 1 ? 1 : (Geo<LBW, NQ * 8, KS>::LDS * 4 + 1024 <= 53 * 1024 ? 3 : 2); }
+template <int NQ, int LBW, int KS, int NC = 1>
+constexpr int wino_waves() { return KS > 1 ? 1 : (NC > 1 ? 2 : (Geo<LBW, NQ * 8, KS>::LDS * 4 + 1024 <= 53 * 1024 ? 3 : 2)); }
 
 // VAR: the epilogue compiled in - 0 forward + BatchNorm column sums, 1 forward + eval-mode BatchNorm (+ residual) + activation,
 // 2 input gradient (+ addend) + BatchNorm-backward epilogue, 3 plain (forward or input gradient, + residual / addend)
-template <int NQ, int VAR, int LBW, int KS = 1>
-__global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS>())) void conv_wino(const WinoP p) {
+// NC (round 6): column tiles of 32 output channels per workgroup.  With NC = 1 the grid's y dimension walks the column tiles,
+// so a 64-channel conv stages every patch and transforms every input group TWICE (0.73-0.80 in the step
+// where the 32-channel instance is at 0.85-0.88); NC = 2 keeps both tiles' accumulators (2 x 64 registers) in the wave: one
+// staging, one B^T d B per 8-channel group, 32 MFMAs behind it instead of 16; the epilogue runs once per column tile.
+template <int NQ, int VAR, int LBW, int KS = 1, int NC = 1>
+__global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS, NC>())) void conv_wino(const WinoP p) {
     using G = Geo<LBW, NQ * 8, KS>;
     constexpr int NT = 256 * KS, NQW = NQ / KS;            // threads; k groups per wave
     static_assert(NQ % KS == 0, "K splits evenly over the wave sets");
@@ -98,6 +102,7 @@ __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS>())) void conv_wi
     __shared__ __attribute__((aligned(16))) float L[G::LDS];
     __shared__ float sred[2 * 4 * KS * 32];
     float* const X = L;
+    static_assert(NC == 1 || KS == 1, "column tiles per workgroup and the K split are alternatives");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -106,18 +111,20 @@ __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS>())) void conv_wi
     int bm = blockIdx.x;
     if (p.xcd_remap && (gridDim.x & 7) == 0 && gridDim.x >= 16)            // each XCD (and its L2) works through a contiguous
         bm = (bm & 7) * ((int)gridDim.x >> 3) + (bm >> 3);                  // range of blocks: halos are L2 hits
-    const int n0 = blockIdx.y * 32;
+    const int n00 = blockIdx.y * (32 * NC);
     const int img = bm / p.nblk;                                            // (uniform: scalar arithmetic)
     const int rblk = bm - img * p.nblk;
     const int bby = rblk / p.nbw, bbx = rblk - bby * p.nbw;
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.u, 0, p.ubytes, 0x00020000);
-    const unsigned bo = (unsigned)((((blockIdx.y * 16 + wid * 4) * NQ) * 64 + lane) * 16);
-    f32x4 bn[4];
+    const unsigned bo = (unsigned)((((blockIdx.y * NC * 16 + wid * 4) * NQ) * 64 + lane) * 16);
+    f32x4 bn[NC][4];
     auto issue_b = [&](int q) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bn[j] = bload(ur, bo + (unsigned)((j * NQ + kh * NQW + q) * 1024));
+        for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bn[ct][j] = bload(ur, bo + (unsigned)(((ct * 16 + j) * NQ + kh * NQW + q) * 1024));
     };
     issue_b(0);
 
@@ -177,20 +184,24 @@ __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS>())) void conv_wi
     const float* const la = L + ((2 * byl + ra) * PWL + bxl) * PP + 4 * lh + kh * (NQW * 8);
     const float* const lb = L + ((2 * byl + rb) * PWL + bxl) * PP + 4 * lh + kh * (NQW * 8);
 
-    f32x16 acc[4];
+    f32x16 acc[NC][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int ct = 0; ct < NC; ++ct)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][j][r] = 0.f;
 
     __syncthreads();                                        // the patch is complete
 #pragma unroll
     for (int q = 0; q < NQW; ++q) {
-        f32x4 rc[4], v[4], bc[4];
+        f32x4 rc[4], v[4], bc[NC][4];
         __builtin_amdgcn_sched_barrier(0);                  // (nothing of group q + 1 is hoisted above group q's MFMAs)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bc[j] = bn[j];
-        if (q + 1 < NQW) issue_b(q + 1);                     // the next group's filters fly under this group's 16 MFMAs
+        for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bc[ct][j] = bn[ct][j];
+        if (q + 1 < NQW) issue_b(q + 1);                     // the next group's filters fly under this group's 16 NC MFMAs
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int o = ((c & 1) * HALF + (c >> 1)) * PP + 8 * q;
@@ -208,10 +219,12 @@ __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS>())) void conv_wi
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int ct = 0; ct < NC; ++ct)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bc[j][e], acc[j], 0, 0, 0);
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[ct][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][e], bc[ct][j][e], acc[ct][j], 0, 0, 0);
     }
 
     // ---- inverse transform, column half (inside the wave):  M A,  A^T = [1 1 1 0; 0 1 -1 -1] ---------------------------
@@ -231,137 +244,150 @@ __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS>())) void conv_wi
     const bool recompute = VAR == 2 && !mask_on && p.bnb_act != ADVMIX_ACT_NONE;
     const bool has_res = VAR != 0 && p.res != nullptr;
     const int cq = tid & 7;
-    const int col = n0 + 4 * cq;
-    const bool cvalid = col < p.Co;                         // (Co = 48: the second column tile is half empty - its filters are zero)
     // item k of this thread: tile tl0 + (NT / 32) k of the block, output position (oa, ob) = bits 1, 0 of tid / 8 - the SAME for all
     // its items; the tile walks down the block: BW divides NT / 32, so tx stays and ty advances by (NT / 32) / BW per item
     const int tl0 = tid >> 5, oa = (tid >> 4) & 1, ob = (tid >> 3) & 1;
     constexpr int TSTEP = (NT / 32) / BW;                   // tile rows per item
     static_assert((NT / 32) % BW == 0, "an item step is whole tile rows");
     const int tx = bbx * BW + (tl0 & (BW - 1)), ty0 = bby * BH + (tl0 >> LBW);
-    const bool xok = tx < p.Wt && cvalid;
+    const bool xok_t = tx < p.Wt;
     const int pix0 = (img * p.H + 2 * ty0 + oa) * p.W + 2 * tx + ob;
     const int pstep = 2 * TSTEP * p.W;                      // pixels per item
-    unsigned yo[NI];
-    f32x4 oa4[NI], oc4[NI];
-    unsigned mb[NI];
+    // the epilogue's read operands (addend / residual, c, mask bytes) of column tile ct + 1 are requested before the items of
+    // column tile ct are worked through: with NC = 1 they arrive under the exchange, with NC = 2 the second set arrives under
+    // the first tile's epilogue (requested all at once they would not fit the registers beside 128 accumulators)
+    unsigned yo[NC][NI];
+    f32x4 oa4[NC][NI], oc4[NC][NI];
+    unsigned mb[NC][NI];
+    auto fetch = [&](const int ct) {
+        const int col = n00 + 32 * ct + 4 * cq;
+        const bool xok = xok_t && col < p.Co;
 #pragma unroll
-    for (int k = 0; k < NI; ++k) {
-        const bool ok = xok && ty0 + TSTEP * k < p.Ht;
-        const int pix = pix0 + pstep * k;
-        yo[k] = ok ? (unsigned)((pix * p.Co + col) * 4) : OOB;
-        oa4[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        oc4[k] = oa4[k];
-        mb[k] = 0u;
-        if (VAR != 0 && has_res) oa4[k] = bload(rr, yo[k]);  // requested now, they arrive under the exchange
-        if constexpr (VAR == 2) {
-            oc4[k] = bload(cr, yo[k]);
-            if (mask_on && ok) mb[k] = p.bnb_mask[yo[k] >> 4];      // byte (pixel * Co + column) / 4; bit e: channel col + e
+        for (int k = 0; k < NI; ++k) {
+            const bool ok = xok && ty0 + TSTEP * k < p.Ht;
+            const int pix = pix0 + pstep * k;
+            yo[ct][k] = ok ? (unsigned)((pix * p.Co + col) * 4) : OOB;
+            oa4[ct][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            oc4[ct][k] = oa4[ct][k];
+            mb[ct][k] = 0u;
+            if (VAR != 0 && has_res) oa4[ct][k] = bload(rr, yo[ct][k]);  // requested now, they arrive under the exchange
+            if constexpr (VAR == 2) {
+                oc4[ct][k] = bload(cr, yo[ct][k]);
+                if (mask_on && ok) mb[ct][k] = p.bnb_mask[yo[ct][k] >> 4];      // byte (pixel * Co + column) / 4; bit e: channel col + e
+            }
         }
-    }
+    };
+    fetch(0);
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+        const int n0 = n00 + 32 * ct;
+        const int col = n0 + 4 * cq;
+        const bool cvalid = col < p.Co;                         // (Co = 48: the second column tile is half empty - its filters are zero)
 
-    __syncthreads();                                        // every wave is done with the patch: the region becomes the exchange image
-    {
-        float* const xw = &X[(wv * 2 * 32 + 4 * lh) * XP + l31];      // D[tile row acc_row(r, lh)][column l31]
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float t0 = (acc[0][r] + acc[1][r]) + acc[2][r];
-            const float t1 = (acc[1][r] - acc[2][r]) - acc[3][r];
-            xw[((r & 3) + 8 * (r >> 2)) * XP] = t0;
-            xw[(32 + (r & 3) + 8 * (r >> 2)) * XP] = t1;
-        }
-    }
-    __syncthreads();
-    // ---- row half (across the waves) and the fused epilogue (conv_direct.hip's arithmetic), per item.  The epilogue VARIANT
-    // is a template parameter: a SIMD issues VALU and MFMA instructions one after the other (csrc/conv_pw.hip's knock-outs), so
-    // every instruction of an epilogue the launch does not use was paid for in the run-time-generic first version ------------
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    const float bb_slope = act_neg_slope(p.bnb_act);
-    const int colc = cvalid ? col : 0;
-    auto ld4 = [&](const float* q) { return *reinterpret_cast<const f32x4*>(q + colc); };   // (colc % 4 == 0: one 16-byte load)
-    f32x4 bn_is = {1.f, 1.f, 1.f, 1.f}, bn_g = bn_is, bn_b = {0.f, 0.f, 0.f, 0.f}, bn_m = bn_b;
-    if constexpr (VAR == 1) {
-        const f32x4 rv = ld4(p.bn_rv);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bn_is[e] = 1.0f / sqrtf(rv[e] + p.bn_eps);
-        bn_g = ld4(p.bn_gamma); bn_b = ld4(p.bn_beta); bn_m = ld4(p.bn_rm);
-    }
-    f32x4 bb_mu = {0.f, 0.f, 0.f, 0.f}, bb_is = bb_mu, bb_g = bb_mu, bb_b = bb_mu;
-    if constexpr (VAR == 2) {
-        bb_mu = ld4(p.bnb_mean); bb_is = ld4(p.bnb_invstd);
-        if (recompute) { bb_g = ld4(p.bnb_gamma); bb_b = ld4(p.bnb_beta); }
-    }
-    const float sg2 = oa ? -1.f : 1.f;                      // Y[0][b] = T0 + T1 + T2,  Y[1][b] = T1 - T2 - T3
-    const float* const xr0 = &X[((oa * 2 + ob) * 32 + tl0) * XP + 4 * cq];
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {                   // (the K shares of the wave sets add up here)
-            const float* const xp = xr0 + (4 * kk * 2 * 32 + (NT / 32) * k) * XP;
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp);
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(xp + 2 * 32 * XP);
-            const f32x4 x2 = *reinterpret_cast<const f32x4*>(xp + 4 * 32 * XP);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += __builtin_fmaf(sg2, x1[e] + x2[e], x0[e]);
-        }
-        const bool valid = yo[k] != OOB;
-        if constexpr (VAR == 0) {
-            if (valid) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { s1[e] += v[e]; s2[e] = __builtin_fmaf(v[e], v[e], s2[e]); }
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float o = v[e];
-                if constexpr (VAR == 1) {
-                    o = (o - bn_m[e]) * bn_is[e] * bn_g[e] + bn_b[e];
-                    o += oa4[k][e];
-                    o = act_fwd(o, p.act);
-                } else {
-                    o += oa4[k][e];
-                    if constexpr (VAR == 2) {
-                        const float xh = (oc4[k][e] - bb_mu[e]) * bb_is[e];
-                        if (mask_on) o = ((mb[k] >> e) & 1u) ? o : o * bb_slope;
-                        else if (recompute) o = __builtin_fmaf(xh, bb_g[e], bb_b[e]) > 0.f ? o : o * bb_slope;
-                        if (valid) { s1[e] += o; s2[e] = __builtin_fmaf(o, xh, s2[e]); }
-                    }
-                }
-                v[e] = o;
-            }
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yo[k], 0, STORE_AUX);
-    }
-    if constexpr (VAR == 0 || VAR == 2) {
-        // a wave = 8 (tile, position) items x 8 channel quads (lane = 8 i + cq): the items add up by shuffles, the waves in LDS
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-            for (int d = 8; d < 64; d <<= 1) {
-                s1[e] += __shfl_xor(s1[e], d, 64);
-                s2[e] += __shfl_xor(s2[e], d, 64);
-            }
-        }
-        if (lane < 8) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sred[wv * 32 + 4 * lane + e] = s1[e];
-                sred[(4 * KS + wv) * 32 + 4 * lane + e] = s2[e];
+        __syncthreads();                                        // every wave is done with the patch (with the previous column tile's image): the region becomes the exchange image
+        {
+            float* const xw = &X[(wv * 2 * 32 + 4 * lh) * XP + l31];      // D[tile row acc_row(r, lh)][column l31]
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float t0 = (acc[ct][0][r] + acc[ct][1][r]) + acc[ct][2][r];
+                const float t1 = (acc[ct][1][r] - acc[ct][2][r]) - acc[ct][3][r];
+                xw[((r & 3) + 8 * (r >> 2)) * XP] = t0;
+                xw[(32 + (r & 3) + 8 * (r >> 2)) * XP] = t1;
             }
         }
         __syncthreads();
-        if (tid < 32) {
-            double d1 = 0.0, d2 = 0.0;
-#pragma unroll
-            for (int k = 0; k < 4 * KS; ++k) {
-                d1 += (double)sred[k * 32 + tid];
-                d2 += (double)sred[(4 * KS + k) * 32 + tid];
+        if (ct + 1 < NC) fetch(ct + 1);
+        // ---- row half (across the waves) and the fused epilogue (conv_direct.hip's arithmetic), per item.  The epilogue VARIANT
+        // is a template parameter: a SIMD issues VALU and MFMA instructions one after the other (csrc/conv_pw.hip's knock-outs), so
+        // every instruction of an epilogue the launch does not use was paid for in the run-time-generic first version ------------
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        const float bb_slope = act_neg_slope(p.bnb_act);
+        const int colc = cvalid ? col : 0;
+        auto ld4 = [&](const float* q) { return *reinterpret_cast<const f32x4*>(q + colc); };   // (colc % 4 == 0: one 16-byte load)
+        f32x4 bn_is = {1.f, 1.f, 1.f, 1.f}, bn_g = bn_is, bn_b = {0.f, 0.f, 0.f, 0.f}, bn_m = bn_b;
+        if constexpr (VAR == 1) {
+            const f32x4 rv = ld4(p.bn_rv);
+    #pragma unroll
+            for (int e = 0; e < 4; ++e) bn_is[e] = 1.0f / sqrtf(rv[e] + p.bn_eps);
+            bn_g = ld4(p.bn_gamma); bn_b = ld4(p.bn_beta); bn_m = ld4(p.bn_rm);
+        }
+        f32x4 bb_mu = {0.f, 0.f, 0.f, 0.f}, bb_is = bb_mu, bb_g = bb_mu, bb_b = bb_mu;
+        if constexpr (VAR == 2) {
+            bb_mu = ld4(p.bnb_mean); bb_is = ld4(p.bnb_invstd);
+            if (recompute) { bb_g = ld4(p.bnb_gamma); bb_b = ld4(p.bnb_beta); }
+        }
+        const float sg2 = oa ? -1.f : 1.f;                      // Y[0][b] = T0 + T1 + T2,  Y[1][b] = T1 - T2 - T3
+        const float* const xr0 = &X[((oa * 2 + ob) * 32 + tl0) * XP + 4 * cq];
+    #pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {                   // (the K shares of the wave sets add up here)
+                const float* const xp = xr0 + (4 * kk * 2 * 32 + (NT / 32) * k) * XP;
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xp);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(xp + 2 * 32 * XP);
+                const f32x4 x2 = *reinterpret_cast<const f32x4*>(xp + 4 * 32 * XP);
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += __builtin_fmaf(sg2, x1[e] + x2[e], x0[e]);
             }
-            const int sl = (int)blockIdx.x % p.stats_nbg;  // slot-major [2][slots][Co]: consecutive doubles per workgroup
-            if (n0 + tid < p.Co) {
-                atomicAdd(p.stats + (int64_t)sl * p.Co + n0 + tid, d1);
-                atomicAdd(p.stats + ((int64_t)p.stats_nbg + sl) * p.Co + n0 + tid, d2);
+            const bool valid = yo[ct][k] != OOB;
+            if constexpr (VAR == 0) {
+                if (valid) {
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) { s1[e] += v[e]; s2[e] = __builtin_fmaf(v[e], v[e], s2[e]); }
+                }
+            } else {
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float o = v[e];
+                    if constexpr (VAR == 1) {
+                        o = (o - bn_m[e]) * bn_is[e] * bn_g[e] + bn_b[e];
+                        o += oa4[ct][k][e];
+                        o = act_fwd(o, p.act);
+                    } else {
+                        o += oa4[ct][k][e];
+                        if constexpr (VAR == 2) {
+                            const float xh = (oc4[ct][k][e] - bb_mu[e]) * bb_is[e];
+                            if (mask_on) o = ((mb[ct][k] >> e) & 1u) ? o : o * bb_slope;
+                            else if (recompute) o = __builtin_fmaf(xh, bb_g[e], bb_b[e]) > 0.f ? o : o * bb_slope;
+                            if (valid) { s1[e] += o; s2[e] = __builtin_fmaf(o, xh, s2[e]); }
+                        }
+                    }
+                    v[e] = o;
+                }
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, yo[ct][k], 0, STORE_AUX);
+        }
+        if constexpr (VAR == 0 || VAR == 2) {
+            // a wave = 8 (tile, position) items x 8 channel quads (lane = 8 i + cq): the items add up by shuffles, the waves in LDS
+    #pragma unroll
+            for (int e = 0; e < 4; ++e) {
+    #pragma unroll
+                for (int d = 8; d < 64; d <<= 1) {
+                    s1[e] += __shfl_xor(s1[e], d, 64);
+                    s2[e] += __shfl_xor(s2[e], d, 64);
+                }
+            }
+            if (lane < 8) {
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sred[wv * 32 + 4 * lane + e] = s1[e];
+                    sred[(4 * KS + wv) * 32 + 4 * lane + e] = s2[e];
+                }
+            }
+            __syncthreads();
+            if (tid < 32) {
+                double d1 = 0.0, d2 = 0.0;
+    #pragma unroll
+                for (int k = 0; k < 4 * KS; ++k) {
+                    d1 += (double)sred[k * 32 + tid];
+                    d2 += (double)sred[(4 * KS + k) * 32 + tid];
+                }
+                const int sl = (int)blockIdx.x % p.stats_nbg;  // slot-major [2][slots][Co]: consecutive doubles per workgroup
+                if (n0 + tid < p.Co) {
+                    atomicAdd(p.stats + (int64_t)sl * p.Co + n0 + tid, d1);
+                    atomicAdd(p.stats + ((int64_t)p.stats_nbg + sl) * p.Co + n0 + tid, d2);
+                }
             }
         }
     }
@@ -433,8 +459,19 @@ static int wino_lbw(int Ht, int Wt, int Ci) {
     return Ci <= 48 ? 3 : 2;                                // (96 / 128 channels: 72 / 95 KB against 80 / 106)
 }
 
-// 0: not served; otherwise the number of workgroups the launch would have (blocks of 32 tiles x column tiles of 32) - what a
-// caller needs to decide whether the chip is filled (ops.py: WINO_MIN_WGS).
+// Column tiles per workgroup (template parameter NC).  Default 1.  ADVMIX_WINO_NC=2: both column tiles of a 64-channel conv in one
+// workgroup (one staging, one input transform - VERDICT r5 next 3).  Built, parity-green and measured in round 6
+// (profiles/r06c_ab_wino_nc.log, EXPERIMENTS M): 64->64 @32x24 13.7 / 13.7 / 15.3 / 15.9 us against 13.4 / 13.4 / 14.2 / 14.5
+// (forward + sums / eval / input gradient with mask / sign from c), @64x48 33.4 / 43.2 / 47.3 / 42.5 against 34.9 / 35.5 / 38.8 /
+// 38.4, the step 835.2 / 834.6 against 841.6 / 841.5 images/s: half as many workgroups (192: a quarter of the CUs idle) at two
+// waves per SIMD and two epilogues in a row cost more than the second staging saved.  Kept as the A/B switch.
+static int wino_nc(int Ci, int Co) {
+    static const int want = [] { const char* e = getenv("ADVMIX_WINO_NC"); return e ? atoi(e) : 1; }();
+    return (want >= 2 && Ci == 64 && Co % 64 == 0) ? 2 : 1;
+}
+
+// 0: not served; otherwise the launch's work units (blocks of 32 tiles x column tiles of 32; a workgroup holds wino_nc() of
+// them) - what a caller needs to decide whether the chip is filled (ops.py: WINO_MIN_WGS).
 extern "C" int advmix_conv_wino_config(int N, int H, int W, int Ci, int Co) {
     if (!wino_shape_ok(N, H, W, Ci, Co)) return 0;
     const int lbw = wino_lbw(H / 2, W / 2, Ci);
@@ -460,7 +497,8 @@ static int wino_launch(int role, wino::WinoP& p, hipStream_t st) {
     const int lbw = wino_lbw(p.Ht, p.Wt, p.Ci);
     p.nbw = cdiv(p.Wt, 1 << lbw);
     p.nblk = p.nbw * cdiv(p.Ht, 32 >> lbw);
-    dim3 g(p.N * p.nblk, cdiv(p.Co, 32));
+    const int nc = wino_nc(p.Ci, p.Co);
+    dim3 g(p.N * p.nblk, cdiv(p.Co, 32 * nc));
     const int NQ = p.Ci / 8;
     // the epilogue variant (template parameter VAR): forward + sums / forward + eval BatchNorm / input gradient + BatchNorm backward / plain
     int var;
@@ -469,24 +507,26 @@ static int wino_launch(int role, wino::WinoP& p, hipStream_t st) {
     else if (role == 1 && p.bnb_c) var = 2;
     else if (!p.stats && !p.bn_gamma && (role == 1 || p.act == ADVMIX_ACT_NONE)) var = 3;
     else return ADVMIX_EINVAL;                              // (e.g. sums AND an eval epilogue in one launch: not a combination the step uses)
-#define WL(NQ_, VAR_, LBW_, KS_) hipLaunchKernelGGL((wino::conv_wino<NQ_, VAR_, LBW_, KS_>), g, dim3(256 * KS_), 0, st, p)
-#define WR(NQ_, LBW_, KS_) do { if (var == 0) WL(NQ_, 0, LBW_, KS_); else if (var == 1) WL(NQ_, 1, LBW_, KS_); else if (var == 2) WL(NQ_, 2, LBW_, KS_); else WL(NQ_, 3, LBW_, KS_); } while (0)
-    if (NQ == 4 && lbw == 3) WR(4, 3, 1);
-    else if (NQ == 4) WR(4, 2, 1);
-    else if (NQ == 8 && lbw == 3) WR(8, 3, 1);
-    else if (NQ == 8) WR(8, 2, 1);
-    else if (NQ == 16 && lbw == 3) WR(16, 3, 2);
-    else if (NQ == 16) WR(16, 2, 2);
-    else if (NQ == 6 && lbw == 3) WR(6, 3, 1);              // HRNet-W48's 48- and 96-channel branches
-    else if (NQ == 6) WR(6, 2, 1);
-    else if (NQ == 12 && lbw == 3) WR(12, 3, 1);
-    else if (NQ == 12) WR(12, 2, 1);
+#define WL(NQ_, VAR_, LBW_, KS_, NC_) hipLaunchKernelGGL((wino::conv_wino<NQ_, VAR_, LBW_, KS_, NC_>), g, dim3(256 * KS_), 0, st, p)
+#define WR(NQ_, LBW_, KS_, NC_) do { if (var == 0) WL(NQ_, 0, LBW_, KS_, NC_); else if (var == 1) WL(NQ_, 1, LBW_, KS_, NC_); else if (var == 2) WL(NQ_, 2, LBW_, KS_, NC_); else WL(NQ_, 3, LBW_, KS_, NC_); } while (0)
+    if (NQ == 4 && lbw == 3) WR(4, 3, 1, 1);
+    else if (NQ == 4) WR(4, 2, 1, 1);
+    else if (NQ == 8 && lbw == 3 && nc == 2) WR(8, 3, 1, 2);
+    else if (NQ == 8 && nc == 2) WR(8, 2, 1, 2);
+    else if (NQ == 8 && lbw == 3) WR(8, 3, 1, 1);
+    else if (NQ == 8) WR(8, 2, 1, 1);
+    else if (NQ == 16 && lbw == 3) WR(16, 3, 2, 1);
+    else if (NQ == 16) WR(16, 2, 2, 1);
+    else if (NQ == 6 && lbw == 3) WR(6, 3, 1, 1);           // HRNet-W48's 48- and 96-channel branches
+    else if (NQ == 6) WR(6, 2, 1, 1);
+    else if (NQ == 12 && lbw == 3) WR(12, 3, 1, 1);
+    else if (NQ == 12) WR(12, 2, 1, 1);
     else return ADVMIX_EINVAL;
 #undef WR
 #undef WL
     if (advmix_opts().trace_shapes) {
         char nm[48];
-        snprintf(nm, sizeof nm, "conv_wino<%d, %d, %d, %d>", NQ, var, lbw, NQ == 16 ? 2 : 1);
+        snprintf(nm, sizeof nm, "conv_wino<%d, %d, %d, %d, %d>", NQ, var, lbw, NQ == 16 ? 2 : 1, nc);
         advmix_trace_launch(nm, g, role == 0 ? (p.stats ? "fwd+sums" : (p.bn_gamma ? "fwd+bn_eval" : "fwd")) : (p.bnb_c ? "dgrad+bnb" : "dgrad"),
                             p.N, p.H, p.W, p.Ci, p.H, p.W, p.Co, 3, 3, 1, 2.0 * p.N * (double)p.H * p.W * p.Co * p.Ci * 9);
     }

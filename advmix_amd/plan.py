@@ -134,7 +134,11 @@ def hrnet_plan(extra, num_joints):
         tp = 'transition%d' % (st - 1)
         nxt = []
         for i in range(nb):                               # pose_hrnet.py:323-356 + :433-452
-            P.tag = 's%d.m0.b%d' % (st, i)
+            # a transition conv opens its branch's chain - except where ONE tensor feeds several of them (layer1's output
+            # under transition1's two convs): those ride at the tail of the producer's chain, where the second input gradient
+            # takes the first as its epilogue's addend; from two chains the autograd engine adds them itself with a torch
+            # kernel on the critical path (100 MB tensors at 64x48x256, B = 32: tools/fanin_report.py)
+            P.tag = 's%d.m0.b%d' % (st, i) if len(cur) > 1 else 'stem'
             if i < len(cur):
                 if P.ch[cur[i]] != widths[i]:
                     nxt.append(P.conv_bn(cur[i], '%s.%d.0' % (tp, i), '%s.%d.1' % (tp, i),

@@ -26,6 +26,10 @@ class GradSync:
         self.pieces = 3             # the backward pass is cut into this many pieces per network (see reduce_async)
         self._cuts = {}
         self.trace = None           # a list: reduce_async records (flat, lo, hi, copy before, copy after) of every exchange
+        # self-diagnosis of an N-rank run: with ``meter`` on, finish() brackets its wait with two events on
+        # the compute stream and reduce_async counts the bytes it hands to the collective; exchange_report() reads them
+        self.meter = False
+        self._waits, self._bytes, self._exchanges = [], 0, 0
         # RCCL ("nccl") averages in the collective; any other backend (gloo: the CPU tests, and the two-ranks-on-one-GPU
         # test of the whole path) sums and scales
         self._avg = self.world > 1 and dist.get_backend(group) == 'nccl' or (self.world == 1 and force and
@@ -49,6 +53,9 @@ class GradSync:
         if not self.active or hi <= lo:
             return
         chunk = flat[lo:hi]
+        if self.meter:
+            self._bytes += (hi - lo) * flat.element_size()
+            self._exchanges += 1
         if flat.is_cuda:
             cur = torch.cuda.current_stream(flat.device)
             side = self._side_stream(flat.device)
@@ -77,7 +84,30 @@ class GradSync:
     def finish(self):
         """The current stream waits for every reduce_async issued so far."""
         if self._side is not None:
-            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+            cur = torch.cuda.current_stream(self._side.device)
+            if self.meter and not torch.cuda.is_current_stream_capturing():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)                              # done when the compute stream has reached the wait ...
+                cur.wait_stream(self._side)
+                e1.record(cur)                              # ... done when the exchange has let it pass
+                self._waits.append((e0, e1))
+            else:
+                cur.wait_stream(self._side)
+
+    def exchange_report(self, steps=1, reset=True):
+        """{'exchange_wait_ms': time per step the compute stream stood in finish() waiting for the gradient exchange (what an
+        all-reduce that is NOT hidden behind the backward pass costs the step), 'exchange_bytes': bytes handed to the
+        collectives per step, 'exchanges': collective ranges per step} since ``meter`` was switched on / the last report.
+        Synchronises the device (reads event times)."""
+        wait = 0.0
+        if self._waits:
+            torch.cuda.synchronize(self._side.device)
+            wait = sum(a.elapsed_time(b) for a, b in self._waits)
+        out = {'exchange_wait_ms': wait / max(steps, 1), 'exchange_bytes': self._bytes // max(steps, 1),
+               'exchanges': self._exchanges / max(steps, 1)}
+        if reset:
+            self._waits, self._bytes, self._exchanges = [], 0, 0
+        return out
 
     def _side_stream(self, device):
         if self._side is None and device.type == 'cuda':

@@ -170,6 +170,7 @@ def main():
         return x
 
     verification = None
+    exchange = None
     dt_loop = None
     hold = {}
     if a.through_loop:
@@ -216,12 +217,18 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        if sync is not None:
+            sync.meter = True                               # (two events per finish(): what the exchange makes the step wait)
         t0 = time.perf_counter()
         lv, acc = run_steps(a.steps)
         torch.cuda.synchronize()
+        dt_own = time.perf_counter() - t0                   # this rank's own clock, before it waits for the slowest one
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
+        if sync is not None:
+            sync.meter = False
+            exchange = BP.rank_diagnosis(sync, dt_own, a.steps, device)
         if not a.no_through_loop and sync is None:
             # (one rank: a second capture in one process is fine there; with the data-parallel runner it is not attempted)
             # SURVEY 8 d1's step includes the H2D of step 1: the same workload through train_advmix itself, beside the
@@ -278,13 +285,15 @@ def main():
             line['grad_exchange_verified'] = verification[0] if verification is not None else None
             line['dp_verification'] = dict(verification[1], exec=line['config']['exec'],
                                            transport=dist.get_backend()) if verification is not None else 'skipped (--no-verify)'
+            if exchange is not None:
+                line['ranks'] = exchange                    # per-rank step time, exchange wait, bytes: why an efficiency is what it is
         if variant:
             line['INVALID_variant_build_flags'] = variant   # measurement build: never a benchmark result
         if not a.no_roofline:
             from bench_roofline import time_conv_family
             widths = HRNET_STAGES.get('hrnet_w48' if a.workload == 'hrnet_w48' else 'hrnet_w32')
             line['roofline'] = time_conv_family(a.batch, device, family=tuple(
-                (c, (H // 4) >> i, (W // 4) >> i) for i, c in enumerate(widths)))
+                (c, (H // 4) >> i, (W // 4) >> i) for i, c in enumerate(widths)), workload=a.workload)
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(a.workload)
 

@@ -446,6 +446,14 @@ def test_bench_n_rank_line_proves_itself_or_exits_non_zero(corrupt):
     want = {'': (True, True, True), 'weight': (False, True, True), 'nan': (False, False, True), 'exchange': (True, True, False)}[corrupt]
     assert (line['replicas_identical'], line['all_finite'], line['grad_exchange_verified']) == want, line
     assert out.returncode == (0 if not corrupt else 5), (out.returncode, out.stderr[-1500:])
+    # an N-rank line explains itself - per-rank step time, what the exchange made the step wait, bytes, knobs
+    r = line['ranks']
+    assert set(r) >= {'ms_per_step', 'exchange_wait_ms', 'exchange_bytes_per_step', 'exchange_ranges_per_step', 'bucket_mib',
+                      'backward_pieces', 'launch_lanes', 'NCCL_MAX_NCHANNELS', 'transport'}
+    assert len(r['ms_per_step']['per_rank']) == 2 == len(r['exchange_wait_ms']['per_rank'])
+    assert r['ms_per_step']['min'] <= r['ms_per_step']['max'] and r['ms_per_step']['min'] > 0
+    nparam = 3 * 8 * 9 + 8 + 8 + 8 + 8 * 2 + 2                        # the self-test's little network: one exchange of all of it per step
+    assert r['exchange_bytes_per_step'] == 4 * nparam and r['exchange_ranges_per_step'] == 1.0 and r['transport'] == 'gloo'
 
 
 def test_bench_refuses_to_run_fewer_ranks_than_asked():

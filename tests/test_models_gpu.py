@@ -1697,6 +1697,12 @@ def test_bench_falls_back_to_the_eager_step_when_the_graphs_do_not_verify():
     assert line['replicas_identical'] is True and line['all_finite'] is True
     v = line['dp_verification']
     assert v['exec'] == 'eager' and all(v['checks'].values()) and 'graph_attempt' in v and v['graph_attempt']['verified'] is True
+    # the line's self-diagnosis: this rank's own step time, what the two exchanges made the compute stream
+    # wait (real RCCL all-reduces on the side stream, measured between two events), the bytes of D's + G's flat gradients
+    r = line['ranks']
+    assert r['transport'] == 'nccl' and len(r['ms_per_step']['per_rank']) == 1 and r['ms_per_step']['max'] > 0
+    assert r['exchange_wait_ms']['max'] >= 0.0 and r['exchange_ranges_per_step'] == 6.0      # three pieces per network
+    assert 200e6 < r['exchange_bytes_per_step'] < 260e6                                       # 108.9 + 111.6 MiB
 
 
 @pytest.mark.parametrize('transport', ['device', 'host round trip'])

@@ -267,6 +267,8 @@ def replicas_selftest(a, backend, rank, world, local):
     sync.trace = []
     corrupt = os.environ.get('ADVMIX_BENCH_CORRUPT', '')
     lv = 0.0
+    sync.meter = True
+    t0 = time.perf_counter()
     for step in range(3):
         opt.zero_grad()
         loss = net(torch.randn(4, 3, 8, 8)).square().mean()
@@ -279,8 +281,11 @@ def replicas_selftest(a, backend, rank, world, local):
         for p in net.parameters():
             p.grad.copy_(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        sync.finish()
         opt.step()
         lv = float(loss)
+    dt_own = time.perf_counter() - t0
+    sync.meter = False
     with torch.no_grad():
         if corrupt == 'weight' and rank == 1:
             next(net.parameters()).view(-1)[5] += 1e-7
@@ -290,6 +295,7 @@ def replicas_selftest(a, backend, rank, world, local):
     line = {'metric': 'replicas self-test', 'n_gpus': a.gpus, 'rccl_ranks': dist.get_world_size(), 'backend': backend,
             'corrupt': corrupt or None}
     failed = dp_verdict(line, sync, [opt], (verification[0], {}), lv)
+    line['ranks'] = rank_diagnosis(sync, dt_own, 3, torch.device('cpu'))     # the N-rank line's self-diagnosis (same fields as the step's)
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
@@ -441,3 +447,23 @@ def through_loop(a, cfg, args, nets, crit, opts, sync, rank, world, n_warm, n_ti
     finally:
         F_.GRAPH_EXEC = old_exec
         F_.release_graphs()
+
+
+def rank_diagnosis(sync, dt_own, steps, device):
+    """What makes an N-rank line explain itself: every rank's OWN time per step (before the closing
+    barrier: a straggler shows as max >> min), the time per step its compute stream stood waiting for the gradient exchange
+    (dp.GradSync.finish between two events: an all-reduce NOT hidden behind the backward pass - RCCL's kernels beside four
+    compute lanes, or a slow link - shows here), the bytes exchanged, and the knobs in force.  One small all-gather."""
+    import torch.distributed as dist
+    from advmix_amd import ops
+    rep = sync.exchange_report(steps)
+    mine = torch.tensor([dt_own / steps * 1e3, rep['exchange_wait_ms']], device=device, dtype=torch.float64)
+    rows = torch.stack(sync._gather(mine)).cpu()
+    ms, wait = rows[:, 0].tolist(), rows[:, 1].tolist()
+    return {'ms_per_step': {'min': round(min(ms), 3), 'max': round(max(ms), 3), 'per_rank': [round(v, 3) for v in ms]},
+            'exchange_wait_ms': {'min': round(min(wait), 3), 'max': round(max(wait), 3), 'per_rank': [round(v, 3) for v in wait],
+                                 'what': 'time per step the compute stream waits in GradSync.finish() for the all-reduces '
+                                         '(two events around the wait; 0 = fully hidden behind the backward pass)'},
+            'exchange_bytes_per_step': int(rep['exchange_bytes']), 'exchange_ranges_per_step': rep['exchanges'],
+            'bucket_mib': sync.bucket_elems * 4 // (1 << 20), 'backward_pieces': sync.pieces, 'launch_lanes': ops.MAX_LANES,
+            'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS'), 'transport': dist.get_backend() if dist.is_initialized() else None}

@@ -16,24 +16,55 @@ KIND_WEIGHT = {'fwd+BN-sums': 2, 'fwd+BN-eval+ReLU': 1, 'dgrad+addend+BN-bwd-sum
                'dgrad+BN-bwd-sums (sign from c)': 1, 'wgrad': 1}
 
 
-def _pmc_file(pattern):
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        return json.load(f), os.path.relpath(files[-1], ROOT)
+WINOGRAD_MULTIPLY_SAVING = 2.25    # F(2x2,3x3) and F(3x3,2x2): 16 multiplies where the direct form has 36
 
 
-def _latest_pmc():
-    """HBM bytes per launch of the dominant kernel from this round's rocprofv3 PMC passes (tools/pmc_conv.sh +
-    tools/summarize_pmc.py: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate --pmc runs); newest profiles/r*_pmc file."""
+def branch_convs_per_pass(workload):
+    """{channels: number of 3x3 / stride 1 C -> C convs of the network's BRANCHES in one pass} from the plan the product
+    executes (plan.hrnet_plan: HRNet-W32 64 / 64 / 56 / 24) - what a family member's launches-per-step weight is multiplied by
+    (without it ``dominant`` was the member with the largest weight x time of ONE conv per shape)."""
+    from bench_common import WORKLOADS
+    from advmix_amd.plan import hrnet_plan
+    net, extra, J = WORKLOADS[workload][:3]
+    if net != 'pose_hrnet':
+        return {}
+    P = hrnet_plan(extra, J)
+    shape = {n: sh for n, sh, _k in P.params}
+    out = {}
+    for st in P.steps:
+        if st[0] == 'conv' and st[1].startswith('stage') and '.branches.' in st[1]:
+            co, ci, r, s_ = shape[st[1] + '.weight']
+            if (r, s_) == (3, 3) and st[4] == 1 and co == ci:
+                out[co] = out.get(co, 0) + 1
+    return out
+
+
+def _profile_file(kind, pattern):
+    """(parsed JSON or None, repo-relative path) of the profile summary of ``kind``: the file profiles/LATEST.json names (written
+    by tools/collect_r06.sh: the collection's tag, git head and the files it produced - VERDICT r5 weak 9: with hundreds of
+    files under profiles/ the 'latest set' is machine-selected), else the last match of ``pattern`` in name order."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_conv32_epi.json')))
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        return round(json.load(f)['hbm_bytes_per_launch']), os.path.relpath(files[-1], ROOT)
+    path = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'LATEST.json')) as f:
+            path = json.load(f).get('files', {}).get(kind)
+    except (OSError, ValueError):
+        pass
+    if path and os.path.exists(os.path.join(ROOT, path)):
+        full = os.path.join(ROOT, path)
+    else:
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
+        if not files:
+            return None, None
+        full = files[-1]
+    if full.endswith('.json'):
+        with open(full) as f:
+            return json.load(f), os.path.relpath(full, ROOT)
+    return full, os.path.relpath(full, ROOT)
+
+
+def _pmc_file(pattern, kind=None):
+    return _profile_file(kind or pattern, pattern)
 
 
 def _time_shares():
@@ -41,12 +72,11 @@ def _time_shares():
     per-shape profile of the headline step (serialized one-lane trace joined with the library's launch log:
     tools/profile_step.sh, tools/kernel_shapes.py)."""
     import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_per_shape_1lane.csv')))
-    if not files:
+    full, rel = _profile_file('per_shape_1lane', 'r*_per_shape_1lane.csv')
+    if not full:
         return None
     cls = {}
-    for r in csv.DictReader(open(files[-1])):
+    for r in csv.DictReader(open(full)):
         k, shp = r['kernel'], r['shape']
         share = float(r['share_of_kernel_time'] or 0)
         if k.startswith('ALL MFMA'):
@@ -80,11 +110,11 @@ def _time_shares():
     out = {c: {'share_of_kernel_time': round(v[0], 4),
                'frac_of_fp32_mfma_peak_time_weighted': round(v[2] / v[1] / FP32_MFMA_PEAK_TFLOPS, 4) if v[1] > 0 else None}
            for c, v in sorted(cls.items(), key=lambda kv: -kv[1][0])}
-    out['source'] = os.path.relpath(files[-1], ROOT)
+    out['source'] = rel
     return out
 
 
-def time_conv_family(B, device, iters=100, family=None):
+def time_conv_family(B, device, iters=100, family=None, workload='hrnet_w32'):
     """The roofline object.  The step's time is the MFMA convs'  and no single launch dominates: the four
     branch resolutions of HRNet-W32 each run the same 1.81 GFLOP 3x3 conv as forward (+ BatchNorm column sums, or + eval
     BatchNorm + ReLU for the teacher), input gradient (+ the BatchNorm-backward sums of its producer) and weight gradient.
@@ -100,8 +130,9 @@ def time_conv_family(B, device, iters=100, family=None):
     P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())       # noqa: E731
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     members, hbm = [], []
-    tot_f = tot_t = 0.0
+    tot_f = tot_t = tot_own = 0.0
     family = family or CONV_FAMILY
+    per_pass = branch_convs_per_pass(workload)              # convs of each width in one pass of the network (W32: 64 / 64 / 56 / 24)
     for C, H, W in family:
         rows = B * H * W
         x = torch.randn(B, H, W, C, device=device)
@@ -174,8 +205,14 @@ def time_conv_family(B, device, iters=100, family=None):
             ms, rr = _event_time(run, iters if not (kind == 'wgrad' and grouped) else max(iters // 4, 10))
             if kind == 'wgrad' and grouped:
                 ms, rr = ms / NG, [v / NG for v in rr]      # per problem of the eight-problem launch
-            wgt = KIND_WEIGHT[kind]
+            wgt = KIND_WEIGHT[kind] * per_pass.get(C, 1)    # launches of this member per AdvMix step
+            # Winograd paths multiply 2.25x fewer numbers than the direct form whose FLOPs ``frac`` is quoted on: ``frac`` can
+            # exceed 1.0 for them without any work being skipped - ``frac_own`` prices the kernel's OWN
+            # multiplies against the same peak, ``ceiling_frac`` is what ``frac`` could reach at all
+            wino_path = (kind == 'wgrad' and wgw) or (kind != 'wgrad' and (wino or (smap and skind == 'smapw')))
+            own = flops / WINOGRAD_MULTIPLY_SAVING if wino_path else flops
             tot_f += wgt * flops
+            tot_own += wgt * own
             tot_t += wgt * ms * 1e-3
             members.append({
                 'kernel': '3x3 s1 %d->%d @%dx%d %s' % (C, C, H, W, kind if not (kind == 'wgrad' and grouped) else 'wgrad (1 of 8 problems of one launch)'),
@@ -183,7 +220,10 @@ def time_conv_family(B, device, iters=100, family=None):
                 'us_per_launch': round(ms * 1e3, 2), 'us_per_launch_runs': [round(v * 1e3, 2) for v in rr],
                 'algorithmic_gflop_per_launch': round(flops / 1e9, 3),
                 'tflops': round(flops / (ms * 1e-3) / 1e12, 2), 'frac': round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                'launches_per_step_weight': wgt, 'weight_x_us': round(wgt * ms * 1e3, 2)})
+                'own_gflop_per_launch': round(own / 1e9, 3),
+                'frac_own': round(own / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                'ceiling_frac': WINOGRAD_MULTIPLY_SAVING if wino_path else 1.0,
+                'launches_per_step': wgt, 'launches_per_step_x_us': round(wgt * ms * 1e3, 1)})
         if wino or smap:
             bank.release()
         if C in (family[0][0], family[2][0]):               # the two BatchNorm kernels left on the train path
@@ -205,32 +245,41 @@ def time_conv_family(B, device, iters=100, family=None):
                             'algorithmic_bytes_per_launch': nbytes, 'achieved_GBps': round(nbytes / (ms * 1e-3) / 1e9, 1),
                             'frac_of_8TBps': round(nbytes / (ms * 1e-3) / 1e9 / 8000.0, 4)})
     headline = B == 32 and family == CONV_FAMILY
-    dominant = max(members, key=lambda m: m['weight_x_us'])      # the member the step spends most time in (weight x time)
+    dominant = max(members, key=lambda m: m['launches_per_step_x_us'])      # the member the step spends most time in (launches per step x time)
     traffic = src = None
     if headline:                                            # HBM bytes per launch of the dominant member, when a PMC pass of it is committed
-        d, src = _pmc_file('r*_pmc_dominant.json')
+        d, src = _pmc_file('r*_pmc_dominant.json', 'pmc_dominant')
         d = (d or {}).get('members', {}).get(dominant['kernel']) if d and 'members' in d else d      # (one file, keyed by member)
         if d and d.get('kernel') == dominant['kernel']:
             traffic = round(d['hbm_bytes_per_launch'])
         else:
             src = None
-    step_util = None
+    step_util = busy = None
     if headline:                                            # SQ_VALU_MFMA_BUSY_CYCLES summed over one step (tools/pmc_step.sh)
-        d, f = _pmc_file('r*_pmc_step_mfma.json')
+        d, f = _pmc_file('r*_pmc_step_mfma.json', 'pmc_step_mfma')
         if d:
+            busy = round(d['mfma_utilisation_of_step'], 4)
             step_util = {'mfma_busy_simd_cycles_per_step': round(d['mfma_busy_cycles_per_step']),
                          'algorithmic_simd_cycles_per_step_direct_form': round(118.58e9 * 32 / 64),
-                         'utilisation_at_the_profiled_step_time': round(d['mfma_utilisation_of_step'], 4), 'source': f}
+                         'utilisation_at_the_profiled_step_time': busy, 'source': f}
     agg = tot_f / tot_t / 1e12
     Cd = int(dominant['kernel'].split('->')[1].split(' ')[0])
     Hd, Wd = (int(v) for v in dominant['kernel'].split('@')[1].split(' ')[0].split('x'))
     nt = 5 if 'addend' in dominant['kernel'] else (4 if 'dgrad' in dominant['kernel'] else 2)   # tensors of rows x C floats it must move
     algo_bytes = nt * B * Hd * Wd * Cd * 4 + 9 * Cd * Cd * 4
     return {'bound': 'mfma',
-            'kernel': 'conv_wino / conv_direct / conv_wgrad family: 3x3 s1 C->C at the four HRNet branch resolutions of this workload x '
-                      '{fwd+BN sums, fwd+BN eval, dgrad+BN-bwd sums, wgrad}, launch-count weighted, algorithmic (direct-convolution) FLOPs',
+            'kernel': 'conv_wino / conv_smapw / wgrad_wino / conv_direct family: 3x3 s1 C->C at the four HRNet branch resolutions of this '
+                      'workload x {fwd+BN sums, fwd+BN eval, dgrad+BN-bwd sums, wgrad}, weighted by launches per step (role weight x convs '
+                      'of that width per pass: %s), algorithmic (direct-convolution) FLOPs' % per_pass,
             'achieved': round(agg, 3), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(agg / FP32_MFMA_PEAK_TFLOPS, 4),
+            # north_star names MFMA utilisation: the two readings side by side.  ``frac`` = algorithmic (direct-form) FLOP/s of the
+            # family over the fp32 matrix peak - a throughput; the Winograd members multiply 2.25x fewer numbers, so their ceiling on
+            # this scale is 2.25 (``ceiling_frac`` per member).  ``frac_own`` = the family's OWN multiplies over the same peak;
+            # ``mfma_busy_frac`` = the MFMA pipe's busy cycles of the WHOLE step by counter (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x
+            # 2.4 GHz x step time), profiles/: tools/pmc_step.sh).
+            'frac_own': round(tot_own / tot_t / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            'mfma_busy_frac': busy,
             'traffic': traffic, 'traffic_unit': 'HBM bytes per launch of the dominant member (rocprofv3 PMC, corrected)',
             'traffic_source': src, 'traffic_algorithmic_bytes': algo_bytes,
             'traffic_ratio': round(traffic / algo_bytes, 3) if traffic else None,

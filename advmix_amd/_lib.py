@@ -38,6 +38,7 @@ SIGNATURES = {
     'advmix_conv_wino_config': [_i] * 5,
     'advmix_wino_weights': [_p, _p, _i, _p],
     'advmix_conv3x3_wino_fwd': [_p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _f, _p, _i, _p, _p, _p],
+    'advmix_conv3x3_wino_fwd_inbn': [_p, _p, _p] + [_i] * 5 + [_p, _i, _p, _p, _f, _p, _p, _p, _p, _p, _f, _p, _p, _p],
     'advmix_conv3x3_wino_dgrad': [_p, _p, _p, _p] + [_i] * 5 + [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p],
     'advmix_conv_pw_config': [_i] * 5,
     'advmix_pw_weights': [_p, _p, _i, _p],
@@ -58,6 +59,7 @@ SIGNATURES = {
     'advmix_deconv4x4s2_wino_fwd': [_p, _p, _p, _p, _p, _p, _l] + [_i] * 5 + [_p],
     'advmix_wgrad_wino_config': [_i] * 5,
     'advmix_conv3x3_wgrad_wino_group': [_i, _p, _p, _p] + [_i] * 5 + [_p],
+    'advmix_conv3x3_wgrad_wino_group_bn': [_i, _p, _p, _p, _p, _p, _p, _p] + [_i] * 5 + [_p],
     'advmix_conv_wgrad': [_p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_wgrad_group': [_i, _p, _p, _p] + [_i] * 11 + [_p],
     'advmix_conv_wgrad_multi': [_i, _p, _p, _p, _p, _p],

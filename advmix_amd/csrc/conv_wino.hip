@@ -52,6 +52,17 @@ struct WinoP {
     const float *bnb_c, *bnb_mean, *bnb_invstd, *bnb_gamma, *bnb_beta;
     int bnb_act;
     int xcd_remap;
+    // INBN (round 6): the input is the RAW output c of the producing conv; its train-mode BatchNorm + ReLU is applied while the
+    // patch is staged.  in_slots: the producer's column sums [2][in_ns][Ci] (fp64, as its epilogue left them), in_rows = N H W.
+    // Every workgroup derives mean / invstd itself; workgroup (0, 0) also publishes them (saved for the backward pass) and
+    // updates the running statistics - what advmix_norm_apply_slots does in its own launch.
+    const double* in_slots;
+    int in_ns;
+    double in_rows;
+    float in_eps, in_momentum;
+    const float *in_gamma, *in_beta;
+    float *in_mean, *in_invstd, *in_rmean, *in_rvar;
+    long long* in_nbt;
 };
 
 __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
@@ -59,6 +70,57 @@ __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rsrc, unsigned vof
     return __builtin_bit_cast(f32x4, v);
 }
 __device__ __forceinline__ int acc_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }   // v_mfma_f32_32x32x2 D layout
+
+// INBN: the producer's slots reduced by the whole workgroup - thread (part, channel) adds every NP-th slot of its channel (all
+// loads issued before the first add: one L2 round trip, under the patch loads already in flight), the parts meet in LDS
+// (``red``: the patch region, not yet written) - then thread ch < C derives mean / invstd exactly as norm_apply_slots_kernel
+// does (norm.hip) and leaves (mean, invstd, gamma, beta) in ``bnp``; workgroup (0, 0) publishes mean / invstd and updates the
+// running statistics.  Contains one __syncthreads(); the caller adds the one that makes ``bnp`` visible.
+template <int C, int NT>
+__device__ __forceinline__ void in_bn_params(const WinoP& p, float* bnp, double* red, int tid) {
+    constexpr int NP = NT / C >= 4 ? 4 : (NT / C >= 2 ? 2 : 1);
+    constexpr int PER = 16 / NP;                            // slots per part at most (in_ns <= 16: the entry point checks)
+    const int ns = p.in_ns;
+    if (tid < NP * C) {
+        const int part = tid / C, ch = tid - part * C;
+        double v0[PER], v1[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int k = part + NP * i;
+            v0[i] = k < ns ? p.in_slots[(int64_t)k * C + ch] : 0.0;
+            v1[i] = k < ns ? p.in_slots[((int64_t)ns + k) * C + ch] : 0.0;
+        }
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { s0 += v0[i]; s1 += v1[i]; }
+        red[(2 * part) * C + ch] = s0;
+        red[(2 * part + 1) * C + ch] = s1;
+    }
+    __syncthreads();
+    if (tid < C) {
+        double s0 = red[tid], s1 = red[C + tid];
+#pragma unroll
+        for (int q = 1; q < NP; ++q) { s0 += red[(2 * q) * C + tid]; s1 += red[(2 * q + 1) * C + tid]; }
+        const double m = s0 / p.in_rows;
+        double var = s1 / p.in_rows - m * m;
+        if (var < 0) var = 0;
+        const float mu = (float)m, is = (float)(1.0 / sqrt(var + (double)p.in_eps));
+        bnp[tid] = mu;
+        bnp[C + tid] = is;
+        bnp[2 * C + tid] = p.in_gamma[tid];
+        bnp[3 * C + tid] = p.in_beta[tid];
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            p.in_mean[tid] = mu;
+            p.in_invstd[tid] = is;
+            if (p.in_rmean) {
+                const double unb = p.in_rows > 1 ? var * p.in_rows / (p.in_rows - 1) : var;
+                p.in_rmean[tid] = (float)((1.0 - p.in_momentum) * (double)p.in_rmean[tid] + (double)p.in_momentum * m);
+                p.in_rvar[tid] = (float)((1.0 - p.in_momentum) * (double)p.in_rvar[tid] + (double)p.in_momentum * unb);
+            }
+            if (tid == 0 && p.in_nbt) *p.in_nbt += 1;
+        }
+    }
+}
 
 // Geometry of a workgroup's block of BW x BH = 32 tiles and of its input patch in LDS.  Pixel (pr, pc) of the
 // (2 BH + 2) x (2 BW + 2) patch lives at position pr * PWL + (pc & 1) * HALF + (pc >> 1), PP = C + 4 floats per position:
@@ -91,7 +153,12 @@ constexpr int wino_waves() { return KS > 1 ? 1 : (NC > 1 ? 2 : (Geo<LBW, NQ * 8,
 // so a 64-channel conv stages every patch and transforms every input group TWICE (0.73-0.80 in the step
 // where the 32-channel instance is at 0.85-0.88); NC = 2 keeps both tiles' accumulators (2 x 64 registers) in the wave: one
 // staging, one B^T d B per 8-channel group, 32 MFMAs behind it instead of 16; the epilogue runs once per column tile.
-template <int NQ, int VAR, int LBW, int KS = 1, int NC = 1>
+// INBN (round 6): 1 = the input tensor is the raw output c of a conv whose train-mode BatchNorm + ReLU has NOT
+// been applied: act(fma((c - mean) * invstd, gamma, beta)) - norm_apply_slots' very expression, so that the backward pass's
+// "sign from c" epilogue and the weight gradient's staging see the same activation bit for bit - is applied to every element
+// on its way into LDS (~1.3 loads per input element, four VALU operations each), and the separate norm_apply_slots launch with
+// its y tensor disappears: +0.3 ... +1.3 us on the conv against 6.2 ... 10.2 us for the launch (profiles/r06d_microbench_wino_inbn.log).
+template <int NQ, int VAR, int LBW, int KS = 1, int NC = 1, int INBN = 0>
 __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS, NC>())) void conv_wino(const WinoP p) {
     using G = Geo<LBW, NQ * 8, KS>;
     constexpr int NT = 256 * KS, NQW = NQ / KS;            // threads; k groups per wave
@@ -101,6 +168,7 @@ __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS, NC>())) void con
     // row half ([wave][b][r / 4][lane][4]), then the wave-private transposers of the epilogue
     __shared__ __attribute__((aligned(16))) float L[G::LDS];
     __shared__ float sred[2 * 4 * KS * 32];
+    __shared__ __attribute__((aligned(16))) float bnp[INBN ? 4 * NQ * 8 : 4];      // INBN: mean, invstd, gamma, beta per input channel
     float* const X = L;
     static_assert(NC == 1 || KS == 1, "column tiles per workgroup and the K split are alternatives");
 
@@ -143,18 +211,35 @@ __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS, NC>())) void con
             int pr = px0 / PW, pc = px0 - pr * PW;
             const int gbase = ((img * p.H + hb) * p.W + wb) * C + cs * 4;        // element offset of patch pixel (0, 0) (may be negative)
             unsigned lo[NIT];
+            unsigned okm = 0u;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const bool ok = pr < PH && (unsigned)(hb + pr) < (unsigned)p.H && (unsigned)(wb + pc) < (unsigned)p.W;
                 stg[it] = bload(xr, ok ? (unsigned)((gbase + (pr * p.W + pc) * C) * 4) : OOB);
+                okm |= ok ? (1u << it) : 0u;
                 lo[it] = pr < PH ? (unsigned)((pr * PWL + (pc & 1) * HALF + (pc >> 1)) * PP + cs * 4) : 0xffffffffu;
                 pc += DPC; pr += DPR;
                 if (pc >= PW) { pc -= PW; ++pr; }
+            }
+            if constexpr (INBN) {
+                static_assert(NIT <= 32, "one bit per staged piece");
+                in_bn_params<C, NT>(p, bnp, reinterpret_cast<double*>(L), tid);      // (the patch loads are in flight meanwhile)
+                __syncthreads();
+                const f32x4 mu = *reinterpret_cast<const f32x4*>(&bnp[cs * 4]), is = *reinterpret_cast<const f32x4*>(&bnp[C + cs * 4]);
+                const f32x4 g = *reinterpret_cast<const f32x4*>(&bnp[2 * C + cs * 4]), b = *reinterpret_cast<const f32x4*>(&bnp[3 * C + cs * 4]);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = fmaxf(__builtin_fmaf((stg[it][e] - mu[e]) * is[e], g[e], b[e]), 0.f);
+                        stg[it][e] = ((okm >> it) & 1u) ? t : 0.f;      // (the zero ring pads the ACTIVATION, not c)
+                    }
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 if (lo[it] != 0xffffffffu) *reinterpret_cast<f32x4*>(&L[lo[it]]) = stg[it];
         } else {
+            unsigned okm = 0u;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int s = tid + NT * it;
@@ -163,12 +248,27 @@ __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS, NC>())) void con
                 const int h = hb + pr, w = wb + pc;
                 const bool ok = s < NS && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
                 stg[it] = bload(xr, ok ? (unsigned)((((img * p.H + h) * p.W + w) * C + cs * 4) * 4) : OOB);
+                okm |= ok ? (1u << it) : 0u;
+            }
+            if constexpr (INBN) {
+                static_assert(NIT <= 32, "one bit per staged piece");
+                in_bn_params<C, NT>(p, bnp, reinterpret_cast<double*>(L), tid);
+                __syncthreads();
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int s = tid + NT * it;
                 const int px = s / (C / 4), cs = s % (C / 4);
                 const int pr = px / PW, pc = px % PW;
+                if constexpr (INBN) {
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(&bnp[cs * 4]), is = *reinterpret_cast<const f32x4*>(&bnp[C + cs * 4]);
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(&bnp[2 * C + cs * 4]), b = *reinterpret_cast<const f32x4*>(&bnp[3 * C + cs * 4]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = fmaxf(__builtin_fmaf((stg[it][e] - mu[e]) * is[e], g[e], b[e]), 0.f);
+                        stg[it][e] = ((okm >> it) & 1u) ? t : 0.f;
+                    }
+                }
                 if (s < NS) *reinterpret_cast<f32x4*>(&L[(pr * PWL + (pc & 1) * HALF + (pc >> 1)) * PP + cs * 4]) = stg[it];
             }
         }
@@ -508,7 +608,10 @@ static int wino_launch(int role, wino::WinoP& p, hipStream_t st) {
     else if (!p.stats && !p.bn_gamma && (role == 1 || p.act == ADVMIX_ACT_NONE)) var = 3;
     else return ADVMIX_EINVAL;                              // (e.g. sums AND an eval epilogue in one launch: not a combination the step uses)
 #define WL(NQ_, VAR_, LBW_, KS_, NC_) hipLaunchKernelGGL((wino::conv_wino<NQ_, VAR_, LBW_, KS_, NC_>), g, dim3(256 * KS_), 0, st, p)
-#define WR(NQ_, LBW_, KS_, NC_) do { if (var == 0) WL(NQ_, 0, LBW_, KS_, NC_); else if (var == 1) WL(NQ_, 1, LBW_, KS_, NC_); else if (var == 2) WL(NQ_, 2, LBW_, KS_, NC_); else WL(NQ_, 3, LBW_, KS_, NC_); } while (0)
+#define WI(NQ_, LBW_, KS_, NC_) hipLaunchKernelGGL((wino::conv_wino<NQ_, 0, LBW_, KS_, NC_, 1>), g, dim3(256 * KS_), 0, st, p)
+#define WR(NQ_, LBW_, KS_, NC_) do { if (inbn) WI(NQ_, LBW_, KS_, NC_); else if (var == 0) WL(NQ_, 0, LBW_, KS_, NC_); else if (var == 1) WL(NQ_, 1, LBW_, KS_, NC_); else if (var == 2) WL(NQ_, 2, LBW_, KS_, NC_); else WL(NQ_, 3, LBW_, KS_, NC_); } while (0)
+    const bool inbn = p.in_slots != nullptr;                // (forward + column sums only: the entry point checks)
+    if (inbn && var != 0) return ADVMIX_EINVAL;
     if (NQ == 4 && lbw == 3) WR(4, 3, 1, 1);
     else if (NQ == 4) WR(4, 2, 1, 1);
     else if (NQ == 8 && lbw == 3 && nc == 2) WR(8, 3, 1, 2);
@@ -522,12 +625,13 @@ static int wino_launch(int role, wino::WinoP& p, hipStream_t st) {
     else if (NQ == 12 && lbw == 3) WR(12, 3, 1, 1);
     else if (NQ == 12) WR(12, 2, 1, 1);
     else return ADVMIX_EINVAL;
+#undef WI
 #undef WR
 #undef WL
     if (advmix_opts().trace_shapes) {
         char nm[48];
-        snprintf(nm, sizeof nm, "conv_wino<%d, %d, %d, %d, %d>", NQ, var, lbw, NQ == 16 ? 2 : 1, nc);
-        advmix_trace_launch(nm, g, role == 0 ? (p.stats ? "fwd+sums" : (p.bn_gamma ? "fwd+bn_eval" : "fwd")) : (p.bnb_c ? "dgrad+bnb" : "dgrad"),
+        snprintf(nm, sizeof nm, "conv_wino<%d, %d, %d, %d, %d, %d>", NQ, var, lbw, NQ == 16 ? 2 : 1, nc, inbn ? 1 : 0);
+        advmix_trace_launch(nm, g, role == 0 ? (p.stats ? (inbn ? "bn_in+fwd+sums" : "fwd+sums") : (p.bn_gamma ? "fwd+bn_eval" : "fwd")) : (p.bnb_c ? "dgrad+bnb" : "dgrad"),
                             p.N, p.H, p.W, p.Ci, p.H, p.W, p.Co, 3, 3, 1, 2.0 * p.N * (double)p.H * p.W * p.Co * p.Ci * 9);
     }
     ADVMIX_CHECK_LAUNCH();
@@ -576,6 +680,34 @@ extern "C" int advmix_conv3x3_wino_fwd(const float* x, const float* u, float* y,
     return rc;
 }
 
+// advmix_conv3x3_wino_fwd (train role: raw output + column sums into ``stats``) whose input is the RAW output c of the preceding
+// conv, with that conv's train-mode BatchNorm + ReLU applied while the patch is staged: y = conv(relu(BN_train(c))).  in_slots:
+// the column (sum, sum of squares) of c as the producer's epilogue left them, [2][in_ns][Ci] with in_ns <= 16; the launch derives
+// mean / invstd (biased variance, eps) from them, writes them to in_mean / in_invstd (the backward pass's saved statistics),
+// updates in_rmean / in_rvar (momentum, unbiased variance; may be NULL) and increments *in_nbt (may be NULL) - everything
+// advmix_norm_apply_slots does, without its launch and without the activation tensor.  One launch replaces
+// norm_apply_slots + conv for the inner edge conv1 -> bn1 -> relu -> conv2 of lib/models/pose_hrnet.py:41-57 (BasicBlock) and
+// :77-88 (Bottleneck conv1 -> conv2).  ADVMIX_EINVAL (nothing launched) where advmix_conv3x3_wino_fwd refuses, or in_ns > 16.
+extern "C" int advmix_conv3x3_wino_fwd_inbn(const float* c_in, const float* u, float* y, int N, int H, int W, int Ci, int Co,
+                                            const double* in_slots, int in_ns, const float* in_gamma, const float* in_beta,
+                                            float in_eps, float* in_mean, float* in_invstd, float* in_rmean, float* in_rvar,
+                                            long long* in_nbt, float in_momentum, double* stats, int* stats_ns, void* stream) {
+    if (!in_slots || !in_gamma || !in_beta || !in_mean || !in_invstd || !stats || !stats_ns) return ADVMIX_EINVAL;
+    if (in_ns < 1 || in_ns > 16 || (in_ns & (in_ns - 1)) || (in_rmean != nullptr) != (in_rvar != nullptr)) return ADVMIX_EINVAL;
+    if (advmix_opts().deterministic) return ADVMIX_EINVAL;
+    wino::WinoP p;
+    int rc = wino_fill(p, c_in, u, y, N, H, W, Ci, Co);
+    if (rc) return rc;
+    p.stats = stats;
+    p.stats_nbg = wino_slots(stats_ns);
+    p.in_slots = in_slots; p.in_ns = in_ns; p.in_rows = (double)N * H * W; p.in_eps = in_eps; p.in_momentum = in_momentum;
+    p.in_gamma = in_gamma; p.in_beta = in_beta; p.in_mean = in_mean; p.in_invstd = in_invstd;
+    p.in_rmean = in_rmean; p.in_rvar = in_rvar; p.in_nbt = in_nbt;
+    rc = wino_launch(0, p, (hipStream_t)stream);
+    if (rc == ADVMIX_OK) *stats_ns = p.stats_nbg;
+    return rc;
+}
+
 // advmix_conv_tr_w_add / advmix_conv_tr_w_bnb for the same convs: dx = conv(dy, rotated transposed filters) + addend from the
 // role 1 image ``u`` (n = Cin, k = Cout); with ``bn_c`` the BatchNorm-backward epilogue of advmix_conv_tr_w_bnb (same
 // arguments, same arithmetic).  dy: [N,H,W,Co], dx / addend / bn_c / mask: [N,H,W,Ci].
@@ -603,3 +735,7 @@ extern "C" int advmix_conv3x3_wino_dgrad(const float* dy, const float* u, const 
     if (rc == ADVMIX_OK && bn_c) *stats_ns = p.stats_nbg;
     return rc;
 }
+
+// This translation unit's share of advmix_build_flags(): 0 in the shipped library (the measurement switch WN_INBN - BatchNorm + ReLU
+// applied to the input patch while it is staged - lives in tools/variants/conv_wino_inbn.patch, which makes this return 64).
+int advmix_conv_wino_build_flags(void) { return 0; }

@@ -36,6 +36,13 @@ struct WP {
     int runs;                    // runs of blocks per (problem, channel pair): workgroups = n * pairs * runs
     int bpr;                     // blocks per run
     int xbytes, ybytes;
+    // round 6: problem i's x operand may be the RAW output c of the conv that precedes it, its train-mode BatchNorm + ReLU not
+    // applied (conv_wino's INBN forward never wrote the activation): bn_mean[i] != NULL -> relu(fma((c - mean) * invstd, gamma,
+    // beta)) - norm_apply_slots' very expression - is applied to every x element while it is staged; NULL: x as it is
+    const float* bn_mean[MAXP];
+    const float* bn_invstd[MAXP];
+    const float* bn_gamma[MAXP];
+    const float* bn_beta[MAXP];
 };
 
 __device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
@@ -68,6 +75,16 @@ __global__ __launch_bounds__(256, 3) void wgrad_wino(const WP p) {
     f32x4 acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the staging thread's channel quad is fixed (256 threads, 8 quads): its BatchNorm parameters, once per workgroup
+    const bool xbn = p.bn_mean[prob] != nullptr;            // (uniform)
+    f32x4 bmu = {0.f, 0.f, 0.f, 0.f}, bis = bmu, bga = bmu, bbe = bmu;
+    if (xbn) {
+        const int ch = cit * 32 + (tid & 7) * 4;
+        bmu = *reinterpret_cast<const f32x4*>(p.bn_mean[prob] + ch);
+        bis = *reinterpret_cast<const f32x4*>(p.bn_invstd[prob] + ch);
+        bga = *reinterpret_cast<const f32x4*>(p.bn_gamma[prob] + ch);
+        bbe = *reinterpret_cast<const f32x4*>(p.bn_beta[prob] + ch);
+    }
 
     const float* const xl = XL + (16 * qb + c16) * PLX;     // this lane's input-channel plane
     const float* const dl = DL + (16 * qa + c16) * PLY;     // ... and output-channel plane
@@ -81,6 +98,8 @@ __global__ __launch_bounds__(256, 3) void wgrad_wino(const WP p) {
             constexpr int NY = DH * (DW / 2) * 8, NYI = (NY + 255) / 256;
             const int hb = 2 * BH * bby - 1, wb = 2 * BW * bbx - 1;
             f32x4 sx[NXI][2], sy[NYI][2];
+            unsigned okx = 0u;                              // which staged x pieces lie inside the image (the ring pads the ACTIVATION)
+            static_assert(2 * NXI <= 32, "one bit per staged piece");
 #pragma unroll
             for (int it = 0; it < NXI; ++it) {
                 const int s = tid + 256 * it;
@@ -93,6 +112,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_wino(const WP p) {
                     const int w = wb + pc + k;
                     const bool ok = okh && (unsigned)w < (unsigned)p.W;
                     sx[it][k] = bload(xr, ok ? (unsigned)((((img * p.H + h) * p.W + w) * p.Ci + cit * 32 + cs * 4) * 4) : OOB);
+                    okx |= ok ? (1u << (2 * it + k)) : 0u;
                 }
             }
 #pragma unroll
@@ -108,6 +128,17 @@ __global__ __launch_bounds__(256, 3) void wgrad_wino(const WP p) {
                     const bool ok = okh && w < p.W;
                     sy[it][k] = bload(yr, ok ? (unsigned)((((img * p.H + h) * p.W + w) * p.Co + cot * 32 + cs * 4) * 4) : OOB);
                 }
+            }
+            if (xbn) {
+#pragma unroll
+                for (int it = 0; it < NXI; ++it)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = fmaxf(__builtin_fmaf((sx[it][k][e] - bmu[e]) * bis[e], bga[e], bbe[e]), 0.f);
+                            sx[it][k][e] = ((okx >> (2 * it + k)) & 1u) ? t : 0.f;
+                        }
             }
             __syncthreads();                                // the previous block's operands have been read
 #pragma unroll
@@ -235,14 +266,25 @@ extern "C" int advmix_wgrad_wino_config(int N, int H, int W, int Ci, int Co) {
 // ([Co][3][3][Ci], fp32 atomics): dw[i] += sum_pixels dy[i] (x) x[i].  dy[i]: [N,H,W,Co], x[i]: [N,H,W,Ci].  Replaces
 // advmix_conv_wgrad_group for the branch convs of HRNet (pose_hrnet.py:22-57 backward).  ADVMIX_EINVAL (nothing launched):
 // odd sizes, channel counts that are not multiples of 32, deterministic mode (atomics), n out of range.
-extern "C" int advmix_conv3x3_wgrad_wino_group(int n, const float* const* dy, const float* const* x, float* const* dw, int N,
-                                               int H, int W, int Co, int Ci, void* stream) {
+//
+// advmix_conv3x3_wgrad_wino_group_bn: the same with a per-problem BatchNorm on the x operand - bn_mean / bn_invstd / bn_gamma /
+// bn_beta are arrays of n pointers (the arrays or single entries may be NULL); where entry i is given, x[i] is the RAW output c
+// of the conv that precedes problem i and relu(BN(c)) (saved batch statistics) is applied while x is staged: the activation
+// advmix_conv3x3_wino_fwd_inbn never wrote.
+extern "C" int advmix_conv3x3_wgrad_wino_group_bn(int n, const float* const* dy, const float* const* x, float* const* dw,
+                                                  const float* const* bn_mean, const float* const* bn_invstd,
+                                                  const float* const* bn_gamma, const float* const* bn_beta, int N, int H, int W,
+                                                  int Co, int Ci, void* stream) {
     if (n < 1 || n > wgw::MAXP || !dy || !x || !dw || !wgw_shape_ok(N, H, W, Ci, Co)) return ADVMIX_EINVAL;
     if (advmix_opts().deterministic) return ADVMIX_EINVAL;
     wgw::WP p{};
     for (int i = 0; i < n; ++i) {
         if (!dy[i] || !x[i] || !dw[i]) return ADVMIX_EINVAL;
         p.x[i] = x[i]; p.dy[i] = dy[i]; p.dw[i] = dw[i];
+        if (bn_mean && bn_mean[i]) {
+            if (!bn_invstd || !bn_gamma || !bn_beta || !bn_invstd[i] || !bn_gamma[i] || !bn_beta[i]) return ADVMIX_EINVAL;
+            p.bn_mean[i] = bn_mean[i]; p.bn_invstd[i] = bn_invstd[i]; p.bn_gamma[i] = bn_gamma[i]; p.bn_beta[i] = bn_beta[i];
+        }
     }
     p.n = n; p.N = N; p.H = H; p.W = W; p.Ci = Ci; p.Co = Co;
     p.Ht = H / 2; p.Wt = W / 2;
@@ -272,4 +314,9 @@ extern "C" int advmix_conv3x3_wgrad_wino_group(int n, const float* const* dy, co
     }
     ADVMIX_CHECK_LAUNCH();
     return ADVMIX_OK;
+}
+
+extern "C" int advmix_conv3x3_wgrad_wino_group(int n, const float* const* dy, const float* const* x, float* const* dw, int N,
+                                               int H, int W, int Co, int Ci, void* stream) {
+    return advmix_conv3x3_wgrad_wino_group_bn(n, dy, x, dw, nullptr, nullptr, nullptr, nullptr, N, H, W, Co, Ci, stream);
 }

@@ -242,11 +242,16 @@ WGRAD_GROUP = __import__('os').environ.get('ADVMIX_WGRAD_GROUP', '1') != '0'
 _WG_DEFER = []          # a stack of pending lists: [(a, b, grad, geom)] of the Chain.bwd calls in progress
 
 
-def _wgrad(st, lane, a, b, w, geom, park=False, v=None):
+def _wgrad(st, lane, a, b, w, geom, park=False, v=None, xbn=None):
     """Weight gradient accumulated into w.grad (atomics, or ordered partials in deterministic mode).  ``park``: a and b stay
     as they are until the autograd pass ends (ConvBN.bwd: a fresh dc, a saved activation), so a SMALL problem may wait for
-    a mixed launch (_wgrad_single); the U-Net's plain convs hand over gradients that later backward ops update in place."""
+    a mixed launch (_wgrad_single); the U-Net's plain convs hand over gradients that later backward ops update in place.
+    ``xbn`` (round 6): b is the RAW output of the preceding conv and (mean, invstd, gamma, beta, record) its BatchNorm - the
+    forward applied it on load (ConvBN.fwd ``in_bn``); the Winograd weight gradient does the same while it stages b, every
+    other kernel gets the activation materialised (ConvBN.materialize)."""
     g = _grad_buf(w, st)
+    if xbn is not None and (DETERMINISTIC or geom[7:] != (3, 3, 1, 1)):
+        b, xbn = keep(ConvBN.materialize(xbn[4], st)), None   # (no Winograd weight gradient will take it)
     if DETERMINISTIC:
         ws = _workspace(a.device, 0, lane)
         call('advmix_conv_wgrad_det', _p(a), _p(b), _p(g), *geom, _p(ws), WS_BYTES, st)
@@ -254,8 +259,10 @@ def _wgrad(st, lane, a, b, w, geom, park=False, v=None):
         pass                                                                     #  input transform of b a preceding launch left)
     elif _WG_DEFER and WGRAD_GROUP and ((geom[3] % 64 == 0 and geom[6] % 4 == 0)
                                         or (geom[3] == 32 and geom[6] == 32 and geom[7:] == (3, 3, 1, 1))):
-        _WG_DEFER[-1].append((a, b, g, geom, park))         # (a - a kept temporary - and b stay alive in the pending list)
-    elif not _wgrad_wino(st, [(a, b, g)], geom):            # (a lone 3x3 with enough work, e.g. transition1's 256 -> 32 @64x48)
+        _WG_DEFER[-1].append((a, b, g, geom, park, xbn))    # (a - a kept temporary - and b stay alive in the pending list)
+    elif not _wgrad_wino(st, [(a, b, g, xbn)], geom):       # (a lone 3x3 with enough work, e.g. transition1's 256 -> 32 @64x48)
+        if xbn is not None:
+            b = keep(ConvBN.materialize(xbn[4], st))
         _wgrad_single(st, a, b, g, geom, park)
 
 
@@ -351,8 +358,9 @@ WGRAD_WINO_MIN_UNITS = int(__import__('os').environ.get('ADVMIX_WGRAD_WINO_MIN_U
 
 
 def _wgrad_wino(st, grp, geom):
-    """The group's weight gradients through the Winograd kernel (csrc/wgrad_wino.hip) when it serves the geometry and there
-    is enough work to fill the chip; False = not taken."""
+    """The group's weight gradients [(dy, x, grad[, xbn])] through the Winograd kernel (csrc/wgrad_wino.hip) when it serves the
+    geometry and there is enough work to fill the chip; False = not taken.  ``xbn`` per problem: x is the raw output of the
+    preceding conv, its BatchNorm + ReLU (saved statistics) is applied while x is staged (see _wgrad)."""
     B, Ha, Wa, Ca, Hb, Wb, Cb, R, S, stride, pad = geom       # a = dy [B,Ha,Wa,Ca], b = x [B,Hb,Wb,Cb]
     if not (WGRAD_WINO and WINO and (R, S, stride, pad) == (3, 3, 1, 1)) or DETERMINISTIC:
         return False
@@ -360,8 +368,17 @@ def _wgrad_wino(st, grp, geom):
         return False
     n = len(grp)
     arr = ctypes.c_void_p * n
-    rc = lib.advmix_conv3x3_wgrad_wino_group(n, arr(*[x[0].data_ptr() for x in grp]), arr(*[x[1].data_ptr() for x in grp]),
-                                             arr(*[x[2].data_ptr() for x in grp]), B, Hb, Wb, Ca, Cb, st)
+    xb = [x[3] if len(x) > 3 else None for x in grp]
+    if any(v is not None for v in xb):
+        col = lambda k: arr(*[(v[k].data_ptr() if v is not None else None) for v in xb])      # noqa: E731
+        rc = lib.advmix_conv3x3_wgrad_wino_group_bn(n, arr(*[x[0].data_ptr() for x in grp]), arr(*[x[1].data_ptr() for x in grp]),
+                                                    arr(*[x[2].data_ptr() for x in grp]), col(0), col(1), col(2), col(3),
+                                                    B, Hb, Wb, Ca, Cb, st)
+        if rc == 0:
+            COUNTERS['wgrad_wino_bn'] = COUNTERS.get('wgrad_wino_bn', 0) + sum(1 for v in xb if v is not None)
+    else:
+        rc = lib.advmix_conv3x3_wgrad_wino_group(n, arr(*[x[0].data_ptr() for x in grp]), arr(*[x[1].data_ptr() for x in grp]),
+                                                 arr(*[x[2].data_ptr() for x in grp]), B, Hb, Wb, Ca, Cb, st)
     if rc == 0:
         COUNTERS['wgrad_wino'] = COUNTERS.get('wgrad_wino', 0) + 1
         return True
@@ -373,14 +390,16 @@ def _wgrad_wino(st, grp, geom):
 def _flush_wgrads(st, pending):
     """Launch the collected weight gradients: groups of 2-8 of one geometry as one launch, the rest one by one."""
     by = {}
-    for a, b, g, geom, park in pending:
-        by.setdefault(geom, []).append((a, b, g, park))
+    for a, b, g, geom, park, xbn in pending:
+        by.setdefault(geom, []).append((a, b, g, xbn, park))
     for geom, items in by.items():
         for i in range(0, len(items), 8):
             grp = items[i:i + 8]
             n = len(grp)
             if _wgrad_wino(st, grp, geom):
                 continue
+            # no kernel below applies a BatchNorm on load: the activation as a tensor for the problems that deferred theirs
+            grp = [(a, b if xbn is None else keep(ConvBN.materialize(xbn[4], st)), g, None, park) for a, b, g, xbn, park in grp]
             if n >= 2:
                 arr = ctypes.c_void_p * n
                 rc = lib.advmix_conv_wgrad_group(n, arr(*[x[0].data_ptr() for x in grp]), arr(*[x[1].data_ptr() for x in grp]),
@@ -390,7 +409,7 @@ def _flush_wgrads(st, pending):
                     continue
                 if rc != 1:
                     raise RuntimeError('advmix_conv_wgrad_group failed: %d' % rc)
-            for a, b, g, park in grp:
+            for a, b, g, _x, park in grp:
                 _wgrad_single(st, a, b, g, geom, park)
 
 
@@ -851,7 +870,36 @@ class ConvBN:
     NHWC = (0, 7)
 
     @staticmethod
-    def fwd(st, lane, t, meta, needs):
+    def materialize(pend, st):
+        """The activation act(BN(c)) of a DEFERRED train-mode ConvBN (see ``fwd``) as a tensor after all: by norm_apply_slots
+        when nobody has derived the batch statistics yet (it publishes them), by norm_apply from the published ones otherwise.
+        Cached in the record: the producer's and the consumer's backward may both ask."""
+        if pend.get('y') is not None:
+            return pend['y']
+        c = pend['c']
+        B, Co, Ho, Wo = c.shape
+        y = empty_nhwc(B, Co, Ho, Wo, c.device)
+        rows = B * Ho * Wo
+        if not pend['published']:
+            call('advmix_norm_apply_slots', _p(c), pend['slots'], pend['ns'], rows, Co, pend['eps'], _p(pend['gamma']),
+                 _p(pend['beta']), None, _p(y), pend['act'], _p(pend['mean']), _p(pend['invstd']), _p(pend['rmean']),
+                 _p(pend['rvar']), _p(pend['nbt']), pend['momentum'], None, st)
+            pend['published'] = True
+        else:
+            call('advmix_norm_apply', _p(c), _p(pend['mean']), _p(pend['invstd']), _p(pend['gamma']), _p(pend['beta']), None,
+                 _p(y), Co, 1, rows, Co, pend['act'], st)
+        pend['y'] = y
+        COUNTERS['inbn_materialized'] = COUNTERS.get('inbn_materialized', 0) + 1
+        return y
+
+    @staticmethod
+    def fwd(st, lane, t, meta, needs, defer=False, in_bn=None):
+        """``defer`` (round 6; ops.Chain decides): a train-mode layer whose activation has ONE reader - the 3x3 Winograd conv
+        that follows it in the same chain - stops after the conv and its column sums: the output handed on is the RAW conv
+        output c, and ``extra[6]`` is the record ('pend') of everything norm_apply_slots would have needed.  ``in_bn``: such a
+        record of THIS layer's input; the conv applies that BatchNorm + ReLU while it stages its input
+        (advmix_conv3x3_wino_fwd_inbn: +0.3 ... +1.3 us on the conv instead of a 6 ... 10 us launch and a tensor), derives and
+        publishes the statistics on the way; where the kernel refuses, the activation is materialised first."""
         x, w, gamma, beta, rmean, rvar, nbt, residual = t
         stride, pad, act, training, momentum, eps = meta[:6]
         arena, fwd_off, bwd_off = meta[6:9] if len(meta) > 6 else (None, 0, 0)
@@ -864,11 +912,18 @@ class ConvBN:
         Wo = (Wi + 2 * pad - S) // stride + 1
         rows = B * Ho * Wo
         geom = (B, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad)
-        y = empty_nhwc(B, Co, Ho, Wo, x.device)
         fused_ok = _direct_ok() and Ci % 16 == 0
         wu = _wino_images(w, B, Hi, Wi, Ci, Co, R, S, stride, pad) if fused_ok else None
+        xbn = None                                          # (mean, invstd, gamma, beta) of the BatchNorm this conv applied on load
+        if in_bn is not None and not (training and wu is not None and wu[2] == 'wino' and not DETERMINISTIC
+                                      and arena is not None and arena.t is not None):
+            x = keep(ConvBN.materialize(in_bn, st))         # (not the fused kernel's case after all)
+            in_bn = None
+        y = empty_nhwc(B, Co, Ho, Wo, x.device) if not defer else None
         if not training:
             rc = 1
+            if y is None:
+                y = empty_nhwc(B, Co, Ho, Wo, x.device)
             if wu is not None:                              # Winograd F(2x2,3x3): same fused epilogue, 2.25x fewer MFMAs
                 rc = _W3[wu[2]][0](_p(x), wu[0], _p(y), B, Hi, Wi, Ci, Co, _p(gamma), _p(beta), _p(rmean),
                                                  _p(rvar), eps, _p(res), act, None, None, st)
@@ -902,7 +957,22 @@ class ConvBN:
                 nbg, target = ctypes.c_int(-cap), _p(ws)    # the layer's slots (ns = 1) - no extra pass over c
             else:
                 nbg, target = ctypes.c_int(STAT_SLOTS_ASK), slots
-            if wu is not None and not DETERMINISTIC:
+            if in_bn is not None:
+                rc = lib.advmix_conv3x3_wino_fwd_inbn(
+                    _p(x), wu[0], _p(c), B, Hi, Wi, Ci, Co, in_bn['slots'], in_bn['ns'], _p(in_bn['gamma']), _p(in_bn['beta']),
+                    in_bn['eps'], _p(in_bn['mean']), _p(in_bn['invstd']), _p(in_bn['rmean']), _p(in_bn['rvar']), _p(in_bn['nbt']),
+                    in_bn['momentum'], target, ctypes.byref(nbg), st)
+                if rc == 0:
+                    in_bn['published'] = True
+                    xbn = (in_bn['mean'], in_bn['invstd'], in_bn['gamma'], in_bn['beta'], in_bn)
+                    COUNTERS['wino'] = COUNTERS.get('wino', 0) + 1
+                    COUNTERS['inbn'] = COUNTERS.get('inbn', 0) + 1
+                elif rc == 1:                               # refused (nothing launched): the activation as a tensor, then as ever
+                    x = keep(ConvBN.materialize(in_bn, st))
+                    in_bn = None
+                else:
+                    raise RuntimeError('advmix_conv3x3_wino_fwd_inbn failed: %d' % rc)
+            if rc == 1 and wu is not None and not DETERMINISTIC:
                 rc = _W3[wu[2]][0](_p(x), wu[0], _p(c), B, Hi, Wi, Ci, Co, None, None, None, None, 0.0, None, 0,
                                                  target, ctypes.byref(nbg), st)
                 if rc == 0:
@@ -913,6 +983,15 @@ class ConvBN:
             if rc == 0 and DETERMINISTIC:
                 call('advmix_stats_fold', target, nbg.value, Co, slots, st)
                 nbg.value = 1
+            if rc == 0 and defer and res is None and not DETERMINISTIC and nbg.value <= 16 and arena is not None and arena.t is not None:
+                # deferred: the reader applies BatchNorm + activation itself (or materialises); everything it needs, in one record
+                pend = {'c': c, 'slots': slots, 'ns': nbg.value, 'gamma': gamma, 'beta': beta, 'eps': eps, 'mean': mean,
+                        'invstd': invstd, 'rmean': rmean, 'rvar': rvar, 'nbt': nbt, 'momentum': momentum, 'act': act,
+                        'published': False, 'y': None}
+                extra = (False, arena, arena.pass_id, bwd_off, None, True, pend, xbn)     # (slot_fwd: the sign of y can be recomputed from c)
+                return (c,), (x, w, c, None, mean, invstd, gamma, beta), extra
+            if y is None:
+                y = empty_nhwc(B, Co, Ho, Wo, x.device)
             if rc == 0:
                 if res is not None and act != ACT_NONE and Co % 16 == 0 and any(needs) and BNB_FUSED and ACT_MASK:
                     # y = act(BN(c) + residual): the consumer's BatchNorm-backward epilogue needs the SIGN of y only - a bit
@@ -940,7 +1019,7 @@ class ConvBN:
                  _p(nbt), momentum, _p(ws), st)
             call('advmix_norm_apply', _p(c), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(res), _p(y),
                  Co, 1, rows, Co, act, st)
-        extra = (residual is not None, arena, arena.pass_id if arena is not None else 0, bwd_off, mask, slot_fwd)
+        extra = (residual is not None, arena, arena.pass_id if arena is not None else 0, bwd_off, mask, slot_fwd, None, xbn)
         if len(meta) > 9 and meta[9] and arena is not None and arena.t is not None and act == ACT_NONE and any(needs) \
                 and BNB_FUSED and FUSE_BNB and not DETERMINISTIC:
             # the only consumer is a fuse sum in another launch group: its backward can produce this layer's sums
@@ -953,7 +1032,7 @@ class ConvBN:
     def bnb_target(saved, extra, meta):
         """What the input-gradient conv of this layer's CONSUMER needs to fold this layer's BatchNorm-backward
         statistics into its epilogue (None if the layer's backward slots cannot be used for this pass)."""
-        has_res, arena, pass_id, bwd_off, mask, slot_fwd = extra
+        has_res, arena, pass_id, bwd_off, mask, slot_fwd = extra[:6]
         act = meta[2]
         if arena is None or act not in (ACT_NONE, ACT_RELU):
             return None
@@ -971,11 +1050,13 @@ class ConvBN:
         if not training:
             raise RuntimeError('advmix_amd: backward through eval-mode BatchNorm is not on the hot path')
         has_res, arena, _pass, bwd_off = extra[:4]
+        pend = extra[6] if len(extra) > 6 else None         # this layer's activation was deferred to its reader (see fwd)
+        xbn = extra[7] if len(extra) > 7 else None          # this layer's conv applied its INPUT's BatchNorm on load: x is raw
         x, w, c, y, mean, invstd, gamma, beta = saved
         dy = nhwc(grads[0])
         B, Ci, Hi, Wi = x.shape
         Co, _, R, S = w.shape
-        Ho, Wo = y.shape[2], y.shape[3]
+        Ho, Wo = c.shape[2], c.shape[3]
         rows = B * Ho * Wo
         need_res = has_res and needs[7]
         if not pre and arena is not None:                   # sums left by the backward of a fuse sum in another group
@@ -994,6 +1075,8 @@ class ConvBN:
         else:
             if need_res:
                 dres = dy if act == ACT_NONE else empty_nhwc(B, Co, Ho, Wo, x.device)
+            if y is None:                                   # deferred, and no input-gradient epilogue carried its sums: the
+                y = keep(ConvBN.materialize(pend, st))      # statistics pass below wants the activation as a tensor
             ws = _workspace(x.device, lib.advmix_norm_ws_bytes(1, Co), lane)
             call('advmix_norm_bwd', _p(dy), _p(y), Co, _p(c), _p(mean), _p(invstd), _p(gamma), _p(dc),
                  _p(dres) if (need_res and act != ACT_NONE) else None, _p(dg), _p(db), 1, rows, Co, act,
@@ -1002,7 +1085,7 @@ class ConvBN:
         if needs[0]:
             dx = _conv_dgrad(st, dc, w, x, B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad, add_to, bnb, lane)
         if needs[1]:
-            _wgrad(st, lane, dc, x, w, (B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad), park=True)
+            _wgrad(st, lane, dc, x, w, (B, Ho, Wo, Co, Hi, Wi, Ci, R, S, stride, pad), park=True, xbn=xbn)
         return dx, None, None, None, None, None, None, dres
 
 
@@ -1293,6 +1376,7 @@ def unit_grad(device):
 
 
 FANIN_FUSED = __import__('os').environ.get('ADVMIX_FANIN', '1') != '0'
+INBN = __import__('os').environ.get('ADVMIX_INBN', '1') != '0'        # BatchNorm + ReLU of an inner edge applied by the reading conv on load (A/B switch)
 
 
 def _add(st, a, b):
@@ -1334,15 +1418,58 @@ class Chain:
         return len(meta[2])
 
     @staticmethod
+    def inbn_plan(subs, out_slots):
+        """{producer index j: consumer index k}: sub j is a train-mode conv + BatchNorm + ReLU without a residual whose output
+        slot has exactly ONE reader - the conv input of sub k, a 3x3 / stride 1 / pad 1 conv + BatchNorm - and does not leave the
+        chain: conv1 -> bn1 -> relu -> conv2 of a BasicBlock / Bottleneck (lib/models/pose_hrnet.py:41-57, :77-88).  For these
+        pairs the activation need never be a tensor: the reader applies it while staging its input (ConvBN.fwd ``in_bn``)."""
+        uses = {}
+        for k, (_o, refs, _m, _d) in enumerate(subs):
+            for pos, r in enumerate(refs):
+                if r is not None and r[0] == 's':
+                    uses.setdefault(r[1], []).append((k, pos))
+        plan = {}
+        for j, (op, refs, m, dst) in enumerate(subs):
+            if op is not ConvBN or not m[3] or m[2] != ACT_RELU or (len(refs) > 7 and refs[7] is not None) or dst in out_slots:
+                continue
+            u = uses.get(dst, [])
+            if len(u) != 1 or u[0][1] != 0:
+                continue
+            k = u[0][0]
+            kop, _kr, km, _kd = subs[k]
+            if kop is ConvBN and km[3] and km[0] == 1 and km[1] == 1 and k > j:
+                plan[j] = k
+        return plan
+
+    @staticmethod
     def fwd(st, lane, t, meta, needs):
         subs, ext_slots, out_slots = meta[:3]
         val = {s_: t[i] for i, s_ in enumerate(ext_slots)}
         need = {s_: bool(needs[i]) for i, s_ in enumerate(ext_slots)}
         saved, rec = [], []
-        for op, refs, smeta, dst in subs:
+        plan = (meta[4] if len(meta) > 4 else Chain.inbn_plan(subs, out_slots)) if INBN else {}
+        pending = {}                                       # consumer index -> the deferred producer's record
+        for si, (op, refs, smeta, dst) in enumerate(subs):
             tin = tuple(None if r is None else (val[r[1]] if r[0] == 's' else t[r[1]]) for r in refs)
             nin = tuple(False if r is None else (need[r[1]] if r[0] == 's' else bool(needs[r[1]])) for r in refs)
-            o, sv, ex = op.fwd(st, lane, tin, smeta, nin)
+            kw = {}
+            if si in plan:                                 # defer this layer's BatchNorm + ReLU to its reader - if that reader is
+                kref = subs[plan[si]][1][1]                # one the Winograd kernel will take at this batch size (its filters carry images)
+                wk = val[kref[1]] if kref[0] == 's' else t[kref[1]]
+                c_shape = tin[1].shape
+                x_shape = tin[0].shape
+                Ho = (x_shape[2] + 2 * smeta[1] - c_shape[2]) // smeta[0] + 1
+                Wo = (x_shape[3] + 2 * smeta[1] - c_shape[3]) // smeta[0] + 1
+                hit = _wino_images(wk, x_shape[0], Ho, Wo, wk.shape[1], wk.shape[0], wk.shape[2], wk.shape[3], 1, 1) \
+                    if (wk.shape[1] == c_shape[0] and tuple(wk.shape[2:]) == (3, 3) and _direct_ok()) else None
+                if hit is not None and hit[2] == 'wino' and not DETERMINISTIC:
+                    kw['defer'] = True
+            if si in pending:
+                kw['in_bn'] = pending.pop(si)
+            o, sv, ex = op.fwd(st, lane, tin, smeta, nin, **kw)
+            pend = ex[6] if (kw.get('defer') and ex is not None and len(ex) > 6) else None
+            if pend is not None:
+                pending[plan[si]] = pend
             wants = any(nin)
             if not wants:                                  # nothing to differentiate: drop the references, but only
                 _KEEP.extend(v for v in sv if torch.is_tensor(v))   # after the lanes have joined (see keep())
@@ -1350,7 +1477,13 @@ class Chain:
             keep(o[0])                                     # an intermediate nobody saved must outlive the lanes
             val[dst], need[dst] = o[0], wants
             if SLOT_TAP is not None:
-                SLOT_TAP(subs, dst, o[0], st)
+                if pend is None:
+                    SLOT_TAP(subs, dst, o[0], st)
+                if 'in_bn' in kw:                           # the activation this layer applied on load, as a tensor for the observer
+                    src = refs[0][1]                        # (the reader has published the statistics by now; observation only)
+                    n_mat = COUNTERS.get('inbn_materialized', 0)
+                    SLOT_TAP(subs, src, ConvBN.materialize(dict(kw['in_bn'], y=None), st), st)
+                    COUNTERS['inbn_materialized'] = n_mat   # (the observer's copy is not the product's)
             rec.append((len(saved), len(sv), ex, nin))
             saved += list(sv)
         return tuple(val[s_] for s_ in out_slots), tuple(saved), rec

@@ -581,7 +581,7 @@ class PlanNet(nn.Module):
                         names.append(t.name)
                 subs.append((op, tuple(refs), meta, self._dst(sub)))
             subs = tuple(subs)
-            cached = ((subs, tuple(ext), tuple(outs), ops.Chain.bnb_plan(subs)), tuple(names))
+            cached = ((subs, tuple(ext), tuple(outs), ops.Chain.bnb_plan(subs), ops.Chain.inbn_plan(subs, tuple(outs))), tuple(names))
             self._chain_meta[key] = cached
         meta, names = cached
         return (ops.Chain, tuple(slots[s] for s in meta[1]) + tuple(T[n] for n in names), meta)

@@ -130,6 +130,20 @@ int advmix_wino_weights(const void* ents, const int* blk_ent, int blocks, void* 
 int advmix_conv3x3_wino_fwd(const float* x, const float* u, float* y, int N, int H, int W, int Ci, int Co,
                             const float* bn_gamma, const float* bn_beta, const float* bn_rm, const float* bn_rv,
                             float bn_eps, const float* residual, int act, double* stats, int* stats_ns, void* stream);
+/* advmix_conv3x3_wino_fwd's train role (raw output y + its column sums into stats) on an input that is the RAW output c_in of
+ * the preceding conv: that conv's train-mode BatchNorm + ReLU is applied while the input patch is staged, so
+ * y = conv(relu(BN_train(c_in))) without the advmix_norm_apply_slots launch and without the activation tensor.  in_slots: the
+ * column (sum, sum of squares) of c_in as the producer's epilogue left them, [2][in_ns][Ci], in_ns a power of two <= 16.  The
+ * launch derives mean / invstd (biased variance, in_eps), writes them to in_mean / in_invstd (saved for the backward pass),
+ * updates in_rmean / in_rvar (in_momentum, unbiased variance; both may be NULL) and increments *in_nbt (may be NULL).  The
+ * activation is spelled as norm_apply_slots spells it - fma((c - mean) * invstd, gamma, beta) - so the backward pass's
+ * "sign from c" epilogue (advmix_conv3x3_wino_dgrad with bn_gamma / bn_beta) agrees with it bit for bit.  Replaces the
+ * BatchNorm2d + ReLU between conv1 and conv2 of lib/models/pose_hrnet.py:41-57 (BasicBlock) and :77-88 (Bottleneck).
+ * ADVMIX_EINVAL (nothing launched) where advmix_conv3x3_wino_fwd refuses, for in_ns > 16, in deterministic mode. */
+int advmix_conv3x3_wino_fwd_inbn(const float* c_in, const float* u, float* y, int N, int H, int W, int Ci, int Co,
+                                 const double* in_slots, int in_ns, const float* in_gamma, const float* in_beta,
+                                 float in_eps, float* in_mean, float* in_invstd, float* in_rmean, float* in_rvar,
+                                 long long* in_nbt, float in_momentum, double* stats, int* stats_ns, void* stream);
 /* advmix_conv_tr_w_add (bn_c NULL) / advmix_conv_tr_w_bnb (bn_c given) from the role 1 image u: dx[N,H,W,Ci] from
  * dy[N,H,W,Co]; addend, bn_c and act_mask are laid out like dx. */
 int advmix_conv3x3_wino_dgrad(const float* dy, const float* u, const float* addend, float* dx, int N, int H, int W,
@@ -237,6 +251,14 @@ int advmix_conv4x4s2_wino_fwd(const float* x, const float* u, const float* bias,
 int advmix_wgrad_wino_config(int N, int H, int W, int Ci, int Co);
 int advmix_conv3x3_wgrad_wino_group(int n, const float* const* dy, const float* const* x, float* const* dw, int N, int H, int W,
                                     int Co, int Ci, void* stream);
+/* The same with a per-problem BatchNorm on the x operand: bn_mean / bn_invstd / bn_gamma / bn_beta are arrays of n pointers
+ * (an array, or single entries, may be NULL).  Where entry i is given, x[i] is the RAW output c of the conv preceding problem i
+ * and relu(fma((c - mean) * invstd, gamma, beta)) - the saved batch statistics - is applied while x is staged: the activation
+ * advmix_conv3x3_wino_fwd_inbn never wrote (weight gradient of conv2 in lib/models/pose_hrnet.py:41-57). */
+int advmix_conv3x3_wgrad_wino_group_bn(int n, const float* const* dy, const float* const* x, float* const* dw,
+                                       const float* const* bn_mean, const float* const* bn_invstd,
+                                       const float* const* bn_gamma, const float* const* bn_beta, int N, int H, int W,
+                                       int Co, int Ci, void* stream);
 
 /* Transposed gather with <= 4 output channels: the input gradient of a network's FIRST conv (3 image channels; taken
  * when the images come from the generator - lib/core/function.py:146-160 back-propagates loss_G through the frozen

@@ -323,6 +323,13 @@ def gen_c4b32(M):
     np.savez_compressed(os.path.join(OUT, 'c4_b32_forward.npz'), **res)
 
 
+def gen_c4b32step(M):
+    """C4 at ITS benchmarked batch, the STEP (VERDICT r5 weak 1 c): ONE iteration of the real train_advmix on HRNet-W48 384x288,
+    B = 32, UnetGenerator(9, 3, 5) - losses, both D outputs (strided samples) and the parameter checksums after the update.
+    ~45 GB of host memory (run it alone: ``ulimit -v`` below the container's 62 GB turns an overrun into a MemoryError)."""
+    gen_advmix(M, (C4_B32_CASE + (1,),), 'c4_b32_advmix_steps.npz', 'c4_b32_advmix_checksums.json', downs=5, plain=False)
+
+
 def gen_c5trunk(M):
     gen_forward(M, (C5_TRUNK_CASE,), 'c5_trunk_forward.npz')
 
@@ -710,7 +717,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     M = import_reference()
-    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe', 'c4', 'b32', 'benchtiles', 'c1', 'autoaug', 'c5trunk', 'nmsvis', 'accuracy', 'c4b32']
+    which = sys.argv[1:] or ['keys', 'loss', 'nms', 'forward', 'advmix', 'validate', 'inputpipe', 'c4', 'b32', 'benchtiles', 'c1', 'autoaug', 'c5trunk', 'nmsvis', 'accuracy', 'c4b32']      # ('c4b32step': on request - it needs the whole container's memory)
     for w in which:
         globals()['gen_' + w](M)
         print('done', w, flush=True)

@@ -722,6 +722,83 @@ def test_branch_through_the_plan_executor_with_pinned_masks(case):
     assert took.get('wgrad_wino', 0) + took.get('wgrad_group', 0) >= 1, took
 
 
+@pytest.mark.parametrize('case', [(32, 32, 64, 48), (32, 64, 32, 24), (32, 128, 16, 12), (16, 64, 64, 48), (32, 48, 24, 18)])
+def test_batch_norm_applied_by_the_reading_conv_on_load(case, monkeypatch):
+    """Round 6: for the inner edge conv1 -> bn1 -> relu -> conv2 of a BasicBlock (pose_hrnet.py:41-57) the
+    product no longer launches norm_apply_slots nor writes the activation: conv2's Winograd kernel applies BatchNorm + ReLU while
+    it stages its input (advmix_conv3x3_wino_fwd_inbn), derives and publishes bn1's batch statistics and running statistics on the
+    way, conv2's weight gradient applies it again while staging (advmix_conv3x3_wgrad_wino_group_bn), bn1's backward takes the sign
+    of the activation from c.  A branch of four BasicBlocks WITHOUT any tap in the graph (a second reader would switch the fusion
+    off) through plan.PlanNet: (a) against the same network with ADVMIX_INBN off - the forward is the same arithmetic (output
+    equal to rounding of the statistics' atomics), running statistics and counters equal, gradients to atomics' rounding; (b)
+    element-wise against fp64 with the device's own masks read through ops.SLOT_TAP.  The last case is an HRNet-W48 width (48
+    channels: the kernel's general staging path)."""
+    from oracle import detinit
+    from advmix_amd import ops
+    from advmix_amd.plan import Plan, PlanNet
+    from plan_functional import SlotRecorder, interpret, pins_of
+    B, C, H, W = case
+    P = Plan(C)
+    P.tag = 'branch'
+    x = 0
+    for k in range(4):
+        x = P.block('BASIC', x, 'b%d' % k, C)
+    P.out = x
+    tag = 'inbn.%d.%d.%d' % (B, C, H)
+    x0 = detinit.normal(tag + '.x', (B, C, H, W))
+    runs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, 'INBN', fused)
+        net = PlanNet(P)
+        init = {}
+        for n, p_ in net.named_parameters():
+            init[n] = detinit.normal(tag + '.' + n, tuple(p_.shape), std=(p_.shape[1] * 9) ** -0.5) if p_.dim() == 4 else \
+                detinit.normal(tag + '.' + n, tuple(p_.shape), std=0.2, mean=1.0 if n.endswith('.weight') else 0.0)
+            with torch.no_grad():
+                p_.copy_(init[n])
+        net = net.cuda().train()
+        c0 = dict(ops.COUNTERS)
+        xd = x0.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        with SlotRecorder() as rec:
+            yd = net(xd)
+        proj = detinit.normal(tag + '.proj', tuple(yd.shape))
+        (yd * proj.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        took = {k: v - c0.get(k, 0) for k, v in ops.COUNTERS.items() if v != c0.get(k, 0)}
+        runs[fused] = dict(y=yd.detach().cpu(), gx=xd.grad.detach().cpu(), g={n: p_.grad.detach().cpu() for n, p_ in net.named_parameters()},
+                           buf={n: b_.detach().cpu().clone() for n, b_ in net.named_buffers()}, took=took, slots=rec.of(net), init=init)
+    a, b = runs[True], runs[False]
+    print(case, 'fused launches', a['took'], '| unfused', b['took'])
+    if C % 32 == 0:
+        assert a['took'].get('inbn', 0) == 4 and a['took'].get('wgrad_wino_bn', 0) == 4 and not a['took'].get('inbn_materialized'), a['took']
+    else:       # 48 channels: no Winograd weight gradient (channel pairs of 32) - the backward pass materialises the four activations
+        assert a['took'].get('inbn', 0) == 4 and not a['took'].get('wgrad_wino_bn') and a['took'].get('inbn_materialized') == 4, a['took']
+    assert not b['took'].get('inbn') and a['took'].get('wino') == b['took'].get('wino') == 16, (a['took'], b['took'])
+    # (a) the same network with and without the fusion
+    sc = float(b['y'].abs().max())
+    assert float((a['y'] - b['y']).abs().max()) <= 2e-6 * sc, float((a['y'] - b['y']).abs().max()) / sc
+    for n in b['buf']:                                       # bn1's running statistics and counters came from conv2's workgroup (0, 0)
+        assert torch.allclose(a['buf'][n].double(), b['buf'][n].double(), rtol=1e-6, atol=1e-7), n
+    assert float((a['gx'] - b['gx']).abs().max()) <= 1e-4 * float(b['gx'].abs().max())
+    for n in b['g']:
+        assert float((a['g'][n] - b['g'][n]).abs().max()) <= 1e-4 * float(b['g'][n].abs().max()) + 1e-9, n
+    # (b) the fused run element-wise against fp64 with its own masks
+    (slots,) = a['slots']
+    pin, pool = pins_of(P, slots)
+    W64 = {n: v.double().requires_grad_(True) for n, v in a['init'].items()}
+    x64 = x0.double().requires_grad_(True)
+    y64 = interpret(P, W64, x64, pin=pin, pool_src=pool)[P.out]
+    proj = detinit.normal(tag + '.proj', tuple(y64.shape)).double()
+    names = list(W64)
+    g64 = dict(zip(names + ['x'], torch.autograd.grad((y64 * proj).sum(), [W64[n] for n in names] + [x64])))
+    got = dict(a['g'], x=a['gx'])
+    rel = _pinned_rel_errors(got, g64, names + ['x'])
+    rel['out'] = float((a['y'].double() - y64.detach()).abs().max() / y64.abs().max())
+    top = sorted(rel.items(), key=lambda kv: -kv[1])[:3]
+    print(case, 'fused run vs fp64 with its own masks: worst of %d tensors' % len(rel), [(k, '%.2e' % v) for k, v in top])
+    assert top[0][1] <= PINNED_TOL, top
+
+
 def test_layer1_bottlenecks_through_the_plan_executor_with_pinned_masks():
     """HRNet's layer1 (pose_hrnet.py:59-98, 286: four Bottlenecks 64 -> 256 @64x48, the first with its 1x1 shortcut conv) at the
     benchmarked batch the same way: the streaming 1x1 kernel of csrc/conv_pw.hip (64 -> 256: forward + sums, and the input
@@ -941,6 +1018,55 @@ def test_every_benchmarked_network_at_its_benchmarked_tiles(tag):
         if key.startswith(tag + '.bn.'):
             assert_close(key, sd[key[len(tag) + 4:]], g[key])
     print(tag, 'worst err/bound ratios', {k: round(x, 3) for k, x in rep.items()})
+
+
+def test_c4_step_at_its_benchmarked_batch_against_the_real_reference():
+    """C4's whole STEP was parity-tested at B = 2 only.  One iteration of the REAL train_advmix on
+    HRNet-W48 384x288, B = 32, UnetGenerator(9, 3, 5) (tests/golden/c4_b32_advmix_steps.npz, oracle/gen_golden.py::gen_c4b32step:
+    ~45 GB of host memory in the build container - which is why the CPU oracle's step is NOT re-run here beside it) against one
+    advmix_step of the product from the same state and batch:
+      * loss_D = 0.9 L(D(tmp), target) + 0.1 L(D(tmp), teacher) - a function of the generator's forward, the mix, the teacher and
+        the student's first forward, all before any update - to the heat-map bound;
+      * out2 = D'(tmp), the student's output AFTER Adam's first step, UN-forced: that step is lr * sign(g) wherever |g| >> eps,
+        so the two updated networks agree except where a gradient is rounding noise; element-wise bound 5e-3 + 5e-3 |ref|;
+      * the generator loss -L(out2, target) the reference logged, from the device's out2."""
+    from oracle import configs
+    from oracle.posenet import calibrate
+    from oracle.synth import synth_batch, strided
+    from advmix_amd.core.function import advmix_phase_a, advmix_phase_b
+    from advmix_amd.core.loss import JointsMSELoss
+    from advmix_amd.utils.utils import get_optimizer
+    from advmix_amd import ops as _ops_
+    tag, net, extra, J, B, H, W, downs = 'hrnet_w48_b32', 'pose_hrnet', configs.HRNET_W48, 17, 32, 384, 288, 5
+    ga = gold_npz('c4_b32_advmix_steps.npz')
+    D, T, G = build_states(net, extra, J, unet_downs=downs, salt=10)
+    calib = synth_batch(tag + '.calib', B, J, H, W)[0][0]
+    calibrate(net, T, calib, extra)
+    calibrate(net, D, calib, extra)
+    cfg, mD, mG, mT = product_models(net, extra, J, D, T, G, downs=downs)
+    optD, optG = get_optimizer(cfg, mD), get_optimizer(cfg, mG)
+    mD.train(); mG.train(); mT.eval()
+    crit = JointsMSELoss(True)
+    args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
+    v, t, w = synth_batch(tag + '.it0', B, J, H, W)
+    inputs = [x.cuda().contiguous() for x in v]
+    c0 = dict(_ops_.COUNTERS)
+    loss_D, tmp = advmix_phase_a(args, mD, mG, mT, crit, optD, inputs, t.cuda(), w.cuda())
+    out = advmix_phase_b(args, mD, crit, optD, optG, tmp, t.cuda(), w.cuda())
+    optG.step()
+    torch.cuda.synchronize()
+    took = {k: n - c0.get(k, 0) for k, n in _ops_.COUNTERS.items() if n != c0.get(k, 0)}
+    print(tag, 'launch counters of the step', took)
+    assert took.get('wino', 0) >= 100 and took.get('inbn', 0) >= 2 * 40, took      # the 48 / 96-channel branches on the Winograd kernel, BatchNorm on load
+    want = ga[tag + '.losses'][0]                            # (heat-map loss, distillation loss, generator loss) of the iteration
+    rep = {}
+    assert_close('loss_D vs the real train_advmix', [float(loss_D)], [0.9 * want[0] + 0.1 * want[1]], report=rep)
+    assert_close('out2 vs the real train_advmix (un-forced)', strided(out.cpu().contiguous(), 2048), ga[tag + '.out2.it0'], 5e-3, report=rep)
+    with torch.no_grad():
+        loss_G = float(crit(out, t.cuda(), w.cuda()))
+    assert abs(loss_G - want[2]) <= 1e-3 + 5e-3 * abs(want[2]), (loss_G, want[2])
+    print(tag, 'loss_D %.6f (reference %.6f), generator loss %.6f (reference %.6f), worst err/bound ratios' % (
+        float(loss_D), 0.9 * want[0] + 0.1 * want[1], loss_G, want[2]), {k: round(x, 3) for k, x in rep.items()})
 
 
 def _device_checksums(model, keys):

@@ -912,7 +912,8 @@ int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const 
 
 // conv_wino4.hip's batched GEMM: c[b] = a[b] . w[b]^T for b < nb, a[b] = a + b * rows * K ([rows][K]), w[b] = w + b * Nc * K ([Nc][K]),
 // c[b] = c + b * rows * Nc - a 1x1 convolution over nb images of ``rows`` pixels in which every image has its own filters
-// (ConvD::wimg).  rows % 128 == 0 (no row tile straddles two images), K % 32 == 0, Nc % 4 == 0.  -1: not served.
+// (ConvD::wimg).  rows % 128 == 0 (no row tile straddles two images), K % 32 == 0, Nc % 4 == 0.  -1: not served.  a == NULL: dry run
+// (0 = this shape would be served; nothing is launched).
 int advmix_conv_direct_gemm_batched(const float* a, const float* w, float* c, int nb, int rows, int K, int Nc, hipStream_t st) {
     if (nb <= 0 || rows <= 0 || rows % 128 != 0 || K % 32 != 0 || Nc % 4 != 0) return -1;
     direct::ConvD p;
@@ -920,7 +921,8 @@ int advmix_conv_direct_gemm_batched(const float* a, const float* w, float* c, in
     const int64_t Mmax = (int64_t)nb * rows;
     int rc = prepare(0, a, w, nullptr, c, nb, rows / 128, 128, K, rows / 128, 128, Nc, 1, 1, 1, 0, Mmax, 0, nullptr, nullptr, &p, &bnb);
     if (rc < 0) return -1;
-    p.wimg = Nc * K;
+    if (!a) return 0;                                       // a == NULL: a dry run - "would be served", nothing launched (ADVICE r5:
+    p.wimg = Nc * K;                                        // conv_wino4's entry points ask BEFORE they launch their input transform)
     return direct::launch<0, 32, false, false>(p, Mmax, st, 0);
 }
 

@@ -461,6 +461,8 @@ extern "C" int advmix_conv4x4s2_wino_fwd(const float* x, const float* u, const f
     float* const m = ws + (int64_t)16 * p.rows * 4 * Ci;
     p.m = m;
     hipStream_t st = (hipStream_t)stream;
+    if (advmix_conv_direct_gemm_batched(nullptr, nullptr, nullptr, 16, p.rows, 4 * Ci, Co, st) != 0)
+        return ADVMIX_EINVAL;                               // (asked BEFORE the input transform goes out: "nothing launched" holds)
     hipLaunchKernelGGL(w4::wino4_input, dim3(cdiv((int64_t)p.rows * Ci, 256)), dim3(256), 0, st, p);
     ADVMIX_CHECK_LAUNCH();
     int rc = advmix_conv_direct_gemm_batched(p.v, u, m, 16, p.rows, 4 * Ci, Co, st);
@@ -574,6 +576,8 @@ extern "C" int advmix_deconv4x4s2_wino_fwd(const float* x, const float* u, const
     float* const m = ws + (int64_t)16 * p.rows * Cl;
     p.m = m;
     hipStream_t st = (hipStream_t)stream;
+    if (advmix_conv_direct_gemm_batched(nullptr, nullptr, nullptr, 16, p.rows, Cl, 4 * Ch, st) != 0)
+        return ADVMIX_EINVAL;                               // (asked BEFORE the input transform goes out: "nothing launched" holds)
     hipLaunchKernelGGL(w4::wino4t_input, dim3(cdiv((int64_t)p.rows * (Cl / 4), 256)), dim3(256), 0, st, p);
     ADVMIX_CHECK_LAUNCH();
     int rc = advmix_conv_direct_gemm_batched(p.v, u, m, 16, p.rows, Cl, 4 * Ch, st);

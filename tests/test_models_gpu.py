@@ -1023,20 +1023,32 @@ def test_every_benchmarked_network_at_its_benchmarked_tiles(tag):
 def test_c4_step_at_its_benchmarked_batch_against_the_real_reference():
     """C4's whole STEP was parity-tested at B = 2 only.  One iteration of the REAL train_advmix on
     HRNet-W48 384x288, B = 32, UnetGenerator(9, 3, 5) (tests/golden/c4_b32_advmix_steps.npz, oracle/gen_golden.py::gen_c4b32step:
-    ~45 GB of host memory in the build container - which is why the CPU oracle's step is NOT re-run here beside it) against one
-    advmix_step of the product from the same state and batch:
+    ~45 GB of host memory in the build container) against one advmix_step of the product from the same state and batch:
       * loss_D = 0.9 L(D(tmp), target) + 0.1 L(D(tmp), teacher) - a function of the generator's forward, the mix, the teacher and
-        the student's first forward, all before any update - to the heat-map bound;
-      * out2 = D'(tmp), the student's output AFTER Adam's first step, UN-forced: that step is lr * sign(g) wherever |g| >> eps,
-        so the two updated networks agree except where a gradient is rounding noise; element-wise bound 5e-3 + 5e-3 |ref|;
-      * the generator loss -L(out2, target) the reference logged, from the device's out2."""
+        the student's first forward, all before any update - against the real reference's logged losses, to the heat-map bound;
+      * out2 = D'(tmp), the student's output AFTER Adam's first step, and loss_D again, against the CPU oracle's step
+        teacher-forced as in test_network_parity_at_the_benchmarked_batch (the oracle adopts the device's updated student: Adam's
+        first step is lr * sign(g), so un-forced the two updated networks differ wherever a gradient is rounding noise - the
+        reference's own out2 is 0.18 away at |ref| <= 1.6 - which measures that, not kernels).  The oracle's step needs ~45 GB
+        of host memory: the GPU box's 300 GB limit has room (asserted up front, so that a smaller host skips instead of dying)."""
+    import os
     from oracle import configs
-    from oracle.posenet import calibrate
-    from oracle.synth import synth_batch, strided
-    from advmix_amd.core.function import advmix_phase_a, advmix_phase_b
+    from oracle.posenet import calibrate, trainable
+    from oracle.step import Adam, advmix_step as ostep
+    from oracle.synth import synth_batch
+    from advmix_amd.core.function import advmix_step
     from advmix_amd.core.loss import JointsMSELoss
     from advmix_amd.utils.utils import get_optimizer
     from advmix_amd import ops as _ops_
+    try:
+        with open('/sys/fs/cgroup/memory.max') as f:
+            lim = f.read().strip()
+        lim = int(lim) if lim.isdigit() else None
+    except OSError:
+        lim = None
+    avail = os.sysconf('SC_PHYS_PAGES') * os.sysconf('SC_PAGE_SIZE')
+    if min(avail, lim or avail) < 100 * (1 << 30):
+        pytest.skip('the CPU oracle of this step needs ~45 GB of host memory; this host offers %.0f GB' % (min(avail, lim or avail) / 2 ** 30))
     tag, net, extra, J, B, H, W, downs = 'hrnet_w48_b32', 'pose_hrnet', configs.HRNET_W48, 17, 32, 384, 288, 5
     ga = gold_npz('c4_b32_advmix_steps.npz')
     D, T, G = build_states(net, extra, J, unet_downs=downs, salt=10)
@@ -1045,28 +1057,24 @@ def test_c4_step_at_its_benchmarked_batch_against_the_real_reference():
     calibrate(net, D, calib, extra)
     cfg, mD, mG, mT = product_models(net, extra, J, D, T, G, downs=downs)
     optD, optG = get_optimizer(cfg, mD), get_optimizer(cfg, mG)
+    oD, oG = Adam(D, trainable(D)), Adam(G, list(G))
     mD.train(); mG.train(); mT.eval()
-    crit = JointsMSELoss(True)
     args = types.SimpleNamespace(alpha=0.1, adv_loss_weight=1.0)
     v, t, w = synth_batch(tag + '.it0', B, J, H, W)
-    inputs = [x.cuda().contiguous() for x in v]
     c0 = dict(_ops_.COUNTERS)
-    loss_D, tmp = advmix_phase_a(args, mD, mG, mT, crit, optD, inputs, t.cuda(), w.cuda())
-    out = advmix_phase_b(args, mD, crit, optD, optG, tmp, t.cuda(), w.cuda())
-    optG.step()
+    loss_D, out = advmix_step(args, mD, mG, mT, JointsMSELoss(True), optD, optG, [x.cuda().contiguous() for x in v], t.cuda(), w.cuda())
     torch.cuda.synchronize()
     took = {k: n - c0.get(k, 0) for k, n in _ops_.COUNTERS.items() if n != c0.get(k, 0)}
     print(tag, 'launch counters of the step', took)
-    assert took.get('wino', 0) >= 100 and took.get('inbn', 0) >= 2 * 40, took      # the 48 / 96-channel branches on the Winograd kernel, BatchNorm on load
+    assert took.get('wino', 0) >= 600 and took.get('inbn', 0) >= 2 * 60, took      # the 48 / 96-channel branches on the Winograd kernel, BatchNorm on load
     want = ga[tag + '.losses'][0]                            # (heat-map loss, distillation loss, generator loss) of the iteration
     rep = {}
     assert_close('loss_D vs the real train_advmix', [float(loss_D)], [0.9 * want[0] + 0.1 * want[1]], report=rep)
-    assert_close('out2 vs the real train_advmix (un-forced)', strided(out.cpu().contiguous(), 2048), ga[tag + '.out2.it0'], 5e-3, report=rep)
-    with torch.no_grad():
-        loss_G = float(crit(out, t.cuda(), w.cuda()))
-    assert abs(loss_G - want[2]) <= 1e-3 + 5e-3 * abs(want[2]), (loss_G, want[2])
-    print(tag, 'loss_D %.6f (reference %.6f), generator loss %.6f (reference %.6f), worst err/bound ratios' % (
-        float(loss_D), 0.9 * want[0] + 0.1 * want[1], loss_G, want[2]), {k: round(x, 3) for k, x in rep.items()})
+    ref = ostep(net, extra, D, G, T, oD, oG, v, t, w, alpha=0.1, after_D_step=lambda: pull_params(mD, D), unet_kw={'num_downs': downs})
+    assert_close('loss_D', loss_D, ref['loss_D'], report=rep)
+    assert_close('out2', out, ref['out2'], report=rep)
+    print(tag, 'loss_D %.6f (real reference %.6f, oracle %.6f); worst err/bound ratios' % (
+        float(loss_D), 0.9 * want[0] + 0.1 * want[1], float(ref['loss_D'])), {k: round(x, 3) for k, x in rep.items()})
 
 
 def _device_checksums(model, keys):

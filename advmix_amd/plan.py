@@ -551,6 +551,15 @@ class PlanNet(nn.Module):
         self.invalidate_filter_images()
         return r
 
+    def train(self, mode=True):
+        """nn.Module.train; a network that (re-)enters training mode is no longer the frozen teacher core.function marked
+        ``wino_static``: its filters will change through raw kernels (FlatAdam) that torch's version counters do not see, so
+        the mark and the cached images' key are dropped."""
+        if mode and getattr(self, 'wino_static', False):
+            self.wino_static = False
+            self.invalidate_filter_images()
+        return super().train(mode)
+
     def invalidate_filter_images(self):
         """Have the next forward pass re-make the Winograd / small-map filter images even for a network marked
         ``wino_static`` (see _wino_refresh).  Needed only after writing a frozen network's filters in a way torch's version
@@ -660,7 +669,7 @@ class PlanNet(nn.Module):
             # a FROZEN eval-mode network (the AdvMix teacher: core.function marks it): its filters change only through torch
             # (load_state_dict, param.copy_ / mul_ ...) - which bumps the parameters' version counters - so the images are re-made
             # only then; writes torch does not see (param.data, collectives, raw kernels): invalidate_filter_images()
-            key = tuple(w._version for w in ws)
+            key = tuple((w._version, w.data_ptr()) for w in ws)      # (re-pointed storage - FlatAdam, .to() - counts as a change too)
             if getattr(bank, 'static_key', None) == key:
                 return
             bank.static_key = key

@@ -738,3 +738,23 @@ def test_launcher_rank_environment_shared_device_detection_and_cpu_budget():
     assert keep['OMP_NUM_THREADS'] == '5' and keep['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] == '1'
     src = open(os.path.join(ROOT, 'bench.py')).read()      # the driver's torch.distributed.run form: same rule in bench.py
     assert "os.environ.get('ADVMIX_BENCH_SHARE_GPU') == '1'" in src.split('\nimport torch\n')[0]
+
+
+def test_design_quotes_the_adopted_trace_summary():
+    """DESIGN.md quoted a superseded trace.  Its one machine-checked line must name the trace summary that
+    profiles/LATEST.json (tools/adopt_profiles.py) adopted and carry exactly its busy / in-flight / idle numbers; the files the
+    manifest names exist; bench.py's roofline object selects its profile files through the same manifest."""
+    import importlib.util
+    man_path = os.path.join(ROOT, 'profiles', 'LATEST.json')
+    if not os.path.exists(man_path):
+        pytest.skip('no collection adopted yet (tools/adopt_profiles.py)')
+    man = json.load(open(man_path))
+    assert man['tag'] and man['head'] and all(os.path.exists(os.path.join(ROOT, f)) for f in man['files'].values()), man
+    spec = importlib.util.spec_from_file_location('_cdn', os.path.join(ROOT, 'tools', 'check_design_numbers.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.check() is None, mod.check()
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import bench_roofline as R
+    assert R._profile_file('per_shape_1lane', 'r*_per_shape_1lane.csv')[1] == man['files']['per_shape_1lane']
+    assert R._time_shares()['source'] == man['files']['per_shape_1lane']

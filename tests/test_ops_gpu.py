@@ -842,6 +842,18 @@ def test_winograd_4x4_stride2_conv(case, monkeypatch):
     bank.release()
 
 
+def test_winograd_conv_with_two_column_tiles_per_workgroup():
+    """ADVMIX_WINO_NC=2 (csrc/conv_wino.hip, template parameter NC: both column tiles of a 64-channel conv in one workgroup -
+    VERDICT r5 next 3, measured slower in the step and kept as the A/B switch): the library reads the switch once per
+    process, so the Winograd op tests run again in a child process with it set.  Every role, every 64-channel shape, the
+    same fp64 bounds."""
+    import os, subprocess, sys
+    here = os.path.abspath(__file__)
+    out = subprocess.run([sys.executable, '-m', 'pytest', here, '-q', '-x', '-k', 'test_winograd_conv_all_roles'],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, ADVMIX_WINO_NC='2'))
+    assert out.returncode == 0 and ' passed' in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
 @pytest.mark.parametrize('case', WINO_CASES + SMAP_CASES + PW_CASES)
 def test_winograd_conv_all_roles(case, monkeypatch):
     """csrc/conv_wino.hip (round 5): the Winograd F(2x2,3x3) kernel in every role the step uses - forward + BatchNorm column

@@ -8,7 +8,8 @@ T=${1:-r06}; O=gpurun_out/$T; mkdir -p $O
 line() { python -c "import sys,json; d=json.loads(open('$1').read().strip().splitlines()[-1]); print('$2', d['value'], d['ms_per_step'])"; }
 # 1. the step's trace + per-shape table first: bench.py's roofline quotes the per-shape table of THIS collection
 tools/profile_step.sh $T > $O/profile_step.log 2>&1
-for f in stats_4lanes.csv stats_1lane.csv trace_summary_4lanes.txt per_shape_1lane.csv per_shape_1lane.txt; do cp gpurun_out/prof_$T/$f $O/ 2>/dev/null; done
+cp gpurun_out/prof_$T/stats_4lane.csv $O/stats_4lanes.csv 2>/dev/null
+for f in stats_1lane.csv trace_summary_4lanes.txt per_shape_1lane.csv per_shape_1lane.txt; do cp gpurun_out/prof_$T/$f $O/ 2>/dev/null; done
 # 2. PMC: traffic of the dominant members; MFMA-busy cycles and traffic of the step (against the unprofiled step time of this box)
 tools/pmc_dominant.sh $T > $O/pmc_dominant.log 2>&1; cp gpurun_out/pmc_$T/pmc_dominant.json gpurun_out/pmc_$T/pmc_wino32.json $O/ 2>/dev/null
 python bench.py --no-cpu-baseline --no-roofline --no-through-loop > $O/bench_quick.json 2>> $O/bench.err

@@ -56,7 +56,6 @@ struct ConvEpi {
     int bnb_act;
 };
 int advmix_wgrad_lds_build_flags(void);   // wgrad_lds.hip: its bit of advmix_build_flags() (0 unless a measurement variant)
-int advmix_conv_wino_build_flags(void);   // conv_wino.hip: likewise (64 = WN_INBN, tools/variants/conv_wino_inbn.patch)
 // conv_direct.hip: second-generation conv; returns -1 when the shape is not eligible, -2 when only the
 // fused epilogue is unavailable
 int advmix_conv_direct_dispatch(int mode, const float* x, const float* w, const float* bias, float* y,

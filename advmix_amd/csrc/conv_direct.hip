@@ -1015,8 +1015,7 @@ int advmix_conv_direct_group(int mode, int bt, int n, ConvProb* pr, hipStream_t 
 // Bit mask of the measurement switches this library was compiled with - THE place a measurement build is detected: 0 for the
 // shipped library (__graft_entry__.build(), advmix_amd/_lib.py and bench.py check it).  1 = CD_DBG (parts of the kernel
 // compiled out), 2 = CD_PRELOAD, 4 = CD_CLK, 8 = CD_NO_PRE - all four exist only in tools/variants/conv_direct_dbg.patch -
-// 16 = a store cache policy other than sc1, 32 = WL_DBG (wgrad_lds.hip, tools/variants/wgrad_lds_dbg.patch), 64 = WN_INBN
-// (conv_wino.hip, tools/variants/conv_wino_inbn.patch).
+// 16 = a store cache policy other than sc1, 32 = WL_DBG (wgrad_lds.hip, tools/variants/wgrad_lds_dbg.patch).
 extern "C" int advmix_build_flags(void) {
     int f = 0;
 #ifdef CD_DBG
@@ -1033,7 +1032,6 @@ extern "C" int advmix_build_flags(void) {
 #endif
     if (CD_STORE_AUX != 16) f |= 16;
     f |= advmix_wgrad_lds_build_flags();
-    f |= advmix_conv_wino_build_flags();
     return f;
 }
 

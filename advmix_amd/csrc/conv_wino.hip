@@ -157,7 +157,8 @@ constexpr int wino_waves() { return KS > 1 ? 1 : (NC > 1 ? 2 : (Geo<LBW, NQ * 8,
 // been applied: act(fma((c - mean) * invstd, gamma, beta)) - norm_apply_slots' very expression, so that the backward pass's
 // "sign from c" epilogue and the weight gradient's staging see the same activation bit for bit - is applied to every element
 // on its way into LDS (~1.3 loads per input element, four VALU operations each), and the separate norm_apply_slots launch with
-// its y tensor disappears: +0.3 ... +1.3 us on the conv against 6.2 ... 10.2 us for the launch (profiles/r06d_microbench_wino_inbn.log).
+// its y tensor disappears: +0.3 ... +1.3 us on the conv against 6.2 ... 10.2 us for the launch (profiles/r06d_microbench_wino_inbn.log,
+// tools/microbench_wino_inbn.py).
 template <int NQ, int VAR, int LBW, int KS = 1, int NC = 1, int INBN = 0>
 __global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS, NC>())) void conv_wino(const WinoP p) {
     using G = Geo<LBW, NQ * 8, KS>;
@@ -735,7 +736,3 @@ extern "C" int advmix_conv3x3_wino_dgrad(const float* dy, const float* u, const 
     if (rc == ADVMIX_OK && bn_c) *stats_ns = p.stats_nbg;
     return rc;
 }
-
-// This translation unit's share of advmix_build_flags(): 0 in the shipped library (the measurement switch WN_INBN - BatchNorm + ReLU
-// applied to the input patch while it is staged - lives in tools/variants/conv_wino_inbn.patch, which makes this return 64).
-int advmix_conv_wino_build_flags(void) { return 0; }

@@ -20,10 +20,6 @@ for f in conv_mfma conv_direct conv_wino conv_wino4 conv_smap conv_pw wgrad_dire
       cp $in $D/wgrad_lds.hip && cp $R/advmix_amd/csrc/common.h $D/ && patch -s $D/wgrad_lds.hip $R/tools/variants/wgrad_lds_dbg.patch
       in=$D/wgrad_lds.hip; DEFS="$DEFS -I$R/advmix_amd/csrc -I$R/include"
     fi
-    if [ $f = conv_wino ] && echo "$DEFS" | grep -q "WN_INBN"; then     # (round 6: BatchNorm + ReLU applied while the patch is staged)
-      cp $in $D/conv_wino.hip && cp $R/advmix_amd/csrc/common.h $D/ && patch -s $D/conv_wino.hip $R/tools/variants/conv_wino_inbn.patch
-      in=$D/conv_wino.hip; DEFS="$DEFS -I$R/advmix_amd/csrc -I$R/include"
-    fi
     /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -std=c++17 -Wno-unused-result $DEFS -c $in -o $D/$f.$NAME.o
     objs="$objs $D/$f.$NAME.o"
   else

@@ -145,7 +145,7 @@ struct Geo {
 // the halves meet in the exchange of the inverse transform, which adds across waves anyway.
 // waves per SIMD the register allocator may assume: what the LDS footprint admits anyway (three workgroups of <= 53 KB per CU)
 template <int NQ, int LBW, int KS, int NC = 1>
-constexpr int wino_waves() { return KS > 1 ? 1 : (NC > 1 ? 2 : (Geo<LBW, NQ * 8, KS>::LDS * 4 + 1024 <= 53 * 1024 ? 3 : 2)); }
+constexpr int wino_waves() { return KS > 1 || Geo<LBW, NQ * 8, KS>::LDS * 4 + 4096 > 80 * 1024 ? 1 : (NC > 1 ? 2 : (Geo<LBW, NQ * 8, KS>::LDS * 4 + 1024 <= 53 * 1024 ? 3 : 2)); }
 
 // VAR: the epilogue compiled in - 0 forward + BatchNorm column sums, 1 forward + eval-mode BatchNorm (+ residual) + activation,
 // 2 input gradient (+ addend) + BatchNorm-backward epilogue, 3 plain (forward or input gradient, + residual / addend)

@@ -107,23 +107,46 @@ def _advance(runs):
         pos += len(g)
 
 
-def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, inputs, target, target_weight,
-                   cuts=None):
-    """function.py:137-154: G forward, softmax-mix, D forward on the detached mix, teacher forward,
-    heat-map + KD loss, D backward.  Leaves D's gradients in ``optimizer.flat_grads``.
-    ``cuts`` (data parallel) = (model.plan_cuts(), model_G.plan_cuts()): both forwards run with their autograd graph
-    cut at those levels and the backward pass is NOT run here; it is returned as closures (see _backward_pieces) so
-    that the caller can all-reduce each finished gradient range beside the next piece, together with G's cut record
-    for advmix_phase_b."""
+def teacher_forward(model_teacher, clean):
+    """function.py:148-149: the frozen teacher's heat-maps for the clean view, under no_grad, marked for the static filter
+    images (plan.PlanNet._wino_refresh re-makes a frozen eval-mode network's Winograd images only when its filters change)."""
+    getattr(model_teacher, 'module', model_teacher).wino_static = True
+    for p_ in model_teacher.parameters():                                 # the teacher only ever runs under no_grad - nothing
+        if p_.requires_grad:                                              # reads its gradients (checked per call: a state
+            p_.requires_grad = False                                      # restore may re-arm the flags)
+    with torch.no_grad():
+        return model_teacher(clean).detach()
+
+
+def advmix_phase_a1(args, model, model_G, model_teacher, optimizer, inputs, cuts=None, teacher_output=None):
+    """First half of advmix_phase_a, function.py:137-149: G forward, softmax-mix, D forward on the detached mix and the
+    teacher's forward.  Returns the state advmix_phase_a2 finishes the phase from.  ``teacher_output``: the teacher's
+    heat-maps when the caller computes them itself (graph.AdvMixGraphRunner replays the teacher's forward as a graph of its
+    own beside this half, ADVMIX_PAIR_TEACHER=2); otherwise the teacher runs here - its levels as members of the student's
+    launch groups (1, the default), on a stream and lane set of its own from the start of the phase (2, eager), or after the
+    student (0)."""
     G_input = ops.cat_views(inputs)                                       # :137
-    getattr(model_teacher, 'module', model_teacher).wino_static = True    # (frozen, eval mode: plan.PlanNet._wino_refresh re-makes its filter images only when they change)
+    getattr(model_teacher, 'module', model_teacher).wino_static = True    # (frozen, eval mode: see teacher_forward)
     pair = _PAIR_TEACHER if all(hasattr(m, 'begin') for m in (model, model_G, model_teacher)) else 0
-    if pair:
+    if teacher_output is not None:
+        pair = -1
+    if pair > 0:
         # the (frozen) teacher's levels as members of the student's launch groups: a sequential network is one chain per
         # pass, so the teacher shares the chip with it instead of running on its own afterwards
         for p_ in model_teacher.parameters():                             # function.py:148: the teacher only ever runs under
             if p_.requires_grad:                                          # no_grad - nothing reads its gradients (checked per
                 p_.requires_grad = False                                  # call: a state restore may re-arm the flags)
+    t_side = None
+    if pair == 2 and inputs[0].is_cuda and not torch.cuda.is_current_stream_capturing():
+        # eager form of mode 2: the teacher's whole forward on a stream and a lane set of its own, started BEFORE the
+        # generator's - it needs the clean view only - so that it runs beside the generator's single-lane forward and on into
+        # the student's; joined before the loss reads its heat-maps.  (NOT inside a capture: tensors allocated under a second
+        # current stream while capturing raced / crashed hipStreamEndCapture - the graph runner replays a teacher graph instead.)
+        cur = torch.cuda.current_stream(inputs[0].device)
+        t_side = ops.aux_stream(inputs[0].device)
+        t_side.wait_stream(cur)
+        with torch.cuda.stream(t_side), ops.lane_set(1), torch.no_grad():
+            teacher_output = model_teacher(inputs[0])                     # :148-149
     if cuts:
         model_G.cut_levels = tuple(c[0] for c in cuts[1])
     logits = model_G(G_input)                                             # :138 (softmax fused below)
@@ -134,7 +157,13 @@ def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, in
     tmp = ops.softmax_mix(logits, inputs)                                 # :138,142-144
     if cuts:
         model.cut_levels = tuple(c[0] for c in cuts[0])
-    if pair:
+    if t_side is not None:
+        D_output_detach = model(tmp.detach())                             # :146
+        torch.cuda.current_stream(inputs[0].device).wait_stream(t_side)
+        teacher_output = teacher_output.detach()
+    elif pair < 0:
+        D_output_detach = model(tmp.detach())                             # :146 (the teacher's heat-maps come from the caller)
+    elif pair:
         rt = model_teacher.begin(inputs[0])
         rd = model.begin(tmp.detach())                                    # :146
         while not rd.done:
@@ -148,11 +177,28 @@ def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, in
             teacher_output = model_teacher(inputs[0])                     # :148-149
     pairs_D = model.last_cuts if cuts else None
     model.cut_levels = ()
-    loss_D = _blend(criterion, D_output_detach, target, 1 - args.alpha, teacher_output, args.alpha, target_weight)   # :151-153
+    return {'tmp': tmp, 'out': D_output_detach, 'teacher': teacher_output, 'pairs_D': pairs_D, 'pairs_G': pairs_G}
+
+
+def advmix_phase_a2(args, model, criterion, state, target, target_weight, cuts=None):
+    """Second half of advmix_phase_a, function.py:151-154: the heat-map + distillation loss and D's backward pass."""
+    loss_D = _blend(criterion, state['out'], target, 1 - args.alpha, state['teacher'], args.alpha, target_weight)   # :151-153
     if cuts:
-        return loss_D.detach(), tmp, _backward_pieces(loss_D, model, cuts[0], pairs_D), pairs_G
+        return loss_D.detach(), state['tmp'], _backward_pieces(loss_D, model, cuts[0], state['pairs_D']), state['pairs_G']
     _backward(loss_D)
-    return loss_D.detach(), tmp
+    return loss_D.detach(), state['tmp']
+
+
+def advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer, inputs, target, target_weight,
+                   cuts=None):
+    """function.py:137-154: G forward, softmax-mix, D forward on the detached mix, teacher forward,
+    heat-map + KD loss, D backward.  Leaves D's gradients in ``optimizer.flat_grads``.
+    ``cuts`` (data parallel) = (model.plan_cuts(), model_G.plan_cuts()): both forwards run with their autograd graph
+    cut at those levels and the backward pass is NOT run here; it is returned as closures (see _backward_pieces) so
+    that the caller can all-reduce each finished gradient range beside the next piece, together with G's cut record
+    for advmix_phase_b."""
+    state = advmix_phase_a1(args, model, model_G, model_teacher, optimizer, inputs, cuts)
+    return advmix_phase_a2(args, model, criterion, state, target, target_weight, cuts)
 
 
 def advmix_phase_b(args, model, criterion, optimizer, optimizer_G, tmp, target, target_weight, cuts_G=None,

@@ -17,7 +17,8 @@ consumed while capturing the next; all share one memory pool."""
 import torch
 
 from . import ops
-from .core.function import advmix_phase_a, advmix_phase_b, advmix_step, plain_step
+from .core.function import (advmix_phase_a, advmix_phase_a1, advmix_phase_a2, advmix_phase_b, advmix_step, plain_step,
+                            teacher_forward, _PAIR_TEACHER)
 
 
 def _snapshot(models, optimizers):
@@ -74,13 +75,43 @@ class AdvMixGraphRunner:
             return self.seq.capture(fn)
 
         sync = grad_sync if (grad_sync is not None and grad_sync.active) else None
-        if sync is None:
+        self.tseq = None
+        if sync is None and _PAIR_TEACHER == 2:
+            # ADVMIX_PAIR_TEACHER=2 (round 6): the frozen teacher's forward is a HIP graph of its OWN (own memory pool, own lane
+            # set: its kernels run beside the step's), replayed on a side stream at the start of the step - it needs the clean
+            # view only - beside the generator's single-lane forward and the student's; phase a is captured in two halves and
+            # the loss half waits for it.
+            self.tseq = ops.GraphSeq(dev)
+            self.tside = ops.aux_stream(dev)
+            with ops.lane_set(1):
+                teacher_forward(model_teacher, self.inputs[0])        # (eager once: lane set 1's streams and scratch exist)
+                torch.cuda.synchronize(dev)
+                box_t = {}
+
+                def seg_t():
+                    box_t['out'] = teacher_forward(model_teacher, self.inputs[0])
+                self.tseg, _ = self.tseq.capture(seg_t)
+            self._tout = box_t['out']
+            box = {}
+
+            def seg_a1():
+                box['state'] = advmix_phase_a1(args, model, model_G, model_teacher, optimizer, self.inputs, None, self._tout)
+            g, _ = capture(seg_a1)
+            self.segments.append((g, None))
+
+            def seg_a2():
+                self.loss_D, self._tmp = advmix_phase_a2(args, model, criterion, box['state'], self.target, self.tw)
+                box.clear()
+            g, _ = capture(seg_a2)
+            self.segments.append((g, None, False, True))   # (4th field: wait for the teacher's graph before this segment)
+        elif sync is None:
             def seg_a():
                 self.loss_D, self._tmp = advmix_phase_a(args, model, model_G, model_teacher, criterion, optimizer,
                                                         self.inputs, self.target, self.tw)
             g, _ = capture(seg_a)
             self.segments.append((g, None))
 
+        if sync is None:
             def seg_b():
                 self.output = advmix_phase_b(args, model, criterion, optimizer, optimizer_G, self._tmp,
                                              self.target, self.tw)
@@ -138,10 +169,16 @@ class AdvMixGraphRunner:
         if hop:
             rs.wait_stream(cur)                            # load_batch's copies, the previous step's consumers
         with torch.cuda.stream(rs):
+            if self.tseq is not None:                      # the teacher's graph beside the first half of phase a
+                self.tside.wait_stream(rs)
+                with torch.cuda.stream(self.tside):
+                    self.tseq.graphs[self.tseg].replay()
             for seg in self.segments:
                 g, red = seg[0], seg[1]
                 if len(seg) > 2 and seg[2] and self.sync is not None:
                     self.sync.finish()                     # this segment's optimizer step consumes reduced gradients
+                if len(seg) > 3 and seg[3]:
+                    rs.wait_stream(self.tside)             # the loss reads the teacher's heat-maps
                 self.seq.replay(g)
                 if red is not None and self.sync is not None:
                     self.sync.reduce_async(red[0].flat_grads, red[1], red[2])

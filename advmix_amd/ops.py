@@ -152,7 +152,7 @@ def _workspace(device, nbytes, lane):
     are stream-ordered."""
     if nbytes > WS_BYTES:
         raise ValueError('norm workspace of %d bytes exceeds the per-lane scratch (%d)' % (nbytes, WS_BYTES))
-    key = (device.index, lane)
+    key = (device.index, _LANE_SET[0], lane)
     w = _ws_cache.get(key)
     if w is None:
         w = torch.zeros(WS_BYTES // 4, device=device, dtype=torch.float32)   # ticket words start at 0
@@ -167,13 +167,42 @@ def _ensure_workspaces(device, n):
 
 
 _lane_streams = {}
+_LANE_SET = [0]         # which set of launch-lane streams and per-lane scratch launch groups use right now (see lane_set)
 
 
 def _lanes(device, n):
-    ss = _lane_streams.setdefault(device.index, [])
+    ss = _lane_streams.setdefault((device.index, _LANE_SET[0]), [])
     while len(ss) < n:
         ss.append(torch.cuda.Stream(device=device))
     return ss[:n]
+
+
+class lane_set:
+    """``with ops.lane_set(k):`` - launch groups issued inside fork onto lane-stream set k and use its per-lane scratch
+    (set 0 is the default).  For a network that runs on its OWN stream beside another one (round 6: the frozen teacher's
+    forward beside the generator's and the student's, core.function.advmix_phase_a): sharing the lane streams would chain the
+    two networks' launch groups behind each other, sharing the scratch would race."""
+
+    def __init__(self, k):
+        self.k = int(k)
+
+    def __enter__(self):
+        self.prev = _LANE_SET[0]
+        _LANE_SET[0] = self.k
+
+    def __exit__(self, *exc):
+        _LANE_SET[0] = self.prev
+
+
+_aux_streams = {}
+
+
+def aux_stream(device, k=1):
+    """A stream of its own for lane set k's network (created once per device)."""
+    key = (device.index, k)
+    if key not in _aux_streams:
+        _aux_streams[key] = torch.cuda.Stream(device=device)
+    return _aux_streams[key]
 
 
 _DIRECT = {'ok': __import__('os').environ.get('ADVMIX_BT', '1') != '0'}

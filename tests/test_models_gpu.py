@@ -1433,6 +1433,21 @@ def test_teacher_riding_in_the_students_launch_groups_changes_no_result(monkeypa
         assert torch.equal(ba[k], bb[k]), k
 
 
+def test_teacher_as_a_graph_of_its_own_beside_the_step():
+    """ADVMIX_PAIR_TEACHER=2 (round 6, EXPERIMENTS M6: measured 0.8 % slower than the teacher riding in the student's launch
+    groups, kept as the A/B switch): the frozen teacher's forward is a HIP graph of its own - own memory pool, own lane set -
+    replayed on a side stream at the start of the step beside the generator's and the student's forward; phase a is captured in
+    two halves and the loss half waits for it (eagerly: a stream and lane set of its own inside advmix_phase_a1).  The switch is
+    read at import, so the tests that hold the graph runner, the loops and the smoke step to the reference run again in a
+    child process with it set."""
+    import os, subprocess, sys
+    here = os.path.abspath(__file__)
+    out = subprocess.run([sys.executable, '-m', 'pytest', here, '-q', '-x', '-k',
+                          'graph_runner_matches or loops_graph or train_advmix_loop_first or smoke_entry or advmix_and_plain_steps_vs_oracle_and_golden and tiny'],
+                         capture_output=True, text=True, timeout=1200, env=dict(os.environ, ADVMIX_PAIR_TEACHER='2'))
+    assert out.returncode == 0 and ' passed' in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
 def test_train_advmix_loop_first_iteration_matches_reference():
     """The loop mirror itself (function.py:107-197): batches in the reference loader's format, meters, the
     tensorboard counter; the first iteration's loss_D equals the number the REAL train_advmix recorded."""

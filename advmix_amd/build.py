@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(HERE, 'libadvmix_hip.so')
 SOURCES = ['conv_mfma.hip', 'conv_direct.hip', 'conv_wino.hip', 'conv_wino4.hip', 'conv_smap.hip', 'conv_pw.hip', 'wgrad_direct.hip', 'wgrad_lds.hip', 'wgrad_wino.hip', 'norm.hip', 'pointwise.hip', 'advmix_ops.hip', 'postproc.hip', 'inputpipe.hip', 'nms.hip']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-munsafe-fp-atomics', '-std=c++17',
-         '-Wno-unused-result']
+         '-Wno-unused-result', '-Wno-pass-failed']     # (pass-failed: 'occupancy target not met' where LDS, not registers, is the limit)
 # Every kernel must fit its registers: a kernel with scratch (spilled VGPRs) is refused - none of the library's kernels needs
 # any, a spill is always an accident of a register cap, and spilling builds were among the suspects of round 3's
 # two-process NaN hunt (conv_direct.hip, at its launch bounds).  The compiler reports each kernel's scratch; the build reads it.

@@ -143,9 +143,12 @@ struct Geo {
 // KS: K is split over KS sets of four waves (workgroup = 4 KS waves): the 128-channel branch (16 x 12 maps: 64 blocks x 4
 // column tiles = one workgroup per CU at B = 32) gets two waves per SIMD that way, each multiplying half of the channels;
 // the halves meet in the exchange of the inverse transform, which adds across waves anyway.
-// waves per SIMD the register allocator may assume: what the LDS footprint admits anyway (three workgroups of <= 53 KB per CU)
-template <int NQ, int LBW, int KS, int NC = 1>
-constexpr int wino_waves() { return KS > 1 || Geo<LBW, NQ * 8, KS>::LDS * 4 + 4096 > 80 * 1024 ? 1 : (NC > 1 ? 2 : (Geo<LBW, NQ * 8, KS>::LDS * 4 + 1024 <= 53 * 1024 ? 3 : 2)); }
+// waves per SIMD the register allocator may assume: what the LDS footprint admits anyway (three workgroups of <= 53 KB per CU);
+// round 6: FOUR for the 32-channel forward variants - their 40 KB admit it for the eval / plain epilogues, and the tighter register
+// budget (79-124 VGPRs beside the accumulators) schedules all three better: 13.0 -> 12.4 us forward + sums, 12.8 -> 11.5 eval,
+// launch to launch (the BatchNorm-backward variant loses at that budget and keeps three; in the step: no difference, r06j)
+template <int NQ, int LBW, int KS, int NC = 1, int VAR = 0>
+constexpr int wino_waves() { return NQ == 4 && NC == 1 && VAR != 2 ? 4 : (KS > 1 || Geo<LBW, NQ * 8, KS>::LDS * 4 + 4096 > 80 * 1024 ? 1 : (NC > 1 ? 2 : (Geo<LBW, NQ * 8, KS>::LDS * 4 + 1024 <= 53 * 1024 ? 3 : 2))); }
 
 // VAR: the epilogue compiled in - 0 forward + BatchNorm column sums, 1 forward + eval-mode BatchNorm (+ residual) + activation,
 // 2 input gradient (+ addend) + BatchNorm-backward epilogue, 3 plain (forward or input gradient, + residual / addend)
@@ -160,7 +163,7 @@ constexpr int wino_waves() { return KS > 1 || Geo<LBW, NQ * 8, KS>::LDS * 4 + 40
 // its y tensor disappears: +0.3 ... +1.3 us on the conv against 6.2 ... 10.2 us for the launch (profiles/r06d_microbench_wino_inbn.log,
 // tools/microbench_wino_inbn.py).
 template <int NQ, int VAR, int LBW, int KS = 1, int NC = 1, int INBN = 0>
-__global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS, NC>())) void conv_wino(const WinoP p) {
+__global__ __launch_bounds__(256 * KS, (wino_waves<NQ, LBW, KS, NC, VAR>())) void conv_wino(const WinoP p) {
     using G = Geo<LBW, NQ * 8, KS>;
     constexpr int NT = 256 * KS, NQW = NQ / KS;            // threads; k groups per wave
     static_assert(NQ % KS == 0, "K splits evenly over the wave sets");

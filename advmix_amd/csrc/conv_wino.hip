@@ -148,7 +148,12 @@ struct Geo {
 // budget (79-124 VGPRs beside the accumulators) schedules all three better: 13.0 -> 12.4 us forward + sums, 12.8 -> 11.5 eval,
 // launch to launch (the BatchNorm-backward variant loses at that budget and keeps three; in the step: no difference, r06j)
 template <int NQ, int LBW, int KS, int NC = 1, int VAR = 0>
-constexpr int wino_waves() { return NQ == 4 && NC == 1 && VAR != 2 ? 4 : (KS > 1 || Geo<LBW, NQ * 8, KS>::LDS * 4 + 4096 > 80 * 1024 ? 1 : (NC > 1 ? 2 : (Geo<LBW, NQ * 8, KS>::LDS * 4 + 1024 <= 53 * 1024 ? 3 : 2))); }
+constexpr int wino_waves() {
+    if (NQ == 4 && NC == 1 && VAR != 2) return 4;                       // (64 / 128 channels: no difference measured)
+    if (KS > 1 || Geo<LBW, NQ * 8, KS>::LDS * 4 + 4096 > 80 * 1024) return 1;
+    if (NC > 1) return 2;
+    return Geo<LBW, NQ * 8, KS>::LDS * 4 + 1024 <= 53 * 1024 ? 3 : 2;
+}
 
 // VAR: the epilogue compiled in - 0 forward + BatchNorm column sums, 1 forward + eval-mode BatchNorm (+ residual) + activation,
 // 2 input gradient (+ addend) + BatchNorm-backward epilogue, 3 plain (forward or input gradient, + residual / addend)

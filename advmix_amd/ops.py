@@ -305,13 +305,19 @@ WGRAD_MULTI_FLUSH = int(__import__('os').environ.get('ADVMIX_WGRAD_MULTI_FLUSH',
 _WG_SMALL = {}          # {autograd graph task id: [(a, b, grad, geom)]} across the launch groups of THAT pass
 
 
+_graph_task_id = getattr(torch._C, '_current_graph_task_id', None)
+if _graph_task_id is None:                                   # (a torch without the accessor: one list, as before round 6 - the
+    def _graph_task_id():                                    #  forward-side clean-up then never fires, parking still works)
+        return 0
+
+
 def _pass_key():
     """The autograd pass in progress (-1: none).  ADVICE r5 (medium): the parked problems used to live in one process-global
     list, so what a pass that RAISED had parked (its end-of-pass callback never runs) went out with the next pass - stale
     dc / x products accumulated into live gradients - and a nested ``autograd.grad`` could flush its outer pass's problems.
     Graph-task ids grow monotonically and a nested pass runs inside one node of its outer pass.  (Not keyed by thread: the
     engine runs a pass's CUDA nodes on its device thread, the forward that cleans up runs on the caller's.)"""
-    return torch._C._current_graph_task_id()
+    return _graph_task_id()
 
 
 def _park_list(key, create=False):
@@ -328,7 +334,7 @@ def drop_stale_parked():
     """Outside any autograd pass (forward side of a launch group): whatever is still held was parked by a pass that raised -
     never launched, only released.  (One process drives one GPU from one thread at a time; a forward on one thread beside
     another thread's backward pass is not a supported way to use the library.)"""
-    if _WG_SMALL and torch._C._current_graph_task_id() < 0:
+    if _WG_SMALL and _graph_task_id() < 0:
         _WG_SMALL.clear()
 
 
@@ -340,10 +346,14 @@ def _wgrad_single(st, a, b, g, geom, park):
         key = _pass_key()
         if key >= 0:                                         # (not inside an autograd pass: nobody would flush)
             lst = _park_list(key, create=True)
-            if not lst:                                      # one callback per pass, bound to THIS pass's list
-                torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_small_wgrads_at_end(key))
-            lst.append((a, b, g, geom))
-            return
+            try:
+                if not lst:                                  # one callback per pass, bound to THIS pass's list
+                    torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_small_wgrads_at_end(key))
+                lst.append((a, b, g, geom))
+                return
+            except RuntimeError:                             # (no pass in progress after all: launch it now)
+                if not lst:
+                    _WG_SMALL.pop(key, None)
     call('advmix_conv_wgrad', _p(a), _p(b), _p(g), *geom, st)
 
 
